@@ -1,0 +1,1133 @@
+// gpx_api.hip -- host side of libgpx.so: the C ABI of include/gpx.h over the HIP stages.
+//
+// Mirrors gp_regression::GPRegressor<Cov>::{create, evaluate x4, update} of the reference
+// (include/gp_regression/gp_regressor.hpp:110-182, :194-357, :367-479) with the data on the GPU:
+//
+//   create   : permute (Eigen's diagonal-pivot rule, decided by the original diagonal) -> kbuild
+//              -> blocked right-looking LDL^T (diag block + inverse | panel solve | MFMA trailing
+//              update) -> alpha by block substitution + fp64 matrix-free residual refinement
+//              [-> normals] [-> inverse factor X = L^-1 by recursive doubling on the GEMM core]
+//   evaluate : mean/gradient kernel; variance v = k(0) - sum_j (X k)_j^2 / D_j per query batch
+//              as one fused GEMM (Kqp tile built on the device, never the Nq x Nq matrix).
+//
+// There is no CPU compute path: without a HIP device every compute entry point fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gpx_internal.hpp"
+
+using namespace gpx;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            int code__ = (e__ == hipErrorOutOfMemory) ? GPX_E_OOM : GPX_E_HIP;                         \
+            return fail(code__, std::string(#expr) + ": " + hipGetErrorString(e__));                   \
+        }                                                                                              \
+    } while (0)
+
+extern "C" const char *gpx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *gpx_version(void) { return "gpx 0.1 (gfx950)"; }
+extern "C" int gpx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+extern "C" size_t gpx_padded_n(size_t n) { return ((n + PANEL - 1) / PANEL) * PANEL; }
+
+namespace gpx {
+CovHost make_cov(const gpx_kernel &k)
+{
+    CovHost c{};
+    c.id = k.id;
+    const double p0 = k.p[0], p1 = k.p[1];
+    switch (k.id) {
+    case GPX_KERNEL_GAUSSIAN:  // sigma^2 exp(-d / l^2)   kernels/gaussian.hpp:15-20,:36-42
+        c.a = p0 * p0;
+        c.s = 1.0 / (p1 * p1);
+        c.k0 = c.a;
+        break;
+    case GPX_KERNEL_LAPLACE:  // 2 sigma exp(-d / l)     kernels/laplace.hpp:37-42
+        c.a = 2 * p0;
+        c.s = 1.0 / p1;
+        c.k0 = c.a;
+        break;
+    case GPX_KERNEL_THINPLATE:  // 2d^3 - 3R d^2 + R^3   kernels/thin_plate.hpp:12-15
+        c.R = p0;
+        c.R3 = p0 * p0 * p0;
+        c.k0 = c.R3;
+        break;
+    case GPX_KERNEL_MATERN32:
+        c.a = p0 * p0;
+        c.s = std::sqrt(3.0) / p1;
+        c.k0 = c.a;
+        break;
+    case GPX_KERNEL_MATERN52:
+        c.a = p0 * p0;
+        c.s = std::sqrt(5.0) / p1;
+        c.k0 = c.a;
+        break;
+    }
+    return c;
+}
+}  // namespace gpx
+
+// ------------------------------------------------------------------------------------------------
+enum { EV_T0 = 0, EV_KBUILD, EV_FACTOR, EV_SOLVE, EV_NORMALS, EV_INV0, EV_INV1, EV_M0, EV_M1, EV_V1, EV_COUNT };
+
+struct gpx_model {
+    int device = 0, prec = 0;
+    size_t esz = 4;
+    gpx_kernel kern{};
+    CovHost cov{};
+    gpx_options opt{};
+    int n = 0, npad = 0, nblk = 0;
+    bool ready = false, has_s2 = false, has_inverse = false, has_normals = false;
+    std::vector<double> hx, hy, hz, hlabel, hs2;  // caller order
+    std::vector<int> perm;                        // internal position -> caller index
+    double R = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
+    size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;
+
+    // double vectors (npad each, internal order): x y z label s2 alpha r f
+    double *dvecs = nullptr;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_lab = nullptr, *d_s2 = nullptr, *d_alpha = nullptr,
+           *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
+    // state blob part 0 (T, npad each): x y z alpha dinv
+    void *blob0 = nullptr;
+    size_t blob0_bytes = 0;
+    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_alpha = nullptr, *t_dinv = nullptr;
+    // other T vectors: s2 d b y xs
+    void *tvecs = nullptr;
+    void *t_s2 = nullptr, *t_d = nullptr, *t_b = nullptr, *t_yv = nullptr, *t_xs = nullptr;
+    void *Kmat = nullptr;  // npad x npad, L D L^T in place
+    void *linv = nullptr;  // nblk x 128 x 128
+    void *Wp = nullptr;    // npad x 256 panel workspace
+    void *X = nullptr;     // npad x npad inverse factor (state blob part 1)
+    int *d_info = nullptr; // [0] first bad pivot (1-based), [1] negative pivots, [2..3] argmax pair
+    float *d_tmax = nullptr;
+    int *d_tij = nullptr;
+    // evaluation workspaces (grown on demand, guarded by mtx)
+    double *ws_pred = nullptr;
+    size_t ws_pred_doubles = 0;
+    void *ws_kqp = nullptr;
+    size_t ws_kqp_bytes = 0;
+    void *ws_partial = nullptr;
+    size_t ws_partial_bytes = 0;
+    double *ws_grad = nullptr;
+    size_t ws_grad_doubles = 0;
+    double *ws_host_io = nullptr;  // device staging for the host-pointer evaluate
+    size_t ws_host_io_doubles = 0;
+    int qbatch = 8192;
+    std::mutex mtx;
+    gpx_stats stats{};
+    bool stats_create_pending = false, stats_eval_pending = false;
+    bool eval_had_var = false;
+};
+
+static void free_dev(gpx_model *m)
+{
+    auto F = [](void *p) {
+        if (p)
+            (void)hipFree(p);
+    };
+    F(m->dvecs);
+    F(m->blob0);
+    F(m->tvecs);
+    F(m->Kmat);
+    F(m->linv);
+    F(m->Wp);
+    F(m->X);
+    F(m->d_info);
+    F(m->d_tmax);
+    F(m->d_tij);
+    F(m->ws_pred);
+    F(m->ws_kqp);
+    F(m->ws_partial);
+    F(m->ws_grad);
+    F(m->ws_host_io);
+    F(m->d_normals);
+    m->dvecs = nullptr;
+    m->blob0 = m->tvecs = m->Kmat = m->linv = m->Wp = m->X = nullptr;
+    m->d_info = nullptr;
+    m->d_tmax = nullptr;
+    m->d_tij = nullptr;
+    m->ws_pred = nullptr;
+    m->ws_kqp = m->ws_partial = nullptr;
+    m->ws_grad = nullptr;
+    m->ws_host_io = nullptr;
+    m->d_normals = nullptr;
+    m->ws_pred_doubles = m->ws_kqp_bytes = m->ws_partial_bytes = m->ws_grad_doubles = m->ws_host_io_doubles = 0;
+    for (auto &e : m->gemm_ev)
+        (void)hipEventDestroy(e);
+    m->gemm_ev.clear();
+}
+
+extern "C" void gpx_model_destroy(gpx_model *m)
+{
+    if (!m)
+        return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(m->device);
+    if (m->stream)
+        (void)hipStreamSynchronize(m->stream);
+    free_dev(m);
+    for (auto &e : m->ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (m->stream)
+        (void)hipStreamDestroy(m->stream);
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    delete m;
+}
+
+static int ensure(void **p, size_t *have, size_t need)
+{
+    if (*have >= need && *p)
+        return GPX_OK;
+    if (*p)
+        HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, need));
+    *have = need;
+    return GPX_OK;
+}
+
+// Eigen 3.2 LDLT pivot rule restated: at step k pick the FIRST largest |diagonal| among the
+// not-yet-eliminated rows and swap it to k.  The left-looking algorithm never updates the
+// trailing diagonal before it is chosen, so the sequence depends on diag(K) only.
+static void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
+{
+    const int n = (int)diag.size();
+    perm.resize(n);
+    for (int i = 0; i < n; ++i)
+        perm[i] = i;
+    bool uniform = true;
+    for (int i = 1; i < n && uniform; ++i)
+        uniform = std::fabs(diag[i]) == std::fabs(diag[0]);
+    if (uniform)
+        return;
+    std::vector<double> d(diag);
+    for (int k = 0; k < n; ++k) {
+        int big = k;
+        double bv = std::fabs(d[k]);
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(d[i]) > bv) {
+                bv = std::fabs(d[i]);
+                big = i;
+            }
+        if (big != k) {
+            std::swap(d[k], d[big]);
+            std::swap(perm[k], perm[big]);
+        }
+    }
+}
+
+static int alloc_model(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad, e = m->esz;
+    HIPCHK(hipMalloc((void **)&m->dvecs, sizeof(double) * (np * 8 + 8)));
+    m->d_x = m->dvecs;
+    m->d_y = m->d_x + np;
+    m->d_z = m->d_y + np;
+    m->d_lab = m->d_z + np;
+    m->d_s2 = m->d_lab + np;
+    m->d_alpha = m->d_s2 + np;
+    m->d_r = m->d_alpha + np;
+    m->d_f = m->d_r + np;
+    m->d_rmax = m->d_f + np;
+    m->blob0_bytes = e * np * 5;
+    HIPCHK(hipMalloc(&m->blob0, m->blob0_bytes));
+    char *b = (char *)m->blob0;
+    m->t_x = b;
+    m->t_y = b + e * np;
+    m->t_z = b + 2 * e * np;
+    m->t_alpha = b + 3 * e * np;
+    m->t_dinv = b + 4 * e * np;
+    HIPCHK(hipMalloc(&m->tvecs, e * np * 5));
+    b = (char *)m->tvecs;
+    m->t_s2 = b;
+    m->t_d = b + e * np;
+    m->t_b = b + 2 * e * np;
+    m->t_yv = b + 3 * e * np;
+    m->t_xs = b + 4 * e * np;
+    HIPCHK(hipMalloc((void **)&m->d_info, sizeof(int) * 8));
+    return GPX_OK;
+}
+
+static hipEvent_t *gemm_events(gpx_model *m, size_t idx)
+{
+    while (m->gemm_ev.size() < 2 * (idx + 1)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess)
+            return nullptr;
+        m->gemm_ev.push_back(e);
+    }
+    return &m->gemm_ev[2 * idx];
+}
+
+// ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
+static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
+{
+    for (int kb = 0; kb < m->nblk; ++kb)
+        launch_fwd_step(m->prec, kb, m->nblk, m->Kmat, m->npad, m->linv, b, ytmp, m->stream);
+    launch_scale_vec(m->prec, m->npad, ytmp, m->t_dinv, m->stream);
+    for (int kb = m->nblk - 1; kb >= 0; --kb)
+        launch_bwd_step(m->prec, kb, m->Kmat, m->npad, m->linv, ytmp, x, m->stream);
+}
+
+// ---- blocked right-looking LDL^T -----------------------------------------------------------------
+static void factorize(gpx_model *m)
+{
+    const int np = m->npad;
+    const size_t e = m->esz;
+    char *K = (char *)m->Kmat;
+    char *W = (char *)m->Wp;
+    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
+    auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * PANEL + c) * e); };
+    size_t gemm_idx = 0;
+    for (int c0 = 0; c0 < np; c0 += PANEL) {
+        const int blk = c0 / TILE;
+        for (int half = 0; half < 2; ++half) {
+            const int cc = c0 + half * TILE;  // first column of this 128-wide half panel
+            const int r0 = cc + TILE;         // first row below the diagonal block
+            launch_diag_ldl(m->prec, Kp(cc, cc), np, m->linv, m->t_d, m->t_dinv, m->d_info, blk + half, m->stream);
+            if (r0 >= np)
+                continue;
+            GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
+            t.A = Kp(r0, cc), t.lda = np;
+            t.B = (char *)m->linv + (size_t)(blk + half) * TILE * TILE * e, t.ldb = TILE;
+            t.C = Kp(r0, cc), t.ldc = np;
+            t.M = np - r0, t.N = TILE, t.K = TILE;
+            t.b_lower = 1;
+            t.epi = EPI_TRSM;
+            t.W = Wpp(r0, half * TILE), t.ldw = PANEL;
+            t.colscale = (char *)m->t_dinv + (size_t)cc * e;
+            launch_gemm(m->prec, t, m->stream);
+            if (half == 0) {
+                GemmArgs s;  // second half panel (incl. its diagonal block) -= W_a * L_a^T
+                s.A = Wpp(r0, 0), s.lda = PANEL;
+                s.B = Kp(r0, cc), s.ldb = np;
+                s.C = Kp(r0, r0), s.ldc = np;
+                s.M = np - r0, s.N = TILE, s.K = TILE;
+                s.alpha = -1.0, s.beta = 1;
+                launch_gemm(m->prec, s, m->stream);
+            } else {
+                GemmArgs s;  // trailing matrix -= [W_a W_b] * [L_a L_b]^T, lower tiles only, K = 256
+                s.A = Wpp(r0, 0), s.lda = PANEL;
+                s.B = Kp(r0, c0), s.ldb = np;
+                s.C = Kp(r0, r0), s.ldc = np;
+                s.M = np - r0, s.N = np - r0, s.K = PANEL;
+                s.alpha = -1.0, s.beta = 1;
+                s.lower_only = 1;
+                hipEvent_t *ev = gemm_events(m, gemm_idx);
+                if (ev)
+                    (void)hipEventRecord(ev[0], m->stream);
+                launch_gemm(m->prec, s, m->stream);
+                if (ev) {
+                    (void)hipEventRecord(ev[1], m->stream);
+                    ++gemm_idx;
+                }
+            }
+        }
+    }
+    m->gemm_ev_used_factor = gemm_idx;
+}
+
+// ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
+static int build_inverse(gpx_model *m)
+{
+    if (m->has_inverse)
+        return GPX_OK;
+    const int np = m->npad;
+    const size_t e = m->esz;
+    if (!m->X)
+        HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
+    void *Tws = nullptr;
+    HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
+    (void)hipEventRecord(m->ev[EV_INV0], m->stream);
+    launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
+    char *L = (char *)m->Kmat, *X = (char *)m->X, *Tw = (char *)Tws;
+    auto off = [&](size_t r, size_t c) { return (r * np + c) * e; };
+    for (long b = TILE; b < np; b *= 2) {
+        // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
+        int P = 0;
+        for (long base = 0; base + b < np; base += 2 * b)
+            ++P;
+        if (P == 0)
+            break;
+        const long last_base = (long)(P - 1) * 2 * b;
+        const int m_last = (int)std::min<long>(b, np - (last_base + b));
+        const long stride = 2 * b * (long)np + 2 * b;
+        GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
+        g1.A = L + off(b, 0), g1.lda = np;
+        g1.B = X + off(0, 0), g1.ldb = np;
+        g1.C = Tw + off(b, 0), g1.ldc = np;
+        g1.M = (int)b, g1.N = (int)b, g1.K = (int)b;
+        g1.sA = g1.sB = g1.sC = stride;
+        g1.batch = P, g1.M_last = m_last;
+        g1.nn = 1, g1.b_lower = 1;
+        launch_gemm(m->prec, g1, m->stream);
+        GemmArgs g2;  // X21 = -X22 * T  (A lower)
+        g2.A = X + off(b, b), g2.lda = np;
+        g2.B = Tw + off(b, 0), g2.ldb = np;
+        g2.C = X + off(b, 0), g2.ldc = np;
+        g2.M = (int)b, g2.N = (int)b, g2.K = (int)b;
+        g2.sA = g2.sB = g2.sC = stride;
+        g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
+        g2.nn = 1, g2.a_lower = 1;
+        g2.alpha = -1.0;
+        launch_gemm(m->prec, g2, m->stream);
+    }
+    (void)hipEventRecord(m->ev[EV_INV1], m->stream);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipFree(Tws));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
+        m->stats.t_inverse_ms = ms;
+    m->has_inverse = true;
+    return GPX_OK;
+}
+
+// ---- create: everything after the host arrays are in place ---------------------------------------
+static int build_model(gpx_model *m)
+{
+    const int n = m->n, np = m->npad;
+    const size_t e = m->esz;
+    HIPCHK(hipSetDevice(m->device));
+    factor_init(m->prec);
+    // Eigen's pivot order from the original diagonal k(0) + sigma2_i
+    std::vector<double> diag(n);
+    for (int i = 0; i < n; ++i)
+        diag[i] = m->cov.k0 + (m->has_s2 ? m->hs2[i] : 0.0);
+    eigen_pivot_order(diag, m->perm);
+    // host staging (internal order, zero padded)
+    std::vector<double> st((size_t)np * 5, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const int i = m->perm[k];
+        st[k] = m->hx[i];
+        st[np + k] = m->hy[i];
+        st[2 * (size_t)np + k] = m->hz[i];
+        st[3 * (size_t)np + k] = m->hlabel[i];
+        st[4 * (size_t)np + k] = m->has_s2 ? m->hs2[i] : 0.0;
+    }
+    if (!m->dvecs) {
+        int rc = alloc_model(m);
+        if (rc)
+            return rc;
+        HIPCHK(hipMalloc(&m->Kmat, e * (size_t)np * np));
+        HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
+        HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * PANEL));
+        const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
+        HIPCHK(hipMalloc((void **)&m->d_tmax, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc((void **)&m->d_tij, sizeof(int) * 2 * ntiles));
+    }
+    {  // workspace of the matrix-free residual / normals passes (n queries against npad points)
+        size_t need = predict_ws_doubles(n, np, m->opt.with_normals != 0) * sizeof(double);
+        if (need) {
+            int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+            if (rc)
+                return rc;
+        }
+    }
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 5, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np * 3 + 64, s));
+    HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
+    launch_cast_vec(m->prec, np, np, m->d_x, m->t_x, s);
+    launch_cast_vec(m->prec, np, np, m->d_y, m->t_y, s);
+    launch_cast_vec(m->prec, np, np, m->d_z, m->t_z, s);
+    launch_cast_vec(m->prec, np, np, m->d_s2, m->t_s2, s);
+    // ---- kernel matrix ----
+    (void)hipEventRecord(m->ev[EV_T0], s);
+    const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
+    launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
+    launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
+    (void)hipEventRecord(m->ev[EV_KBUILD], s);
+    // ---- factorisation ----
+    factorize(m);
+    (void)hipEventRecord(m->ev[EV_FACTOR], s);
+    // ---- alpha = K^-1 y with fp64-residual refinement ----
+    int ir = m->opt.ir_steps >= 0 ? m->opt.ir_steps : (m->prec == GPX_PREC_F64 ? 1 : 2);
+    for (int it = 0;; ++it) {
+        // right-hand side: y (first pass) or the fp64 residual
+        launch_cast_vec(m->prec, n, np, it == 0 ? m->d_lab : m->d_r, m->t_b, s);
+        solve_ldl(m, m->t_b, m->t_yv, m->t_xs);
+        launch_axpy_cast(m->prec, n, np, m->d_alpha, m->t_xs, m->t_alpha, s);
+        // r = y - K alpha in fp64, matrix-free from the fp64 points
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z,
+                       m->d_f, nullptr, m->ws_pred, s);
+        HIPCHK(hipMemsetAsync(m->d_rmax, 0, sizeof(double), s));
+        launch_residual(n, m->d_lab, m->d_f, m->d_s2, m->d_alpha, m->d_r, m->d_rmax, s);
+        if (it >= ir)
+            break;
+    }
+    m->stats.ir_steps_done = ir;
+    (void)hipEventRecord(m->ev[EV_SOLVE], s);
+    // ---- normals at the training points (create<true>, gp_regressor.hpp:166-181) ----
+    if (m->opt.with_normals) {
+        if (!m->d_normals)
+            HIPCHK(hipMalloc((void **)&m->d_normals, sizeof(double) * 3 * (size_t)n));
+        launch_predict(m->prec, m->cov, np, m->t_x, m->t_y, m->t_z, m->t_alpha, n, m->d_x, m->d_y, m->d_z, m->d_f,
+                       m->d_normals, m->ws_pred, s);
+        launch_normalize_rows3(n, m->d_normals, s);
+        m->has_normals = true;
+    }
+    (void)hipEventRecord(m->ev[EV_NORMALS], s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    int info[4];
+    double rmax = 0;
+    HIPCHK(hipMemcpy(info, m->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&rmax, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost));
+    float ms;
+    m->stats = gpx_stats{};
+    if (hipEventElapsedTime(&ms, m->ev[EV_T0], m->ev[EV_KBUILD]) == hipSuccess)
+        m->stats.t_kbuild_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_KBUILD], m->ev[EV_FACTOR]) == hipSuccess)
+        m->stats.t_factor_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_FACTOR], m->ev[EV_SOLVE]) == hipSuccess)
+        m->stats.t_solve_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_SOLVE], m->ev[EV_NORMALS]) == hipSuccess)
+        m->stats.t_normals_ms = ms;
+    double tg = 0;
+    for (size_t i = 0; i < m->gemm_ev_used_factor; ++i)
+        if (hipEventElapsedTime(&ms, m->gemm_ev[2 * i], m->gemm_ev[2 * i + 1]) == hipSuccess)
+            tg += ms;
+    m->stats.t_factor_gemm_ms = tg;
+    m->stats.factor_gemm_launches = (int64_t)m->gemm_ev_used_factor;
+    m->stats.n = n;
+    m->stats.n_padded = np;
+    m->stats.n_negative_pivots = info[1];
+    m->stats.ir_steps_done = ir;
+    m->stats.alpha_residual = rmax;
+    if (info[0] != 0)
+        return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(info[0] - 1));
+    // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64
+    {
+        const int a = info[2], b = info[3];
+        if (a >= 0 && a < n && b >= 0 && b < n) {
+            const int ia = m->perm[a], ib = m->perm[b];
+            const double dx = m->hx[ia] - m->hx[ib], dy = m->hy[ia] - m->hy[ib], dz = m->hz[ia] - m->hz[ib];
+            m->R = std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    m->ready = true;
+    if (m->opt.prepare_variance) {
+        int rc = build_inverse(m);
+        if (rc)
+            return rc;
+    }
+    return GPX_OK;
+}
+
+static int check_opts(const gpx_options *opt, gpx_options &o)
+{
+    std::memset(&o, 0, sizeof(o));
+    o.device = -1;
+    o.ir_steps = -1;
+    if (opt)
+        o = *opt;
+    if (o.precision != GPX_PREC_F32 && o.precision != GPX_PREC_F64)
+        return fail(GPX_E_BAD_ARG, "options.precision must be GPX_PREC_F32 or GPX_PREC_F64");
+    if (o.query_batch < 0 || (o.query_batch % TILE) != 0)
+        return fail(GPX_E_BAD_ARG, "options.query_batch must be a non-negative multiple of 128");
+    return GPX_OK;
+}
+
+static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, gpx_model **out)
+{
+    if (kernel->id < GPX_KERNEL_GAUSSIAN || kernel->id > GPX_KERNEL_MATERN52)
+        return fail(GPX_E_BAD_ARG, "unknown kernel id");
+    int ndev = gpx_device_count();
+    if (ndev <= 0)
+        return fail(GPX_E_NO_DEVICE, "no HIP device available (libgpx has no CPU path)");
+    int dev = o.device;
+    if (dev < 0)
+        HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev)
+        return fail(GPX_E_BAD_ARG, "options.device out of range");
+    HIPCHK(hipSetDevice(dev));
+    gpx_model *m = new gpx_model();
+    m->device = dev;
+    m->prec = o.precision;
+    m->esz = o.precision == GPX_PREC_F64 ? 8 : 4;
+    m->kern = *kernel;
+    m->cov = make_cov(*kernel);
+    m->opt = o;
+    m->n = (int)n;
+    m->npad = (int)gpx_padded_n(n);
+    m->nblk = m->npad / TILE;
+    m->qbatch = o.query_batch > 0 ? o.query_batch : 8192;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete m;
+        return fail(GPX_E_HIP, "hipStreamCreate failed");
+    }
+    for (auto &e : m->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            gpx_model_destroy(m);
+            return fail(GPX_E_HIP, "hipEventCreate failed");
+        }
+    *out = m;
+    return GPX_OK;
+}
+
+static int validate_train(size_t n, const double *x, const double *y, const double *z, const double *label)
+{
+    if (!x || !y || !z || !label)
+        return n == 0 ? fail(GPX_E_EMPTY, "All input data is empty!") : fail(GPX_E_NULL, "Empty data pointer");
+    if (n == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    return GPX_OK;
+}
+
+static int check_finite(size_t n, const double *v, const char *what)
+{
+    if (!v)
+        return GPX_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(v[i]))
+            return fail(GPX_E_NAN_INPUT, std::string("non-finite value in ") + what);
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_create(const gpx_kernel *kernel, size_t n, const double *x, const double *y,
+                                const double *z, const double *label, const double *sigma2,
+                                const gpx_options *opt, gpx_model **out)
+{
+    if (!out)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!kernel)
+        return fail(GPX_E_NULL, "Empty kernel pointer");
+    int rc = validate_train(n, x, y, z, label);
+    if (rc)
+        return rc;
+    if (n > (size_t)1 << 20)
+        return fail(GPX_E_BAD_ARG, "n too large");
+    if ((rc = check_finite(n, x, "coord_x")) || (rc = check_finite(n, y, "coord_y")) ||
+        (rc = check_finite(n, z, "coord_z")) || (rc = check_finite(n, label, "label")) ||
+        (rc = check_finite(n, sigma2, "sigma2")))
+        return rc;
+    gpx_options o;
+    if ((rc = check_opts(opt, o)))
+        return rc;
+    gpx_model *m = nullptr;
+    if ((rc = new_model(kernel, n, o, &m)))
+        return rc;
+    m->hx.assign(x, x + n);
+    m->hy.assign(y, y + n);
+    m->hz.assign(z, z + n);
+    m->hlabel.assign(label, label + n);
+    m->has_s2 = sigma2 != nullptr;
+    if (sigma2)
+        m->hs2.assign(sigma2, sigma2 + n);
+    else
+        m->hs2.assign(n, 0.0);
+    rc = build_model(m);
+    if (rc) {
+        std::string keep = g_err;
+        gpx_model_destroy(m);
+        g_err = keep;
+        return rc;
+    }
+    *out = m;  // the C++ shim's shared_ptr reset releases any previous model (gp_regressor.hpp:116-117)
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, const double *y, const double *z,
+                                const double *label, const double *sigma2)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty model pointer");
+    int rc = validate_train(n_new, x, y, z, label);
+    if (rc)
+        return rc;
+    if ((rc = check_finite(n_new, x, "coord_x")) || (rc = check_finite(n_new, y, "coord_y")) ||
+        (rc = check_finite(n_new, z, "coord_z")) || (rc = check_finite(n_new, label, "label")) ||
+        (rc = check_finite(n_new, sigma2, "sigma2")))
+        return rc;
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const double keepR = m->R;  // update() does not refresh R (gp_regressor.hpp:454-455)
+    m->hx.insert(m->hx.end(), x, x + n_new);
+    m->hy.insert(m->hy.end(), y, y + n_new);
+    m->hz.insert(m->hz.end(), z, z + n_new);
+    m->hlabel.insert(m->hlabel.end(), label, label + n_new);
+    if (sigma2) {
+        m->hs2.insert(m->hs2.end(), sigma2, sigma2 + n_new);
+        m->has_s2 = true;
+    } else {
+        m->hs2.insert(m->hs2.end(), n_new, 0.0);
+    }
+    free_dev(m);
+    m->ready = m->has_inverse = m->has_normals = false;
+    m->n = (int)m->hx.size();
+    m->npad = (int)gpx_padded_n(m->n);
+    m->nblk = m->npad / TILE;
+    rc = build_model(m);  // refactor from scratch, as :457-459
+    m->R = keepR;
+    return rc;
+}
+
+// ---- evaluate ------------------------------------------------------------------------------------
+static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
+                           double *f, double *v, double *grad, double *tx, double *ty, hipStream_t s)
+{
+    const int np = m->npad;
+    const size_t e = m->esz;
+    const bool want_basis = tx || ty;
+    double *g = grad;
+    if (want_basis && !g) {
+        int rc = ensure((void **)&m->ws_grad, &m->ws_grad_doubles, sizeof(double) * 3 * nq);
+        if (rc)
+            return rc;
+        g = m->ws_grad;
+    }
+    size_t need = predict_ws_doubles((long)nq, np, g != nullptr) * sizeof(double);
+    if (need) {
+        int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+        if (rc)
+            return rc;
+    }
+    if (v) {
+        int rc = build_inverse(m);
+        if (rc)
+            return rc;
+        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        if ((rc = ensure(&m->ws_kqp, &m->ws_kqp_bytes, e * qb * np)))
+            return rc;
+        if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
+            return rc;
+    }
+    (void)hipEventRecord(m->ev[EV_M0], s);
+    launch_predict(m->prec, m->cov, np, m->t_x, m->t_y, m->t_z, m->t_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred,
+                   s);
+    if (want_basis)
+        launch_tangent_basis((long)nq, g, tx, ty, s);
+    (void)hipEventRecord(m->ev[EV_M1], s);
+    m->gemm_ev_used_var = 0;
+    if (v) {
+        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        size_t gi = 0;
+        for (size_t q0 = 0; q0 < nq; q0 += qb) {
+            const size_t nv = std::min(qb, nq - q0);
+            const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
+            launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
+                       qz + q0, m->ws_kqp, s);
+            GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
+            a.A = m->X, a.lda = np;
+            a.B = m->ws_kqp, a.ldb = np;
+            a.M = np, a.N = (int)ntile, a.K = np;
+            a.a_lower = 1;
+            a.epi = EPI_COLSQ;
+            a.rowweight = m->t_dinv;
+            a.partial = m->ws_partial, a.ldp = (long)qb;
+            hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
+            if (ev)
+                (void)hipEventRecord(ev[0], s);
+            launch_gemm(m->prec, a, s);
+            if (ev) {
+                (void)hipEventRecord(ev[1], s);
+                ++gi;
+            }
+            launch_var_finish(m->prec, m->cov.k0, m->nblk, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+        }
+        m->gemm_ev_used_var = gi;
+    }
+    (void)hipEventRecord(m->ev[EV_V1], s);
+    m->stats_eval_pending = true;
+    m->eval_had_var = v != nullptr;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    return GPX_OK;
+}
+
+static int check_query(const gpx_model *m, size_t nq, const void *qx, const void *qy, const void *qz, const void *f)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!m->ready)
+        return fail(GPX_E_STATE, "model is not ready (shell not committed or create failed)");
+    if (nq == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    if (!qx || !qy || !qz)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (!f)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_evaluate_device(const gpx_model *cm, size_t nq, const void *d_qx, const void *d_qy,
+                                         const void *d_qz, void *d_f, void *d_v, void *d_grad, void *d_tx,
+                                         void *d_ty, void *stream)
+{
+    int rc = check_query(cm, nq, d_qx, d_qy, d_qz, d_f);
+    if (rc)
+        return rc;
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    return evaluate_locked(m, nq, (const double *)d_qx, (const double *)d_qy, (const double *)d_qz, (double *)d_f,
+                           (double *)d_v, (double *)d_grad, (double *)d_tx, (double *)d_ty, s);
+}
+
+extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
+                                  const double *qz, double *f, double *v, double *grad, double *tx, double *ty)
+{
+    int rc = check_query(cm, nq, qx, qy, qz, f);
+    if (rc)
+        return rc;
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    // device staging: qx qy qz | f | v | grad | tx | ty
+    const size_t total = nq * (3 + 1 + 1 + 3 + 3 + 3);
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * total)))
+        return rc;
+    double *d = m->ws_host_io;
+    double *dqx = d, *dqy = d + nq, *dqz = d + 2 * nq, *df = d + 3 * nq, *dv = d + 4 * nq, *dg = d + 5 * nq,
+           *dtx = d + 8 * nq, *dty = d + 11 * nq;
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemcpyAsync(dqx, qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqy, qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqz, qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    rc = evaluate_locked(m, nq, dqx, dqy, dqz, df, v ? dv : nullptr, grad ? dg : nullptr, tx ? dtx : nullptr,
+                         ty ? dty : nullptr, s);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(f, df, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    if (v)
+        HIPCHK(hipMemcpyAsync(v, dv, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    if (grad)
+        HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
+    if (tx)
+        HIPCHK(hipMemcpyAsync(tx, dtx, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
+    if (ty)
+        HIPCHK(hipMemcpyAsync(ty, dty, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_prepare_variance(gpx_model *m)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!m->ready)
+        return fail(GPX_E_STATE, "model is not ready");
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    return build_inverse(m);
+}
+
+extern "C" int gpx_model_sync(const gpx_model *m)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GPX_OK;
+}
+
+static void resolve_eval_stats(gpx_model *m)
+{
+    if (!m->stats_eval_pending)
+        return;
+    if (hipStreamSynchronize(m->stream) != hipSuccess)
+        return;
+    float ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_M0], m->ev[EV_M1]) == hipSuccess)
+        m->stats.t_mean_ms = ms;
+    m->stats.t_var_ms = 0;
+    if (m->eval_had_var && hipEventElapsedTime(&ms, m->ev[EV_M1], m->ev[EV_V1]) == hipSuccess)
+        m->stats.t_var_ms = ms;
+    double tg = 0;
+    for (size_t i = 0; i < m->gemm_ev_used_var; ++i) {
+        const size_t k = m->gemm_ev_used_factor + i;
+        if (hipEventElapsedTime(&ms, m->gemm_ev[2 * k], m->gemm_ev[2 * k + 1]) == hipSuccess)
+            tg += ms;
+    }
+    m->stats.t_var_gemm_ms = tg;
+    m->stats.var_gemm_launches = (int64_t)m->gemm_ev_used_var;
+    m->stats_eval_pending = false;
+}
+
+extern "C" int gpx_model_get(const gpx_model *cm, int field, void *dst, size_t bytes)
+{
+    if (!cm)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!dst)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    const size_t n = (size_t)m->n;
+    auto need = [&](size_t b) { return bytes >= b ? GPX_OK : fail(GPX_E_SIZE_MISMATCH, "destination too small"); };
+    int rc;
+    switch (field) {
+    case GPX_FIELD_N: {
+        if ((rc = need(sizeof(int64_t))))
+            return rc;
+        *(int64_t *)dst = (int64_t)n;
+        return GPX_OK;
+    }
+    case GPX_FIELD_R:
+        if ((rc = need(sizeof(double))))
+            return rc;
+        *(double *)dst = m->R;
+        return GPX_OK;
+    case GPX_FIELD_P: {
+        if ((rc = need(sizeof(double) * 3 * n)))
+            return rc;
+        double *o = (double *)dst;
+        for (size_t i = 0; i < n; ++i) {
+            o[3 * i] = m->hx[i];
+            o[3 * i + 1] = m->hy[i];
+            o[3 * i + 2] = m->hz[i];
+        }
+        return GPX_OK;
+    }
+    case GPX_FIELD_Y:
+        if ((rc = need(sizeof(double) * n)))
+            return rc;
+        std::memcpy(dst, m->hlabel.data(), sizeof(double) * n);
+        return GPX_OK;
+    case GPX_FIELD_S2:
+        if ((rc = need(sizeof(double) * n)))
+            return rc;
+        std::memcpy(dst, m->hs2.data(), sizeof(double) * n);
+        return GPX_OK;
+    case GPX_FIELD_PERM:
+        if ((rc = need(sizeof(int32_t) * n)))
+            return rc;
+        std::memcpy(dst, m->perm.data(), sizeof(int32_t) * n);
+        return GPX_OK;
+    case GPX_FIELD_STATS:
+        if ((rc = need(sizeof(gpx_stats))))
+            return rc;
+        HIPCHK(hipSetDevice(m->device));
+        resolve_eval_stats(m);
+        std::memcpy(dst, &m->stats, sizeof(gpx_stats));
+        return GPX_OK;
+    default:
+        break;
+    }
+    if (!m->ready)
+        return fail(GPX_E_STATE, "model is not ready");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (field == GPX_FIELD_ALPHA) {
+        if ((rc = need(sizeof(double) * n)))
+            return rc;
+        std::vector<double> a(n);
+        HIPCHK(hipMemcpy(a.data(), m->d_alpha, sizeof(double) * n, hipMemcpyDeviceToHost));
+        double *o = (double *)dst;
+        for (size_t k = 0; k < n; ++k)
+            o[m->perm[k]] = a[k];
+        return GPX_OK;
+    }
+    if (field == GPX_FIELD_D) {
+        if ((rc = need(sizeof(double) * n)))
+            return rc;
+        double *o = (double *)dst;
+        if (m->prec == GPX_PREC_F64) {
+            HIPCHK(hipMemcpy(o, m->t_d, sizeof(double) * n, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> t(n);
+            HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * n, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < n; ++k)
+                o[k] = t[k];
+        }
+        return GPX_OK;
+    }
+    if (field == GPX_FIELD_NORMALS) {
+        if (!m->has_normals)
+            return fail(GPX_E_STATE, "model was created without normals");
+        if ((rc = need(sizeof(double) * 3 * n)))
+            return rc;
+        std::vector<double> g(3 * n);
+        HIPCHK(hipMemcpy(g.data(), m->d_normals, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+        double *o = (double *)dst;
+        for (size_t k = 0; k < n; ++k)
+            for (int c = 0; c < 3; ++c)
+                o[3 * (size_t)m->perm[k] + c] = g[3 * k + c];
+        return GPX_OK;
+    }
+    if (field == GPX_FIELD_KPP) {
+        // rebuilt on demand in caller order: kbuild on the un-permuted points, mirrored on the host
+        if ((rc = need(sizeof(double) * n * n)))
+            return rc;
+        const int np = m->npad;
+        const size_t e = m->esz;
+        std::vector<double> st((size_t)np * 4, 0.0);
+        for (size_t i = 0; i < n; ++i) {
+            st[i] = m->hx[i];
+            st[np + i] = m->hy[i];
+            st[2 * (size_t)np + i] = m->hz[i];
+            st[3 * (size_t)np + i] = m->hs2[i];
+        }
+        double *dd = nullptr;
+        void *tt = nullptr, *Kt = nullptr;
+        float *tm = nullptr;
+        int *tj = nullptr;
+        const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
+        HIPCHK(hipMalloc((void **)&dd, sizeof(double) * 4 * np));
+        HIPCHK(hipMalloc(&tt, e * 4 * np));
+        HIPCHK(hipMalloc(&Kt, e * (size_t)np * np));
+        HIPCHK(hipMalloc((void **)&tm, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc((void **)&tj, sizeof(int) * 2 * ntiles));
+        HIPCHK(hipMemcpy(dd, st.data(), sizeof(double) * 4 * np, hipMemcpyHostToDevice));
+        char *tb = (char *)tt;
+        for (int c = 0; c < 4; ++c)
+            launch_cast_vec(m->prec, np, np, dd + (size_t)c * np, tb + (size_t)c * np * e, m->stream);
+        launch_kbuild(m->prec, m->cov, (int)n, np, tb, tb + np * e, tb + 2 * np * e, tb + 3 * np * e, Kt, tm, tj,
+                      m->stream);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        std::vector<char> hk(e * (size_t)np * np);
+        HIPCHK(hipMemcpy(hk.data(), Kt, hk.size(), hipMemcpyDeviceToHost));
+        double *o = (double *)dst;
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = 0; j <= i; ++j) {
+                // tiles strictly above the block diagonal are not written: read the lower element
+                double val = m->prec == GPX_PREC_F64 ? ((double *)hk.data())[i * np + j]
+                                                     : (double)((float *)hk.data())[i * np + j];
+                o[i * n + j] = val;
+                o[j * n + i] = val;
+            }
+        (void)hipFree(dd);
+        (void)hipFree(tt);
+        (void)hipFree(Kt);
+        (void)hipFree(tm);
+        (void)hipFree(tj);
+        return GPX_OK;
+    }
+    return fail(GPX_E_BAD_ARG, "unknown field");
+}
+
+// ---- sharded query grid: shell / blob / commit ---------------------------------------------------
+extern "C" int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const gpx_options *opt, gpx_model **out)
+{
+    if (!out)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!kernel)
+        return fail(GPX_E_NULL, "Empty kernel pointer");
+    if (n == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    gpx_options o;
+    int rc = check_opts(opt, o);
+    if (rc)
+        return rc;
+    gpx_model *m = nullptr;
+    if ((rc = new_model(kernel, n, o, &m)))
+        return rc;
+    rc = alloc_model(m);
+    if (rc == GPX_OK) {
+        hipError_t e = hipMalloc(&m->X, m->esz * (size_t)m->npad * m->npad);
+        if (e != hipSuccess)
+            rc = fail(e == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, hipGetErrorString(e));
+    }
+    if (rc) {
+        std::string keep = g_err;
+        gpx_model_destroy(m);
+        g_err = keep;
+        return rc;
+    }
+    m->perm.resize(n);
+    for (size_t i = 0; i < n; ++i)
+        m->perm[i] = (int)i;
+    m->hx.assign(n, 0.0);
+    m->hy.assign(n, 0.0);
+    m->hz.assign(n, 0.0);
+    m->hlabel.assign(n, 0.0);
+    m->hs2.assign(n, 0.0);
+    m->stats.n = (int64_t)n;
+    m->stats.n_padded = m->npad;
+    *out = m;
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_state_blob(gpx_model *m, int part, void **d_ptr, size_t *bytes)
+{
+    if (!m || !d_ptr || !bytes)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (part == 0) {
+        *d_ptr = m->blob0;
+        *bytes = m->blob0_bytes;
+        return GPX_OK;
+    }
+    if (part == 1) {
+        if (!m->X)
+            return fail(GPX_E_STATE, "inverse factor not built (call gpx_model_prepare_variance)");
+        *d_ptr = m->X;
+        *bytes = m->esz * (size_t)m->npad * m->npad;
+        return GPX_OK;
+    }
+    return fail(GPX_E_BAD_ARG, "part must be 0 (vectors) or 1 (inverse factor)");
+}
+
+extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!m->blob0)
+        return fail(GPX_E_STATE, "model has no device state");
+    m->ready = true;
+    if (with_variance) {
+        if (!m->X)
+            return fail(GPX_E_STATE, "inverse factor buffer missing");
+        m->has_inverse = true;
+    }
+    return GPX_OK;
+}
+
+// ---- stand-alone kbuild (tests / roofline leg) ---------------------------------------------------
+extern "C" int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_x,
+                              const void *d_y, const void *d_z, const void *d_s2, void *d_K, void *d_rmax,
+                              void *stream)
+{
+    if (!kernel || !d_x || !d_y || !d_z || !d_s2 || !d_K)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (n == 0 || n_padded % PANEL != 0 || n_padded < n)
+        return fail(GPX_E_BAD_ARG, "n_padded must be gpx_padded_n(n)");
+    const int nt = (int)(n_padded / TILE), ntiles = nt * (nt + 1) / 2;
+    static thread_local float *tm = nullptr;
+    static thread_local int *tj = nullptr;
+    static thread_local int cap = 0;
+    if (cap < ntiles) {
+        if (tm)
+            (void)hipFree(tm);
+        if (tj)
+            (void)hipFree(tj);
+        HIPCHK(hipMalloc((void **)&tm, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc((void **)&tj, sizeof(int) * (2 * ntiles + 2)));
+        cap = ntiles;
+    }
+    CovHost c = make_cov(*kernel);
+    launch_kbuild(precision, c, (int)n, (int)n_padded, d_x, d_y, d_z, d_s2, d_K, tm, tj, (hipStream_t)stream);
+    (void)d_rmax;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, hipGetErrorString(le));
+    return GPX_OK;
+}

@@ -1,0 +1,110 @@
+// gpx_internal.hpp -- declarations shared by the HIP translation units of libgpx.so.
+// Device code is written for gfx950 (CDNA4, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gpx.h"
+
+namespace gpx {
+
+constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
+constexpr int PANEL = 256;  // outer panel of the factorisation = 2 diagonal blocks
+constexpr int WAVE = 64;
+
+// Host-side description of a covariance function, lowered to Cov<T> for the device.
+struct CovHost {
+    int id;
+    double a;   // amplitude: sigma^2 (Gaussian, Matern) or 2*sigma (Laplace)
+    double s;   // decay:     1/l^2 (Gaussian), 1/l (Laplace), sqrt3/l, sqrt5/l
+    double R;   // thin plate
+    double R3;
+    double k0;  // k(0)
+};
+CovHost make_cov(const gpx_kernel &k);
+
+template <typename T>
+struct Cov {
+    T a, s, R, R3;
+};
+template <typename T>
+inline Cov<T> lower_cov(const CovHost &h)
+{
+    return Cov<T>{(T)h.a, (T)h.s, (T)h.R, (T)h.R3};
+}
+
+// ---- pairwise (kernel-matrix) stages : gpx_pairwise.hip -----------------------------------
+// K (lower block-triangle, identity on padding), per-tile maxima of the squared distance.
+void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
+                   const void *s2, void *K, float *tile_max_d2, int *tile_max_ij, hipStream_t st);
+// picks the global maximum of the per-tile maxima -> out_ij[2]
+void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile_max_ij, int *out_ij,
+                           hipStream_t st);
+// Kqp[q][j] = k(|q - p_j|), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
+void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
+                long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
+                hipStream_t st);
+
+// ---- prediction : gpx_predict.hip -----------------------------------------------------------
+// f[q] = sum_j k(|q-p_j|) alpha_j ; grad[q] = sum_j alpha_j k'(.)(q-p_j)  (double outputs).
+// ws: device doubles, at least predict_ws_doubles(nq, n, grad) long.
+size_t predict_ws_doubles(long nq, int n_chunk_src, bool grad);
+void launch_predict(int prec, const CovHost &cov, int n_pad_pts, const void *px, const void *py, const void *pz,
+                    const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
+                    double *grad /*nq x 3 row-major or null*/, double *ws, hipStream_t st);
+// v[q] = k0 - sum_m partial[m][q]
+void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *partial, long nq, double *v,
+                       hipStream_t st);
+void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st);
+// r = y - f - s2*alpha (all double, n entries); also max|r| -> *rmax (atomic, pre-zeroed)
+void launch_residual(int n, const double *y, const double *f, const double *s2, const double *alpha, double *r,
+                     double *rmax, hipStream_t st);
+void launch_axpy_cast(int prec, int n, int npad, double *alpha_d, const void *delta /*T*/, void *alpha_t,
+                      hipStream_t st);  // alpha_d += delta ; alpha_t = (T)alpha_d (zero padded)
+void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st);
+void launch_normalize_rows3(long n, double *g, hipStream_t st);
+
+// ---- MFMA GEMM core : gpx_gemm.hip ----------------------------------------------------------
+enum GemmEpi { EPI_STORE = 0, EPI_TRSM = 1, EPI_COLSQ = 2 };
+struct GemmArgs {
+    const void *A = nullptr, *B = nullptr;
+    void *C = nullptr;
+    long lda = 0, ldb = 0, ldc = 0;
+    int M = 0, N = 0, K = 0;        // multiples of TILE (K: of the k-tile)
+    long sA = 0, sB = 0, sC = 0;    // batch strides, elements
+    int batch = 1;
+    int M_last = -1;                // M of the last batch entry (<= M), -1: same
+    int k_eq_m = 0;                 // K of an entry equals its M (ragged last entry)
+    double alpha = 1.0;
+    int beta = 0;                   // 0 or 1
+    int nn = 0;                     // 0: C = A * B^T (B is [n][k]); 1: C = A * B (B is [k][n])
+    int lower_only = 0;             // square C: compute only tiles with m-tile >= n-tile
+    int a_lower = 0;                // A lower-triangular: k < m0 + TILE
+    int b_lower = 0;                // B lower-triangular: nn: k >= n0 ; nt: k < n0 + TILE
+    int epi = EPI_STORE;
+    void *W = nullptr;              // EPI_TRSM: un-scaled product
+    long ldw = 0;
+    const void *colscale = nullptr; // EPI_TRSM: C = acc * colscale[n]
+    const void *rowweight = nullptr; // EPI_COLSQ: partial[mt][n] = sum_rows acc^2 * rowweight[m]
+    void *partial = nullptr;
+    long ldp = 0;
+};
+void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
+
+// ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
+// LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower
+// inverse to linv (TILE x TILE, row-major, zeros above the diagonal), d / 1/d vectors, info.
+void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
+                     hipStream_t st);
+void launch_place_diag(int prec, int nblk, const void *linv_blocks, void *X, long ldx, hipStream_t st);
+// forward/backward block substitution steps on a vector (T), see gpx_factor.hip
+// fwd: step kb of L y = b (b is consumed, y receives block kb); bwd: step kb of L^T x = y.
+void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const void *linv_blocks, void *b, void *y,
+                     hipStream_t st);
+void launch_bwd_step(int prec, int kb, const void *L, long ld, const void *linv_blocks, void *y, void *x,
+                     hipStream_t st);
+void factor_init(int prec);  // per-device one-time kernel attributes (LDS size of diag_ldl)
+void launch_scale_vec(int prec, int npad, void *b, const void *dinv, hipStream_t st);
+
+}  // namespace gpx

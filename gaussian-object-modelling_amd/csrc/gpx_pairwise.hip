@@ -1,0 +1,252 @@
+// gpx_pairwise.hip -- kernel-matrix construction on gfx950.
+//
+//   kbuild : K[i][j] = k(|p_i - p_j|) + sigma2_i * delta_ij   (lower block-triangle, 128x128 tiles)
+//            replaces buildEuclideanDistanceMatrix + the kernel loop of GPRegressor::create
+//            (reference gp_regressor.hpp:132-159, :548-557) and Kpp.maxCoeff() (:135).
+//   kqp    : Kqp[q][j] = k(|q - p_j|) for one batch of queries (gp_regressor.hpp:300-303), the
+//            B operand of the variance GEMM.
+//
+// Both are HBM-write-bound: every lane produces 4 consecutive columns and issues one 16-byte
+// (fp32) / two 16-byte (fp64) stores, a wave writes 2 x 512 contiguous bytes per instruction.
+// Distances are direct differences (dx^2+dy^2+dz^2): exact 0 on the diagonal, never negative
+// (documented deviation from the reference's norm expansion).
+#include "gpx_cov.hpp"
+
+namespace gpx {
+
+template <typename T>
+struct Vec4 {
+    T v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T *dst, const T (&o)[4])
+{
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        *reinterpret_cast<double2 *>(dst) = make_double2(o[0], o[1]);
+        *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[2], o[3]);
+    }
+}
+
+__device__ __forceinline__ void tri_decode(int t, int &ti, int &tj)
+{
+    int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > t)
+        --i;
+    while ((i + 1) * (i + 2) / 2 <= t)
+        ++i;
+    ti = i;
+    tj = t - i * (i + 1) / 2;
+}
+
+template <typename T, int KID>
+__global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ x,
+                                                     const T *__restrict__ y, const T *__restrict__ z,
+                                                     const T *__restrict__ s2, T *__restrict__ K,
+                                                     float *__restrict__ tmax, int *__restrict__ tij)
+{
+    __shared__ T rx[TILE], ry[TILE], rz[TILE], rs[TILE];
+    __shared__ float wbest[4];
+    __shared__ int wbi[4], wbj[4];
+    int ti, tj;
+    tri_decode((int)blockIdx.x, ti, tj);
+    const int tid = threadIdx.x;
+    if (tid < TILE) {
+        int gi = ti * TILE + tid;
+        rx[tid] = x[gi];
+        ry[tid] = y[gi];
+        rz[tid] = z[gi];
+        rs[tid] = s2[gi];
+    }
+    const int tx = tid & 31, ty = tid >> 5;
+    const int gj0 = tj * TILE + tx * 4;
+    T cx[4], cy[4], cz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cx[c] = x[gj0 + c];
+        cy[c] = y[gj0 + c];
+        cz[c] = z[gj0 + c];
+    }
+    __syncthreads();
+    float best = -1.0f;
+    int bi = 0, bj = 0;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int li = ty + 8 * r;
+        const int gi = ti * TILE + li;
+        const T ax = rx[li], ay = ry[li], az = rz[li];
+        T out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = gj0 + c;
+            T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            T d2 = dx * dx + dy * dy + dz * dz;
+            T kv = cov_k<T, KID>(cov, d2);
+            if (gi == gj)
+                kv += rs[li];
+            if (gi < n && gj < n) {
+                if ((float)d2 > best) {
+                    best = (float)d2;
+                    bi = gi;
+                    bj = gj;
+                }
+            } else {
+                kv = (gi == gj) ? T(1) : T(0);  // identity on the padding
+            }
+            out[c] = kv;
+        }
+        store4<T>(K + (size_t)gi * npad + gj0, out);
+    }
+    // block maximum of the squared distance (for Model::R)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(best, off);
+        int oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+        if (ob > best) {
+            best = ob;
+            bi = oi;
+            bj = oj;
+        }
+    }
+    if ((tid & 63) == 0) {
+        wbest[tid >> 6] = best;
+        wbi[tid >> 6] = bi;
+        wbj[tid >> 6] = bj;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (wbest[w] > best) {
+                best = wbest[w];
+                bi = wbi[w];
+                bj = wbj[w];
+            }
+        tmax[blockIdx.x] = best;
+        tij[2 * blockIdx.x] = bi;
+        tij[2 * blockIdx.x + 1] = bj;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const float *__restrict__ tmax,
+                                                             const int *__restrict__ tij, int *__restrict__ out)
+{
+    __shared__ float sb[256];
+    __shared__ int si[256];
+    float best = -2.0f;
+    int bt = 0;
+    for (int t = threadIdx.x; t < ntiles; t += 256)
+        if (tmax[t] > best) {
+            best = tmax[t];
+            bt = t;
+        }
+    sb[threadIdx.x] = best;
+    si[threadIdx.x] = bt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s && sb[threadIdx.x + s] > sb[threadIdx.x]) {
+            sb[threadIdx.x] = sb[threadIdx.x + s];
+            si[threadIdx.x] = si[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = tij[2 * si[0]];
+        out[1] = tij[2 * si[0] + 1];
+    }
+}
+
+template <typename T, int KID>
+__global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ px,
+                                                  const T *__restrict__ py, const T *__restrict__ pz,
+                                                  long nq_valid, const double *__restrict__ qx,
+                                                  const double *__restrict__ qy, const double *__restrict__ qz,
+                                                  T *__restrict__ Kqp)
+{
+    __shared__ T rx[TILE], ry[TILE], rz[TILE];
+    const int tid = threadIdx.x;
+    const long q0 = (long)blockIdx.y * TILE;
+    if (tid < TILE) {
+        long q = q0 + tid;
+        bool ok = q < nq_valid;
+        rx[tid] = ok ? (T)qx[q] : T(0);
+        ry[tid] = ok ? (T)qy[q] : T(0);
+        rz[tid] = ok ? (T)qz[q] : T(0);
+    }
+    const int tx = tid & 31, ty = tid >> 5;
+    const int gj0 = blockIdx.x * TILE + tx * 4;
+    T cx[4], cy[4], cz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cx[c] = px[gj0 + c];
+        cy[c] = py[gj0 + c];
+        cz[c] = pz[gj0 + c];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int li = ty + 8 * r;
+        const long q = q0 + li;
+        const T ax = rx[li], ay = ry[li], az = rz[li];
+        T out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            T d2 = dx * dx + dy * dy + dz * dz;
+            T kv = cov_k<T, KID>(cov, d2);
+            out[c] = (q < nq_valid && gj0 + c < n) ? kv : T(0);
+        }
+        store4<T>(Kqp + (size_t)q * npad + gj0, out);
+    }
+}
+
+template <typename T>
+static void kbuild_t(const CovHost &h, int n, int npad, const void *x, const void *y, const void *z,
+                     const void *s2, void *K, float *tmax, int *tij, hipStream_t st)
+{
+    const int nt = npad / TILE;
+    const int ntiles = nt * (nt + 1) / 2;
+    Cov<T> c = lower_cov<T>(h);
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_kernel<T, KID>), dim3(ntiles), dim3(256), 0, st, c, n, npad,
+                                              (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K,
+                                              tmax, tij));
+}
+
+void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
+                   const void *s2, void *K, float *tmax, int *tij, hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)
+        kbuild_t<double>(cov, n, npad, x, y, z, s2, K, tmax, tij, st);
+    else
+        kbuild_t<float>(cov, n, npad, x, y, z, s2, K, tmax, tij, st);
+}
+
+void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *out_ij, hipStream_t st)
+{
+    hipLaunchKernelGGL(reduce_tilemax_kernel, dim3(1), dim3(256), 0, st, ntiles, tmax, tij, out_ij);
+}
+
+template <typename T>
+static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz,
+                  long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
+                  hipStream_t st)
+{
+    Cov<T> c = lower_cov<T>(h);
+    dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<T, KID>), grid, dim3(256), 0, st, c, n, npad,
+                                              (const T *)px, (const T *)py, (const T *)pz, nq_valid, qx, qy, qz,
+                                              (T *)Kqp));
+}
+
+void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
+                long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
+                hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)
+        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st);
+    else
+        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st);
+}
+
+}  // namespace gpx

@@ -1,0 +1,318 @@
+"""ctypes binding of libgpx.so (include/gpx.h) for tests and bench.
+
+This is plumbing over the C ABI, not a compute path: every numeric call goes to the HIP library and
+raises GpxError when the library or a GPU is missing -- there is no Python / NumPy fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpx.so")
+
+GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
+KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
+              "matern32": MATERN32, "matern52": MATERN52}
+F32, F64 = 0, 1
+
+OK = 0
+E_NULL, E_EMPTY, E_LABELED_QUERY, E_SIZE_MISMATCH, E_SINGULAR, E_NAN_INPUT, E_HIP, E_OOM, E_NO_DEVICE, \
+    E_BAD_ARG, E_STATE = (-1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11)
+
+(FIELD_N, FIELD_R, FIELD_ALPHA, FIELD_P, FIELD_Y, FIELD_S2, FIELD_NORMALS, FIELD_STATS, FIELD_D, FIELD_PERM,
+ FIELD_KPP) = range(11)
+
+
+class GpxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gpx error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+class Kernel(C.Structure):
+    _fields_ = [("id", C.c_int32), ("reserved", C.c_int32), ("p", C.c_double * 4)]
+
+
+class Options(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("device", C.c_int32), ("with_normals", C.c_int32),
+                ("ir_steps", C.c_int32), ("prepare_variance", C.c_int32), ("query_batch", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("t_kbuild_ms", C.c_double), ("t_factor_ms", C.c_double), ("t_solve_ms", C.c_double),
+                ("t_inverse_ms", C.c_double), ("t_normals_ms", C.c_double), ("t_mean_ms", C.c_double),
+                ("t_var_ms", C.c_double), ("t_var_gemm_ms", C.c_double), ("t_factor_gemm_ms", C.c_double),
+                ("n", C.c_int64), ("n_padded", C.c_int64), ("n_negative_pivots", C.c_int64),
+                ("ir_steps_done", C.c_int64), ("alpha_residual", C.c_double),
+                ("var_gemm_launches", C.c_int64), ("factor_gemm_launches", C.c_int64),
+                ("reserved", C.c_double * 4)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/gpx.h declares
+EXPORTS = [
+    "gpx_last_error", "gpx_version", "gpx_device_count", "gpx_model_create", "gpx_model_update",
+    "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_prepare_variance", "gpx_model_get",
+    "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
+    "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libgpx.so (raises if the HIP extension has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpxError(E_STATE, "libgpx.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                       % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.gpx_last_error.restype = C.c_char_p
+    L.gpx_version.restype = C.c_char_p
+    L.gpx_device_count.restype = C.c_int
+    L.gpx_padded_n.restype = C.c_size_t
+    L.gpx_padded_n.argtypes = [C.c_size_t]
+    L.gpx_model_create.restype = C.c_int
+    L.gpx_model_create.argtypes = [C.POINTER(Kernel), C.c_size_t, dp, dp, dp, dp, dp, C.POINTER(Options),
+                                   C.POINTER(vp)]
+    L.gpx_model_update.restype = C.c_int
+    L.gpx_model_update.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp]
+    L.gpx_model_evaluate.restype = C.c_int
+    L.gpx_model_evaluate.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.gpx_model_evaluate_device.restype = C.c_int
+    L.gpx_model_evaluate_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.gpx_model_prepare_variance.restype = C.c_int
+    L.gpx_model_prepare_variance.argtypes = [vp]
+    L.gpx_model_get.restype = C.c_int
+    L.gpx_model_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.gpx_model_sync.restype = C.c_int
+    L.gpx_model_sync.argtypes = [vp]
+    L.gpx_model_destroy.restype = None
+    L.gpx_model_destroy.argtypes = [vp]
+    L.gpx_model_create_shell.restype = C.c_int
+    L.gpx_model_create_shell.argtypes = [C.POINTER(Kernel), C.c_size_t, C.POINTER(Options), C.POINTER(vp)]
+    L.gpx_model_state_blob.restype = C.c_int
+    L.gpx_model_state_blob.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.gpx_model_commit.restype = C.c_int
+    L.gpx_model_commit.argtypes = [vp, C.c_int]
+    L.gpx_dev_kbuild.restype = C.c_int
+    L.gpx_dev_kbuild.argtypes = [C.POINTER(Kernel), C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
+    L.gpx_pcd_read.restype = C.c_long
+    L.gpx_pcd_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
+    L.gpx_node_training_set.restype = C.c_int
+    L.gpx_node_training_set.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_double, C.c_double, dp, dp, dp, dp, dp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise GpxError(rc, lib().gpx_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().gpx_device_count()
+
+
+def make_kernel(name, *params):
+    kid = KERNEL_IDS[name] if isinstance(name, str) else int(name)
+    k = Kernel()
+    k.id = kid
+    vals = list(params) + [1.0] * (2 - len(params))
+    for i, v in enumerate(vals[:4]):
+        k.p[i] = float(v)
+    return k
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _as_d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Model:
+    """gp_regression::Model + GPRegressor<Cov>::{create, evaluate, update} over the C ABI."""
+
+    def __init__(self, kernel, x, y, z, label, sigma2=None, precision=F32, with_normals=False, ir_steps=-1,
+                 prepare_variance=False, query_batch=0, device=-1, _shell_n=None):
+        self._L = lib()
+        self._h = C.c_void_p(None)
+        self.kernel = kernel
+        self.precision = precision
+        opt = Options()
+        opt.precision = int(precision)
+        opt.device = int(device)
+        opt.with_normals = int(bool(with_normals))
+        opt.ir_steps = int(ir_steps)
+        opt.prepare_variance = int(bool(prepare_variance))
+        opt.query_batch = int(query_batch)
+        if _shell_n is not None:
+            _check(self._L.gpx_model_create_shell(C.byref(kernel), int(_shell_n), C.byref(opt), C.byref(self._h)))
+            return
+        x, y, z, label = _as_d(x), _as_d(y), _as_d(z), _as_d(label)
+        if not (len(x) == len(y) == len(z) == len(label)):
+            raise GpxError(E_SIZE_MISMATCH, "coordinate / label length mismatch")
+        s2p = None
+        if sigma2 is not None and len(sigma2):
+            sigma2 = _as_d(sigma2)
+            if len(sigma2) != len(x):
+                raise GpxError(E_SIZE_MISMATCH, "sigma2 length mismatch")
+            s2p = _dptr(sigma2)
+        _check(self._L.gpx_model_create(C.byref(kernel), len(x), _dptr(x), _dptr(y), _dptr(z), _dptr(label), s2p,
+                                        C.byref(opt), C.byref(self._h)))
+
+    @classmethod
+    def shell(cls, kernel, n, precision=F32, query_batch=0, device=-1):
+        return cls(kernel, None, None, None, None, precision=precision, query_batch=query_batch, device=device,
+                   _shell_n=n)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.gpx_model_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- accessors ----
+    def _get(self, field, arr):
+        _check(self._L.gpx_model_get(self._h, field, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return arr
+
+    @property
+    def n(self):
+        return int(self._get(FIELD_N, np.zeros(1, dtype=np.int64))[0])
+
+    @property
+    def R(self):
+        return float(self._get(FIELD_R, np.zeros(1))[0])
+
+    @property
+    def alpha(self):
+        return self._get(FIELD_ALPHA, np.zeros(self.n))
+
+    @property
+    def P(self):
+        return self._get(FIELD_P, np.zeros((self.n, 3)))
+
+    @property
+    def Y(self):
+        return self._get(FIELD_Y, np.zeros(self.n))
+
+    @property
+    def S2(self):
+        return self._get(FIELD_S2, np.zeros(self.n))
+
+    @property
+    def D(self):
+        return self._get(FIELD_D, np.zeros(self.n))
+
+    @property
+    def perm(self):
+        return self._get(FIELD_PERM, np.zeros(self.n, dtype=np.int32))
+
+    @property
+    def normals(self):
+        return self._get(FIELD_NORMALS, np.zeros((self.n, 3)))
+
+    @property
+    def Kpp(self):
+        n = self.n
+        return self._get(FIELD_KPP, np.zeros((n, n)))
+
+    @property
+    def stats(self):
+        s = Stats()
+        _check(self._L.gpx_model_get(self._h, FIELD_STATS, C.byref(s), C.sizeof(s)))
+        return s.as_dict()
+
+    # ---- operations ----
+    def update(self, x, y, z, label, sigma2=None):
+        x, y, z, label = _as_d(x), _as_d(y), _as_d(z), _as_d(label)
+        s2p = None
+        if sigma2 is not None and len(sigma2):
+            sigma2 = _as_d(sigma2)
+            s2p = _dptr(sigma2)
+        _check(self._L.gpx_model_update(self._h, len(x), _dptr(x), _dptr(y), _dptr(z), _dptr(label), s2p))
+
+    def prepare_variance(self):
+        _check(self._L.gpx_model_prepare_variance(self._h))
+
+    def sync(self):
+        _check(self._L.gpx_model_sync(self._h))
+
+    def evaluate(self, qx, qy, qz, want_v=False, want_grad=False, want_basis=False, label=None):
+        """Host arrays in, dict of host arrays out (f [, v, grad, tx, ty])."""
+        if label is not None and len(label):
+            raise GpxError(E_LABELED_QUERY, "Query is already labeled!")
+        qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)
+        nq = len(qx)
+        f = np.empty(nq)
+        v = np.empty(nq) if want_v else None
+        g = np.empty((nq, 3)) if want_grad else None
+        tx = np.empty((nq, 3)) if want_basis else None
+        ty = np.empty((nq, 3)) if want_basis else None
+        p = lambda a: _dptr(a) if a is not None else None
+        _check(self._L.gpx_model_evaluate(self._h, nq, _dptr(qx), _dptr(qy), _dptr(qz), p(f), p(v), p(g), p(tx),
+                                          p(ty)))
+        out = {"f": f}
+        if v is not None:
+            out["v"] = v
+        if g is not None:
+            out["grad"] = g
+        if tx is not None:
+            out["tx"], out["ty"] = tx, ty
+        return out
+
+    def evaluate_device(self, nq, d_qx, d_qy, d_qz, d_f, d_v=None, d_grad=None, d_tx=None, d_ty=None, stream=None):
+        """Raw device pointers (ints, e.g. torch.Tensor.data_ptr()) of fp64 arrays; asynchronous."""
+        vp = lambda a: C.c_void_p(int(a)) if a else None
+        _check(self._L.gpx_model_evaluate_device(self._h, int(nq), vp(d_qx), vp(d_qy), vp(d_qz), vp(d_f), vp(d_v),
+                                                 vp(d_grad), vp(d_tx), vp(d_ty), vp(stream)))
+
+    def state_blob(self, part):
+        ptr = C.c_void_p(None)
+        nbytes = C.c_size_t(0)
+        _check(self._L.gpx_model_state_blob(self._h, int(part), C.byref(ptr), C.byref(nbytes)))
+        return int(ptr.value), int(nbytes.value)
+
+    def commit(self, with_variance=True):
+        _check(self._L.gpx_model_commit(self._h, int(bool(with_variance))))
+
+
+def pcd_read(path):
+    L = lib()
+    n = L.gpx_pcd_read(path.encode(), None, 0)
+    if n < 0:
+        raise GpxError(int(n), "cannot read PCD file %s" % path)
+    xyz = np.zeros((n, 3), dtype=np.float32)
+    n2 = L.gpx_pcd_read(path.encode(), xyz.ctypes.data_as(C.POINTER(C.c_float)), n)
+    if n2 != n:
+        raise GpxError(int(n2), "cannot decode PCD file %s" % path)
+    return xyz
+
+
+def node_training_set(xyz, sigma2=0.1, rad=2.0):
+    L = lib()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    n = len(xyz)
+    out = [np.zeros(n + 15) for _ in range(5)]
+    rc = L.gpx_node_training_set(xyz.ctypes.data_as(C.POINTER(C.c_float)), n, float(sigma2), float(rad),
+                                 *[_dptr(a) for a in out])
+    if rc < 0:
+        raise GpxError(rc, "gpx_node_training_set failed")
+    return tuple(a[:n + rc] for a in out)

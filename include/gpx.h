@@ -1,0 +1,178 @@
+/*
+ * gpx.h -- C ABI of libgpx.so: MI355X (gfx950) GP-regression hot path.
+ *
+ * Drop-in boundary for the reference's gp_regression::GPRegressor<Cov> (header-only C++ over
+ * Eigen; /root/reference/include/gp_regression/gp_regressor.hpp).  Every entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ *   - All API scalars and arrays are IEEE double, as in the reference (std::vector<double>,
+ *     Eigen::MatrixXd); gpx_options.precision selects the arithmetic used on the device.
+ *   - Host entry points copy caller-owned host arrays in/out.  The *_device entry points take
+ *     device pointers (HIP) and a stream and never synchronise the host.
+ *   - Functions return GPX_OK (0) or a negative gpx_status; gpx_last_error() gives the
+ *     thread-local message.  Nothing throws across this boundary.
+ *   - There is NO CPU compute fallback: without a HIP device every compute call fails with
+ *     GPX_E_HIP / GPX_E_NO_DEVICE.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_VERSION_MAJOR 0
+#define GPX_VERSION_MINOR 1
+
+typedef enum {
+    GPX_OK = 0,
+    GPX_E_NULL = -1,          /* "Empty data pointer" / "Empty Model pointer"  gp_regressor.hpp:198,:225,:285,:335,:374,:565-566 */
+    GPX_E_EMPTY = -2,         /* "All input data is empty!"                    gp_regressor.hpp:567-571 */
+    GPX_E_LABELED_QUERY = -3, /* "Query is already labeled!"                   gp_regressor.hpp:230-231,:290-291,:340-341 */
+    GPX_E_SIZE_MISMATCH = -4, /* new: the reference does not validate lengths */
+    GPX_E_SINGULAR = -5,      /* zero / non-finite pivot in the LDL^T factorisation */
+    GPX_E_NAN_INPUT = -6,
+    GPX_E_HIP = -7,           /* HIP runtime error (message holds hipGetErrorString) */
+    GPX_E_OOM = -8,
+    GPX_E_NO_DEVICE = -9,
+    GPX_E_BAD_ARG = -10,
+    GPX_E_STATE = -11         /* model not ready (e.g. shell not committed) */
+} gpx_status;
+
+/* Covariance functions on the UN-squared distance d (reference semantics kept verbatim):
+ *   GAUSSIAN  sigma^2 * exp(-d/l^2)              kernels/gaussian.hpp:15-27   p = {sigma, length}
+ *   LAPLACE   2*sigma * exp(-d/l)                kernels/laplace.hpp:37-49    p = {sigma, length}
+ *   THINPLATE 2d^3 - 3R d^2 + R^3                kernels/thin_plate.hpp:12-20 p = {R}
+ *   MATERN32  sigma^2 (1+s) e^-s,  s=sqrt3 d/l   matlab_src/test_gp_regression_3Dsurf.m:117-119
+ *   MATERN52  sigma^2 (1+s+s^2/3) e^-s, s=sqrt5 d/l                       ... :121-123
+ * "computediff" follows each reference kernel (k'(d) for Gaussian/Laplace, k'(d)/d for
+ * ThinPlate); the Matern kernels use k'(d)/d. */
+typedef enum {
+    GPX_KERNEL_GAUSSIAN = 0,
+    GPX_KERNEL_LAPLACE = 1,
+    GPX_KERNEL_THINPLATE = 2,
+    GPX_KERNEL_MATERN32 = 3,
+    GPX_KERNEL_MATERN52 = 4
+} gpx_kernel_id;
+
+typedef struct gpx_kernel {
+    int32_t id;  /* gpx_kernel_id */
+    int32_t reserved;
+    double p[4];
+} gpx_kernel;
+
+typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1 } gpx_precision;
+
+typedef struct gpx_options {
+    int32_t precision;     /* gpx_precision; F32 adds fp64-residual iterative refinement of alpha */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    int32_t with_normals;  /* create<true>: normals at the training points (gp_regressor.hpp:166-181) */
+    int32_t ir_steps;      /* refinement steps for alpha; -1 = default (2 for F32, 1 for F64) */
+    int32_t prepare_variance; /* 1: build the inverse factor inside create (else lazily at first variance query) */
+    int32_t query_batch;   /* queries per variance batch (multiple of 128); 0 = default */
+    int32_t reserved[6];
+} gpx_options;
+
+typedef struct gpx_model gpx_model; /* opaque; replaces struct Model, gp_regressor.hpp:71-87 */
+
+/* Per-stage device timings (HIP events) of the last create / evaluate on this model, ms. */
+typedef struct gpx_stats {
+    double t_kbuild_ms, t_factor_ms, t_solve_ms, t_inverse_ms, t_normals_ms; /* create */
+    double t_mean_ms, t_var_ms;                                              /* last evaluate */
+    double t_var_gemm_ms;   /* the variance GEMM launches only (subset of t_var_ms) */
+    double t_factor_gemm_ms; /* trailing-update GEMM launches only (subset of t_factor_ms) */
+    int64_t n, n_padded, n_negative_pivots, ir_steps_done;
+    double alpha_residual;  /* max |y - K alpha| after refinement (fp64, matrix-free) */
+    int64_t var_gemm_launches, factor_gemm_launches;
+    double reserved[4];
+} gpx_stats;
+
+typedef enum {
+    GPX_FIELD_N = 0,        /* int64  */
+    GPX_FIELD_R = 1,        /* double: Model::R, max pairwise training distance (gp_regressor.hpp:135) */
+    GPX_FIELD_ALPHA = 2,    /* double[n]   Model::alpha (:163), caller's point order */
+    GPX_FIELD_P = 3,        /* double[3n]  Model::P, row-major n x 3 */
+    GPX_FIELD_Y = 4,        /* double[n]   Model::Y */
+    GPX_FIELD_S2 = 5,       /* double[n]   Model::S2 (zeros when create had no sigma2) */
+    GPX_FIELD_NORMALS = 6,  /* double[3n]  Model::N, row-major; only if with_normals */
+    GPX_FIELD_STATS = 7,    /* gpx_stats */
+    GPX_FIELD_D = 8,        /* double[n]   diagonal D of P K P^T = L D L^T (Eigen LDLT::vectorD) */
+    GPX_FIELD_PERM = 9,     /* int32[n]    internal position -> caller index */
+    GPX_FIELD_KPP = 10      /* double[n*n] Model::Kpp row-major (symmetric), caller order; rebuilt on demand */
+} gpx_field;
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char *gpx_last_error(void); /* thread-local */
+const char *gpx_version(void);
+int gpx_device_count(void);       /* number of HIP devices, 0 if none / no driver */
+
+/* ---- model: GPRegressor<Cov>::create<withNormals>(data, gp), gp_regressor.hpp:110-182 ------
+ * kernel == CovType held by GPRegressor::kernel_ (:97, setCovFunction :488-491).
+ * x,y,z,label: n doubles each (Data::coord_x/y/z/label, :51-54).  sigma2: n doubles or NULL
+ * (== empty Data::sigma2: no diagonal noise, :154).  *out replaces any previous model, as
+ * create resets gp (:116-117). */
+int gpx_model_create(const gpx_kernel *kernel, size_t n, const double *x, const double *y, const double *z,
+                     const double *label, const double *sigma2, const gpx_options *opt, gpx_model **out);
+
+/* GPRegressor<Cov>::update<withNormals>(new_data, gp), gp_regressor.hpp:367-479: append n_new
+ * points and refactor from scratch (:457-459).  Model::R is not refreshed (:454-455). */
+int gpx_model_update(gpx_model *m, size_t n_new, const double *x, const double *y, const double *z,
+                     const double *label, const double *sigma2);
+
+/* GPRegressor<Cov>::evaluate(gp, query, f [,v [,N [,Tx,Ty]]]), gp_regressor.hpp:332-357,
+ * :282-324, :222-273, :194-212.  f: nq (required).  v, grad, tx, ty: NULL or nq / 3nq / 3nq / 3nq
+ * doubles (row-major nq x 3).  grad is the UN-normalised gradient (:247-250), zero-initialised.
+ * tx/ty follow computeTangentBasis (:29-44).  v_i = k(0) - k_i^T K^-1 k_i (diagonal of :316-319).
+ * Re-entrant on a const model (src/gp_node.cpp:1027-1038 calls it from hundreds of threads). */
+int gpx_model_evaluate(const gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
+                       double *f, double *v, double *grad, double *tx, double *ty);
+
+/* Same, with every array already resident on the model's device (double), enqueued on `stream`
+ * (a hipStream_t, or NULL for the model's own stream); returns without synchronising. */
+int gpx_model_evaluate_device(const gpx_model *m, size_t nq, const void *d_qx, const void *d_qy,
+                              const void *d_qz, void *d_f, void *d_v, void *d_grad, void *d_tx, void *d_ty,
+                              void *stream);
+
+/* Ensure the inverse factor needed by variance queries exists (else built at first use). */
+int gpx_model_prepare_variance(gpx_model *m);
+
+int gpx_model_get(const gpx_model *m, int field, void *dst, size_t bytes);
+int gpx_model_sync(const gpx_model *m); /* hipStreamSynchronize on the model's stream */
+void gpx_model_destroy(gpx_model *m);
+
+/* ---- one model, query grid sharded over ranks (one process per GPU) -----------------------
+ * The rank that factorised exports its read-only state as ONE contiguous device blob
+ * (points, alpha, D, inverse factor); the host moves it with RCCL (torch.distributed
+ * broadcast over xGMI) into the blob of a shell created with the same kernel/n/options on the
+ * other ranks, then commits it.  No reference equivalent (the reference is single-process). */
+int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const gpx_options *opt, gpx_model **out);
+int gpx_model_state_blob(gpx_model *m, int with_variance, void **d_ptr, size_t *bytes);
+int gpx_model_commit(gpx_model *m, int with_variance);
+
+/* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------
+ * kbuild: K[i][j] = k(|p_i-p_j|) + sigma2_i*delta_ij on the lower block-triangle of an
+ * n_padded x n_padded row-major matrix of `precision` scalars (identity on the padding);
+ * replaces buildEuclideanDistanceMatrix + the kernel loop, gp_regressor.hpp:132-159, :548-557.
+ * d_x,d_y,d_z,d_s2: device arrays of `precision` scalars, n_padded long. d_rmax: device float/double
+ * receiving max pairwise distance (:135) or NULL. */
+int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_x,
+                   const void *d_y, const void *d_z, const void *d_s2, void *d_K, void *d_rmax, void *stream);
+size_t gpx_padded_n(size_t n); /* leading dimension / padded order used for n training points */
+
+/* ---- PCD input + node-equivalent data preparation (host) ----------------------------------
+ * gpx_pcd_read: pcl::io::loadPCDFile (src/gp_node.cpp:557) for ascii / binary /
+ * binary_compressed files; xyz as float.  Returns the number of points, or a negative status.
+ * If xyz == NULL only the count is returned.
+ * gpx_node_training_set: deMeanAndNormalizeData + prepareExtData + prepareData + computeGP's
+ * concatenation (src/gp_node.cpp:85-117, :793-914): out arrays must hold n_points+15 doubles. */
+long gpx_pcd_read(const char *path, float *xyz, size_t capacity_points);
+int gpx_node_training_set(const float *xyz, size_t n_points, double sigma2, double out_sphere_rad, double *x,
+                          double *y, double *z, double *label, double *s2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

@@ -1,0 +1,633 @@
+/*
+ * gp_oracle.c -- CPU fp64 restatement of the reference GP-regression hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.  The
+ * product path (libgpx.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED.  The reference's own tests hold no golden values and no
+ * assertions for this path (tests/test_gaussian.cpp, tests/test_gp.cpp and
+ * tests/test_eigen.cpp only print), and the reference itself cannot be built
+ * here: its arithmetic lives in Eigen 3 (find_package(Eigen), CMakeLists.txt:25,
+ * no version pin, not vendored, not installed, no network).  This file therefore
+ * restates, function by function,
+ *     include/gp_regression/gp_regressor.hpp      (create / evaluate x4 / update)
+ *     include/gp_regression/kernels/{gaussian,laplace,thin_plate}.hpp
+ *     matlab_src/test_gp_regression_3Dsurf.m:117-123   (Matern closed forms)
+ * and, for Eigen::LDLT (gp_regressor.hpp:81,:161-163), the published algorithm
+ * of Eigen 3.2.x LDLT.h (ldlt_inplace<Lower>::unblocked + LDLT::solve), written
+ * from its public description.  What pins it instead: analytic known-answer
+ * tests, GP identities and an independent NumPy/SciPy computation committed as
+ * fixtures under tests/golden/ (tests/golden/make_golden.py).
+ *
+ * All arithmetic is IEEE double, as in the reference (std::vector<double>,
+ * Eigen::MatrixXd).  Matrices are column-major like Eigen's default.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_GAUSSIAN 0
+#define ORC_LAPLACE 1
+#define ORC_THINPLATE 2
+#define ORC_MATERN32 3
+#define ORC_MATERN52 4
+
+/* distance formulation */
+#define ORC_DIST_DIRECT 0    /* sqrt(dx^2+dy^2+dz^2): the build's documented deviation */
+#define ORC_DIST_EXPANSION 1 /* gp_regressor.hpp:548-557 literally; may yield NaN */
+
+typedef struct {
+    int id;
+    double p0; /* sigma (Gaussian/Laplace/Matern)  | R (ThinPlate) */
+    double p1; /* length (Gaussian/Laplace/Matern) | unused        */
+} orc_kernel;
+
+/* ---- K1..K5: scalar radial kernels on the un-squared distance -------------------------- */
+
+/* kernels/gaussian.hpp:15-20, laplace.hpp:37-42, thin_plate.hpp:12-15,
+ * matlab_src/test_gp_regression_3Dsurf.m:117-119 (Matern-3/2), :121-123 (Matern-5/2). */
+double orc_k(const orc_kernel *k, double d)
+{
+    switch (k->id) {
+    case ORC_GAUSSIAN: {
+        double sigma2 = k->p0 * k->p0;
+        double inv_length2 = 1.0 / (k->p1 * k->p1);
+        double power = -1 * d * inv_length2; /* sic: un-squared distance */
+        return sigma2 * exp(power);
+    }
+    case ORC_LAPLACE: {
+        double inv_length = 1.0 / k->p1;
+        double power = -1 * d * inv_length;
+        return 2 * k->p0 * exp(power); /* sic: amplitude 2*sigma */
+    }
+    case ORC_THINPLATE: {
+        double R = k->p0, R3 = R * R * R;
+        return 2 * d * d * d - 3 * R * d * d + R3;
+    }
+    case ORC_MATERN32: {
+        double s = sqrt(3.0) * d / k->p1;
+        return k->p0 * k->p0 * (1 + s) * exp(-s);
+    }
+    case ORC_MATERN52: {
+        double s = sqrt(5.0) * d / k->p1;
+        return k->p0 * k->p0 * (1 + s + (5 * d * d) / (3 * k->p1 * k->p1)) * exp(-s);
+    }
+    }
+    return NAN;
+}
+
+/* computediff: gaussian.hpp:22-27 (k'(d)), laplace.hpp:44-49 (k'(d)), thin_plate.hpp:17-20
+ * (k'(d)/d); the new Matern kernels use k'(d)/d. */
+double orc_kdiff(const orc_kernel *k, double d)
+{
+    switch (k->id) {
+    case ORC_GAUSSIAN:
+        return -1 * (1.0 / (k->p1 * k->p1)) * orc_k(k, d);
+    case ORC_LAPLACE:
+        return -1 * (1.0 / k->p1) * orc_k(k, d);
+    case ORC_THINPLATE:
+        return -6 * (k->p0 - d);
+    case ORC_MATERN32: {
+        double s = sqrt(3.0) * d / k->p1;
+        return -3 * k->p0 * k->p0 / (k->p1 * k->p1) * exp(-s);
+    }
+    case ORC_MATERN52: {
+        double s = sqrt(5.0) * d / k->p1;
+        return -(5 * k->p0 * k->p0 / (3 * k->p1 * k->p1)) * (1 + s) * exp(-s);
+    }
+    }
+    return NAN;
+}
+
+/* computediffdiff: 0 in every reference kernel (gaussian.hpp:29-34 etc.). */
+double orc_kdiffdiff(const orc_kernel *k, double d)
+{
+    (void)k;
+    (void)d;
+    return 0.0;
+}
+
+/* ---- F1: buildEuclideanDistanceMatrix, gp_regressor.hpp:548-557 ------------------------- */
+/* D (m x n, column-major) = distance between A_i and B_j. */
+void orc_dist_matrix(int mode, int m, int n, const double *ax, const double *ay, const double *az,
+                     const double *bx, const double *by, const double *bz, double *D)
+{
+    if (mode == ORC_DIST_EXPANSION) {
+        /* D = -2*A*B^T; D.colwise() += rowsum(A.A); D.rowwise() += rowsum(B.B)^T; sqrt */
+        for (int j = 0; j < n; ++j) {
+            double bb = bx[j] * bx[j] + by[j] * by[j] + bz[j] * bz[j];
+            for (int i = 0; i < m; ++i) {
+                double aa = ax[i] * ax[i] + ay[i] * ay[i] + az[i] * az[i];
+                double ab = ax[i] * bx[j] + ay[i] * by[j] + az[i] * bz[j];
+                double v = -2 * ab;
+                v += aa;
+                v += bb;
+                D[(size_t)j * m + i] = sqrt(v); /* NaN when v < 0, as in the reference */
+            }
+        }
+    } else {
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i) {
+                double dx = ax[i] - bx[j], dy = ay[i] - by[j], dz = az[i] - bz[j];
+                D[(size_t)j * m + i] = sqrt(dx * dx + dy * dy + dz * dz);
+            }
+    }
+}
+
+/* ---- F4/F5: Eigen::LDLT<MatrixXd> (gp_regressor.hpp:161-163) ---------------------------- */
+/* In-place, lower triangle, column-major, left-looking, "diagonal pivoting" on the stored
+ * diagonal of the not-yet-processed block (Eigen 3.2.x ldlt_inplace<Lower>::unblocked).
+ * On exit: strict lower = L (unit), diagonal = D, transp[k] = row swapped with k at step k.
+ * Returns 0, or k+1 if the factorisation stopped early at step k (pivot below cutoff). */
+int orc_ldlt(int n, double *A, int *transp)
+{
+    double cutoff = 0.0;
+    double *temp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int ret = 0;
+#define M(i, j) A[(size_t)(j) * n + (i)]
+    for (int k = 0; k < n; ++k) {
+        /* largest |diagonal| in the remaining block (first maximum, like maxCoeff) */
+        int big = k;
+        double bigv = fabs(M(k, k));
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(M(i, i)) > bigv) {
+                bigv = fabs(M(i, i));
+                big = i;
+            }
+        if (k == 0)
+            cutoff = fabs(2.220446049250313e-16 * bigv);
+        if (bigv < cutoff) {
+            for (int i = k; i < n; ++i)
+                transp[i] = i;
+            ret = k + 1;
+            break;
+        }
+        transp[k] = big;
+        if (k != big) {
+            /* symmetric swap touching only the lower triangle */
+            for (int j = 0; j < k; ++j) {
+                double t = M(k, j);
+                M(k, j) = M(big, j);
+                M(big, j) = t;
+            }
+            for (int i = big + 1; i < n; ++i) {
+                double t = M(i, k);
+                M(i, k) = M(i, big);
+                M(i, big) = t;
+            }
+            {
+                double t = M(k, k);
+                M(k, k) = M(big, big);
+                M(big, big) = t;
+            }
+            for (int i = k + 1; i < big; ++i) {
+                double t = M(i, k);
+                M(i, k) = M(big, i);
+                M(big, i) = t;
+            }
+        }
+        int rs = n - k - 1;
+        if (k > 0) {
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j) {
+                temp[j] = M(j, j) * M(k, j); /* D(0:k) .* A10^T */
+                acc += M(k, j) * temp[j];
+            }
+            M(k, k) -= acc;
+            if (rs > 0) {
+                /* A21 -= A20 * temp : column-major saxpy over columns j<k */
+                double *a21 = &M(k + 1, k);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (rs > 512)
+#endif
+                for (int ib = 0; ib < rs; ib += 256) {
+                    int ie = ib + 256 < rs ? ib + 256 : rs;
+                    for (int j = 0; j < k; ++j) {
+                        const double *a20 = &M(k + 1, j);
+                        double t = temp[j];
+                        for (int i = ib; i < ie; ++i)
+                            a21[i] -= a20[i] * t;
+                    }
+                }
+            }
+        }
+        if (rs > 0 && fabs(M(k, k)) > cutoff) {
+            double d = M(k, k);
+            for (int i = k + 1; i < n; ++i)
+                M(i, k) /= d;
+        }
+    }
+#undef M
+    free(temp);
+    return ret;
+}
+
+/* LDLT::solve for nrhs right-hand sides (column-major n x nrhs, in place):
+ * x = P^T L^-T D^+ L^-1 P b, with Eigen 3.2.x's pseudo-inverse rule for D. */
+void orc_ldlt_solve(int n, const double *A, const int *transp, int nrhs, double *B)
+{
+#define M(i, j) A[(size_t)(j) * n + (i)]
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (fabs(M(i, i)) > dmax)
+            dmax = fabs(M(i, i));
+    double tol = dmax * 2.220446049250313e-16;
+    if (tol < 1.0 / 1.7976931348623157e308)
+        tol = 1.0 / 1.7976931348623157e308;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) if (nrhs > 8)
+#endif
+    for (int r = 0; r < nrhs; ++r) {
+        double *b = B + (size_t)r * n;
+        for (int k = 0; k < n; ++k) /* b = P b */
+            if (transp[k] != k) {
+                double t = b[k];
+                b[k] = b[transp[k]];
+                b[transp[k]] = t;
+            }
+        for (int j = 0; j < n; ++j) { /* L y = b (unit lower), column-oriented */
+            double bj = b[j];
+            if (bj != 0.0)
+                for (int i = j + 1; i < n; ++i)
+                    b[i] -= M(i, j) * bj;
+        }
+        for (int i = 0; i < n; ++i) /* D^+ */
+            b[i] = fabs(M(i, i)) > tol ? b[i] / M(i, i) : 0.0;
+        for (int j = n - 1; j >= 0; --j) { /* L^T x = y */
+            double acc = b[j];
+            for (int i = j + 1; i < n; ++i)
+                acc -= M(i, j) * b[i];
+            b[j] = acc;
+        }
+        for (int k = n - 1; k >= 0; --k) /* x = P^T x */
+            if (transp[k] != k) {
+                double t = b[k];
+                b[k] = b[transp[k]];
+                b[transp[k]] = t;
+            }
+    }
+#undef M
+}
+
+/* ---- T2: Model (gp_regressor.hpp:71-87) ------------------------------------------------- */
+typedef struct {
+    orc_kernel kern;
+    int dist_mode;
+    int n;
+    int has_s2;
+    double R;              /* gp->R, :135 */
+    double *px, *py, *pz;  /* gp->P */
+    double *Y, *S2;        /* gp->Y, gp->S2 */
+    double *Kpp;           /* kernel matrix after :144-159 (column-major) */
+    double *ldlt;          /* cholesker's private copy */
+    int *transp;
+    double *alpha;         /* :163 */
+    double *normals;       /* n x 3 row-major, only with normals (:166-181) */
+    int ldlt_info;
+} orc_model;
+
+static double *dup_vec(const double *v, int n)
+{
+    double *r = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (v && n > 0)
+        memcpy(r, v, sizeof(double) * (size_t)n);
+    return r;
+}
+
+void orc_free(orc_model *m)
+{
+    if (!m)
+        return;
+    free(m->px);
+    free(m->py);
+    free(m->pz);
+    free(m->Y);
+    free(m->S2);
+    free(m->Kpp);
+    free(m->ldlt);
+    free(m->transp);
+    free(m->alpha);
+    free(m->normals);
+    free(m);
+}
+
+static void factor_and_solve(orc_model *m)
+{
+    int n = m->n;
+    size_t nn = (size_t)n * n;
+    free(m->ldlt);
+    free(m->transp);
+    free(m->alpha);
+    m->ldlt = (double *)malloc(sizeof(double) * nn);
+    memcpy(m->ldlt, m->Kpp, sizeof(double) * nn);
+    m->transp = (int *)malloc(sizeof(int) * (size_t)n);
+    m->ldlt_info = orc_ldlt(n, m->ldlt, m->transp); /* :161-162 */
+    m->alpha = dup_vec(m->Y, n);
+    orc_ldlt_solve(n, m->ldlt, m->transp, 1, m->alpha); /* :163 */
+}
+
+/* F2/F3/F4/F5/F6: GPRegressor::create<withNormals>, gp_regressor.hpp:110-182.
+ * sigma2 may be NULL (== empty vector, :154).  Normals are zero-initialised before the
+ * accumulation of :172 (the reference accumulates into un-initialised storage). */
+orc_model *orc_create(const orc_kernel *kern, int n, const double *x, const double *y, const double *z,
+                      const double *label, const double *sigma2, int with_normals, int dist_mode)
+{
+    orc_model *m = (orc_model *)calloc(1, sizeof(orc_model));
+    m->kern = *kern;
+    m->dist_mode = dist_mode;
+    m->n = n;
+    m->has_s2 = sigma2 != NULL;
+    m->px = dup_vec(x, n);
+    m->py = dup_vec(y, n);
+    m->pz = dup_vec(z, n);
+    m->Y = dup_vec(label, n);
+    m->S2 = dup_vec(sigma2, n);
+    size_t nn = (size_t)n * n;
+    m->Kpp = (double *)malloc(sizeof(double) * (nn ? nn : 1));
+    orc_dist_matrix(dist_mode, n, n, x, y, z, x, y, z, m->Kpp); /* :132 */
+    double R = -INFINITY;                                       /* :135 maxCoeff */
+    for (size_t i = 0; i < nn; ++i)
+        if (m->Kpp[i] > R)
+            R = m->Kpp[i];
+    m->R = R;
+    double *Kdiff = NULL;
+    if (with_normals)
+        Kdiff = (double *)malloc(sizeof(double) * nn);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n > 256)
+#endif
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) { /* :144-159 */
+            size_t ij = (size_t)j * n + i;
+            double d = m->Kpp[ij];
+            if (with_normals)
+                Kdiff[ij] = orc_kdiff(kern, d);
+            if (sigma2 && i == j)
+                m->Kpp[ij] = orc_k(kern, d) + sigma2[i];
+            else
+                m->Kpp[ij] = orc_k(kern, d);
+        }
+    factor_and_solve(m);
+    if (with_normals) { /* :166-181 */
+        m->normals = (double *)calloc((size_t)n * 3, sizeof(double));
+        for (int i = 0; i < n; ++i) {
+            double gx = 0, gy = 0, gz = 0;
+            for (int j = 0; j < n; ++j) {
+                double w = m->alpha[j] * Kdiff[(size_t)j * n + i];
+                gx += w * (x[i] - x[j]);
+                gy += w * (y[i] - y[j]);
+                gz += w * (z[i] - z[j]);
+            }
+            double nrm = sqrt(gx * gx + gy * gy + gz * gz);
+            if (nrm > 0) { /* Eigen normalize() */
+                gx /= nrm;
+                gy /= nrm;
+                gz /= nrm;
+            }
+            m->normals[3 * i + 0] = gx;
+            m->normals[3 * i + 1] = gy;
+            m->normals[3 * i + 2] = gz;
+        }
+        free(Kdiff);
+    }
+    return m;
+}
+
+/* F11: GPRegressor::update, gp_regressor.hpp:367-479: append, rebuild Kpp blocks, refactor
+ * from scratch (:457-459).  R is NOT refreshed (:454-455).  sigma2 NULL => no noise on the
+ * new diagonal (the reference's block assignment would mis-size). */
+int orc_update(orc_model *m, int nn_, const double *x, const double *y, const double *z, const double *label,
+               const double *sigma2)
+{
+    int p = m->n, n = nn_, t = p + n;
+    double *nx = (double *)malloc(sizeof(double) * t), *ny = (double *)malloc(sizeof(double) * t),
+           *nz = (double *)malloc(sizeof(double) * t), *nY = (double *)malloc(sizeof(double) * t),
+           *nS = (double *)calloc(t, sizeof(double));
+    memcpy(nx, m->px, sizeof(double) * p);
+    memcpy(ny, m->py, sizeof(double) * p);
+    memcpy(nz, m->pz, sizeof(double) * p);
+    memcpy(nY, m->Y, sizeof(double) * p);
+    if (m->has_s2)
+        memcpy(nS, m->S2, sizeof(double) * p);
+    memcpy(nx + p, x, sizeof(double) * n);
+    memcpy(ny + p, y, sizeof(double) * n);
+    memcpy(nz + p, z, sizeof(double) * n);
+    memcpy(nY + p, label, sizeof(double) * n);
+    if (sigma2)
+        memcpy(nS + p, sigma2, sizeof(double) * n);
+    double *K = (double *)malloc(sizeof(double) * (size_t)t * t);
+    for (int j = 0; j < p; ++j) /* conservativeResize keeps the old block (:442) */
+        memcpy(K + (size_t)j * t, m->Kpp + (size_t)j * p, sizeof(double) * p);
+    double *Kpn = (double *)malloc(sizeof(double) * (size_t)p * n);
+    double *Knn = (double *)malloc(sizeof(double) * (size_t)n * n);
+    orc_dist_matrix(m->dist_mode, n, n, x, y, z, x, y, z, Knn);             /* :397 */
+    orc_dist_matrix(m->dist_mode, p, n, m->px, m->py, m->pz, x, y, z, Kpn); /* :398 */
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < p; ++i) { /* :408-421, :444-445 */
+            double v = orc_k(&m->kern, Kpn[(size_t)j * p + i]);
+            K[(size_t)(p + j) * t + i] = v;
+            K[(size_t)i * t + (p + j)] = v;
+        }
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) { /* :424-440, :443 */
+            double v = orc_k(&m->kern, Knn[(size_t)j * n + i]);
+            if (sigma2 && i == j)
+                v += sigma2[i];
+            K[(size_t)(p + j) * t + (p + i)] = v;
+        }
+    free(Kpn);
+    free(Knn);
+    free(m->px);
+    free(m->py);
+    free(m->pz);
+    free(m->Y);
+    free(m->S2);
+    free(m->Kpp);
+    m->px = nx;
+    m->py = ny;
+    m->pz = nz;
+    m->Y = nY;
+    m->S2 = nS;
+    m->Kpp = K;
+    m->n = t;
+    factor_and_solve(m);
+    return 0;
+}
+
+/* computeTangentBasis, gp_regressor.hpp:29-44.  isApprox(UnitX,1e-3):
+ * ||N-UnitX||^2 <= 1e-6 * min(||N||^2, 1). */
+void orc_tangent_basis(const double g[3], double N[3], double Tx[3], double Ty[3])
+{
+    double nrm = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    for (int c = 0; c < 3; ++c)
+        N[c] = nrm > 0 ? g[c] / nrm : g[c];
+    double nn = N[0] * N[0] + N[1] * N[1] + N[2] * N[2];
+    double diff2 = (N[0] - 1) * (N[0] - 1) + N[1] * N[1] + N[2] * N[2];
+    double mn = nn < 1.0 ? nn : 1.0;
+    int approx_x = diff2 <= 1e-3 * 1e-3 * mn;
+    double e[3] = {0, 0, 0};
+    e[approx_x ? 1 : 0] = 1.0;
+    double dot = N[0] * e[0] + N[1] * e[1] + N[2] * e[2];
+    for (int c = 0; c < 3; ++c)
+        Tx[c] = e[c] - N[c] * dot;
+    double tn = sqrt(Tx[0] * Tx[0] + Tx[1] * Tx[1] + Tx[2] * Tx[2]);
+    if (tn > 0)
+        for (int c = 0; c < 3; ++c)
+            Tx[c] /= tn;
+    Ty[0] = N[1] * Tx[2] - N[2] * Tx[1];
+    Ty[1] = N[2] * Tx[0] - N[0] * Tx[2];
+    Ty[2] = N[0] * Tx[1] - N[1] * Tx[0];
+    tn = sqrt(Ty[0] * Ty[0] + Ty[1] * Ty[1] + Ty[2] * Ty[2]);
+    if (tn > 0)
+        for (int c = 0; c < 3; ++c)
+            Ty[c] /= tn;
+}
+
+/* F7..F10: GPRegressor::evaluate, gp_regressor.hpp:332-357 (f), :282-324 (f,v),
+ * :222-273 (f,v,grad), :194-212 (+Tx,Ty).  Any output pointer may be NULL.
+ * grad/tx/ty are nq x 3 row-major.  Variance is the diagonal of Kqq - Kqp*solve(Kpq)
+ * (:316-319), computed one query column at a time so the Nq x Nq matrix never exists
+ * (SURVEY D6); orc_evaluate_fullcov below is the literal form for small Nq.
+ * The gradient starts from zero. */
+void orc_evaluate(const orc_model *m, int nq, const double *qx, const double *qy, const double *qz, double *f,
+                  double *v, double *grad, double *tx, double *ty)
+{
+    int n = m->n;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+        double *kq = (double *)malloc(sizeof(double) * (size_t)n);
+        double *sol = (double *)malloc(sizeof(double) * (size_t)n);
+        double zero = 0.0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int i = 0; i < nq; ++i) {
+            double gx = 0, gy = 0, gz = 0, fi = 0;
+            for (int j = 0; j < n; ++j) {
+                double d;
+                orc_dist_matrix(m->dist_mode, 1, 1, qx + i, qy + i, qz + i, m->px + j, m->py + j, m->pz + j, &d);
+                if (grad || tx || ty) { /* :247 */
+                    double w = m->alpha[j] * orc_kdiff(&m->kern, d);
+                    gx += w * (qx[i] - m->px[j]);
+                    gy += w * (qy[i] - m->py[j]);
+                    gz += w * (qz[i] - m->pz[j]);
+                }
+                kq[j] = orc_k(&m->kern, d); /* :248 / :303 / :351 */
+                fi += kq[j] * m->alpha[j];  /* :252 / :305 / :353 */
+            }
+            if (f)
+                f[i] = fi;
+            if (v) {
+                double dqq;
+                orc_dist_matrix(m->dist_mode, 1, 1, qx + i, qy + i, qz + i, qx + i, qy + i, qz + i, &dqq);
+                if (m->dist_mode == ORC_DIST_DIRECT)
+                    dqq = zero;
+                double kqq = orc_k(&m->kern, dqq); /* :309-312 diagonal */
+                memcpy(sol, kq, sizeof(double) * (size_t)n);
+                orc_ldlt_solve(n, m->ldlt, m->transp, 1, sol); /* :316 */
+                double acc = 0;
+                for (int j = 0; j < n; ++j)
+                    acc += kq[j] * sol[j]; /* :318 */
+                v[i] = kqq - acc;          /* :319 */
+            }
+            if (grad) {
+                grad[3 * i + 0] = gx;
+                grad[3 * i + 1] = gy;
+                grad[3 * i + 2] = gz;
+            }
+            if (tx || ty) { /* :204-211 */
+                double g[3] = {gx, gy, gz}, N[3], Tx[3], Ty[3];
+                orc_tangent_basis(g, N, Tx, Ty);
+                for (int c = 0; c < 3; ++c) {
+                    if (tx)
+                        tx[3 * i + c] = Tx[c];
+                    if (ty)
+                        ty[3 * i + c] = Ty[c];
+                }
+            }
+        }
+        free(kq);
+        free(sol);
+    }
+}
+
+/* Literal gp_regressor.hpp:307-319: full Nq x Nq covariance, then its diagonal.
+ * Only for small nq (tests); also returns the full matrix when Vfull != NULL. */
+void orc_evaluate_fullcov(const orc_model *m, int nq, const double *qx, const double *qy, const double *qz,
+                          double *v, double *Vfull)
+{
+    int n = m->n;
+    double *Dqp = (double *)malloc(sizeof(double) * (size_t)nq * n);
+    double *Kpq = (double *)malloc(sizeof(double) * (size_t)nq * n);
+    double *Kqq = (double *)malloc(sizeof(double) * (size_t)nq * nq);
+    orc_dist_matrix(m->dist_mode, nq, n, qx, qy, qz, m->px, m->py, m->pz, Dqp);
+    for (size_t i = 0; i < (size_t)nq * n; ++i)
+        Dqp[i] = orc_k(&m->kern, Dqp[i]); /* Kqp, nq x n col-major */
+    for (int i = 0; i < nq; ++i)
+        for (int j = 0; j < n; ++j)
+            Kpq[(size_t)i * n + j] = Dqp[(size_t)j * nq + i]; /* :308 */
+    orc_dist_matrix(m->dist_mode, nq, nq, qx, qy, qz, qx, qy, qz, Kqq);
+    for (size_t i = 0; i < (size_t)nq * nq; ++i)
+        Kqq[i] = orc_k(&m->kern, Kqq[i]);
+    orc_ldlt_solve(n, m->ldlt, m->transp, nq, Kpq); /* :316 */
+    for (int c = 0; c < nq; ++c)
+        for (int r = 0; r < nq; ++r) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j)
+                acc += Dqp[(size_t)j * nq + r] * Kpq[(size_t)c * n + j];
+            double val = Kqq[(size_t)c * nq + r] - acc; /* :318 */
+            if (Vfull)
+                Vfull[(size_t)c * nq + r] = val;
+            if (r == c && v)
+                v[r] = val; /* :319 */
+        }
+    free(Dqp);
+    free(Kpq);
+    free(Kqq);
+}
+
+/* ---- accessors ---------------------------------------------------------------------------- */
+int orc_n(const orc_model *m) { return m->n; }
+double orc_R(const orc_model *m) { return m->R; }
+int orc_ldlt_info(const orc_model *m) { return m->ldlt_info; }
+void orc_get_alpha(const orc_model *m, double *out) { memcpy(out, m->alpha, sizeof(double) * (size_t)m->n); }
+void orc_get_Kpp(const orc_model *m, double *out)
+{
+    memcpy(out, m->Kpp, sizeof(double) * (size_t)m->n * m->n);
+}
+void orc_get_ldlt(const orc_model *m, double *out, int *transp)
+{
+    memcpy(out, m->ldlt, sizeof(double) * (size_t)m->n * m->n);
+    memcpy(transp, m->transp, sizeof(int) * (size_t)m->n);
+}
+int orc_get_normals(const orc_model *m, double *out)
+{
+    if (!m->normals)
+        return -1;
+    memcpy(out, m->normals, sizeof(double) * (size_t)m->n * 3);
+    return 0;
+}
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int t)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}

@@ -1,0 +1,271 @@
+"""ctypes front-end of the CPU oracle (oracle/gp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of gp_oracle.c.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+PARITY UNPINNED: the reference holds no golden vectors for this path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
+KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
+              "matern32": MATERN32, "matern52": MATERN52}
+DIST_DIRECT, DIST_EXPANSION = 0, 1
+
+
+class OrcKernel(C.Structure):
+    _fields_ = [("id", C.c_int), ("p0", C.c_double), ("p1", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (building the checker is not using it)."""
+    targets = [os.path.join(_HERE, n) for n in ("libgp_oracle.so", "libgp_oracle_omp.so")]
+    src = os.path.join(_HERE, "gp_oracle.c")
+    stale = force or any((not os.path.exists(t)) or os.path.getmtime(t) < os.path.getmtime(src) for t in targets)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+
+
+_libs = {}
+
+
+def _lib(omp=False):
+    key = bool(omp)
+    if key in _libs:
+        return _libs[key]
+    path = os.path.join(_HERE, "libgp_oracle_omp.so" if omp else "libgp_oracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int)
+    kp = C.POINTER(OrcKernel)
+    L.orc_k.restype = C.c_double
+    L.orc_k.argtypes = [kp, C.c_double]
+    L.orc_kdiff.restype = C.c_double
+    L.orc_kdiff.argtypes = [kp, C.c_double]
+    L.orc_kdiffdiff.restype = C.c_double
+    L.orc_kdiffdiff.argtypes = [kp, C.c_double]
+    L.orc_dist_matrix.restype = None
+    L.orc_dist_matrix.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp]
+    L.orc_ldlt.restype = C.c_int
+    L.orc_ldlt.argtypes = [C.c_int, dp, ip]
+    L.orc_ldlt_solve.restype = None
+    L.orc_ldlt_solve.argtypes = [C.c_int, dp, ip, C.c_int, dp]
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [kp, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int]
+    L.orc_update.restype = C.c_int
+    L.orc_update.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    L.orc_evaluate.restype = None
+    L.orc_evaluate.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.orc_evaluate_fullcov.restype = None
+    L.orc_evaluate_fullcov.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    L.orc_tangent_basis.restype = None
+    L.orc_tangent_basis.argtypes = [dp, dp, dp, dp]
+    L.orc_free.restype = None
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_n.restype = C.c_int
+    L.orc_n.argtypes = [C.c_void_p]
+    L.orc_R.restype = C.c_double
+    L.orc_R.argtypes = [C.c_void_p]
+    L.orc_ldlt_info.restype = C.c_int
+    L.orc_ldlt_info.argtypes = [C.c_void_p]
+    L.orc_get_alpha.argtypes = [C.c_void_p, dp]
+    L.orc_get_Kpp.argtypes = [C.c_void_p, dp]
+    L.orc_get_ldlt.argtypes = [C.c_void_p, dp, ip]
+    L.orc_get_normals.restype = C.c_int
+    L.orc_get_normals.argtypes = [C.c_void_p, dp]
+    L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    if omp:
+        # never oversubscribe: a GPU box exposes many more hardware threads than its CPU share
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except Exception:
+            avail = os.cpu_count() or 1
+        L.orc_set_num_threads(max(1, min(avail, int(os.environ.get("GP_ORACLE_THREADS", "8")))))
+    _libs[key] = L
+    return L
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_kernel(name, *params):
+    """make_kernel('gaussian', sigma, length) / ('thinplate', R) / ('matern52', sigma, length)."""
+    kid = KERNEL_IDS[name] if isinstance(name, str) else int(name)
+    p = list(params) + [1.0] * (2 - len(params))
+    return OrcKernel(kid, float(p[0]), float(p[1]))
+
+
+def k(kern, d, omp=False):
+    L = _lib(omp)
+    return np.array([L.orc_k(C.byref(kern), float(x)) for x in np.atleast_1d(d)])
+
+
+def kdiff(kern, d, omp=False):
+    L = _lib(omp)
+    return np.array([L.orc_kdiff(C.byref(kern), float(x)) for x in np.atleast_1d(d)])
+
+
+def kdiffdiff(kern, d):
+    L = _lib()
+    return np.array([L.orc_kdiffdiff(C.byref(kern), float(x)) for x in np.atleast_1d(d)])
+
+
+def dist_matrix(A, B, mode=DIST_DIRECT):
+    """A: (m,3), B: (n,3) -> (m,n) distances (gp_regressor.hpp:548-557)."""
+    L = _lib()
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    m, n = len(A), len(B)
+    D = np.empty((n, m), dtype=np.float64)  # column-major m x n
+    ax, pax = _d(A[:, 0]); ay, pay = _d(A[:, 1]); az, paz = _d(A[:, 2])
+    bx, pbx = _d(B[:, 0]); by, pby = _d(B[:, 1]); bz, pbz = _d(B[:, 2])
+    L.orc_dist_matrix(mode, m, n, pax, pay, paz, pbx, pby, pbz, D.ctypes.data_as(C.POINTER(C.c_double)))
+    return D.T.copy()
+
+
+def ldlt(A):
+    """Eigen-style LDLT of symmetric A. Returns (packed lower/diag matrix, transpositions, info)."""
+    L = _lib()
+    A = np.array(A, dtype=np.float64, order="F")
+    n = A.shape[0]
+    t = np.zeros(n, dtype=np.int32)
+    info = L.orc_ldlt(n, A.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_int)))
+    return A, t, info
+
+
+def ldlt_solve(F, t, b):
+    L = _lib()
+    F = np.asfortranarray(F, dtype=np.float64)
+    b = np.array(b, dtype=np.float64)
+    one = b.ndim == 1
+    B = np.array(b.reshape(len(b), -1), dtype=np.float64, order="F")
+    t = np.ascontiguousarray(t, dtype=np.int32)
+    L.orc_ldlt_solve(F.shape[0], F.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_int)),
+                     B.shape[1], B.ctypes.data_as(C.POINTER(C.c_double)))
+    return B[:, 0].copy() if one else np.ascontiguousarray(B)
+
+
+def tangent_basis(g):
+    L = _lib()
+    g, pg = _d(g)
+    N = np.zeros(3); Tx = np.zeros(3); Ty = np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    L.orc_tangent_basis(pg, N.ctypes.data_as(dp), Tx.ctypes.data_as(dp), Ty.ctypes.data_as(dp))
+    return N, Tx, Ty
+
+
+class Model:
+    """gp_regression::Model + GPRegressor<Cov>::{create,evaluate,update} (oracle side)."""
+
+    def __init__(self, kern, x, y, z, label, sigma2=None, with_normals=False, dist_mode=DIST_DIRECT, omp=False):
+        self._L = _lib(omp)
+        self.kern = kern
+        x, px = _d(x); y, py = _d(y); z, pz = _d(z); lab, pl = _d(label)
+        if sigma2 is not None and len(sigma2):
+            s2, ps = _d(sigma2)
+        else:
+            ps = None
+        self._h = self._L.orc_create(C.byref(kern), len(x), px, py, pz, pl, ps, int(with_normals), int(dist_mode))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return self._L.orc_n(self._h)
+
+    @property
+    def R(self):
+        return self._L.orc_R(self._h)
+
+    @property
+    def ldlt_info(self):
+        return self._L.orc_ldlt_info(self._h)
+
+    @property
+    def alpha(self):
+        a = np.empty(self.n)
+        self._L.orc_get_alpha(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return a
+
+    @property
+    def Kpp(self):
+        n = self.n
+        a = np.empty((n, n))
+        self._L.orc_get_Kpp(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return a.T.copy()
+
+    def ldlt(self):
+        n = self.n
+        a = np.empty((n, n))
+        t = np.empty(n, dtype=np.int32)
+        self._L.orc_get_ldlt(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_int)))
+        return a.T.copy(), t
+
+    @property
+    def normals(self):
+        a = np.empty((self.n, 3))
+        rc = self._L.orc_get_normals(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return a if rc == 0 else None
+
+    def update(self, x, y, z, label, sigma2=None):
+        x, px = _d(x); y, py = _d(y); z, pz = _d(z); lab, pl = _d(label)
+        if sigma2 is not None and len(sigma2):
+            s2, ps = _d(sigma2)
+        else:
+            ps = None
+        return self._L.orc_update(self._h, len(x), px, py, pz, pl, ps)
+
+    def evaluate(self, qx, qy, qz, want_v=False, want_grad=False, want_basis=False):
+        """Returns dict(f=..., v=..., grad=..., tx=..., ty=...)."""
+        qx, px = _d(qx); qy, py = _d(qy); qz, pz = _d(qz)
+        nq = len(qx)
+        dp = C.POINTER(C.c_double)
+        f = np.empty(nq)
+        out = {"f": f}
+        v = np.empty(nq) if want_v else None
+        g = np.empty((nq, 3)) if (want_grad or want_basis) else None
+        tx = np.empty((nq, 3)) if want_basis else None
+        ty = np.empty((nq, 3)) if want_basis else None
+        ptr = lambda a: a.ctypes.data_as(dp) if a is not None else None
+        self._L.orc_evaluate(self._h, nq, px, py, pz, ptr(f), ptr(v), ptr(g), ptr(tx), ptr(ty))
+        if v is not None:
+            out["v"] = v
+        if g is not None:
+            out["grad"] = g
+        if tx is not None:
+            out["tx"] = tx
+            out["ty"] = ty
+        return out
+
+    def evaluate_fullcov(self, qx, qy, qz):
+        qx, px = _d(qx); qy, py = _d(qy); qz, pz = _d(qz)
+        nq = len(qx)
+        dp = C.POINTER(C.c_double)
+        v = np.empty(nq)
+        V = np.empty((nq, nq))
+        self._L.orc_evaluate_fullcov(self._h, nq, px, py, pz, v.ctypes.data_as(dp), V.ctypes.data_as(dp))
+        return v, V.T.copy()
+
+
+def num_threads(omp=True):
+    return _lib(omp).orc_num_threads()
+
+
+def set_num_threads(t):
+    _lib(True).orc_set_num_threads(int(t))
