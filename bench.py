@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the GP-regression hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the hot path over one batch of synthetic input:
+    train   : gpx_model_create  (kbuild -> blocked LDL^T on MFMA -> alpha + fp64-residual refinement ->
+              inverse factor)                         N_train = 16384, fp32, Matern-5/2(1,1), sigma2 = 0.1
+    predict : gpx_model_evaluate_device (mean + variance) over N_query = 2^20 lattice points already
+              resident in HBM (the x < 0 half of the 128^3 grid on [-1.01, 1.01]^3).
+Metric (BASELINE.json): GP train+predict time (ms per step) and query-points/s (value).
+
+Multi-GPU (weak scaling, the north star's "independent GP models"): every rank owns one GPU and one
+model of the same shape (its own jitter seed) and its own 2^20 queries; no data-path collective.  value =
+queries of all ranks / max-over-ranks time.  `--mode shard` instead runs ONE model whose query grid is
+x-slab sharded (strong scaling): rank 0 factorises and broadcasts the read-only state (points, alpha, D,
+inverse factor) with RCCL (torch.distributed broadcast over xGMI).
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_TRAIN = 16384
+GRID = 128
+NQ = 1 << 20
+KERNEL = ("matern52", (1.0, 1.0))
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F64_MFMA_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["independent", "shard"], default="independent")
+    ap.add_argument("--n-train", type=int, default=N_TRAIN)
+    ap.add_argument("--nq", type=int, default=NQ)
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--kernel", default=KERNEL[0])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mean-only", action="store_true", help="diagnostic: skip the variance")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_train, nq, kernel_name, kernel_par):
+    """Oracle (CPU fp64 port of the reference algorithm) on a bounded sample, 1 core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    orc = importlib.import_module("gp_oracle")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    ns, nqs = 3072, 1024
+    x, y, z, lab, s2 = ds.fibonacci_training_set(ns)
+    qx, qy, qz = ds.query_grid(11)
+    qx, qy, qz = qx[:nqs], qy[:nqs], qz[:nqs]
+    kern = orc.make_kernel(kernel_name, *kernel_par)
+    t0 = time.perf_counter()
+    m = orc.Model(kern, x, y, z, lab, s2, omp=False)
+    t1 = time.perf_counter()
+    m.evaluate(qx, qy, qz, want_v=True)
+    t2 = time.perf_counter()
+    t_create, t_q = t1 - t0, (t2 - t1) / nqs
+    # cost model of the reference algorithm: create ~ N^3 (unblocked LDL^T), evaluate ~ N^2 per query
+    t_full = t_create * (n_train / ns) ** 3 + t_q * (n_train / ns) ** 2 * nq
+    return {
+        "value": nq / t_full, "unit": "query-points/s", "cores": 1, "kind": "port",
+        "sample": ("oracle/gp_oracle.c (fp64 restatement of gp_regressor.hpp, unblocked LDL^T, per-query solve) "
+                   "timed at N_train=%d (create %.2fs) and %d queries (%.2f ms/query), scaled by N^3 / N^2 to "
+                   "N_train=%d, N_query=%d -> %.0f s per step" % (ns, t_create, nqs, t_q * 1e3, n_train, nq, t_full)),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not under torch.distributed.run: start it as a child (nothing has touched the GPU yet)
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    sharding = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    gpx.lib()  # fail loudly if the HIP extension is missing
+    if not torch.cuda.is_available() or gpx.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (libgpx has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    prec = gpx.F64 if args.precision == "f64" else gpx.F32
+    kpar = (4.0,) if args.kernel == "thinplate" else (1.0, 1.0)
+    kern = gpx.make_kernel(args.kernel, *kpar)
+    n_train, nq = args.n_train, args.nq
+    shard = args.mode == "shard" and world > 1
+
+    # ---- synthetic inputs (SURVEY.md 8d recipe); queries resident in HBM before the timed region ----
+    seed = 20151106 + (0 if shard else rank)
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n_train, seed=seed)
+    t = torch.linspace(-1.01, 1.01, GRID, dtype=torch.float64, device=dev)
+    if shard:
+        # x-slab of the first nq lattice points (strong scaling: total work fixed)
+        lo, hi = sharding.slab_range(nq, rank, world)
+    else:
+        lo, hi = 0, nq
+    idx = torch.arange(lo, hi, device=dev, dtype=torch.int64)
+    qx = t[(idx // (GRID * GRID)) % GRID].contiguous()
+    qy = t[(idx // GRID) % GRID].contiguous()
+    qz = t[idx % GRID].contiguous()
+    nq_local = int(idx.numel())
+    f = torch.empty(nq_local, dtype=torch.float64, device=dev)
+    v = torch.empty(nq_local, dtype=torch.float64, device=dev)
+    want_v = not args.mean_only
+
+    model = [None]
+    stats_acc = []
+
+    def step():
+        if model[0] is not None:
+            model[0].close()
+        if shard:
+            if rank == 0:
+                m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank)
+            else:
+                m = gpx.Model.shell(kern, n_train, precision=prec, device=local_rank)
+            bufs = [sharding.device_blob_as_tensor(torch, *m.state_blob(part), dev)
+                    for part in ((0, 1) if want_v else (0,))]
+            sharding.broadcast_state(dist, bufs, src=0)
+            torch.cuda.synchronize()
+            if rank != 0:
+                m.commit(with_variance=want_v)
+        else:
+            m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank)
+        model[0] = m
+        m.evaluate_device(nq_local, qx.data_ptr(), qy.data_ptr(), qz.data_ptr(), f.data_ptr(),
+                          v.data_ptr() if want_v else None)
+        m.sync()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        stats_acc.append(model[0].stats)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_q = nq if shard else nq * world
+    value = total_q / (elapsed / args.steps)
+
+    if rank == 0:
+        st = {k: float(np.mean([s[k] for s in stats_acc])) for k in stats_acc[0]}
+        peak = PEAK_F64_MFMA_TFLOPS if prec == gpx.F64 else PEAK_F32_MFMA_TFLOPS
+        roof = None
+        if want_v and st["var_gemm_launches"] > 0:
+            launches = st["var_gemm_launches"]
+            avg_ms = st["t_var_gemm_ms"] / launches
+            q_per_launch = nq_local / launches
+            flops_per_launch = float(n_train) ** 2 * q_per_launch  # N^2 flop per query
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<%s,NT,COLSQ> (predict_var)" % args.precision,
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches_per_step": launches,
+                    "algorithmic_flops_per_launch": flops_per_launch}
+        out = {
+            "metric": "GP train+predict query-points/s (N_train=%d, N_query=%d)" % (n_train, nq),
+            "value": value, "unit": "query-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "C3-headline: N_train=%d %s %s(%s) sigma2=0.1, train (kbuild+LDL^T+alpha+inverse "
+                                   "factor) + predict mean%s over N_query=%d lattice points of the 128^3 grid per %s"
+                                   % (n_train, args.precision, args.kernel, ",".join(str(p) for p in kpar),
+                                      "+variance" if want_v else "", nq, "job" if shard else "GPU"),
+                       "mode": args.mode, "n_train": n_train, "n_query": nq, "parallelism": "%s x%d" % (args.mode, world)},
+            "stages_ms": {k: st[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_factor_gemm_ms", "t_solve_ms",
+                                             "t_inverse_ms", "t_mean_ms", "t_var_ms", "t_var_gemm_ms")},
+            "alpha_residual": st["alpha_residual"],
+        }
+        if roof:
+            out["roofline"] = roof
+            fg = st["factor_gemm_launches"]
+            if fg > 0:
+                out["roofline_factor"] = {
+                    "bound": "mfma", "kernel": "gemm_kernel<%s,NT,STORE> (LDL^T trailing update)" % args.precision,
+                    "achieved": (n_train ** 3 / 3.0) / (st["t_factor_gemm_ms"] * 1e-3) / 1e12, "peak": peak,
+                    "unit": "TFLOP/s", "frac": (n_train ** 3 / 3.0) / (st["t_factor_gemm_ms"] * 1e-3) / 1e12 / peak}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n_train, nq, args.kernel, kpar)
+        print(json.dumps(out), flush=True)
+    if model[0] is not None:
+        model[0].close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,21 @@
+// gp_regression::Laplace -- interface of the reference's kernels/laplace.hpp:31-76.
+// 2*sigma * exp(-d / length) (:37-42; the amplitude 2*sigma is the reference's),
+// computediff = -(1/length) * compute (:44-49), computediffdiff = 0.
+#ifndef GPX_SHIM_LAPLACE_HPP
+#define GPX_SHIM_LAPLACE_HPP
+#include <cmath>
+namespace gp_regression
+{
+class Laplace
+{
+public:
+    const double sigma_;
+    const double length_;
+    Laplace() : sigma_(1.0), length_(1.0) {}
+    Laplace(double sigma, double length) : sigma_(sigma), length_(length) {}
+    double compute(double &d) const { return 2.0 * sigma_ * std::exp(-d / length_); }
+    double computediff(double &d) const { return -compute(d) / length_; }
+    double computediffdiff(double &) const { return 0.0; }
+};
+}  // namespace gp_regression
+#endif

@@ -1,0 +1,50 @@
+"""Host logic of the multi-GPU path (one process per GPU, torch.distributed; backend "nccl" = RCCL over
+xGMI on the GPU node, "gloo" in the CPU tests).
+
+Two partitions:
+  * independent models: rank r owns model r and its own queries -- no data-path collective at all;
+  * one model, sharded query grid: contiguous slabs of the query list per rank; ONE exchange step, the
+    broadcast of the factorising rank's read-only state (points, alpha, 1/D [, inverse factor]); outputs
+    are disjoint slabs, gathered only if the caller wants them in one place.
+"""
+
+
+def slab_range(nq, rank, world):
+    """Contiguous slab [lo, hi) of nq queries for `rank` (remainder spread over the low ranks)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(int(nq), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def broadcast_state(dist, buffers, src=0):
+    """Broadcast every tensor of `buffers` from `src` in place (the factor / state blob parts)."""
+    for b in buffers:
+        dist.broadcast(b, src=src)
+
+
+def device_blob_as_tensor(torch, ptr, nbytes, device):
+    """Zero-copy uint8 view of a device allocation owned by libgpx (gpx_model_state_blob)."""
+
+    class _Blob:
+        pass
+
+    b = _Blob()
+    b.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                  "version": 3, "strides": None}
+    return torch.as_tensor(b, device=device)
+
+
+def gather_slabs(dist, torch, local, nq, rank, world, dst=0):
+    """Gather the per-rank output slabs (1-D tensors) on `dst` in query order; returns None elsewhere."""
+    sizes = [slab_range(nq, r, world)[1] - slab_range(nq, r, world)[0] for r in range(world)]
+    width = max(sizes)
+    pad = torch.zeros(width, dtype=local.dtype, device=local.device)
+    pad[: local.numel()] = local
+    bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, gather_list=bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: sizes[r]] for r in range(world)])

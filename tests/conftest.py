@@ -1,0 +1,66 @@
+"""pytest configuration.  `-m "not gpu"` (oracle vs golden vectors, host logic, C-ABI exports) runs
+anywhere; `-m gpu` (parity proper, through the C ABI of libgpx.so) needs an MI355X."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PKG = "gaussian-object-modelling_amd"
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+KERNEL_CASES = {  # golden key -> (kernel name, params)
+    "gaussian": ("gaussian", (1.0, 1.0)), "laplace": ("laplace", (1.0, 1.0)),
+    "thinplate2": ("thinplate", (2.0,)), "thinplate4": ("thinplate", (4.0,)),
+    "matern32": ("matern32", (1.0, 1.0)), "matern52": ("matern52", (1.0, 1.0)),
+}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import gp_oracle
+    gp_oracle.build()
+    return gp_oracle
+
+
+@pytest.fixture(scope="session")
+def ds():
+    return importlib.import_module(PKG + ".datasets")
+
+
+@pytest.fixture(scope="session")
+def gpx():
+    """The ctypes binding; building is __graft_entry__.build()'s job, loading must succeed."""
+    mod = importlib.import_module(PKG + ".gpx")
+    if not os.path.exists(mod.LIB_PATH):
+        ge = importlib.import_module("__graft_entry__")
+        ge.build()
+    mod.lib()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def gpu(gpx):
+    if gpx.device_count() < 1:
+        pytest.skip("no HIP device visible")
+    return gpx
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN_DIR, "gp_golden.npz"))
+
+
+def nerr(a, b):
+    """norm-wise relative error max|a-b| / max|b| (f crosses zero on the surface)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))

@@ -1,0 +1,283 @@
+"""GPU parity suite: the HIP path, called through the C ABI of libgpx.so, against the CPU oracle on the
+same inputs and against the committed golden vectors.  Tolerances (norm-wise, max|a-b| / max|b|, SURVEY
+8d): 1e-10 for fp64 compute, 1e-5 for fp32 compute (north star: "within 1e-5 rel. of the CPU
+reference")."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, KERNEL_CASES, nerr
+
+pytestmark = pytest.mark.gpu
+TOL = {0: 1e-5, 1: 1e-10}  # gpx.F32, gpx.F64
+
+
+def _queries(ds, x, y, z, g=7):
+    qx, qy, qz = ds.query_grid(g)
+    # plus points ON training points and one far outside
+    return (np.concatenate([qx, x[:9], [3.0]]), np.concatenate([qy, y[:9], [0.1]]),
+            np.concatenate([qz, z[:9], [-2.0]]))
+
+
+def _check(gm, om, q, prec, basis=True):
+    qx, qy, qz = q
+    ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True, want_basis=True)
+    out = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True, want_basis=True)
+    tol = TOL[prec]
+    assert nerr(gm.alpha, om.alpha) < tol
+    for key in ("f", "v", "grad"):
+        assert nerr(out[key], ref[key]) < tol, key
+    if basis:
+        # the tangent basis normalises the gradient: compare where the gradient is not tiny
+        gn = np.linalg.norm(ref["grad"], axis=1)
+        ok = gn > 1e-2 * gn.max()
+        for key in ("tx", "ty"):
+            assert np.max(np.abs(out[key][ok] - ref[key][ok])) < tol * 1e3, key
+    # the three evaluate overloads agree with each other
+    f_only = gm.evaluate(qx, qy, qz)["f"]
+    np.testing.assert_array_equal(f_only, gm.evaluate(qx, qy, qz, want_v=True)["f"])
+    return out
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("kkey", list(KERNEL_CASES))
+def test_mugd_node_training_set(gpu, orc, ds, golden, kkey, prec):
+    """C1: resources/mugD.pcd prepared as the node does (N = 277), all six kernel settings, incl. the
+    node's own indefinite ThinPlate(2.0) (src/gp_node.cpp:919)."""
+    kn, par = KERNEL_CASES[kkey]
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+    _check(gm, om, _queries(ds, x, y, z), prec)
+    assert gm.R == pytest.approx(om.R, rel=1e-14)
+    assert gm.stats["n_negative_pivots"] == int(golden["mugD/%s/n_negative" % kkey])
+    # golden vectors (independent NumPy/SciPy)
+    Q = golden["mugD/Q"]
+    out = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True)
+    pre = "mugD/%s/" % kkey
+    tol = TOL[prec]
+    assert nerr(gm.alpha, golden[pre + "alpha"]) < max(tol, 1e-9)
+    for key in ("f", "v", "grad"):
+        assert nerr(out[key], golden[pre + key]) < max(tol, 1e-9), key
+    gm.close()
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("n", [16, 128, 129, 256, 257, 600, 1500])
+def test_ragged_sizes(gpu, orc, ds, n, prec):
+    """Sizes around the 128 / 256 tile and panel edges (padding with an identity block)."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    for kn, par in (("matern52", (1, 1)), ("thinplate", (4.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+        gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+        _check(gm, om, _queries(ds, x, y, z, g=5), prec, basis=False)
+        gm.close()
+
+
+def test_single_training_point(gpu, orc):
+    for prec in (1, 0):
+        gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), [0.2], [0.0], [-0.1], [1.0], [0.1], precision=prec)
+        om = orc.Model(orc.make_kernel("gaussian", 1, 1), [0.2], [0.0], [-0.1], [1.0], [0.1])
+        q = (np.array([0.2, 1.0]), np.array([0.0, 0.5]), np.array([-0.1, 0.0]))
+        ref = om.evaluate(*q, want_v=True)
+        out = gm.evaluate(*q, want_v=True)
+        assert nerr(out["f"], ref["f"]) < TOL[prec] and nerr(out["v"], ref["v"]) < TOL[prec]
+        assert gm.R == 0.0 and gm.n == 1
+        gm.close()
+
+
+def test_empty_sigma2_interpolates(gpu, orc, golden):
+    """Data::sigma2 empty => no diagonal noise (gp_regressor.hpp:154): f(p_i) = y_i, v(p_i) = 0."""
+    x, y, z, lab = (golden["sphere64/" + k] for k in ("x", "y", "z", "label"))
+    for kn, par in (("gaussian", (1, 1)), ("thinplate", (4.0,))):
+        gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, None, precision=gpu.F64)
+        om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, None)
+        out = gm.evaluate(x, y, z, want_v=True)
+        assert np.max(np.abs(out["f"] - lab)) < 1e-8
+        assert np.max(np.abs(out["v"])) < 1e-7 * float(orc.k(orc.make_kernel(kn, *par), 0.0)[0])
+        assert nerr(gm.alpha, om.alpha) < 1e-9
+        np.testing.assert_array_equal(gm.S2, np.zeros(64))
+        gm.close()
+
+
+def test_nonuniform_noise_uses_eigen_pivot_order(gpu, orc, golden):
+    """Per-point sigma2 makes the diagonal non-uniform: the Eigen pivot rule permutes the points."""
+    x, y, z, lab, s2 = (golden["sphere64/" + k].copy() for k in ("x", "y", "z", "label", "sigma2"))
+    s2[::3] = 0.5
+    s2[5] = 2.0
+    om = orc.Model(orc.make_kernel("matern32", 1, 1), x, y, z, lab, s2)
+    for prec in (1, 0):
+        gm = gpu.Model(gpu.make_kernel("matern32", 1, 1), x, y, z, lab, s2, precision=prec)
+        perm = gm.perm
+        assert perm[0] == 5 and sorted(perm) == list(range(64))
+        # D of P K P^T = L D L^T in Eigen's order
+        F, _ = om.ldlt()
+        assert nerr(gm.D, np.diag(F)) < (1e-9 if prec else 1e-4)
+        Q = golden["sphere64/Q"]
+        ref = om.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True)
+        out = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True)
+        assert nerr(out["f"], ref["f"]) < TOL[prec] and nerr(out["v"], ref["v"]) < TOL[prec]
+        gm.close()
+
+
+def test_normals_create_true(gpu, orc, golden):
+    """create<true>: Model::N, gp_regressor.hpp:166-181 (zero-initialised accumulation)."""
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    for kn, par in (("gaussian", (1, 1)), ("thinplate", (2.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2, with_normals=True)
+        for prec in (1, 0):
+            gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec, with_normals=True)
+            assert nerr(gm.normals, om.normals) < TOL[prec] * 10
+            gm.close()
+    gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2)
+    with pytest.raises(gpu.GpxError):
+        _ = gm.normals
+    gm.close()
+
+
+def test_update_appends_and_refactors(gpu, orc, ds, golden):
+    """GPRegressor::update, gp_regressor.hpp:367-479."""
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    kern = ("thinplate", (2.0,))
+    for prec in (1, 0):
+        gm = gpu.Model(gpu.make_kernel(*kern[:1], *kern[1]), x[:250], y[:250], z[:250], lab[:250], s2[:250],
+                       precision=prec)
+        R0 = gm.R
+        gm.evaluate(x[:4], y[:4], z[:4], want_v=True)  # builds the inverse factor; update must drop it
+        gm.update(x[250:], y[250:], z[250:], lab[250:], s2[250:])
+        om = orc.Model(orc.make_kernel(*kern[:1], *kern[1]), x, y, z, lab, s2)
+        assert gm.n == 277 and gm.R == R0
+        _check(gm, om, _queries(ds, x, y, z, g=5), prec, basis=False)
+        np.testing.assert_array_equal(gm.P, np.stack([x, y, z], 1))
+        np.testing.assert_array_equal(gm.Y, lab)
+        gm.close()
+
+
+def test_kpp_accessor(gpu, orc, golden):
+    x, y, z, lab, s2 = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    om = orc.Model(orc.make_kernel("laplace", 1, 1), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel("laplace", 1, 1), x, y, z, lab, s2, precision=gpu.F64)
+    assert nerr(gm.Kpp, om.Kpp) < 1e-14
+    gm.close()
+
+
+def test_variance_batching_and_large_query_sets(gpu, orc, ds):
+    """Queries that straddle variance batches (query_batch) and the 128-query tile, nq >> N."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(300)
+    om = orc.Model(orc.make_kernel("matern52", 1, 1), x, y, z, lab, s2)
+    rng = np.random.default_rng(5)
+    nq = 3 * 256 + 37
+    q = rng.uniform(-1.2, 1.2, size=(3, nq))
+    ref = om.evaluate(q[0], q[1], q[2], want_v=True, want_grad=True)
+    for prec in (1, 0):
+        for qb in (0, 256, 128):
+            gm = gpu.Model(gpu.make_kernel("matern52", 1, 1), x, y, z, lab, s2, precision=prec, query_batch=qb)
+            out = gm.evaluate(q[0], q[1], q[2], want_v=True, want_grad=True)
+            for key in ("f", "v", "grad"):
+                assert nerr(out[key], ref[key]) < TOL[prec], (key, qb)
+            # a single query, the node's call pattern (src/gp_node.cpp:1069-1074)
+            one = gm.evaluate(q[0][:1], q[1][:1], q[2][:1], want_v=True)
+            assert abs(one["f"][0] - out["f"][0]) <= 1e-12 * (1 + abs(out["f"][0])) if prec else True
+            assert abs(one["v"][0] - ref["v"][0]) < TOL[prec] * np.max(np.abs(ref["v"]))
+            gm.close()
+
+
+def test_concurrent_single_point_evaluate(gpu, orc, ds):
+    """fakeDeterministicSampling: hundreds of host threads evaluate ONE point each on the same const
+    model (src/gp_node.cpp:1027-1038); the call must be re-entrant."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(200)
+    gm = gpu.Model(gpu.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=gpu.F64)
+    om = orc.Model(orc.make_kernel("thinplate", 2.0), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(6)
+    ref = om.evaluate(qx, qy, qz, want_v=True)
+    f = np.zeros(len(qx))
+    v = np.zeros(len(qx))
+    errs = []
+
+    def work(i):
+        try:
+            o = gm.evaluate(qx[i:i + 1], qy[i:i + 1], qz[i:i + 1], want_v=True)
+            f[i], v[i] = o["f"][0], o["v"][0]
+        except Exception as e:  # noqa
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(qx))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    assert nerr(f, ref["f"]) < 1e-10 and nerr(v, ref["v"]) < 1e-10
+    gm.close()
+
+
+def test_device_resident_evaluate(gpu, orc, ds):
+    """gpx_model_evaluate_device: inputs/outputs stay in HBM (torch only provides the memory)."""
+    torch = pytest.importorskip("torch")
+    x, y, z, lab, s2 = ds.fibonacci_training_set(400)
+    gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, precision=gpu.F64, prepare_variance=True)
+    om = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(8)
+    dq = [torch.from_numpy(a).cuda() for a in (qx, qy, qz)]
+    nq = len(qx)
+    df, dv = torch.empty(nq, dtype=torch.float64, device="cuda"), torch.empty(nq, dtype=torch.float64, device="cuda")
+    dg = torch.empty(nq, 3, dtype=torch.float64, device="cuda")
+    gm.evaluate_device(nq, dq[0].data_ptr(), dq[1].data_ptr(), dq[2].data_ptr(), df.data_ptr(), dv.data_ptr(),
+                       dg.data_ptr())
+    gm.sync()
+    ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    assert nerr(df.cpu().numpy(), ref["f"]) < 1e-10
+    assert nerr(dv.cpu().numpy(), ref["v"]) < 1e-10
+    assert nerr(dg.cpu().numpy(), ref["grad"]) < 1e-10
+    st = gm.stats
+    assert st["t_mean_ms"] > 0 and st["t_var_ms"] > 0 and st["var_gemm_launches"] == 1
+    gm.close()
+
+
+def test_shell_broadcast_commit_roundtrip(gpu, orc, ds):
+    """Sharded-grid path on one GPU: copy the state blobs of a factorised model into a shell
+    (stand-in for the RCCL broadcast), commit, and evaluate."""
+    torch = pytest.importorskip("torch")
+    import importlib
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    x, y, z, lab, s2 = ds.fibonacci_training_set(300)
+    kern = gpu.make_kernel("matern52", 1, 1)
+    for prec in (1, 0):
+        src = gpu.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=True)
+        dst = gpu.Model.shell(kern, 300, precision=prec)
+        with pytest.raises(gpu.GpxError):
+            dst.evaluate([0.0], [0.0], [0.0])  # not committed yet
+        for part in (0, 1):
+            a = sh.device_blob_as_tensor(torch, *src.state_blob(part), "cuda")
+            b = sh.device_blob_as_tensor(torch, *dst.state_blob(part), "cuda")
+            assert a.numel() == b.numel()
+            b.copy_(a)
+        torch.cuda.synchronize()
+        dst.commit(with_variance=True)
+        qx, qy, qz = ds.query_grid(6)
+        o1 = src.evaluate(qx, qy, qz, want_v=True)
+        o2 = dst.evaluate(qx, qy, qz, want_v=True)
+        np.testing.assert_array_equal(o1["f"], o2["f"])
+        np.testing.assert_array_equal(o1["v"], o2["v"])
+        src.close()
+        dst.close()
+
+
+def test_error_codes_on_device(gpu):
+    k = gpu.make_kernel("gaussian", 1, 1)
+    m = gpu.Model(k, [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.1, 0.1, 0.1])
+    with pytest.raises(gpu.GpxError) as ei:
+        m.evaluate([], [], [])
+    assert ei.value.code == gpu.E_EMPTY and ei.value.message == "All input data is empty!"
+    with pytest.raises(gpu.GpxError) as ei:
+        m.evaluate([0.0], [0.0], [0.0], label=[1.0])
+    assert ei.value.code == gpu.E_LABELED_QUERY
+    m.close()
+    # exactly singular: two coincident points without noise
+    with pytest.raises(gpu.GpxError) as ei:
+        gpu.Model(gpu.make_kernel("thinplate", 1.0), [0.0, 0.0], [0.0, 0.0], [0.0, 0.0], [1.0, 1.0], None,
+                  precision=gpu.F64)
+    assert ei.value.code == gpu.E_SINGULAR

@@ -1,0 +1,66 @@
+"""GPU suite at BASELINE sizes.  The oracle is too slow there (N^3 on one core), so parity is anchored
+(a) against the oracle on a sub-sample of the queries at C2 (N = 4096, fp64), and (b) at N = 16384 by
+size-independent properties: the interpolation identity f(p_i) = y_i - sigma2_i alpha_i, linearity of
+alpha in the labels, 0 <= v <= k(0), and agreement of the fp32 pipeline with the fp64 pipeline."""
+import numpy as np
+import pytest
+
+from conftest import nerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_n4096_fp64_gaussian_against_oracle(gpu, orc, ds):
+    """BASELINE config 2: N = 4096 fp64, Gaussian(1,1), 64^3 grid (oracle on every 1031st grid point)."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(4096)
+    gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, precision=gpu.F64)
+    qx, qy, qz = ds.query_grid(64)
+    out = gm.evaluate(qx, qy, qz, want_v=True)
+    assert out["f"].shape == (64 ** 3,)
+    om = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, omp=True)
+    sel = np.arange(0, 64 ** 3, 1031)
+    ref = om.evaluate(qx[sel], qy[sel], qz[sel], want_v=True)
+    assert nerr(gm.alpha, om.alpha) < 1e-10
+    assert nerr(out["f"][sel], ref["f"]) < 1e-10
+    assert nerr(out["v"][sel], ref["v"]) < 1e-10
+    # fp32 pipeline on the same model, same sub-sample
+    g32 = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, precision=gpu.F32)
+    o32 = g32.evaluate(qx[sel], qy[sel], qz[sel], want_v=True)
+    assert nerr(g32.alpha, om.alpha) < 1e-5
+    assert nerr(o32["f"], ref["f"]) < 1e-5 and nerr(o32["v"], ref["v"]) < 1e-5
+    gm.close()
+    g32.close()
+
+
+@pytest.mark.parametrize("kn,par", [("matern52", (1.0, 1.0)), ("thinplate", (4.0,))])
+def test_n16384_properties(gpu, ds, kn, par):
+    """BASELINE configs 3/4 sizes (N = 16384 fp32; Matern-5/2 and thin-plate R = 4)."""
+    n = 16384
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel(kn, *par)
+    k0 = 1.0 if kn != "thinplate" else par[0] ** 3
+    g32 = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32)
+    st = g32.stats
+    assert st["n_negative_pivots"] == 0 and st["alpha_residual"] < 1e-6
+    a32 = g32.alpha
+    # (1) identity at the training points: k_i = K e_i - sigma2_i e_i  =>  f(p_i) = y_i - sigma2_i alpha_i
+    sel = np.arange(0, n, 7)
+    f_tr = g32.evaluate(x[sel], y[sel], z[sel])["f"]
+    assert np.max(np.abs(f_tr - (lab[sel] - s2[sel] * a32[sel]))) < 1e-5 * max(1.0, np.max(np.abs(a32)) * 0.1)
+    # (2) fp32 pipeline vs fp64 pipeline (itself checked against the oracle at smaller N)
+    g64 = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F64)
+    assert nerr(a32, g64.alpha) < 1e-5
+    qx, qy, qz = ds.query_grid(16)
+    o32 = g32.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    o64 = g64.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    for key in ("f", "v", "grad"):
+        assert nerr(o32[key], o64[key]) < 1e-5, key
+    # (3) variance bounds for an SPD prior + noise: 0 <= v <= k(0)
+    assert o64["v"].min() > -1e-9 * k0 and o64["v"].max() <= k0 * (1 + 1e-12)
+    # (4) linearity of alpha in the labels
+    lab2 = np.cos(3 * x) + 0.5 * z
+    ga = gpu.Model(kern, x, y, z, lab2, s2, precision=gpu.F64)
+    gb = gpu.Model(kern, x, y, z, lab + 2 * lab2, s2, precision=gpu.F64)
+    assert nerr(gb.alpha, g64.alpha + 2 * ga.alpha) < 1e-9
+    for m in (g32, g64, ga, gb):
+        m.close()

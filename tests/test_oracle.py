@@ -1,0 +1,177 @@
+"""CPU suite, part 1: pin the oracle (oracle/gp_oracle.c) with analytic known answers, GP identities
+and the independent NumPy/SciPy golden vectors (tests/golden/make_golden.py).  PARITY UNPINNED against
+the reference itself: its tests hold no values."""
+import numpy as np
+import pytest
+
+from conftest import KERNEL_CASES, nerr
+
+
+def test_kernel_known_answers(orc):
+    # thin_plate.hpp:12-20: k(0) = R^3, k(R) = 0, computediff(R) = 0
+    tp = orc.make_kernel("thinplate", 2.0)
+    assert orc.k(tp, 0.0)[0] == 8.0
+    assert orc.k(tp, 2.0)[0] == 0.0
+    assert orc.kdiff(tp, 2.0)[0] == 0.0
+    assert orc.kdiff(tp, 0.5)[0] == -6 * 1.5
+    # gaussian.hpp:15-27: sigma^2 exp(-d/l^2) on the UN-squared distance
+    g = orc.make_kernel("gaussian", 1.5, 0.5)
+    assert orc.k(g, 0.0)[0] == 2.25
+    assert orc.k(g, 0.25)[0] == pytest.approx(2.25 * np.exp(-1.0), rel=1e-15)
+    assert orc.kdiff(g, 0.25)[0] == pytest.approx(-4 * 2.25 * np.exp(-1.0), rel=1e-15)
+    # laplace.hpp:37-49: 2 sigma exp(-d/l)
+    lp = orc.make_kernel("laplace", 1.5, 0.5)
+    assert orc.k(lp, 0.0)[0] == 3.0
+    assert orc.kdiff(lp, 0.5)[0] == pytest.approx(-2 * 3.0 * np.exp(-1.0), rel=1e-15)
+    # Matern closed forms (matlab_src/test_gp_regression_3Dsurf.m:117-123)
+    d = np.array([0.0, 0.1, 0.7, 2.5])
+    m32 = orc.make_kernel("matern32", 1.2, 0.8)
+    m52 = orc.make_kernel("matern52", 1.2, 0.8)
+    s3, s5 = np.sqrt(3) * d / 0.8, np.sqrt(5) * d / 0.8
+    np.testing.assert_allclose(orc.k(m32, d), 1.44 * (1 + s3) * np.exp(-s3), rtol=1e-15)
+    np.testing.assert_allclose(orc.k(m52, d), 1.44 * (1 + s5 + 5 * d * d / (3 * 0.64)) * np.exp(-s5), rtol=1e-15)
+    # computediff of the Matern kernels is k'(d)/d: check against a central difference
+    for kern in (m32, m52):
+        for dd in (0.3, 1.1):
+            h = 1e-6
+            num = (orc.k(kern, dd + h)[0] - orc.k(kern, dd - h)[0]) / (2 * h) / dd
+            assert orc.kdiff(kern, dd)[0] == pytest.approx(num, rel=1e-7)
+    for kern in (tp, g, lp, m32, m52):  # computediffdiff is a stub returning 0 in every reference kernel
+        assert orc.kdiffdiff(kern, 0.3)[0] == 0.0
+
+
+@pytest.mark.parametrize("sname", ["mugD", "sphere64"])
+@pytest.mark.parametrize("kkey", list(KERNEL_CASES))
+def test_oracle_matches_independent_numpy(orc, golden, sname, kkey):
+    kn, par = KERNEL_CASES[kkey]
+    x, y, z = golden[sname + "/x"], golden[sname + "/y"], golden[sname + "/z"]
+    lab, s2, Q = golden[sname + "/label"], golden[sname + "/sigma2"], golden[sname + "/Q"]
+    m = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+    pre = "%s/%s/" % (sname, kkey)
+    assert m.ldlt_info == 0
+    assert m.R == pytest.approx(float(golden[sname + "/R"]), rel=1e-14)
+    assert nerr(m.alpha, golden[pre + "alpha"]) < 1e-9
+    out = m.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True)
+    assert nerr(out["f"], golden[pre + "f"]) < 1e-10
+    assert nerr(out["v"], golden[pre + "v"]) < 1e-10
+    assert nerr(out["grad"], golden[pre + "grad"]) < 1e-10
+    # inertia: D of the LDL^T has as many negative entries as K has negative eigenvalues
+    F, _ = m.ldlt()
+    assert int((np.diag(F) < 0).sum()) == int(golden[pre + "n_negative"])
+
+
+def test_gp_identities_without_noise(orc, golden):
+    """Empty sigma2 (gp_regressor.hpp:154): the GP interpolates, f(p_i) = y_i and v(p_i) = 0."""
+    x, y, z, lab = (golden["sphere64/" + k] for k in ("x", "y", "z", "label"))
+    for kn, par in (("gaussian", (1, 1)), ("matern32", (1, 1)), ("thinplate", (4.0,))):
+        m = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, None)
+        out = m.evaluate(x, y, z, want_v=True)
+        scale = float(orc.k(orc.make_kernel(kn, *par), 0.0)[0])
+        assert np.max(np.abs(out["f"] - lab)) < 1e-8
+        assert np.max(np.abs(out["v"])) < 1e-8 * scale
+        K = m.Kpp
+        assert np.max(np.abs(K @ m.alpha - lab)) < 1e-9
+
+
+def test_noise_identity(orc, golden):
+    """With sigma2: f(p_i) = y_i - sigma2_i alpha_i (k_i = K e_i - sigma2_i e_i)."""
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    m = orc.Model(orc.make_kernel("matern52", 1, 1), x, y, z, lab, s2)
+    out = m.evaluate(x, y, z)
+    assert np.max(np.abs(out["f"] - (lab - s2 * m.alpha))) < 1e-10
+
+
+def test_distance_expansion_vs_direct(orc, golden):
+    """gp_regressor.hpp:548-557 literally vs the build's direct differences: they agree
+    wherever the expansion is finite; the expansion may produce NaN on (near-)coincident points."""
+    P = np.stack([golden["mugD/" + k] for k in ("x", "y", "z")], 1)
+    De = orc.dist_matrix(P, P, orc.DIST_EXPANSION)
+    Dd = orc.dist_matrix(P, P, orc.DIST_DIRECT)
+    assert np.all(np.diag(Dd) == 0.0)
+    fin = np.isfinite(De)
+    assert np.max(np.abs(De[fin] - Dd[fin])) < 1e-7  # sqrt of an O(1e-16) cancellation error near d = 0
+    off = fin & (Dd > 1e-3)
+    assert np.max(np.abs(De[off] - Dd[off])) < 1e-12
+    # full pipeline in the reference's own formulation agrees away from the training points
+    x, y, z, lab, s2 = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    kern = orc.make_kernel("thinplate", 4.0)
+    me = orc.Model(kern, x, y, z, lab, s2, dist_mode=orc.DIST_EXPANSION)
+    md = orc.Model(kern, x, y, z, lab, s2, dist_mode=orc.DIST_DIRECT)
+    if np.all(np.isfinite(me.alpha)):
+        Q = golden["sphere64/Q"][:56]
+        a = me.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])["f"]
+        b = md.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])["f"]
+        assert nerr(a, b) < 1e-8
+
+
+def test_variance_diagonal_equals_full_covariance(orc, golden):
+    """gp_regressor.hpp:307-319 builds the Nq x Nq matrix; its diagonal is what the build computes."""
+    x, y, z, lab, s2, Q = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2", "Q"))
+    m = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2)
+    Q = Q[:20]
+    v_full, V = m.evaluate_fullcov(Q[:, 0], Q[:, 1], Q[:, 2])
+    v = m.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True)["v"]
+    assert nerr(v, v_full) < 1e-12
+    assert np.max(np.abs(V - V.T)) < 1e-12
+
+
+def test_update_equals_create_on_concatenation(orc, golden):
+    """gp_regressor.hpp:367-479: update appends and refactors from scratch; R is not refreshed."""
+    x, y, z, lab, s2 = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    kern = orc.make_kernel("laplace", 1, 1)
+    m = orc.Model(kern, x[:50], y[:50], z[:50], lab[:50], s2[:50])
+    R0 = m.R
+    m.update(x[50:], y[50:], z[50:], lab[50:], s2[50:])
+    full = orc.Model(kern, x, y, z, lab, s2)
+    assert m.n == 64
+    assert nerr(m.alpha, full.alpha) < 1e-12
+    assert m.R == R0 and full.R >= R0
+
+
+def test_ldlt_against_scipy(orc):
+    rng = np.random.default_rng(3)
+    for n, shift in ((40, 5.0), (65, 0.0)):  # SPD and indefinite
+        A = rng.normal(size=(n, n))
+        A = A + A.T + shift * n * np.eye(n) * (1 if shift else 0) + np.diag(rng.uniform(1, 2, n))
+        F, t, info = orc.ldlt(A)
+        assert info == 0
+        # reconstruct P A P^T = L D L^T
+        L = np.tril(F, -1) + np.eye(n)
+        D = np.diag(np.diag(F))
+        perm = np.arange(n)
+        for k in range(n):
+            perm[[k, t[k]]] = perm[[t[k], k]]
+        assert np.max(np.abs(L @ D @ L.T - A[np.ix_(perm, perm)])) < 1e-9 * np.abs(A).max()
+        b = rng.normal(size=n)
+        assert nerr(orc.ldlt_solve(F, t, b), np.linalg.solve(A, b)) < 1e-9
+        assert int((np.diag(F) < 0).sum()) == int((np.linalg.eigvalsh(A) < 0).sum())
+    # pivot rule: first largest |diagonal| of the not-yet-eliminated block (non-uniform diagonal)
+    A = np.diag([1.0, 5.0, 3.0, 5.0]) + 0.1
+    _, t, _ = orc.ldlt(A)
+    assert list(t[:2]) == [1, 3]
+
+
+def test_tangent_basis(orc):
+    """computeTangentBasis, gp_regressor.hpp:29-44."""
+    N, Tx, Ty = orc.tangent_basis([0.0, 0.0, 2.0])
+    np.testing.assert_allclose(N, [0, 0, 1])
+    np.testing.assert_allclose(Tx, [1, 0, 0])
+    np.testing.assert_allclose(Ty, [0, 1, 0])
+    N, Tx, Ty = orc.tangent_basis([3.0, 0.0, 0.0])  # along UnitX -> falls back to UnitY
+    np.testing.assert_allclose(Tx, [0, 1, 0])
+    np.testing.assert_allclose(Ty, [0, 0, 1])
+    g = np.array([0.3, -1.2, 0.5])
+    N, Tx, Ty = orc.tangent_basis(g)
+    for a, b in ((N, Tx), (N, Ty), (Tx, Ty)):
+        assert abs(np.dot(a, b)) < 1e-14
+    for a in (N, Tx, Ty):
+        assert abs(np.linalg.norm(a) - 1) < 1e-14
+
+
+def test_oracle_normals(orc, golden):
+    """create<true>, gp_regressor.hpp:166-181: normalised gradient at the training points."""
+    x, y, z, lab, s2 = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    m = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, with_normals=True)
+    g = m.evaluate(x, y, z, want_grad=True)["grad"]
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    assert nerr(m.normals, g) < 1e-12
