@@ -106,17 +106,19 @@ struct gpx_model {
     std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
     size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;
 
-    // double vectors (npad each, internal order): x y z label s2 alpha r f
-    double *dvecs = nullptr;
-    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_lab = nullptr, *d_s2 = nullptr, *d_alpha = nullptr,
-           *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
-    // state blob part 0 (T, npad each): x y z alpha dinv
+    // state blob part 0 = everything evaluate() reads besides X, internal order, npad each:
+    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | T x y z 1/D
     void *blob0 = nullptr;
     size_t blob0_bytes = 0;
-    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_alpha = nullptr, *t_dinv = nullptr;
-    // other T vectors: s2 d b y xs
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;
+    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr;
+    // other fp64 vectors (npad each): label s2 r f, then one double for max|r|
+    double *dvecs = nullptr;
+    double *d_lab = nullptr, *d_s2 = nullptr, *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
+    // other T vectors: s2 d b y xs alpha
     void *tvecs = nullptr;
-    void *t_s2 = nullptr, *t_d = nullptr, *t_b = nullptr, *t_yv = nullptr, *t_xs = nullptr;
+    void *t_s2 = nullptr, *t_d = nullptr, *t_b = nullptr, *t_yv = nullptr, *t_xs = nullptr, *t_alpha = nullptr;
+    std::vector<double> hD;  // D kept on the host once the factor has been released (mixed precision)
     void *Kmat = nullptr;  // npad x npad, L D L^T in place
     void *linv = nullptr;  // nblk x 128 x 128
     void *Wp = nullptr;    // npad x 256 panel workspace
@@ -243,34 +245,49 @@ static void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> 
     }
 }
 
-static int alloc_model(gpx_model *m)
+static int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
+{
+    const size_t np = (size_t)m->npad;
+    *bytes = sizeof(double) * np * 4 + esz * np * 4;
+    HIPCHK(hipMalloc(blob, *bytes));
+    return GPX_OK;
+}
+
+static void carve_blob0(gpx_model *m)
 {
     const size_t np = (size_t)m->npad, e = m->esz;
-    HIPCHK(hipMalloc((void **)&m->dvecs, sizeof(double) * (np * 8 + 8)));
-    m->d_x = m->dvecs;
+    m->d_x = (double *)m->blob0;
     m->d_y = m->d_x + np;
     m->d_z = m->d_y + np;
-    m->d_lab = m->d_z + np;
-    m->d_s2 = m->d_lab + np;
-    m->d_alpha = m->d_s2 + np;
-    m->d_r = m->d_alpha + np;
-    m->d_f = m->d_r + np;
-    m->d_rmax = m->d_f + np;
-    m->blob0_bytes = e * np * 5;
-    HIPCHK(hipMalloc(&m->blob0, m->blob0_bytes));
-    char *b = (char *)m->blob0;
+    m->d_alpha = m->d_z + np;
+    char *b = (char *)(m->d_alpha + np);
     m->t_x = b;
     m->t_y = b + e * np;
     m->t_z = b + 2 * e * np;
-    m->t_alpha = b + 3 * e * np;
-    m->t_dinv = b + 4 * e * np;
-    HIPCHK(hipMalloc(&m->tvecs, e * np * 5));
-    b = (char *)m->tvecs;
+    m->t_dinv = b + 3 * e * np;
+}
+
+static int alloc_model(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad, e = m->esz;
+    int rc = alloc_blob0(m, e, &m->blob0, &m->blob0_bytes);
+    if (rc)
+        return rc;
+    carve_blob0(m);
+    HIPCHK(hipMalloc((void **)&m->dvecs, sizeof(double) * (np * 4 + 8)));
+    m->d_lab = m->dvecs;
+    m->d_s2 = m->d_lab + np;
+    m->d_r = m->d_s2 + np;
+    m->d_f = m->d_r + np;
+    m->d_rmax = m->d_f + np;
+    HIPCHK(hipMalloc(&m->tvecs, e * np * 6));
+    char *b = (char *)m->tvecs;
     m->t_s2 = b;
     m->t_d = b + e * np;
     m->t_b = b + 2 * e * np;
     m->t_yv = b + 3 * e * np;
     m->t_xs = b + 4 * e * np;
+    m->t_alpha = b + 5 * e * np;
     HIPCHK(hipMalloc((void **)&m->d_info, sizeof(int) * 8));
     return GPX_OK;
 }
@@ -409,6 +426,44 @@ static int build_inverse(gpx_model *m)
     return GPX_OK;
 }
 
+// ---- MIXED precision: round the fp64 state once to fp32 and release the fp64 factor -----------------
+static int demote_to_f32(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad;
+    hipStream_t s = m->stream;
+    m->hD.resize((size_t)m->n);
+    HIPCHK(hipMemcpy(m->hD.data(), m->t_d, sizeof(double) * (size_t)m->n, hipMemcpyDeviceToHost));
+    void *nb = nullptr, *nX = nullptr;
+    size_t nbytes = 0;
+    int rc = alloc_blob0(m, 4, &nb, &nbytes);
+    if (rc)
+        return rc;
+    HIPCHK(hipMalloc(&nX, sizeof(float) * np * np));
+    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
+    float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
+    launch_cast_d2f(np, (const double *)m->t_x, tf, s);
+    launch_cast_d2f(np, (const double *)m->t_y, tf + np, s);
+    launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
+    launch_cast_d2f(np, (const double *)m->t_dinv, tf + 3 * np, s);
+    launch_cast_d2f(np * np, (const double *)m->X, (float *)nX, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(m->blob0));
+    HIPCHK(hipFree(m->X));
+    HIPCHK(hipFree(m->Kmat));
+    HIPCHK(hipFree(m->linv));
+    HIPCHK(hipFree(m->Wp));
+    HIPCHK(hipFree(m->tvecs));
+    m->Kmat = m->linv = m->Wp = m->tvecs = nullptr;
+    m->t_s2 = m->t_d = m->t_b = m->t_yv = m->t_xs = m->t_alpha = nullptr;
+    m->blob0 = nb;
+    m->blob0_bytes = nbytes;
+    m->X = nX;
+    m->prec = GPX_PREC_F32;
+    m->esz = 4;
+    carve_blob0(m);
+    return GPX_OK;
+}
+
 // ---- create: everything after the host arrays are in place ---------------------------------------
 static int build_model(gpx_model *m)
 {
@@ -451,8 +506,11 @@ static int build_model(gpx_model *m)
         }
     }
     hipStream_t s = m->stream;
-    HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 5, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np * 3 + 64, s));
+    HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 3, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->d_lab, st.data() + 3 * (size_t)np, sizeof(double) * (size_t)np * 2,
+                          hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
+    HIPCHK(hipMemsetAsync(m->d_r, 0, sizeof(double) * (size_t)np * 2 + 64, s));
     HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
     launch_cast_vec(m->prec, np, np, m->d_x, m->t_x, s);
     launch_cast_vec(m->prec, np, np, m->d_y, m->t_y, s);
@@ -488,7 +546,7 @@ static int build_model(gpx_model *m)
     if (m->opt.with_normals) {
         if (!m->d_normals)
             HIPCHK(hipMalloc((void **)&m->d_normals, sizeof(double) * 3 * (size_t)n));
-        launch_predict(m->prec, m->cov, np, m->t_x, m->t_y, m->t_z, m->t_alpha, n, m->d_x, m->d_y, m->d_z, m->d_f,
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z, m->d_f,
                        m->d_normals, m->ws_pred, s);
         launch_normalize_rows3(n, m->d_normals, s);
         m->has_normals = true;
@@ -533,11 +591,13 @@ static int build_model(gpx_model *m)
         }
     }
     m->ready = true;
-    if (m->opt.prepare_variance) {
+    if (m->opt.prepare_variance || m->opt.precision == GPX_PREC_MIXED) {
         int rc = build_inverse(m);
         if (rc)
             return rc;
     }
+    if (m->opt.precision == GPX_PREC_MIXED)
+        return demote_to_f32(m);
     return GPX_OK;
 }
 
@@ -548,8 +608,8 @@ static int check_opts(const gpx_options *opt, gpx_options &o)
     o.ir_steps = -1;
     if (opt)
         o = *opt;
-    if (o.precision != GPX_PREC_F32 && o.precision != GPX_PREC_F64)
-        return fail(GPX_E_BAD_ARG, "options.precision must be GPX_PREC_F32 or GPX_PREC_F64");
+    if (o.precision != GPX_PREC_F32 && o.precision != GPX_PREC_F64 && o.precision != GPX_PREC_MIXED)
+        return fail(GPX_E_BAD_ARG, "options.precision must be GPX_PREC_F32, GPX_PREC_F64 or GPX_PREC_MIXED");
     if (o.query_batch < 0 || (o.query_batch % TILE) != 0)
         return fail(GPX_E_BAD_ARG, "options.query_batch must be a non-negative multiple of 128");
     return GPX_OK;
@@ -570,8 +630,8 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     HIPCHK(hipSetDevice(dev));
     gpx_model *m = new gpx_model();
     m->device = dev;
-    m->prec = o.precision;
-    m->esz = o.precision == GPX_PREC_F64 ? 8 : 4;
+    m->prec = o.precision == GPX_PREC_F32 ? GPX_PREC_F32 : GPX_PREC_F64;  // MIXED trains in fp64
+    m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
     m->kern = *kernel;
     m->cov = make_cov(*kernel);
     m->opt = o;
@@ -682,6 +742,9 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     }
     free_dev(m);
     m->ready = m->has_inverse = m->has_normals = false;
+    m->prec = m->opt.precision == GPX_PREC_F32 ? GPX_PREC_F32 : GPX_PREC_F64;
+    m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
+    m->hD.clear();
     m->n = (int)m->hx.size();
     m->npad = (int)gpx_padded_n(m->n);
     m->nblk = m->npad / TILE;
@@ -721,8 +784,10 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
             return rc;
     }
     (void)hipEventRecord(m->ev[EV_M0], s);
-    launch_predict(m->prec, m->cov, np, m->t_x, m->t_y, m->t_z, m->t_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred,
-                   s);
+    // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
+    // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
+    launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g,
+                   m->ws_pred, s);
     if (want_basis)
         launch_tangent_basis((long)nq, g, tx, ty, s);
     (void)hipEventRecord(m->ev[EV_M1], s);
@@ -951,7 +1016,9 @@ extern "C" int gpx_model_get(const gpx_model *cm, int field, void *dst, size_t b
         if ((rc = need(sizeof(double) * n)))
             return rc;
         double *o = (double *)dst;
-        if (m->prec == GPX_PREC_F64) {
+        if (!m->hD.empty()) {
+            std::memcpy(o, m->hD.data(), sizeof(double) * n);
+        } else if (m->prec == GPX_PREC_F64) {
             HIPCHK(hipMemcpy(o, m->t_d, sizeof(double) * n, hipMemcpyDeviceToHost));
         } else {
             std::vector<float> t(n);
@@ -1041,6 +1108,10 @@ extern "C" int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const 
     gpx_model *m = nullptr;
     if ((rc = new_model(kernel, n, o, &m)))
         return rc;
+    if (o.precision == GPX_PREC_MIXED) {  // the committed state of a MIXED model is the fp32 layout
+        m->prec = GPX_PREC_F32;
+        m->esz = 4;
+    }
     rc = alloc_model(m);
     if (rc == GPX_OK) {
         hipError_t e = hipMalloc(&m->X, m->esz * (size_t)m->npad * m->npad);

@@ -36,8 +36,11 @@ template <typename T, int KID>
 __device__ __forceinline__ T cov_k(const Cov<T> &c, T d2)
 {
     if constexpr (KID == GPX_KERNEL_THINPLATE) {
+        // 2d^3 - 3R d^2 + R^3 == (d - R)^2 (2d + R): the factored form has no cancellation between
+        // O(R^3) terms, which matters in fp32 for d > R (k is small there, the monomials are not).
         T d = dev_sqrt<T>(d2);
-        return d2 * (T(2) * d - T(3) * c.R) + c.R3;  // 2d^3 - 3R d^2 + R^3
+        T e = d - c.R;
+        return e * e * (T(2) * d + c.R);
     } else {
         T d = dev_sqrt<T>(d2);
         T t = c.s * d;
@@ -57,8 +60,9 @@ __device__ __forceinline__ void cov_k_diff(const Cov<T> &c, T d2, T &k, T &kd)
 {
     T d = dev_sqrt<T>(d2);
     if constexpr (KID == GPX_KERNEL_THINPLATE) {
-        k = d2 * (T(2) * d - T(3) * c.R) + c.R3;
-        kd = T(-6) * (c.R - d);
+        T e = d - c.R;
+        k = e * e * (T(2) * d + c.R);
+        kd = T(6) * e;  // -6 (R - d)
     } else {
         T t = c.s * d;
         T e = c.a * dev_exp<T>(-t);

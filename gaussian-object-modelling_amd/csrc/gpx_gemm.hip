@@ -73,24 +73,32 @@ __device__ __forceinline__ void tri_decode_g(int t, int &ti, int &tj)
     tj = t - i * (i + 1) / 2;
 }
 
-template <typename T, bool NN, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmDev<T> g)
+// FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
+// block tile BM x BN = (WGM * FM * 16) x (WGN * FN * 16), 64 * WGM * WGN threads.
+template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
 {
     using MF = MfmaT<T>;
     using acc_t = typename MF::acc_t;
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
     constexpr int BK = MF::BK;
     constexpr int EPC = 16 / sizeof(T);         // elements per 16-byte chunk
     constexpr int BKP = BK + EPC;               // padded k extent of a [row][k] LDS tile
-    constexpr int BNP = TILE + EPC;             // padded n extent of a [k][n] LDS tile (NN)
-    constexpr int A_TILE = TILE * BKP;
-    constexpr int B_TILE = NN ? BK * BNP : TILE * BKP;
-    __shared__ __attribute__((aligned(16))) T smem[2 * A_TILE + 2 * B_TILE];
+    constexpr int BNP = BN + EPC;               // padded n extent of a [k][n] LDS tile (NN)
+    constexpr int A_TILE = BM * BKP;
+    constexpr int B_TILE = NN ? BK * BNP : BN * BKP;
+    constexpr int A_CH = BM * 8 / NT;           // 16-byte chunks per thread, A tile (8 chunks per row)
+    constexpr int B_CH = BN * 8 / NT;           // same for B (both layouts hold BN * BK elements)
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem_raw[];
+    T *smem = reinterpret_cast<T *>(gemm_smem_raw);
     T *As = smem;
     T *Bs = smem + 2 * A_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // ---- which tile ----
     int mt, nt;
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev<T> g)
         if (g.k_eq_m)
             Kz = g.M_last;
     }
-    const int m0 = mt * TILE, n0 = nt * TILE;
+    const int m0 = mt * BM, n0 = nt * BN;
     if (m0 >= Mz)
         return;
     const T *A = g.A + (size_t)z * g.sA;
@@ -115,141 +123,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev<T> g)
 
     int klo = 0, khi = Kz;
     if (g.a_lower)
-        khi = min(khi, m0 + TILE);
+        khi = min(khi, m0 + BM);
     if (g.b_lower) {
         if (NN)
             klo = n0;
         else
-            khi = min(khi, n0 + TILE);
+            khi = min(khi, n0 + BN);
     }
     const int kt0 = klo / BK, kt1 = khi / BK;
 
-    acc_t acc[4][4];
+    acc_t acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[i][j][r] = T(0);
 
-    // ---- staging maps (4 x 16-byte chunks per thread per operand) ----
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;
-            {
-                const int row = c >> 3, kc = c & 7;
-                ra[i] = *reinterpret_cast<const uint4 *>(A + (size_t)(m0 + row) * g.lda + k0 + kc * EPC);
-            }
-            if constexpr (NN) {
-                constexpr int CPR = TILE / EPC;  // chunks per k-row
-                const int kr = c / CPR, cc = c % CPR;
-                rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)(k0 + kr) * g.ldb + n0 + cc * EPC);
-            } else {
-                const int row = c >> 3, kc = c & 7;
-                rb[i] = *reinterpret_cast<const uint4 *>(B + (size_t)(n0 + row) * g.ldb + k0 + kc * EPC);
-            }
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;
-            {
-                const int row = c >> 3, kc = c & 7;
-                *reinterpret_cast<uint4 *>(As + buf * A_TILE + row * BKP + kc * EPC) = ra[i];
-            }
-            if constexpr (NN) {
-                constexpr int CPR = TILE / EPC;
-                const int kr = c / CPR, cc = c % CPR;
-                *reinterpret_cast<uint4 *>(Bs + buf * B_TILE + kr * BNP + cc * EPC) = rb[i];
-            } else {
-                const int row = c >> 3, kc = c & 7;
-                *reinterpret_cast<uint4 *>(Bs + buf * B_TILE + row * BKP + kc * EPC) = rb[i];
-            }
-        }
-    };
+    // ---- staging: 16-byte chunks, global -> registers -> LDS.  Written as straight-line macros on
+    // named register arrays with NO conditionals around them: with lambdas + `if (more)` hipcc demoted
+    // the staging registers to scratch and waited for every global load before the MFMAs.
+    uint4 ra[A_CH], rb[B_CH];
+    const int a_row = tid >> 3, a_kc = tid & 7;  // chunk c = tid + NT * i  ->  row = a_row + (NT/8) * i
+    const T *a_src = A + (size_t)(m0 + a_row) * g.lda + a_kc * EPC;
+    const T *b_src;
+    int b_lds_off;
+    if constexpr (NN) {
+        constexpr int CPR = BN / EPC;  // chunks per k-row
+        b_src = B + (size_t)(tid / CPR) * g.ldb + n0 + (tid % CPR) * EPC;
+        b_lds_off = (tid / CPR) * BNP + (tid % CPR) * EPC;
+    } else {
+        b_src = B + (size_t)(n0 + a_row) * g.ldb + a_kc * EPC;
+        b_lds_off = a_row * BKP + a_kc * EPC;
+    }
+    const int a_lds_off = a_row * BKP + a_kc * EPC;
+    constexpr int ROWS_PER_PASS = NT / 8;                        // rows per pass of the workgroup ([row][k])
+    constexpr int KROWS_PER_PASS = NN ? NT / (BN / EPC) : 1;     // k-rows per pass ([k][n])
+
+#define GPX_GLOAD(KT)                                                                                       \
+    {                                                                                                       \
+        const size_t k0_ = (size_t)(KT) * BK;                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < A_CH; ++i_)                                                 \
+            ra[i_] = *reinterpret_cast<const uint4 *>(a_src + (size_t)(ROWS_PER_PASS * i_) * g.lda + k0_);  \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_CH; ++i_)                                                 \
+        {                                                                                                   \
+            if constexpr (NN)                                                                               \
+                rb[i_] = *reinterpret_cast<const uint4 *>(b_src + (k0_ + KROWS_PER_PASS * i_) * g.ldb);     \
+            else                                                                                            \
+                rb[i_] = *reinterpret_cast<const uint4 *>(b_src + (size_t)(ROWS_PER_PASS * i_) * g.ldb + k0_); \
+        }                                                                                                   \
+    }
+#define GPX_SSTORE(BUF)                                                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < A_CH; ++i_)                                                 \
+            *reinterpret_cast<uint4 *>(As + (BUF) * A_TILE + a_lds_off + ROWS_PER_PASS * i_ * BKP) = ra[i_]; \
+        _Pragma("unroll") for (int i_ = 0; i_ < B_CH; ++i_)                                                 \
+        {                                                                                                   \
+            if constexpr (NN)                                                                               \
+                *reinterpret_cast<uint4 *>(Bs + (BUF) * B_TILE + b_lds_off + KROWS_PER_PASS * i_ * BNP) = rb[i_]; \
+            else                                                                                            \
+                *reinterpret_cast<uint4 *>(Bs + (BUF) * B_TILE + b_lds_off + ROWS_PER_PASS * i_ * BKP) = rb[i_]; \
+        }                                                                                                   \
+    }
 
     const int fr = lane & 15, fg = lane >> 4;
-    auto compute = [&](int buf) {
-        const T *as = As + buf * A_TILE + (wm * 64 + fr) * BKP + 4 * fg;
-        const T *bs = NN ? Bs + buf * B_TILE + (4 * fg) * BNP + wn * 64 + fr
-                         : Bs + buf * B_TILE + (wn * 64 + fr) * BKP + 4 * fg;
-#pragma unroll
-        for (int kc = 0; kc < BK / 16; ++kc) {
-            T a[4][4], b[4][4];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const T *p = as + f * 16 * BKP + kc * 16;
-                if constexpr (sizeof(T) == 4) {
-                    float4 v = *reinterpret_cast<const float4 *>(p);
-                    a[f][0] = v.x, a[f][1] = v.y, a[f][2] = v.z, a[f][3] = v.w;
-                } else {
-                    double2 v0 = *reinterpret_cast<const double2 *>(p);
-                    double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
-                    a[f][0] = v0.x, a[f][1] = v0.y, a[f][2] = v1.x, a[f][3] = v1.y;
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if constexpr (NN) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        b[f][s] = bs[(kc * 16 + s) * BNP + f * 16];
-                } else {
-                    const T *p = bs + f * 16 * BKP + kc * 16;
-                    if constexpr (sizeof(T) == 4) {
-                        float4 v = *reinterpret_cast<const float4 *>(p);
-                        b[f][0] = v.x, b[f][1] = v.y, b[f][2] = v.z, b[f][3] = v.w;
-                    } else {
-                        double2 v0 = *reinterpret_cast<const double2 *>(p);
-                        double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
-                        b[f][0] = v0.x, b[f][1] = v0.y, b[f][2] = v1.x, b[f][3] = v1.y;
-                    }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = MF::run(a[i][s], b[j][s], acc[i][j]);
-        }
-    };
+    const int a_frag_off = (wm * FM * 16 + fr) * BKP + 4 * fg;
+    const int b_frag_off = NN ? (4 * fg) * BNP + wn * FN * 16 + fr : (wn * FN * 16 + fr) * BKP + 4 * fg;
 
-    // ---- main loop: one barrier per k-tile, next tile's global loads in flight over the MFMAs
+    // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
+    // The last iteration re-loads its own tile (clamped index) so that nothing in the loop is conditional.
     if (kt0 < kt1) {
-        gload(kt0);
-        sstore(0);
+        GPX_GLOAD(kt0);
+        GPX_SSTORE(0);
         __syncthreads();
         int buf = 0;
         for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = kt + 1 < kt1;
-            if (more)
-                gload(kt + 1);
-            compute(buf);
-            if (more)
-                sstore(buf ^ 1);
+            const int ktn = min(kt + 1, kt1 - 1);
+            GPX_GLOAD(ktn);
+            {
+                const T *as = As + buf * A_TILE + a_frag_off;
+                const T *bs = Bs + buf * B_TILE + b_frag_off;
+#pragma unroll
+                for (int kc = 0; kc < BK / 16; ++kc) {
+                    T a[FM][4], b[FN][4];
+#pragma unroll
+                    for (int f = 0; f < FM; ++f) {
+                        const T *p = as + f * 16 * BKP + kc * 16;
+                        if constexpr (sizeof(T) == 4) {
+                            float4 v = *reinterpret_cast<const float4 *>(p);
+                            a[f][0] = v.x, a[f][1] = v.y, a[f][2] = v.z, a[f][3] = v.w;
+                        } else {
+                            double2 v0 = *reinterpret_cast<const double2 *>(p);
+                            double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
+                            a[f][0] = v0.x, a[f][1] = v0.y, a[f][2] = v1.x, a[f][3] = v1.y;
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < FN; ++f) {
+                        if constexpr (NN) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                b[f][s] = bs[(kc * 16 + s) * BNP + f * 16];
+                        } else {
+                            const T *p = bs + f * 16 * BKP + kc * 16;
+                            if constexpr (sizeof(T) == 4) {
+                                float4 v = *reinterpret_cast<const float4 *>(p);
+                                b[f][0] = v.x, b[f][1] = v.y, b[f][2] = v.z, b[f][3] = v.w;
+                            } else {
+                                double2 v0 = *reinterpret_cast<const double2 *>(p);
+                                double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
+                                b[f][0] = v0.x, b[f][1] = v0.y, b[f][2] = v1.x, b[f][3] = v1.y;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = MF::run(a[i][s], b[j][s], acc[i][j]);
+                }
+            }
+            GPX_SSTORE(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
+#undef GPX_GLOAD
+#undef GPX_SSTORE
 
     // ---- epilogues ----
     if constexpr (EPI == EPI_STORE) {
         T *C = g.C + (size_t)z * g.sC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * 64 + i * 16 + MF::crow(lane, r);
-                    const int col = n0 + wn * 64 + j * 16 + fr;
+                    const int row = m0 + (wm * FM + i) * 16 + MF::crow(lane, r);
+                    const int col = n0 + (wn * FN + j) * 16 + fr;
                     T *p = C + (size_t)row * g.ldc + col;
                     T v = g.alpha * acc[i][j][r];
                     if (g.beta)
@@ -259,45 +274,76 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev<T> g)
     } else if constexpr (EPI == EPI_TRSM) {
         T *C = g.C + (size_t)z * g.sC;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + fr;
+        for (int j = 0; j < FN; ++j) {
+            const int col = n0 + (wn * FN + j) * 16 + fr;
             const T cs = g.colscale[col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + wm * 64 + i * 16 + MF::crow(lane, r);
+                    const int row = m0 + (wm * FM + i) * 16 + MF::crow(lane, r);
                     const T v = acc[i][j][r];
                     g.W[(size_t)row * g.ldw + col] = v;
                     C[(size_t)row * g.ldc + col] = v * cs;
                 }
         }
     } else {  // EPI_COLSQ
-        __shared__ T red[2][TILE];
-        T w[4][4];
+        T *red = smem;  // [WGM][BN], re-using the staging buffers (all waves are past the k-loop barrier)
+        T w[FM][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                w[i][r] = g.rowweight[m0 + wm * 64 + i * 16 + MF::crow(lane, r)];
+                w[i][r] = g.rowweight[m0 + (wm * FM + i) * 16 + MF::crow(lane, r)];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FN; ++j) {
             T s = T(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     s += acc[i][j][r] * acc[i][j][r] * w[i][r];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             if (fg == 0)
-                red[wm][wn * 64 + j * 16 + fr] = s;
+                red[wm * BN + (wn * FN + j) * 16 + fr] = s;
         }
         __syncthreads();
-        if (tid < TILE)
-            g.partial[(size_t)mt * g.ldp + n0 + tid] = red[0][tid] + red[1][tid];
+        for (int c = tid; c < BN; c += NT) {
+            T s = T(0);
+#pragma unroll
+            for (int w2 = 0; w2 < WGM; ++w2)
+                s += red[w2 * BN + c];
+            g.partial[(size_t)mt * g.ldp + n0 + c] = s;
+        }
     }
 }
+
+template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN>
+static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t st)
+{
+    using MF = MfmaT<T>;
+    constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int BKP = MF::BK + EPC, BNP = BN + EPC;
+    constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? MF::BK * BNP : BN * BKP));
+    static bool attr_done = false;  // one process drives one device
+    auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem);
+        attr_done = true;
+    }
+    const int mt = a.M / BM, nt = a.N / BN;
+    if (mt <= 0 || nt <= 0 || a.batch <= 0)
+        return;
+    dim3 grid = a.lower_only ? dim3(mt * (mt + 1) / 2, 1, a.batch) : dim3(nt, mt, a.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), shmem, st, g);
+}
+
+// tile choice: cfg 0 = 128 x 128 (4 waves), cfg 1 = 256 x 128 (8 waves), cfg 2 = 256 x 256 (8 waves, 128 x 64 each)
+int gemm_tile_m(int cfg) { return cfg == 0 ? 128 : 256; }
+int gemm_tile_n(int cfg) { return cfg == 2 ? 256 : 128; }
 
 template <typename T>
 static void gemm_t(const GemmArgs &a, hipStream_t st)
@@ -316,22 +362,45 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     g.colscale = (const T *)a.colscale;
     g.rowweight = (const T *)a.rowweight;
     g.partial = (T *)a.partial, g.ldp = a.ldp;
-    const int mt = a.M / TILE, nt = a.N / TILE;
-    if (mt <= 0 || nt <= 0 || a.batch <= 0)
-        return;
-    dim3 grid = a.lower_only ? dim3(mt * (mt + 1) / 2, 1, a.batch) : dim3(nt, mt, a.batch);
-#define GPX_GEMM_LAUNCH(NN_, EPI_) hipLaunchKernelGGL((gemm_kernel<T, NN_, EPI_>), grid, dim3(256), 0, st, g)
+    int cfg = a.cfg;
+    // a tile must divide the problem (and the ragged last batch entry); square tiles for lower_only
+    auto fits = [&](int c) {
+        const int bm = gemm_tile_m(c), bn = gemm_tile_n(c);
+        if (a.M % bm || a.N % bn)
+            return false;
+        if (sizeof(T) == 8 && c == 2)
+            return false;  // 128 x 64 fp64 accumulators per wave do not fit 256 VGPRs at 2 waves/SIMD
+        if (a.M_last >= 0 && a.M_last % bm)
+            return false;
+        if (a.lower_only && bm != bn)
+            return false;
+        if (a.b_lower && !a.nn && bn != TILE)
+            return false;
+        return true;
+    };
+    while (cfg > 0 && !fits(cfg))
+        --cfg;
+#define GPX_GEMM_CFG(NN_, EPI_)                                                \
+    do {                                                                       \
+        if (cfg == 2) {                                                        \
+            if constexpr (sizeof(T) == 4)                                      \
+                gemm_launch_cfg<T, NN_, EPI_, 8, 4, 2, 4>(g, a, st);           \
+        } else if (cfg == 1)                                                     \
+            gemm_launch_cfg<T, NN_, EPI_, 4, 4, 4, 2>(g, a, st);               \
+        else                                                                   \
+            gemm_launch_cfg<T, NN_, EPI_, 4, 4, 2, 2>(g, a, st);               \
+    } while (0)
     if (a.epi == EPI_STORE) {
         if (a.nn)
-            GPX_GEMM_LAUNCH(true, EPI_STORE);
+            GPX_GEMM_CFG(true, EPI_STORE);
         else
-            GPX_GEMM_LAUNCH(false, EPI_STORE);
+            GPX_GEMM_CFG(false, EPI_STORE);
     } else if (a.epi == EPI_TRSM) {
-        GPX_GEMM_LAUNCH(false, EPI_TRSM);
+        GPX_GEMM_CFG(false, EPI_TRSM);
     } else {
-        GPX_GEMM_LAUNCH(false, EPI_COLSQ);
+        GPX_GEMM_CFG(false, EPI_COLSQ);
     }
-#undef GPX_GEMM_LAUNCH
+#undef GPX_GEMM_CFG
 }
 
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st)

@@ -64,6 +64,7 @@ void launch_axpy_cast(int prec, int n, int npad, double *alpha_d, const void *de
                       hipStream_t st);  // alpha_d += delta ; alpha_t = (T)alpha_d (zero padded)
 void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st);
 void launch_normalize_rows3(long n, double *g, hipStream_t st);
+void launch_cast_d2f(size_t n, const double *src, float *dst, hipStream_t st);
 
 // ---- MFMA GEMM core : gpx_gemm.hip ----------------------------------------------------------
 enum GemmEpi { EPI_STORE = 0, EPI_TRSM = 1, EPI_COLSQ = 2 };
@@ -83,6 +84,7 @@ struct GemmArgs {
     int a_lower = 0;                // A lower-triangular: k < m0 + TILE
     int b_lower = 0;                // B lower-triangular: nn: k >= n0 ; nt: k < n0 + TILE
     int epi = EPI_STORE;
+    int cfg = 0;                    // preferred tile: 0 = 128x128, 1 = 256x128, 2 = 256x256 (falls back if it does not divide)
     void *W = nullptr;              // EPI_TRSM: un-scaled product
     long ldw = 0;
     const void *colscale = nullptr; // EPI_TRSM: C = acc * colscale[n]
@@ -91,6 +93,8 @@ struct GemmArgs {
     long ldp = 0;
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
+int gemm_tile_m(int cfg);
+int gemm_tile_n(int cfg);
 
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower

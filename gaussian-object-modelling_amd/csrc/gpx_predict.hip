@@ -350,6 +350,21 @@ void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hi
         hipLaunchKernelGGL(cast_vec_kernel<float>, grid, dim3(256), 0, st, n, npad, src, (float *)dst);
 }
 
+__global__ __launch_bounds__(256) void cast_d2f_kernel(size_t n, const double *__restrict__ src,
+                                                       float *__restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[i] = (float)src[i];
+}
+
+void launch_cast_d2f(size_t n, const double *src, float *dst, hipStream_t st)
+{
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192)
+        blocks = 8192;
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, src, dst);
+}
+
 // Eigen row.normalize() of the training-point normals (gp_regressor.hpp:174)
 __global__ __launch_bounds__(256) void normalize_rows3_kernel(long n, double *__restrict__ g)
 {

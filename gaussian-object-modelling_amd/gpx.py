@@ -4,7 +4,9 @@ This is plumbing over the C ABI, not a compute path: every numeric call goes to 
 raises GpxError when the library or a GPU is missing -- there is no Python / NumPy fallback.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -14,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpx.so")
 GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
 KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
               "matern32": MATERN32, "matern52": MATERN52}
-F32, F64 = 0, 1
+F32, F64, MIXED = 0, 1, 2
 
 OK = 0
 E_NULL, E_EMPTY, E_LABELED_QUERY, E_SIZE_MISMATCH, E_SINGULAR, E_NAN_INPUT, E_HIP, E_OOM, E_NO_DEVICE, \
@@ -65,6 +67,27 @@ EXPORTS = [
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, found through $ORIGIN).
+    If libgpx.so pulled in /opt/rocm's copy first, a later `import torch` would load a SECOND HIP runtime
+    into the process and see no GPU.  Loading torch's copy first makes both resolve to one runtime,
+    whatever the import order.  Without torch installed the system runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libgpx.so (raises if the HIP extension has not been built: no fallback)."""
     global _lib
@@ -73,6 +96,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise GpxError(E_STATE, "libgpx.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
                        % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p

@@ -64,10 +64,17 @@ typedef struct gpx_kernel {
     double p[4];
 } gpx_kernel;
 
-typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1 } gpx_precision;
+/* Arithmetic of the factorisation and of the variance contraction (the API is double throughout and the
+ * mean / gradient are always evaluated in fp64):
+ *   F32    kernel matrix, LDL^T, inverse factor and variance GEMM in fp32 (fp32 MFMA); alpha is refined
+ *          with fp64 matrix-free residuals
+ *   F64    everything in fp64 (fp64 MFMA): the reference's arithmetic
+ *   MIXED  train (kernel matrix, LDL^T, alpha, inverse factor) in fp64, then the inverse factor is
+ *          rounded once to fp32 and the variance GEMM runs in fp32; the fp64 factor is released */
+typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1, GPX_PREC_MIXED = 2 } gpx_precision;
 
 typedef struct gpx_options {
-    int32_t precision;     /* gpx_precision; F32 adds fp64-residual iterative refinement of alpha */
+    int32_t precision;     /* gpx_precision */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t with_normals;  /* create<true>: normals at the training points (gp_regressor.hpp:166-181) */
     int32_t ir_steps;      /* refinement steps for alpha; -1 = default (2 for F32, 1 for F64) */
@@ -149,7 +156,8 @@ void gpx_model_destroy(gpx_model *m);
  * broadcast over xGMI) into the blob of a shell created with the same kernel/n/options on the
  * other ranks, then commits it.  No reference equivalent (the reference is single-process). */
 int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const gpx_options *opt, gpx_model **out);
-int gpx_model_state_blob(gpx_model *m, int with_variance, void **d_ptr, size_t *bytes);
+int gpx_model_state_blob(gpx_model *m, int part /*0: points, alpha, 1/D; 1: inverse factor*/, void **d_ptr,
+                         size_t *bytes);
 int gpx_model_commit(gpx_model *m, int with_variance);
 
 /* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------
@@ -170,7 +178,8 @@ size_t gpx_padded_n(size_t n); /* leading dimension / padded order used for n tr
  * concatenation (src/gp_node.cpp:85-117, :793-914): out arrays must hold n_points+15 doubles. */
 long gpx_pcd_read(const char *path, float *xyz, size_t capacity_points);
 int gpx_node_training_set(const float *xyz, size_t n_points, double sigma2, double out_sphere_rad, double *x,
-                          double *y, double *z, double *label, double *s2);
+                          double *y, double *z, double *label, double *s2); /* returns the number of exterior
+                          points appended (15) or a negative gpx_status */
 
 #ifdef __cplusplus
 }

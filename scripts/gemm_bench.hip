@@ -1,0 +1,78 @@
+// gemm_bench.hip -- development harness: times the GEMM core on the two hot shapes.
+//   build: hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/gemm_bench.hip -I gaussian-object-modelling_amd/csrc \
+//          -L gaussian-object-modelling_amd/lib -lgpx -Wl,-rpath,$PWD/gaussian-object-modelling_amd/lib -o /tmp/gemm_bench
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "gpx_internal.hpp"
+using namespace gpx;
+#define CK(x) do { hipError_t err__ = (x); if (err__ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(err__), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <typename T>
+__global__ void fill_kernel(T *d, size_t n, unsigned seed, double scale)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned s = (unsigned)(i * 2654435761u) ^ seed;
+        s = s * 1664525u + 1013904223u;
+        s ^= s >> 15;
+        s = s * 1664525u + 1013904223u;
+        d[i] = (T)(scale * ((double)(s >> 8) / (1 << 24) - 0.5));
+    }
+}
+template <typename T>
+static void fill(T *d, size_t n, unsigned seed, double scale)
+{
+    hipLaunchKernelGGL(fill_kernel<T>, dim3(4096), dim3(256), 0, 0, d, n, seed, scale);
+    CK(hipDeviceSynchronize());
+}
+
+int main(int argc, char **argv)
+{
+    const int N = argc > 1 ? atoi(argv[1]) : 16384;  // matrix order
+    const int NQ = argc > 2 ? atoi(argv[2]) : 8192;  // queries per launch
+    const int prec = argc > 3 ? atoi(argv[3]) : 0;
+    const size_t e = prec ? 8 : 4;
+    void *X, *Kqp, *dinv, *partial, *C, *W;
+    CK(hipMalloc(&X, e * (size_t)N * N));
+    CK(hipMalloc(&Kqp, e * (size_t)NQ * N));
+    CK(hipMalloc(&dinv, e * N));
+    CK(hipMalloc(&partial, e * (size_t)NQ * (N / 128)));
+    CK(hipMalloc(&C, e * (size_t)N * N));
+    CK(hipMalloc(&W, e * (size_t)N * 256));
+    if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*256, 4, 1e-2); }
+    else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*256, 4, 1e-2); }
+    CK(hipMemset(C, 0, e * (size_t)N * N));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int cfg = 0; cfg < 3; ++cfg) {
+        GemmArgs a;
+        a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
+        a.rowweight = dinv; a.partial = partial, a.ldp = NQ; a.cfg = cfg;
+        launch_gemm(prec, a, st);
+        CK(hipStreamSynchronize(st));
+        const int reps = 3;
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch_gemm(prec, a, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        double flop = (double)N * N * NQ;
+        printf("VAR  cfg%d prec%d N=%d NQ=%d : %.3f ms  %.1f TFLOP/s (algorithmic N^2 per query)\n", cfg, prec, N, NQ, ms, flop / ms / 1e9);
+    }
+    for (int cfg = 0; cfg < 3; cfg += 2) {
+        const int M = N - 256;
+        GemmArgs s;
+        s.A = W, s.lda = 256; s.B = X, s.ldb = N; s.C = C, s.ldc = N; s.M = M, s.N = M, s.K = 256; s.alpha = -1, s.beta = 1; s.lower_only = 1; s.cfg = cfg;
+        launch_gemm(prec, s, st);
+        CK(hipStreamSynchronize(st));
+        const int reps = 5;
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch_gemm(prec, s, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        double flop = (double)M * M * 256;  // lower triangle only: M^2/2 * K * 2
+        printf("SYRK cfg%d prec%d M=%d K=256 : %.3f ms  %.1f TFLOP/s\n", cfg, prec, M, ms, flop / ms / 1e9);
+    }
+    return 0;
+}

@@ -64,3 +64,10 @@ def nerr(a, b):
     """norm-wise relative error max|a-b| / max|b| (f crosses zero on the surface)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def verr(v, vref, k0):
+    """Variance error, norm-wise against the larger of max|v_ref| and the prior variance k(0):
+    v = k(0) - (quadratic form), so its rounding error scales with k(0) even where v itself is small."""
+    v, vref = np.asarray(v, dtype=np.float64), np.asarray(vref, dtype=np.float64)
+    return float(np.max(np.abs(v - vref)) / max(float(np.max(np.abs(vref))), float(k0)))
