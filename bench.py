@@ -77,6 +77,19 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
     }
 
 
+def pmc_traffic(args, n_train, q_per_launch):
+    """HBM bytes per launch of the variance GEMM from the committed PMC passes (FETCH_SIZE doubled as the
+    MI355X guide prescribes, + WRITE_SIZE); only valid for the shape those passes were taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not (os.path.exists(path) and args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192):
+        return None
+    try:
+        k = json.load(open(path))["kernels"]["gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2>"]
+        return k["hbm_bytes_per_dispatch"]
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,7 +200,8 @@ def main():
             flops_per_launch = float(n_train) ** 2 * q_per_launch  # N^2 flop per query
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_kernel<%s,NT,COLSQ> (predict_var)" % args.precision,
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": pmc_traffic(args, n_train, q_per_launch),
                     "avg_launch_ms": avg_ms, "launches_per_step": launches,
                     "algorithmic_flops_per_launch": flops_per_launch}
         out = {

@@ -12,12 +12,18 @@
 
 namespace gpx {
 
-constexpr int DLD = TILE + 1;  // LDS leading dimension (conflict-free column walks)
+constexpr int DLD = TILE + 1;  // LDS leading dimension (conflict-free row and column walks)
+constexpr int DT = 1024;  // threads of the diagonal-block kernel
 
+// One 128 x 128 diagonal block, LDS resident: unblocked right-looking LDL^T (no pivoting inside the
+// block), then the unit-lower inverse of L in place.  1024 threads: the trailing update of step j is
+// spread over a 32 x 32 thread grid (<= 16 dependent LDS read-modify-writes per thread and step), the
+// inverse uses 8 lanes per row.  A fully register-resident variant (rows in registers, both loops
+// unrolled 128x) was tried: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
 template <typename T>
-__global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
-                                                       T *__restrict__ d, T *__restrict__ dinv,
-                                                       int *__restrict__ info, int blk)
+__global__ __launch_bounds__(DT) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
+                                                      T *__restrict__ d, T *__restrict__ dinv,
+                                                      int *__restrict__ info, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *S = reinterpret_cast<T *>(smem_raw);  // [TILE][DLD]
@@ -25,12 +31,12 @@ __global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long l
     __shared__ T Ds[TILE];
     const int tid = threadIdx.x;
 
-    for (int idx = tid; idx < TILE * TILE; idx += 256) {
+    for (int idx = tid; idx < TILE * TILE; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         S[i * DLD + j] = A[(size_t)i * lda + j];
     }
     // ---- right-looking LDL^T; column j keeps u_ij = l_ij * d_j until the final scaling ----
-    const int ti = tid >> 4, tk = tid & 15;
+    const int ti = tid >> 5, tk = tid & 31;
     int nneg = 0;
     for (int j = 0; j < TILE; ++j) {
         __syncthreads();
@@ -42,9 +48,9 @@ __global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long l
                 ++nneg;
         }
         const T inv = T(1) / dj;
-        for (int i = j + 1 + ti; i < TILE; i += 16) {
+        for (int i = j + 1 + ti; i < TILE; i += 32) {
             const T lij = S[i * DLD + j] * inv;
-            for (int k = j + 1 + tk; k <= i; k += 16)
+            for (int k = j + 1 + tk; k <= i; k += 32)
                 S[i * DLD + k] -= lij * S[k * DLD + j];
         }
     }
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long l
     }
     __syncthreads();
     // scale to the unit-lower L, write L (strict lower) and D (diagonal) back
-    for (int idx = tid; idx < TILE * TILE; idx += 256) {
+    for (int idx = tid; idx < TILE * TILE; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         if (j < i) {
             const T l = S[i * DLD + j] * Ds[j];
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long l
         }
     }
     // ---- in-place inverse of the unit-lower L:  X L = I, columns from right to left ----
-    //   X[i][j] = -( L[i][j] + sum_{j<k<i} X[i][k] L[k][j] )
-    const int row_off = tid >> 1, h = tid & 1;
+    //   X[i][j] = -( L[i][j] + sum_{j<k<i} X[i][k] L[k][j] ),  8 lanes per row
+    const int row_off = tid >> 3, h = tid & 7;
     for (int j = TILE - 2; j >= 0; --j) {
         __syncthreads();
         if (tid < TILE && tid > j)
@@ -80,14 +86,16 @@ __global__ __launch_bounds__(256) void diag_ldl_kernel(T *__restrict__ A, long l
         const int i = j + 1 + row_off;
         T s = T(0);
         if (i < TILE)
-            for (int k = j + 1 + h; k < i; k += 2)
+            for (int k = j + 1 + h; k < i; k += 8)
                 s += S[i * DLD + k] * tmp[k];
         s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
         if (i < TILE && h == 0)
             S[i * DLD + j] = -(tmp[i] + s);
     }
     __syncthreads();
-    for (int idx = tid; idx < TILE * TILE; idx += 256) {
+    for (int idx = tid; idx < TILE * TILE; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         linv[(size_t)blk * TILE * TILE + idx] = j < i ? S[i * DLD + j] : (j == i ? T(1) : T(0));
     }
@@ -97,7 +105,7 @@ template <typename T>
 static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
 {
     const size_t shmem = (size_t)TILE * DLD * sizeof(T);
-    hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(256), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
+    hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(DT), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
                        (T *)dinv, info, blk);
 }
 
@@ -146,15 +154,21 @@ __device__ __forceinline__ void block_matvec(const T *__restrict__ M, long ldm, 
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T v0 = v_lds[lane], v1 = v_lds[lane + 64];
+    T m0[32], m1[32];  // issue all 64 loads of the wave's 32 rows before any reduction (latency-bound otherwise)
+#pragma unroll
     for (int rr = 0; rr < 32; ++rr) {
-        const int r = wave * 32 + rr;
-        const T *row = M + (size_t)r * ldm;
-        T s = row[lane] * v0 + row[lane + 64] * v1;
+        const T *row = M + (size_t)(wave * 32 + rr) * ldm;
+        m0[rr] = row[lane];
+        m1[rr] = row[lane + 64];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+        T s = m0[rr] * v0 + m1[rr] * v1;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
             s += __shfl_xor(s, off);
         if (lane == 0)
-            out_lds[r] = s;
+            out_lds[wave * 32 + rr] = s;
     }
 }
 
@@ -164,9 +178,14 @@ __device__ __forceinline__ void block_matvec_t(const T *__restrict__ M, long ldm
                                                T *scratch_lds)
 {
     const int c = threadIdx.x & 127, hh = threadIdx.x >> 7;
+    T mv[64];
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+        mv[rr] = M[(size_t)(hh * 64 + rr) * ldm + c];
     T s = T(0);
-    for (int r = hh * 64; r < hh * 64 + 64; ++r)
-        s += M[(size_t)r * ldm + c] * v_lds[r];
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+        s += mv[rr] * v_lds[hh * 64 + rr];
     if (hh == 1)
         scratch_lds[c] = s;
     __syncthreads();

@@ -191,6 +191,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     const int a_frag_off = (wm * FM * 16 + fr) * BKP + 4 * fg;
     const int b_frag_off = NN ? (4 * fg) * BNP + wn * FN * 16 + fr : (wn * FN * 16 + fr) * BKP + 4 * fg;
 
+    // ---- EPI_STORE: fetch the C tile NOW, in fragment layout, so that its latency hides under the k-loop
+    // (the trailing update of the factorisation has only 8 k-tiles per tile; a read-modify-write epilogue
+    // that starts its loads after the last MFMA leaves the matrix pipe idle for ~20 % of the tile).
+    constexpr bool C_PREFETCH = (EPI == EPI_STORE) && (FM * FN <= 16);
+    T cpre[C_PREFETCH ? FM : 1][C_PREFETCH ? FN : 1][4];
+    if constexpr (C_PREFETCH) {
+        const T *Cin = g.C + (size_t)z * g.sC;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    cpre[i][j][r] = Cin[(size_t)(m0 + (wm * FM + i) * 16 + MF::crow(lane, r)) * g.ldc + n0 +
+                                        (wn * FN + j) * 16 + (lane & 15)];
+    }
+
     // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
     // The last iteration re-loads its own tile (clamped index) so that nothing in the loop is conditional.
     if (kt0 < kt1) {
@@ -267,8 +284,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                     const int col = n0 + (wn * FN + j) * 16 + fr;
                     T *p = C + (size_t)row * g.ldc + col;
                     T v = g.alpha * acc[i][j][r];
-                    if (g.beta)
-                        v += *p;
+                    if constexpr (C_PREFETCH) {
+                        v += g.beta ? cpre[i][j][r] : T(0);
+                    } else {
+                        if (g.beta)
+                            v += *p;
+                    }
                     *p = v;
                 }
     } else if constexpr (EPI == EPI_TRSM) {
@@ -341,9 +362,40 @@ static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), shmem, st, g);
 }
 
-// tile choice: cfg 0 = 128 x 128 (4 waves), cfg 1 = 256 x 128 (8 waves), cfg 2 = 256 x 256 (8 waves, 128 x 64 each)
+// tile choice: cfg 0 = 128 x 128 (4 waves of 64 x 64), cfg 2 = 256 x 256 (8 waves of 128 x 64, fp32 only);
+// cfg 1 (256 x 128, 8 waves of 64 x 64) is not instantiated any more
 int gemm_tile_m(int cfg) { return cfg == 0 ? 128 : 256; }
 int gemm_tile_n(int cfg) { return cfg == 2 ? 256 : 128; }
+
+static int pick_cfg(const GemmArgs &a, size_t esz)
+{
+    int cfg = a.cfg;
+    // a tile must divide the problem (and the ragged last batch entry); square tiles for lower_only
+    auto fits = [&](int c) {
+        const int bm = gemm_tile_m(c), bn = gemm_tile_n(c);
+        if (a.M % bm || a.N % bn)
+            return false;
+        if (c == 1)
+            return false;  // 256 x 128 with 8 waves of 64 x 64 measured slower than both others (98 vs 134 TF)
+        if (esz == 8 && c == 2)
+            return false;  // 128 x 64 fp64 accumulators per wave do not fit 256 VGPRs at 2 waves/SIMD
+        if (a.M_last >= 0 && a.M_last % bm)
+            return false;
+        if (a.lower_only && bm != bn)
+            return false;
+        if (a.b_lower && !a.nn && bn != TILE)
+            return false;
+        return true;
+    };
+    while (cfg > 0 && !fits(cfg))
+        --cfg;
+    return cfg;
+}
+
+int gemm_rows_per_partial(int prec, const GemmArgs &g)
+{
+    return gemm_tile_m(pick_cfg(g, prec == GPX_PREC_F64 ? 8 : 4));
+}
 
 template <typename T>
 static void gemm_t(const GemmArgs &a, hipStream_t st)
@@ -362,32 +414,13 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     g.colscale = (const T *)a.colscale;
     g.rowweight = (const T *)a.rowweight;
     g.partial = (T *)a.partial, g.ldp = a.ldp;
-    int cfg = a.cfg;
-    // a tile must divide the problem (and the ragged last batch entry); square tiles for lower_only
-    auto fits = [&](int c) {
-        const int bm = gemm_tile_m(c), bn = gemm_tile_n(c);
-        if (a.M % bm || a.N % bn)
-            return false;
-        if (sizeof(T) == 8 && c == 2)
-            return false;  // 128 x 64 fp64 accumulators per wave do not fit 256 VGPRs at 2 waves/SIMD
-        if (a.M_last >= 0 && a.M_last % bm)
-            return false;
-        if (a.lower_only && bm != bn)
-            return false;
-        if (a.b_lower && !a.nn && bn != TILE)
-            return false;
-        return true;
-    };
-    while (cfg > 0 && !fits(cfg))
-        --cfg;
+    const int cfg = pick_cfg(a, sizeof(T));
 #define GPX_GEMM_CFG(NN_, EPI_)                                                \
     do {                                                                       \
         if (cfg == 2) {                                                        \
             if constexpr (sizeof(T) == 4)                                      \
                 gemm_launch_cfg<T, NN_, EPI_, 8, 4, 2, 4>(g, a, st);           \
-        } else if (cfg == 1)                                                     \
-            gemm_launch_cfg<T, NN_, EPI_, 4, 4, 4, 2>(g, a, st);               \
-        else                                                                   \
+        } else                                                                 \
             gemm_launch_cfg<T, NN_, EPI_, 4, 4, 2, 2>(g, a, st);               \
     } while (0)
     if (a.epi == EPI_STORE) {

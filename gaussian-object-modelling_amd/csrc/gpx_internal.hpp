@@ -93,6 +93,7 @@ struct GemmArgs {
     long ldp = 0;
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
+int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
 int gemm_tile_m(int cfg);
 int gemm_tile_n(int cfg);
 
