@@ -19,12 +19,16 @@ namespace gpx {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-template <typename T>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// MFMA shape policy.  FR = rows/cols of a fragment, NACC = accumulator registers per lane,
+// LG = 64 / FR lane groups; a lane of group g supplies k = 4 g + s (s = 0..3) of a 4*LG-deep chunk.
+template <typename T, bool M32>
 struct MfmaT;
 template <>
-struct MfmaT<float> {
+struct MfmaT<float, false> {  // v_mfma_f32_16x16x4_f32
     using acc_t = f32x4;
-    static constexpr int BK = 32;  // k-tile: 128 bytes per row
+    static constexpr int FR = 16, NACC = 4, LG = 4;
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -33,9 +37,20 @@ struct MfmaT<float> {
     static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 template <>
-struct MfmaT<double> {
+struct MfmaT<float, true> {  // v_mfma_f32_32x32x2_f32
+    using acc_t = f32x16;
+    static constexpr int FR = 32, NACC = 16, LG = 2;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    static __device__ __forceinline__ int crow(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <>
+struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
     using acc_t = f64x4;
-    static constexpr int BK = 16;
+    static constexpr int FR = 16, NACC = 4, LG = 4;
     static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -74,23 +89,25 @@ __device__ __forceinline__ void tri_decode_g(int t, int &ti, int &tj)
 }
 
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
-// block tile BM x BN = (WGM * FM * 16) x (WGN * FN * 16), 64 * WGM * WGN threads.
-template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN>
+// block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
+template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
 {
-    using MF = MfmaT<T>;
+    using MF = MfmaT<T, M32>;
     using acc_t = typename MF::acc_t;
+    constexpr int FR = MF::FR, NACC = MF::NACC, KCH = 4 * MF::LG;
     constexpr int NT = 64 * WGM * WGN;
-    constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
-    constexpr int BK = MF::BK;
+    constexpr int BM = WGM * FM * FR, BN = WGN * FN * FR;
+    constexpr int BK = KBYTES / sizeof(T);      // k-tile: KBYTES bytes of k per staged row
+    constexpr int CPRW = KBYTES / 16;           // 16-byte chunks per staged [row][k] row
     constexpr int EPC = 16 / sizeof(T);         // elements per 16-byte chunk
     constexpr int BKP = BK + EPC;               // padded k extent of a [row][k] LDS tile
     constexpr int BNP = BN + EPC;               // padded n extent of a [k][n] LDS tile (NN)
     constexpr int A_TILE = BM * BKP;
     constexpr int B_TILE = NN ? BK * BNP : BN * BKP;
-    constexpr int A_CH = BM * 8 / NT;           // 16-byte chunks per thread, A tile (8 chunks per row)
-    constexpr int B_CH = BN * 8 / NT;           // same for B (both layouts hold BN * BK elements)
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile / thread mismatch");
+    constexpr int A_CH = BM * CPRW / NT;        // 16-byte chunks per thread, A tile
+    constexpr int B_CH = BN * CPRW / NT;        // same for B (both layouts hold BN * BK elements)
+    static_assert((BM * CPRW) % NT == 0 && (BN * CPRW) % NT == 0 && BK % KCH == 0, "tile / thread mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem_raw[];
     T *smem = reinterpret_cast<T *>(gemm_smem_raw);
     T *As = smem;
@@ -138,14 +155,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < NACC; ++r)
                 acc[i][j][r] = T(0);
 
     // ---- staging: 16-byte chunks, global -> registers -> LDS.  Written as straight-line macros on
     // named register arrays with NO conditionals around them: with lambdas + `if (more)` hipcc demoted
     // the staging registers to scratch and waited for every global load before the MFMAs.
     uint4 ra[A_CH], rb[B_CH];
-    const int a_row = tid >> 3, a_kc = tid & 7;  // chunk c = tid + NT * i  ->  row = a_row + (NT/8) * i
+    const int a_row = tid / CPRW, a_kc = tid % CPRW;  // chunk c = tid + NT * i  ->  row = a_row + (NT/CPRW) * i
     const T *a_src = A + (size_t)(m0 + a_row) * g.lda + a_kc * EPC;
     const T *b_src;
     int b_lds_off;
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
         b_lds_off = a_row * BKP + a_kc * EPC;
     }
     const int a_lds_off = a_row * BKP + a_kc * EPC;
-    constexpr int ROWS_PER_PASS = NT / 8;                        // rows per pass of the workgroup ([row][k])
+    constexpr int ROWS_PER_PASS = NT / CPRW;                     // rows per pass of the workgroup ([row][k])
     constexpr int KROWS_PER_PASS = NN ? NT / (BN / EPC) : 1;     // k-rows per pass ([k][n])
 
 #define GPX_GLOAD(KT)                                                                                       \
@@ -187,15 +204,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
         }                                                                                                   \
     }
 
-    const int fr = lane & 15, fg = lane >> 4;
-    const int a_frag_off = (wm * FM * 16 + fr) * BKP + 4 * fg;
-    const int b_frag_off = NN ? (4 * fg) * BNP + wn * FN * 16 + fr : (wn * FN * 16 + fr) * BKP + 4 * fg;
+    const int fr = lane % FR, fg = lane / FR;
+    const int a_frag_off = (wm * FM * FR + fr) * BKP + 4 * fg;
+    const int b_frag_off = NN ? (4 * fg) * BNP + wn * FN * FR + fr : (wn * FN * FR + fr) * BKP + 4 * fg;
 
     // ---- EPI_STORE: fetch the C tile NOW, in fragment layout, so that its latency hides under the k-loop
     // (the trailing update of the factorisation has only 8 k-tiles per tile; a read-modify-write epilogue
     // that starts its loads after the last MFMA leaves the matrix pipe idle for ~20 % of the tile).
-    constexpr bool C_PREFETCH = (EPI == EPI_STORE) && (FM * FN <= 16);
-    T cpre[C_PREFETCH ? FM : 1][C_PREFETCH ? FN : 1][4];
+    constexpr bool C_PREFETCH = (EPI == EPI_STORE) && (FM * FN * NACC <= 64);
+    T cpre[C_PREFETCH ? FM : 1][C_PREFETCH ? FN : 1][NACC];
     if constexpr (C_PREFETCH) {
         const T *Cin = g.C + (size_t)z * g.sC;
 #pragma unroll
@@ -203,9 +220,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    cpre[i][j][r] = Cin[(size_t)(m0 + (wm * FM + i) * 16 + MF::crow(lane, r)) * g.ldc + n0 +
-                                        (wn * FN + j) * 16 + (lane & 15)];
+                for (int r = 0; r < NACC; ++r)
+                    cpre[i][j][r] = Cin[(size_t)(m0 + (wm * FM + i) * FR + MF::crow(lane, r)) * g.ldc + n0 +
+                                        (wn * FN + j) * FR + fr];
     }
 
     // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
@@ -222,11 +239,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                 const T *as = As + buf * A_TILE + a_frag_off;
                 const T *bs = Bs + buf * B_TILE + b_frag_off;
 #pragma unroll
-                for (int kc = 0; kc < BK / 16; ++kc) {
+                for (int kc = 0; kc < BK / KCH; ++kc) {
                     T a[FM][4], b[FN][4];
 #pragma unroll
                     for (int f = 0; f < FM; ++f) {
-                        const T *p = as + f * 16 * BKP + kc * 16;
+                        const T *p = as + f * FR * BKP + kc * KCH;
                         if constexpr (sizeof(T) == 4) {
                             float4 v = *reinterpret_cast<const float4 *>(p);
                             a[f][0] = v.x, a[f][1] = v.y, a[f][2] = v.z, a[f][3] = v.w;
@@ -241,9 +258,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                         if constexpr (NN) {
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
-                                b[f][s] = bs[(kc * 16 + s) * BNP + f * 16];
+                                b[f][s] = bs[(kc * KCH + s) * BNP + f * FR];
                         } else {
-                            const T *p = bs + f * 16 * BKP + kc * 16;
+                            const T *p = bs + f * FR * BKP + kc * KCH;
                             if constexpr (sizeof(T) == 4) {
                                 float4 v = *reinterpret_cast<const float4 *>(p);
                                 b[f][0] = v.x, b[f][1] = v.y, b[f][2] = v.z, b[f][3] = v.w;
@@ -279,9 +296,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + (wm * FM + i) * 16 + MF::crow(lane, r);
-                    const int col = n0 + (wn * FN + j) * 16 + fr;
+                for (int r = 0; r < NACC; ++r) {
+                    const int row = m0 + (wm * FM + i) * FR + MF::crow(lane, r);
+                    const int col = n0 + (wn * FN + j) * FR + fr;
                     T *p = C + (size_t)row * g.ldc + col;
                     T v = g.alpha * acc[i][j][r];
                     if constexpr (C_PREFETCH) {
@@ -296,13 +313,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
         T *C = g.C + (size_t)z * g.sC;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int col = n0 + (wn * FN + j) * 16 + fr;
+            const int col = n0 + (wn * FN + j) * FR + fr;
             const T cs = g.colscale[col];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + (wm * FM + i) * 16 + MF::crow(lane, r);
+                for (int r = 0; r < NACC; ++r) {
+                    const int row = m0 + (wm * FM + i) * FR + MF::crow(lane, r);
                     const T v = acc[i][j][r];
                     g.W[(size_t)row * g.ldw + col] = v;
                     C[(size_t)row * g.ldc + col] = v * cs;
@@ -310,24 +327,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
         }
     } else {  // EPI_COLSQ
         T *red = smem;  // [WGM][BN], re-using the staging buffers (all waves are past the k-loop barrier)
-        T w[FM][4];
+        T w[FM][NACC];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                w[i][r] = g.rowweight[m0 + (wm * FM + i) * 16 + MF::crow(lane, r)];
+            for (int r = 0; r < NACC; ++r)
+                w[i][r] = g.rowweight[m0 + (wm * FM + i) * FR + MF::crow(lane, r)];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             T s = T(0);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < NACC; ++r)
                     s += acc[i][j][r] * acc[i][j][r] * w[i][r];
-            s += __shfl_xor(s, 16);
+            if constexpr (FR == 16)
+                s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             if (fg == 0)
-                red[wm * BN + (wn * FN + j) * 16 + fr] = s;
+                red[wm * BN + (wn * FN + j) * FR + fr] = s;
         }
         __syncthreads();
         for (int c = tid; c < BN; c += NT) {
@@ -340,16 +358,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     }
 }
 
-template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN>
+template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES = 128, bool M32 = false>
 static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t st)
 {
-    using MF = MfmaT<T>;
-    constexpr int BM = WGM * FM * 16, BN = WGN * FN * 16;
-    constexpr int EPC = 16 / sizeof(T);
-    constexpr int BKP = MF::BK + EPC, BNP = BN + EPC;
-    constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? MF::BK * BNP : BN * BKP));
+    constexpr int FR = M32 ? 32 : 16;
+    constexpr int BM = WGM * FM * FR, BN = WGN * FN * FR;
+    constexpr int EPC = 16 / sizeof(T), BK = KBYTES / sizeof(T);
+    constexpr int BKP = BK + EPC, BNP = BN + EPC;
+    constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? BK * BNP : BN * BKP));
     static bool attr_done = false;  // one process drives one device
-    auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN>;
+    auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN, KBYTES, M32>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem);
@@ -369,7 +387,7 @@ int gemm_tile_n(int cfg) { return cfg == 2 ? 256 : 128; }
 
 static int pick_cfg(const GemmArgs &a, size_t esz)
 {
-    int cfg = a.cfg;
+    int cfg = (a.cfg > 2 || a.cfg < 0) ? 0 : a.cfg;
     // a tile must divide the problem (and the ragged last batch entry); square tiles for lower_only
     auto fits = [&](int c) {
         const int bm = gemm_tile_m(c), bn = gemm_tile_n(c);
@@ -431,6 +449,9 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     } else if (a.epi == EPI_TRSM) {
         GPX_GEMM_CFG(false, EPI_TRSM);
     } else {
+        // Measured on the variance shape (N = 16384, 8192 queries), all within 1.5 %: 128x128 tile 135-136 TF,
+        // 256x256 tile 134-135 TF, 64-byte k rows at 3 workgroups/CU (KBYTES = 64) 136.6 TF, 32x32x2 MFMA
+        // (M32 = true) 133-134 TF.  MFMA pipe ~88 % busy at 2.29 GHz in every variant: not tile-shape limited.
         GPX_GEMM_CFG(false, EPI_COLSQ);
     }
 #undef GPX_GEMM_CFG
