@@ -901,6 +901,60 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
     return GPX_OK;
 }
 
+extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
+                                        const double *qz, double f_tol, size_t capacity, int64_t *idx, double *f,
+                                        double *v, size_t *n_out)
+{
+    if (!n_out || !idx)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    *n_out = 0;
+    int rc = check_query(cm, nq, qx, qy, qz, f);
+    if (rc)
+        return rc;
+    if (!(f_tol >= 0.0))
+        return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t cap = std::min(capacity, nq);
+    const size_t nb = (nq + 255) / 256;
+    // device staging: qx qy qz f_all | compacted sx sy sz fs vs (cap each) | idx (cap int64) | block counters | total
+    const size_t doubles = nq * 4 + cap * 5 + cap + nb / 2 + 4;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    double *d = m->ws_host_io;
+    double *dqx = d, *dqy = d + nq, *dqz = d + 2 * nq, *dfa = d + 3 * nq;
+    double *sx = d + 4 * nq, *sy = sx + cap, *sz = sy + cap, *fs = sz + cap, *vs = fs + cap;
+    long long *didx = (long long *)(vs + cap);
+    unsigned *bc = (unsigned *)(didx + cap);
+    unsigned long long *dtotal = (unsigned long long *)(d + doubles - 2);
+    HIPCHK(hipMemcpyAsync(dqx, qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqy, qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqz, qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s)))
+        return rc;
+    launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, cap, dqx, dqy, dqz, didx, fs, sx, sy, sz, s);
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_out = (size_t)total;
+    const size_t ns = std::min((size_t)total, cap);
+    if (ns > 0) {
+        if (v) {  // variance of the survivors only (their mean is recomputed by the same call; it is cheap)
+            if ((rc = evaluate_locked(m, ns, sx, sy, sz, fs, vs, nullptr, nullptr, nullptr, s)))
+                return rc;
+            HIPCHK(hipMemcpyAsync(v, vs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipMemcpyAsync(f, fs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(idx, didx, sizeof(int64_t) * ns, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (total > cap)
+        return fail(GPX_E_SIZE_MISMATCH, "more surface points than capacity");
+    return GPX_OK;
+}
+
 extern "C" int gpx_model_prepare_variance(gpx_model *m)
 {
     if (!m)

@@ -435,11 +435,14 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     const int cfg = pick_cfg(a, sizeof(T));
 #define GPX_GEMM_CFG(NN_, EPI_)                                                \
     do {                                                                       \
-        if (cfg == 2) {                                                        \
-            if constexpr (sizeof(T) == 4)                                      \
-                gemm_launch_cfg<T, NN_, EPI_, 8, 4, 2, 4>(g, a, st);           \
-        } else                                                                 \
+        if constexpr (sizeof(T) == 8) {                                        \
+            /* fp64: 128 x 128 tile as 8 waves of 64 x 32 (2-3 waves/SIMD): 66 TF vs 43.5 TF for 4 waves of 64 x 64 */ \
+            gemm_launch_cfg<T, NN_, EPI_, 4, 2, 2, 4>(g, a, st);               \
+        } else if (cfg == 2) {                                                 \
+            gemm_launch_cfg<T, NN_, EPI_, 8, 4, 2, 4>(g, a, st);               \
+        } else {                                                               \
             gemm_launch_cfg<T, NN_, EPI_, 4, 4, 2, 2>(g, a, st);               \
+        }                                                                      \
     } while (0)
     if (a.epi == EPI_STORE) {
         if (a.nn)

@@ -56,6 +56,10 @@ void launch_predict(int prec, const CovHost &cov, int n_pad_pts, const void *px,
 // v[q] = k0 - sum_m partial[m][q]
 void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *partial, long nq, double *v,
                        hipStream_t st);
+// survivors of |f| <= tol in query order: idx / f / coordinates compacted (capacity entries at most), *total = count
+void launch_surface_select(long nq, const double *f, double tol, unsigned *block_cnt, unsigned long long *total,
+                           size_t capacity, const double *qx, const double *qy, const double *qz, long long *idx,
+                           double *fs, double *sx, double *sy, double *sz, hipStream_t st);
 void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st);
 // r = y - f - s2*alpha (all double, n entries); also max|r| -> *rmax (atomic, pre-zeroed)
 void launch_residual(int n, const double *y, const double *f, const double *s2, const double *alpha, double *r,

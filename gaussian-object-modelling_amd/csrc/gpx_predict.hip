@@ -270,6 +270,93 @@ void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, h
                        ty);
 }
 
+// ---- iso-surface selection: keep the queries with |f| <= tol, in query order (src/gp_node.cpp:1075) ----
+// Three small passes (count per 256-block, scan of the block counts, scatter) so the order is deterministic.
+__global__ __launch_bounds__(256) void surf_count_kernel(long nq, const double *__restrict__ f, double tol,
+                                                         unsigned *__restrict__ block_cnt)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = q < nq && fabs(f[q]) <= tol;
+    __shared__ unsigned wc[4];
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0)
+        wc[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_cnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(1024) void surf_scan_kernel(long nblocks, unsigned *__restrict__ block_cnt,
+                                                         unsigned long long *__restrict__ total)
+{
+    // exclusive scan of block_cnt in place by ONE workgroup (nblocks <= a few 10^5)
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const long per = (nblocks + 1023) / 1024;
+    const long lo = t * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    unsigned long long s = 0;
+    for (long i = lo; i < hi; ++i)
+        s += block_cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = t ? part[t - 1] : 0;
+    for (long i = lo; i < hi; ++i) {
+        const unsigned c = block_cnt[i];
+        block_cnt[i] = (unsigned)run;  // offsets fit 32 bits: nq < 2^32 survivors
+        run += c;
+    }
+    if (t == 1023)
+        *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void surf_scatter_kernel(long nq, const double *__restrict__ f, double tol,
+                                                           const unsigned *__restrict__ block_off, size_t capacity,
+                                                           const double *__restrict__ qx,
+                                                           const double *__restrict__ qy,
+                                                           const double *__restrict__ qz, long long *__restrict__ idx,
+                                                           double *__restrict__ fs, double *__restrict__ sx,
+                                                           double *__restrict__ sy, double *__restrict__ sz)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool keep = q < nq && fabs(f[q]) <= tol;
+    __shared__ unsigned wc[4];
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0)
+        wc[w] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned base = block_off[blockIdx.x];
+    for (int i = 0; i < w; ++i)
+        base += wc[i];
+    if (keep) {
+        const size_t pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < capacity) {
+            idx[pos] = q;
+            fs[pos] = f[q];
+            sx[pos] = qx[q];
+            sy[pos] = qy[q];
+            sz[pos] = qz[q];
+        }
+    }
+}
+
+void launch_surface_select(long nq, const double *f, double tol, unsigned *block_cnt, unsigned long long *total,
+                           size_t capacity, const double *qx, const double *qy, const double *qz, long long *idx,
+                           double *fs, double *sx, double *sy, double *sz, hipStream_t st)
+{
+    const long nb = (nq + 255) / 256;
+    hipLaunchKernelGGL(surf_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, nq, f, tol, block_cnt);
+    hipLaunchKernelGGL(surf_scan_kernel, dim3(1), dim3(1024), 0, st, nb, block_cnt, total);
+    hipLaunchKernelGGL(surf_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, nq, f, tol, block_cnt, capacity, qx,
+                       qy, qz, idx, fs, sx, sy, sz);
+}
+
 // ---- iterative-refinement helpers ------------------------------------------------------------
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double val)
 {

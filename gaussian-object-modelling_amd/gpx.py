@@ -59,7 +59,8 @@ class Stats(C.Structure):
 # every symbol include/gpx.h declares
 EXPORTS = [
     "gpx_last_error", "gpx_version", "gpx_device_count", "gpx_model_create", "gpx_model_update",
-    "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_prepare_variance", "gpx_model_get",
+    "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_prepare_variance",
+    "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
@@ -114,6 +115,9 @@ def lib():
     L.gpx_model_evaluate.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp, dp, dp, dp]
     L.gpx_model_evaluate_device.restype = C.c_int
     L.gpx_model_evaluate_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.gpx_model_sample_surface.restype = C.c_int
+    L.gpx_model_sample_surface.argtypes = [vp, C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t,
+                                           C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_size_t)]
     L.gpx_model_prepare_variance.restype = C.c_int
     L.gpx_model_prepare_variance.argtypes = [vp]
     L.gpx_model_get.restype = C.c_int
@@ -300,6 +304,27 @@ class Model:
             out["grad"] = g
         if tx is not None:
             out["tx"], out["ty"] = tx, ty
+        return out
+
+    def sample_surface(self, qx, qy, qz, f_tol=0.01, capacity=None, want_v=True):
+        """Batched fakeDeterministicSampling: indices, f and v of the queries with |f| <= f_tol."""
+        qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)
+        nq = len(qx)
+        cap = nq if capacity is None else int(capacity)
+        idx = np.empty(cap, dtype=np.int64)
+        f = np.empty(cap)
+        v = np.empty(cap) if want_v else None
+        n_out = C.c_size_t(0)
+        rc = self._L.gpx_model_sample_surface(self._h, nq, _dptr(qx), _dptr(qy), _dptr(qz), float(f_tol), cap,
+                                              idx.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(f),
+                                              _dptr(v) if v is not None else None, C.byref(n_out))
+        n = int(n_out.value)
+        if rc != OK and rc != E_SIZE_MISMATCH:
+            _check(rc)
+        k = min(n, cap)
+        out = {"idx": idx[:k], "f": f[:k], "n_total": n, "truncated": rc == E_SIZE_MISMATCH}
+        if v is not None:
+            out["v"] = v[:k]
         return out
 
     def evaluate_device(self, nq, d_qx, d_qy, d_qz, d_f, d_v=None, d_grad=None, d_tx=None, d_ty=None, stream=None):

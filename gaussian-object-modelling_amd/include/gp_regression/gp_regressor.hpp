@@ -243,6 +243,34 @@ public:
     }
 #endif
 
+    // Batched form of the node's fakeDeterministicSampling / samplePoint (src/gp_node.cpp:998-1100): keep the
+    // queries with |f| <= f_tol (the node uses 0.01, :1075) and return their position in `query`, mean and
+    // variance; the variance is computed for the survivors only.  New entry, not in the reference
+    // header.
+    void sampleSurface(Model::ConstPtr gp, Data::ConstPtr query, double f_tol, std::vector<size_t> &idx,
+                       std::vector<double> &f, std::vector<double> &v)
+    {
+        if (!gp || !gp->handle_)
+            throw GPRegressionException("Empty Model pointer");
+        assertData(query);
+        if (!query->label.empty())
+            throw GPRegressionException("Query is already labeled!");
+        const size_t nq = query->coord_x.size();
+        if (query->coord_y.size() != nq || query->coord_z.size() != nq)
+            throw GPRegressionException("Input data vectors have different lengths");
+        std::vector<int64_t> pos(nq);
+        f.assign(nq, 0.0);
+        v.assign(nq, 0.0);
+        size_t n = 0;
+        const int rc = gpx_model_sample_surface(gp->handle_, nq, query->coord_x.data(), query->coord_y.data(),
+                                                query->coord_z.data(), f_tol, nq, pos.data(), f.data(), v.data(), &n);
+        if (rc != GPX_OK)
+            throw GPRegressionException(message(rc));
+        idx.assign(pos.begin(), pos.begin() + n);
+        f.resize(n);
+        v.resize(n);
+    }
+
     // update<withNormals>(new_data, gp), :367-479
     template <bool withNormals>
     void update(Data::ConstPtr new_data, Model::Ptr gp)

@@ -143,6 +143,16 @@ int gpx_model_evaluate_device(const gpx_model *m, size_t nq, const void *d_qx, c
                               const void *d_qz, void *d_f, void *d_v, void *d_grad, void *d_tx, void *d_ty,
                               void *stream);
 
+/* Iso-surface sampling: the batched form of the node's fakeDeterministicSampling / samplePoint
+ * (src/gp_node.cpp:998-1100): evaluate the mean on all nq queries, keep those with |f| <= f_tol
+ * (the node's 0.01, :1075) and compute the variance ONLY for the survivors -- the step right after
+ * the hot path, fused so that the dominant variance cost scales with the surface, not the volume.
+ * idx (query positions, ascending), f, v: host arrays of `capacity` entries; *n_out = number of
+ * survivors.  If more than `capacity` survive, the first `capacity` are returned together with
+ * GPX_E_SIZE_MISMATCH (and *n_out holds the full count).  v may be NULL (selection only). */
+int gpx_model_sample_surface(const gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
+                             double f_tol, size_t capacity, int64_t *idx, double *f, double *v, size_t *n_out);
+
 /* Ensure the inverse factor needed by variance queries exists (else built at first use). */
 int gpx_model_prepare_variance(gpx_model *m);
 

@@ -101,6 +101,28 @@ int main(int argc, char **argv)
     }
     EXPECT((int)gf.size() == grid * grid * grid, "all grid points evaluated");
 
+    // ---- the same sampling as ONE batched call: survivors of |f| <= tol, variance only for them ----
+    {
+        Data::Ptr all = std::make_shared<Data>();
+        all->coord_x = gx;
+        all->coord_y = gy;
+        all->coord_z = gz;
+        const double tol = 0.25;
+        std::vector<size_t> idx;
+        std::vector<double> sf, sv;
+        reg_->sampleSurface(obj_gp, all, tol, idx, sf, sv);
+        size_t expect = 0;
+        for (size_t i = 0; i < gf.size(); ++i)
+            if (std::fabs(gf[i]) <= tol)
+                ++expect;
+        EXPECT(idx.size() == expect && expect > 0, "sampleSurface keeps exactly the |f| <= tol points");
+        bool same = idx.size() == sf.size() && idx.size() == sv.size();
+        for (size_t k = 0; same && k < idx.size(); ++k)
+            same = std::fabs(sf[k] - gf[idx[k]]) <= 1e-12 * (1 + std::fabs(gf[idx[k]])) &&
+                   std::fabs(sv[k] - gv[idx[k]]) <= 1e-9 * (1 + std::fabs(gv[idx[k]])) && (k == 0 || idx[k] > idx[k - 1]);
+        EXPECT(same, "sampleSurface values == per-point evaluate, ascending order");
+    }
+
     // ---- atlas_variance.hpp:72-78 : f, v and the gradient at a chart centre ----
     Data::Ptr c = std::make_shared<Data>();
     c->coord_x = {0.3, data_gp->coord_x[5]};

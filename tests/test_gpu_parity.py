@@ -279,6 +279,39 @@ def test_shell_broadcast_commit_roundtrip(gpu, orc, ds):
         dst.close()
 
 
+def test_sample_surface_matches_filtered_evaluate(gpu, orc, ds):
+    """gpx_model_sample_surface == evaluate everywhere, keep |f| <= tol (src/gp_node.cpp:1066-1100),
+    but the variance is only computed for the survivors."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(500)
+    om = orc.Model(orc.make_kernel("thinplate", 2.0), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(29)  # the node's 29^3 lattice (sample_res 0.07 at scale 1.01)
+    ref = om.evaluate(qx, qy, qz, want_v=False)
+    tol = 0.01
+    near = np.abs(np.abs(ref["f"]) - tol)
+    assert near.min() > 1e-9  # no lattice point sits on the threshold
+    keep = np.nonzero(np.abs(ref["f"]) <= tol)[0]
+    assert 50 < len(keep) < len(qx) // 10
+    refv = om.evaluate(qx[keep], qy[keep], qz[keep], want_v=True)["v"]
+    for prec in (1, 0, 2):
+        gm = gpu.Model(gpu.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=prec)
+        out = gm.sample_surface(qx, qy, qz, f_tol=tol)
+        np.testing.assert_array_equal(out["idx"], keep)
+        assert out["n_total"] == len(keep) and not out["truncated"]
+        assert nerr(out["f"], ref["f"][keep]) < 1e-6 if prec == 0 else nerr(out["f"], ref["f"][keep]) < 1e-9
+        assert verr(out["v"], refv, 8.0) < TOL[prec]
+        # identical to the unfused path on the same model
+        full = gm.evaluate(qx, qy, qz, want_v=True)
+        np.testing.assert_allclose(out["v"], full["v"][keep], rtol=0, atol=1e-5 * 8.0 if prec != 1 else 1e-12)
+        # truncation: capacity smaller than the number of survivors
+        small = gm.sample_surface(qx, qy, qz, f_tol=tol, capacity=10)
+        assert small["truncated"] and small["n_total"] == len(keep)
+        np.testing.assert_array_equal(small["idx"], keep[:10])
+        # nothing survives
+        none = gm.sample_surface(qx[:100], qy[:100], qz[:100], f_tol=0.0)
+        assert none["n_total"] == 0 and len(none["idx"]) == 0
+        gm.close()
+
+
 def test_error_codes_on_device(gpu):
     k = gpu.make_kernel("gaussian", 1, 1)
     m = gpu.Model(k, [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.1, 0.1, 0.1])
