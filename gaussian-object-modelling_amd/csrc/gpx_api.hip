@@ -618,6 +618,19 @@ static int check_opts(const gpx_options *opt, gpx_options &o)
     return GPX_OK;
 }
 
+static void set_query_batch(gpx_model *m)
+{
+    if (m->opt.query_batch > 0) {
+        m->qbatch = m->opt.query_batch;
+        return;
+    }
+    // ~512 MiB of Kqp per batch: 8192 queries at N = 16384, more for small models so that one variance
+    // launch still fills the chip (N = 724: 131072 queries -> 6 x 1024 tiles)
+    size_t qb = ((size_t)512 << 20) / ((size_t)m->npad * 4);
+    qb = std::min<size_t>(std::max<size_t>(qb, 8192), 131072);
+    m->qbatch = (int)(qb / 256 * 256);
+}
+
 static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, gpx_model **out)
 {
     if (kernel->id < GPX_KERNEL_GAUSSIAN || kernel->id > GPX_KERNEL_MATERN52)
@@ -641,7 +654,7 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     m->n = (int)n;
     m->npad = (int)gpx_padded_n(n);
     m->nblk = m->npad / TILE;
-    m->qbatch = o.query_batch > 0 ? o.query_batch : 8192;
+    set_query_batch(m);
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");
@@ -751,6 +764,7 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     m->n = (int)m->hx.size();
     m->npad = (int)gpx_padded_n(m->n);
     m->nblk = m->npad / TILE;
+    set_query_batch(m);
     rc = build_model(m);  // refactor from scratch, as :457-459
     m->R = keepR;
     return rc;
@@ -809,7 +823,9 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
             a.M = np, a.N = (int)ntile, a.K = np;
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
-            a.cfg = 2;  // 256 x 256 tiles when they divide the batch (fp32): same speed, half the L2-miss traffic
+            // 256 x 256 tiles (fp32) halve the L2-miss traffic at equal speed, but only when there are enough of
+            // them to fill 256 CUs; small models use 128 x 128 tiles
+            a.cfg = ((size_t)(np / 256) * (ntile / 256) >= 1024) ? 2 : 0;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
