@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--mode", choices=["independent", "shard"], default="independent")
     ap.add_argument("--n-train", type=int, default=N_TRAIN)
     ap.add_argument("--nq", type=int, default=NQ)
-    ap.add_argument("--precision", choices=["f32", "f64", "mixed"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "f64", "mixed", "f32split"], default="f32")
     ap.add_argument("--kernel", default=KERNEL[0])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mean-only", action="store_true", help="diagnostic: skip the variance")
@@ -120,7 +120,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    prec = {"f32": gpx.F32, "f64": gpx.F64, "mixed": gpx.MIXED}[args.precision]
+    prec = {"f32": gpx.F32, "f64": gpx.F64, "mixed": gpx.MIXED, "f32split": gpx.F32_SPLIT}[args.precision]
     kpar = (4.0,) if args.kernel == "thinplate" else (1.0, 1.0)
     kern = gpx.make_kernel(args.kernel, *kpar)
     n_train, nq = args.n_train, args.nq

@@ -98,6 +98,8 @@ struct gpx_model {
     gpx_options opt{};
     int n = 0, npad = 0, nblk = 0;
     bool ready = false, has_s2 = false, has_inverse = false, has_normals = false;
+    bool x_packed = false;  // F32_SPLIT: X holds packed hi/lo halves, the 1/D slot holds the scaled weights
+    float sk = 1.0f;        // power-of-two scale of the kernel values in the split contraction
     std::vector<double> hx, hy, hz, hlabel, hs2;  // caller order
     std::vector<int> perm;                        // internal position -> caller index
     double R = 0;
@@ -425,6 +427,19 @@ static int build_inverse(gpx_model *m)
     float ms = 0;
     if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
         m->stats.t_inverse_ms = ms;
+    if (m->opt.precision == GPX_PREC_F32_SPLIT && !m->x_packed) {
+        if (!m->hD.size()) {  // keep D readable (GPX_FIELD_D) -- the 1/D slot is about to hold the weights
+            std::vector<float> t((size_t)m->n);
+            HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * (size_t)m->n, hipMemcpyDeviceToHost));
+            m->hD.assign(t.begin(), t.end());
+        }
+        int e2 = 0;
+        (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
+        m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
+        launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        m->x_packed = true;
+    }
     m->has_inverse = true;
     return GPX_OK;
 }
@@ -611,8 +626,8 @@ static int check_opts(const gpx_options *opt, gpx_options &o)
     o.ir_steps = -1;
     if (opt)
         o = *opt;
-    if (o.precision != GPX_PREC_F32 && o.precision != GPX_PREC_F64 && o.precision != GPX_PREC_MIXED)
-        return fail(GPX_E_BAD_ARG, "options.precision must be GPX_PREC_F32, GPX_PREC_F64 or GPX_PREC_MIXED");
+    if (o.precision < GPX_PREC_F32 || o.precision > GPX_PREC_F32_SPLIT)
+        return fail(GPX_E_BAD_ARG, "options.precision must be GPX_PREC_F32, _F64, _MIXED or _F32_SPLIT");
     if (o.query_batch < 0 || (o.query_batch % TILE) != 0)
         return fail(GPX_E_BAD_ARG, "options.query_batch must be a non-negative multiple of 128");
     return GPX_OK;
@@ -646,7 +661,8 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     HIPCHK(hipSetDevice(dev));
     gpx_model *m = new gpx_model();
     m->device = dev;
-    m->prec = o.precision == GPX_PREC_F32 ? GPX_PREC_F32 : GPX_PREC_F64;  // MIXED trains in fp64
+    m->prec = (o.precision == GPX_PREC_F32 || o.precision == GPX_PREC_F32_SPLIT) ? GPX_PREC_F32
+                                                                                  : GPX_PREC_F64;  // MIXED trains in fp64
     m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
     m->kern = *kernel;
     m->cov = make_cov(*kernel);
@@ -758,9 +774,11 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     }
     free_dev(m);
     m->ready = m->has_inverse = m->has_normals = false;
-    m->prec = m->opt.precision == GPX_PREC_F32 ? GPX_PREC_F32 : GPX_PREC_F64;
+    m->prec = (m->opt.precision == GPX_PREC_F32 || m->opt.precision == GPX_PREC_F32_SPLIT) ? GPX_PREC_F32
+                                                                                              : GPX_PREC_F64;
     m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
     m->hD.clear();
+    m->x_packed = false;
     m->n = (int)m->hx.size();
     m->npad = (int)gpx_padded_n(m->n);
     m->nblk = m->npad / TILE;
@@ -815,6 +833,21 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
         for (size_t q0 = 0; q0 < nq; q0 += qb) {
             const size_t nv = std::min(qb, nq - q0);
             const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
+            if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
+                launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
+                                 qy + q0, qz + q0, m->ws_kqp, s);
+                hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
+                if (ev2)
+                    (void)hipEventRecord(ev2[0], s);
+                launch_vsplit_gemm(m->X, m->ws_kqp, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
+                                   (long)qb, 2, s);
+                if (ev2) {
+                    (void)hipEventRecord(ev2[1], s);
+                    ++gi;
+                }
+                launch_var_finish(m->prec, m->cov.k0, np / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+                continue;
+            }
             launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
                        qz + q0, m->ws_kqp, s);
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
@@ -1243,6 +1276,12 @@ extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
         if (!m->X)
             return fail(GPX_E_STATE, "inverse factor buffer missing");
         m->has_inverse = true;
+        if (m->opt.precision == GPX_PREC_F32_SPLIT) {  // the received blobs are already packed / scaled
+            int e2 = 0;
+            (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
+            m->sk = (float)std::ldexp(1.0, -e2);
+            m->x_packed = true;
+        }
     }
     return GPX_OK;
 }

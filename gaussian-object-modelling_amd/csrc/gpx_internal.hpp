@@ -101,6 +101,16 @@ int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launc
 int gemm_tile_m(int cfg);
 int gemm_tile_n(int cfg);
 
+// ---- split-fp16 variance contraction : gpx_vsplit.hip ------------------------------------------
+// in place: X (fp32, np x np) -> packed hi/lo halves with a device-chosen power-of-two scale sx;
+// dinv -> w = dinv / (sx sk)^2
+void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st);
+void launch_kqp_split(const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
+                      long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
+                      hipStream_t st);
+void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial, long ldp,
+                        int prefetch, hipStream_t st);
+
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower
 // inverse to linv (TILE x TILE, row-major, zeros above the diagonal), d / 1/d vectors, info.

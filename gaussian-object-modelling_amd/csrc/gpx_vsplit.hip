@@ -1,0 +1,372 @@
+// gpx_vsplit.hip -- the variance contraction on the fp16 matrix cores with fp32-class accuracy
+// (GPX_PREC_F32_SPLIT): every fp32 operand x is carried as two halves,
+//     hi = fp16(s x),   lo = fp16(2^11 (s x - hi))          (s: a power of two bringing max|x| below 1)
+// so that s x = hi + 2^-11 lo to ~2^-22 relative for every entry down to 6e-5 of the largest one (the 2^11
+// keeps lo in the NORMAL fp16 range; without it the small off-diagonal entries of the unit-lower inverse
+// factor would only be resolved to an absolute 2^-25 of its diagonal 1).  Then
+//     x y  ~  hi_x hi_y  +  2^-11 (hi_x lo_y + lo_x hi_y)
+// runs as three v_mfma_f32_32x32x16_f16 into TWO fp32 accumulator sets (main, correction) that are combined
+// once in the epilogue; the dropped lo*lo term is below 2^-22 relative.  Three fp16 MFMAs move 16x more
+// flops per cycle than one fp32 MFMA, so the contraction costs ~5x fewer matrix-pipe cycles; what remains
+// is a staging problem (the operands are as many bytes as in fp32).
+//
+// Packed layout "P16" of a [rows][K] matrix (K a multiple of 32): per row, per block of 32 k, 64 halves =
+// [hi(32) | lo(32)] = 128 bytes.  A row is exactly as long as in fp32, and one k-tile of a row is one
+// 128-byte line -- so global->register->LDS staging is byte-for-byte the one of gpx_gemm.hip.
+//
+//   split_absmax / split_pack : X (fp32, inverse factor)  -> P16, scale chosen on the device
+//   kqp_split                 : Kqp[q][j] = k(|q-p_j|)     -> P16 directly (never stored in fp32)
+//   vsplit_gemm               : partial[mt][q] = sum_rows (X Kqp^T)^2 w[row],  w = 1/D / (sx sk)^2
+#include "gpx_cov.hpp"
+
+namespace gpx {
+
+using half_t = _Float16;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16v = __attribute__((ext_vector_type(16))) float;
+
+// ---- scale + split of the inverse factor ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_absmax_kernel(const float *__restrict__ X, size_t n,
+                                                           unsigned *__restrict__ out_bits)
+{
+    float m = 0.0f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(X + i);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ float pow2_scale_below_one(float amax)
+{
+    // largest power of two s with s * amax < 1 (amax > 0); 1 for an all-zero matrix
+    if (!(amax > 0.0f))
+        return 1.0f;
+    int e;
+    (void)frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, -e);
+}
+
+// scale_inv2[0] = 1 / (sx * sk)^2 ; w[j] = dinv[j] * scale_inv2
+__global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *dinv,
+                                                            const unsigned *__restrict__ amax_bits, float sk, float *w)
+{
+    const float sx = pow2_scale_below_one(__uint_as_float(*amax_bits));
+    const float inv = 1.0f / (sx * sk);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        w[i] = dinv[i] * inv * inv;
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], float s, half8 &hi, half8 &lo)
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float x = v[c] * s;
+        const half_t h = (half_t)x;
+        hi[c] = h;
+        lo[c] = (half_t)((x - (float)h) * 2048.0f);
+    }
+}
+
+// In place: the 32 fp32 values of one k-block (128 bytes) become the 128 bytes [hi(32) | lo(32)] of the same
+// block; one thread owns a whole block, so nothing another thread still has to read is overwritten.
+__global__ __launch_bounds__(256) void split_pack_kernel(float *__restrict__ X, size_t nblocks,
+                                                         const unsigned *__restrict__ amax_bits)
+{
+    const float s = pow2_scale_below_one(__uint_as_float(*amax_bits));
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nblocks; b += (size_t)gridDim.x * 256) {
+        float *blk = X + b * 32;
+        float4 v4[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v4[c] = *reinterpret_cast<const float4 *>(blk + 4 * c);
+        half8 hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v[8] = {v4[2 * c].x, v4[2 * c].y, v4[2 * c].z, v4[2 * c].w,
+                                v4[2 * c + 1].x, v4[2 * c + 1].y, v4[2 * c + 1].z, v4[2 * c + 1].w};
+            split8(v, s, hi[c], lo[c]);
+        }
+        half_t *dst = reinterpret_cast<half_t *>(blk);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<half8 *>(dst + 8 * c) = hi[c];
+            *reinterpret_cast<half8 *>(dst + 32 + 8 * c) = lo[c];
+        }
+    }
+}
+
+// ---- Kqp tile straight into P16 --------------------------------------------------------------------------
+template <int KID>
+__global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk, int n, int npad,
+                                                        const float *__restrict__ px, const float *__restrict__ py,
+                                                        const float *__restrict__ pz, long nq_valid,
+                                                        const double *__restrict__ qx,
+                                                        const double *__restrict__ qy,
+                                                        const double *__restrict__ qz, half_t *__restrict__ P)
+{
+    __shared__ float rx[TILE], ry[TILE], rz[TILE];
+    const int tid = threadIdx.x;
+    const long q0 = (long)blockIdx.y * TILE;
+    if (tid < TILE) {
+        const long q = q0 + tid;
+        const bool ok = q < nq_valid;
+        rx[tid] = ok ? (float)qx[q] : 0.0f;
+        ry[tid] = ok ? (float)qy[q] : 0.0f;
+        rz[tid] = ok ? (float)qz[q] : 0.0f;
+    }
+    const int tx = tid & 15, ty = tid >> 4;  // 16 lanes x 8 columns = 128 training points per row
+    const int gj0 = blockIdx.x * TILE + tx * 8;
+    float cx[8], cy[8], cz[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        cx[c] = px[gj0 + c];
+        cy[c] = py[gj0 + c];
+        cz[c] = pz[gj0 + c];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int r = 0; r < 8; ++r) {
+        const int li = ty + 16 * r;
+        const long q = q0 + li;
+        const float ax = rx[li], ay = ry[li], az = rz[li];
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            const float kv = cov_k<float, KID>(cov, dx * dx + dy * dy + dz * dz);
+            v[c] = (q < nq_valid && gj0 + c < n) ? kv : 0.0f;
+        }
+        half8 hi, lo;
+        split8(v, sk, hi, lo);
+        half_t *dst = P + (size_t)q * (2 * (size_t)npad) + (gj0 / 32) * 64 + (gj0 % 32);
+        *reinterpret_cast<half8 *>(dst) = hi;
+        *reinterpret_cast<half8 *>(dst + 32) = lo;
+    }
+}
+
+// ---- the contraction -----------------------------------------------------------------------------------
+struct VsplitDev {
+    const unsigned char *A;  // P16 X,   row stride 4 K bytes
+    const unsigned char *B;  // P16 Kqp, row stride 4 K bytes
+    int M, N, K;             // rows of X, queries (multiples of 128), K (multiple of 32)
+    const float *w;          // per-row weight (1/D, scales folded in)
+    float *partial;
+    long ldp;
+};
+
+// 128 x 128 tile, 4 waves of 64 x 64 = 2 x 2 fragments of v_mfma_f32_32x32x16_f16; k-tile = 32 (one
+// 128-byte P16 block per row); PF k-tiles of global loads are kept in flight in registers (the matrix work
+// per k-tile is only 768 cycles per wave, far less than a memory round trip).
+template <int PF>
+__global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
+{
+    constexpr int ROWB = 128;          // bytes of one k-tile of a row
+    constexpr int ROWP = ROWB + 16;    // padded LDS row
+    constexpr int TILE_B = TILE * ROWP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
+    unsigned char *As = vs_smem;               // [2][TILE][ROWP]
+    unsigned char *Bs = vs_smem + 2 * TILE_B;  // [2][TILE][ROWP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = blockIdx.x;
+    const int mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy (long-k) row tiles first
+    const int m0 = mt * TILE, n0 = nt * TILE;
+    const int kt1 = min(g.K, m0 + TILE) / 32;  // X is lower-triangular
+    const size_t ldb = (size_t)g.K * 4;        // bytes per P16 row
+
+    f32x16v acc[2][2], cor[2][2];  // main (hi*hi) and correction (hi*lo + lo*hi, scaled by 2^11) sums
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.0f;
+                cor[i][j][r] = 0.0f;
+            }
+
+    // staging: chunk c = tid + 256 i -> row = (tid >> 3) + 32 i, 16-byte chunk (tid & 7) of the 128-byte block
+    const int s_row = tid >> 3, s_kc = tid & 7;
+    const unsigned char *a_src = g.A + (size_t)(m0 + s_row) * ldb + s_kc * 16;
+    const unsigned char *b_src = g.B + (size_t)(n0 + s_row) * ldb + s_kc * 16;
+    const int s_lds = s_row * ROWP + s_kc * 16;
+    // two register slots of 4 + 4 chunks, as NAMED scalars: hipcc demotes (even 1-D) uint4 arrays that live across
+    // the two halves of the unrolled loop to scratch memory, which serialises the loads behind the MFMAs
+    uint4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3;
+    uint4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;
+#define VS_LD1(DST, SRC, I, KO) DST = *reinterpret_cast<const uint4 *>((SRC) + (size_t)(32 * (I)) * ldb + (KO))
+#define VS_GLOAD(SLOT, KT)                                  \
+    {                                                       \
+        const size_t ko_ = (size_t)(KT) * ROWB;             \
+        VS_LD1(ra##SLOT##_0, a_src, 0, ko_);                \
+        VS_LD1(rb##SLOT##_0, b_src, 0, ko_);                \
+        VS_LD1(ra##SLOT##_1, a_src, 1, ko_);                \
+        VS_LD1(rb##SLOT##_1, b_src, 1, ko_);                \
+        VS_LD1(ra##SLOT##_2, a_src, 2, ko_);                \
+        VS_LD1(rb##SLOT##_2, b_src, 2, ko_);                \
+        VS_LD1(ra##SLOT##_3, a_src, 3, ko_);                \
+        VS_LD1(rb##SLOT##_3, b_src, 3, ko_);                \
+    }
+#define VS_ST1(BASE, BUF, I, V) *reinterpret_cast<uint4 *>((BASE) + (BUF) * TILE_B + s_lds + 32 * (I) * ROWP) = V
+#define VS_SSTORE(SLOT, BUF)                    \
+    {                                           \
+        VS_ST1(As, BUF, 0, ra##SLOT##_0);       \
+        VS_ST1(Bs, BUF, 0, rb##SLOT##_0);       \
+        VS_ST1(As, BUF, 1, ra##SLOT##_1);       \
+        VS_ST1(Bs, BUF, 1, rb##SLOT##_1);       \
+        VS_ST1(As, BUF, 2, ra##SLOT##_2);       \
+        VS_ST1(Bs, BUF, 2, rb##SLOT##_2);       \
+        VS_ST1(As, BUF, 3, ra##SLOT##_3);       \
+        VS_ST1(Bs, BUF, 3, rb##SLOT##_3);       \
+    }
+
+    // fragment addresses: lane l -> row (l & 31), k = 8 (l >> 5) + j  (16 bytes), second MFMA k-step +32 bytes;
+    // the lo halves sit 64 bytes further in the block
+    const int f_off = (lane & 31) * ROWP + (lane >> 5) * 16;
+    const int a_frag = (wm * 64) * ROWP + f_off;
+    const int b_frag = (wn * 64) * ROWP + f_off;
+
+#define VS_COMPUTE(BUF)                                                                                      \
+    {                                                                                                        \
+        const unsigned char *as = As + (BUF) * TILE_B + a_frag;                                              \
+        const unsigned char *bs = Bs + (BUF) * TILE_B + b_frag;                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+        {                                                                                                    \
+            half8 ah[2], al[2], bh[2], bl[2];                                                                \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                    \
+            {                                                                                                \
+                ah[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWP + kk * 32);                      \
+                al[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWP + kk * 32 + 64);                 \
+                bh[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWP + kk * 32);                      \
+                bl[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWP + kk * 32 + 64);                 \
+            }                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
+            {                                                                                                \
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);        \
+                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);        \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    // kt1 is a multiple of 4 (K and the tile are multiples of 128), so the 2-deep variant can be unrolled by
+    // two without a remainder and every register-slot index stays a compile-time constant.
+    if (kt1 > 0) {
+        VS_GLOAD(0, 0);
+        if constexpr (PF == 2)
+            VS_GLOAD(1, 1);
+        VS_SSTORE(0, 0);
+        __syncthreads();
+        if constexpr (PF == 1) {
+            int buf = 0;
+            for (int kt = 0; kt < kt1; ++kt) {
+                VS_GLOAD(0, min(kt + 1, kt1 - 1));
+                VS_COMPUTE(buf);
+                VS_SSTORE(0, buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            for (int kt = 0; kt < kt1; kt += 2) {
+                // even tile kt: LDS buffer 0; slot 0 is free -> tile kt+2; slot 1 holds tile kt+1
+                VS_GLOAD(0, min(kt + 2, kt1 - 1));
+                VS_COMPUTE(0);
+                VS_SSTORE(1, 1);
+                __syncthreads();
+                // odd tile kt+1: LDS buffer 1; slot 1 is free -> tile kt+3; slot 0 holds tile kt+2
+                VS_GLOAD(1, min(kt + 3, kt1 - 1));
+                VS_COMPUTE(1);
+                VS_SSTORE(0, 0);
+                __syncthreads();
+            }
+        }
+    }
+#undef VS_COMPUTE
+#undef VS_GLOAD
+#undef VS_SSTORE
+#undef VS_LD1
+#undef VS_ST1
+
+    // ---- epilogue: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
+    float w[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            w[i][r] = g.w[m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
+                s += wv * wv * w[i][r];
+            }
+        s += __shfl_xor(s, 32);
+        if (lane < 32)
+            red[wm * TILE + wn * 64 + j * 32 + lane] = s;
+    }
+    __syncthreads();
+    if (tid < TILE)
+        g.partial[(size_t)mt * g.ldp + n0 + tid] = red[tid] + red[TILE + tid];
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st)
+{
+    // X (fp32) -> P16 in place; dinv -> w = dinv / (sx sk)^2 in place
+    (void)hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
+    const size_t n = (size_t)np * np;
+    hipLaunchKernelGGL(split_absmax_kernel, dim3(2048), dim3(256), 0, st, X, n, amax_bits);
+    hipLaunchKernelGGL(split_pack_kernel, dim3(4096), dim3(256), 0, st, X, n / 32, amax_bits);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((np + 255) / 256), dim3(256), 0, st, np, dinv_to_w, amax_bits, sk,
+                       dinv_to_w);
+}
+
+void launch_kqp_split(const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
+                      long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
+                      hipStream_t st)
+{
+    Cov<float> c = lower_cov<float>(h);
+    dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<KID>), grid, dim3(256), 0, st, c, sk, n, npad,
+                                              (const float *)px, (const float *)py, (const float *)pz, nq_valid, qx,
+                                              qy, qz, (half_t *)P));
+}
+
+void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial,
+                        long ldp, int prefetch, hipStream_t st)
+{
+    VsplitDev g;
+    g.A = (const unsigned char *)Xp;
+    g.B = (const unsigned char *)Kp;
+    g.M = np, g.N = nq_tile, g.K = np;
+    g.w = w;
+    g.partial = partial, g.ldp = ldp;
+    constexpr size_t shmem = 4 * (size_t)TILE * (128 + 16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_done = true;
+    }
+    dim3 grid(nq_tile / TILE, np / TILE);
+    if (prefetch >= 2)
+        hipLaunchKernelGGL(vsplit_gemm_kernel<2>, grid, dim3(256), shmem, st, g);
+    else
+        hipLaunchKernelGGL(vsplit_gemm_kernel<1>, grid, dim3(256), shmem, st, g);
+}
+
+}  // namespace gpx

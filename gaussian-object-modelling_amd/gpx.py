@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgpx.so")
 GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
 KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
               "matern32": MATERN32, "matern52": MATERN52}
-F32, F64, MIXED = 0, 1, 2
+F32, F64, MIXED, F32_SPLIT = 0, 1, 2, 3
 
 OK = 0
 E_NULL, E_EMPTY, E_LABELED_QUERY, E_SIZE_MISMATCH, E_SINGULAR, E_NAN_INPUT, E_HIP, E_OOM, E_NO_DEVICE, \

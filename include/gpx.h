@@ -70,8 +70,11 @@ typedef struct gpx_kernel {
  *          with fp64 matrix-free residuals
  *   F64    everything in fp64 (fp64 MFMA): the reference's arithmetic
  *   MIXED  train (kernel matrix, LDL^T, alpha, inverse factor) in fp64, then the inverse factor is
- *          rounded once to fp32 and the variance GEMM runs in fp32; the fp64 factor is released */
-typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1, GPX_PREC_MIXED = 2 } gpx_precision;
+ *          rounded once to fp32 and the variance GEMM runs in fp32; the fp64 factor is released
+ *   F32_SPLIT  as F32, but the variance contraction runs on the fp16 matrix cores with every fp32 operand
+ *          carried as hi + lo halves (3 MFMA products, fp32 accumulation): ~2^-22 per product instead of
+ *          2^-24, several times faster; opt-in */
+typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1, GPX_PREC_MIXED = 2, GPX_PREC_F32_SPLIT = 3 } gpx_precision;
 
 typedef struct gpx_options {
     int32_t precision;     /* gpx_precision */
