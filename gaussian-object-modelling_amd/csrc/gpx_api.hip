@@ -13,6 +13,7 @@
 // There is no CPU compute path: without a HIP device every compute entry point fails.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -90,6 +91,15 @@ CovHost make_cov(const gpx_kernel &k)
 // ------------------------------------------------------------------------------------------------
 enum { EV_T0 = 0, EV_KBUILD, EV_FACTOR, EV_SOLVE, EV_NORMALS, EV_INV0, EV_INV1, EV_M0, EV_M1, EV_V1, EV_COUNT };
 
+struct gpx_pending {
+    size_t nq;
+    const double *qx, *qy, *qz;
+    double *f, *v, *grad, *tx, *ty;
+    int rc = GPX_OK;
+    bool done = false;
+    std::string err;
+};
+
 struct gpx_model {
     int device = 0, prec = 0;
     size_t esz = 4;
@@ -140,6 +150,15 @@ struct gpx_model {
     double *ws_host_io = nullptr;  // device staging for the host-pointer evaluate
     size_t ws_host_io_doubles = 0;
     int qbatch = 8192;
+    // flat combining of concurrent small evaluate() calls (the node issues one call per grid point from
+    // hundreds of threads, src/gp_node.cpp:1027-1038): whoever finds no leader takes every pending request
+    // and runs them as ONE device batch
+    std::mutex qmtx;
+    std::condition_variable qcv;
+    std::vector<struct gpx_pending *> pending;
+    bool leader_active = false;
+    double *pin = nullptr;  // pinned host staging of the combiner
+    size_t pin_doubles = 0;
     std::mutex mtx;
     gpx_stats stats{};
     bool stats_create_pending = false, stats_eval_pending = false;
@@ -168,6 +187,10 @@ static void free_dev(gpx_model *m)
     F(m->ws_grad);
     F(m->ws_host_io);
     F(m->d_normals);
+    if (m->pin)
+        (void)hipHostFree(m->pin);
+    m->pin = nullptr;
+    m->pin_doubles = 0;
     m->dvecs = nullptr;
     m->blob0 = m->tvecs = m->Kmat = m->linv = m->Wp = m->X = nullptr;
     m->d_info = nullptr;
@@ -913,6 +936,76 @@ extern "C" int gpx_model_evaluate_device(const gpx_model *cm, size_t nq, const v
                            (double *)d_v, (double *)d_grad, (double *)d_tx, (double *)d_ty, s);
 }
 
+// One device batch for a list of host requests: queries are concatenated into pinned staging, evaluated
+// once (the union of the requested outputs), and the results scattered back.
+static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
+{
+    size_t total = 0;
+    bool wv = false, wg = false, wtx = false, wty = false;
+    for (const gpx_pending *r : reqs) {
+        total += r->nq;
+        wv |= r->v != nullptr;
+        wg |= r->grad != nullptr;
+        wtx |= r->tx != nullptr;
+        wty |= r->ty != nullptr;
+    }
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    // layout (host pinned and device alike): qx qy qz | f | v | grad | tx | ty
+    const size_t doubles = total * (3 + 1 + 1 + 3 + 3 + 3);
+    int rc;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    if (m->pin_doubles < doubles) {
+        if (m->pin)
+            HIPCHK(hipHostFree(m->pin));
+        m->pin = nullptr;
+        m->pin_doubles = 0;
+        HIPCHK(hipHostMalloc((void **)&m->pin, sizeof(double) * doubles, hipHostMallocDefault));
+        m->pin_doubles = doubles;
+    }
+    double *h = m->pin, *d = m->ws_host_io;
+    size_t off = 0;
+    for (const gpx_pending *r : reqs) {
+        std::memcpy(h + off, r->qx, sizeof(double) * r->nq);
+        std::memcpy(h + total + off, r->qy, sizeof(double) * r->nq);
+        std::memcpy(h + 2 * total + off, r->qz, sizeof(double) * r->nq);
+        off += r->nq;
+    }
+    double *dqx = d, *dqy = d + total, *dqz = d + 2 * total, *df = d + 3 * total, *dv = d + 4 * total,
+           *dg = d + 5 * total, *dtx = d + 8 * total, *dty = d + 11 * total;
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemcpyAsync(d, h, sizeof(double) * 3 * total, hipMemcpyHostToDevice, s));
+    rc = evaluate_locked(m, total, dqx, dqy, dqz, df, wv ? dv : nullptr, wg ? dg : nullptr, wtx ? dtx : nullptr,
+                         wty ? dty : nullptr, s);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(h + 3 * total, df, sizeof(double) * total * (wv ? 2 : 1), hipMemcpyDeviceToHost, s));
+    if (wg)
+        HIPCHK(hipMemcpyAsync(h + 5 * total, dg, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    if (wtx)
+        HIPCHK(hipMemcpyAsync(h + 8 * total, dtx, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    if (wty)
+        HIPCHK(hipMemcpyAsync(h + 11 * total, dty, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    off = 0;
+    for (const gpx_pending *r : reqs) {
+        std::memcpy(r->f, h + 3 * total + off, sizeof(double) * r->nq);
+        if (r->v)
+            std::memcpy(r->v, h + 4 * total + off, sizeof(double) * r->nq);
+        if (r->grad)
+            std::memcpy(r->grad, h + 5 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        if (r->tx)
+            std::memcpy(r->tx, h + 8 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        if (r->ty)
+            std::memcpy(r->ty, h + 11 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        off += r->nq;
+    }
+    return GPX_OK;
+}
+
+constexpr size_t COMBINE_MAX_NQ = 4096;  // larger calls fill the device on their own
+
 extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
                                   const double *qz, double *f, double *v, double *grad, double *tx, double *ty)
 {
@@ -920,34 +1013,38 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
     if (rc)
         return rc;
     gpx_model *m = const_cast<gpx_model *>(cm);
-    std::lock_guard<std::mutex> lk(m->mtx);
-    HIPCHK(hipSetDevice(m->device));
-    // device staging: qx qy qz | f | v | grad | tx | ty
-    const size_t total = nq * (3 + 1 + 1 + 3 + 3 + 3);
-    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * total)))
-        return rc;
-    double *d = m->ws_host_io;
-    double *dqx = d, *dqy = d + nq, *dqz = d + 2 * nq, *df = d + 3 * nq, *dv = d + 4 * nq, *dg = d + 5 * nq,
-           *dtx = d + 8 * nq, *dty = d + 11 * nq;
-    hipStream_t s = m->stream;
-    HIPCHK(hipMemcpyAsync(dqx, qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dqy, qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(dqz, qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
-    rc = evaluate_locked(m, nq, dqx, dqy, dqz, df, v ? dv : nullptr, grad ? dg : nullptr, tx ? dtx : nullptr,
-                         ty ? dty : nullptr, s);
-    if (rc)
-        return rc;
-    HIPCHK(hipMemcpyAsync(f, df, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
-    if (v)
-        HIPCHK(hipMemcpyAsync(v, dv, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
-    if (grad)
-        HIPCHK(hipMemcpyAsync(grad, dg, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
-    if (tx)
-        HIPCHK(hipMemcpyAsync(tx, dtx, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
-    if (ty)
-        HIPCHK(hipMemcpyAsync(ty, dty, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return GPX_OK;
+    gpx_pending req{nq, qx, qy, qz, f, v, grad, tx, ty};
+    if (nq > COMBINE_MAX_NQ) {
+        std::vector<gpx_pending *> one{&req};
+        return run_requests(m, one);
+    }
+    // flat combining: the calling thread either becomes the leader of a batch or waits for one
+    std::unique_lock<std::mutex> lk(m->qmtx);
+    m->pending.push_back(&req);
+    while (!req.done) {
+        if (!m->leader_active) {
+            m->leader_active = true;
+            std::vector<gpx_pending *> batch;
+            batch.swap(m->pending);
+            lk.unlock();
+            const int brc = run_requests(m, batch);
+            const std::string berr = brc ? g_err : std::string();
+            lk.lock();
+            for (gpx_pending *p : batch) {
+                p->rc = brc;
+                p->err = berr;
+                p->done = true;
+            }
+            m->leader_active = false;
+            m->qcv.notify_all();
+        } else {
+            m->qcv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (req.rc)
+        g_err = req.err;
+    return req.rc;
 }
 
 extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
