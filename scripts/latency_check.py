@@ -30,3 +30,14 @@ for nth in (8, 64, 256):
     print("%d threads: %d single-point calls in %.3f s = %.1f us per call" % (nth, n, dt, dt / n * 1e6), flush=True)
 t = time.perf_counter(); o = m.evaluate(qx, qy, qz, want_v=True); dt = time.perf_counter() - t
 print("one batched call of %d points: %.3f ms; max |f diff| vs threaded = %.2e" % (n, dt * 1e3, np.max(np.abs(o["f"] - f))))
+for prec, name in ((gpx.F64, "f64"), (gpx.F32, "f32")):
+    t = time.perf_counter()
+    for _ in range(20):
+        mm = gpx.Model(gpx.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=prec)
+        mm.close()
+    dt = (time.perf_counter() - t) / 20
+    mm = gpx.Model(gpx.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=prec)
+    st = mm.stats
+    print("create+destroy N=%d %s: %.2f ms wall (device: kbuild %.3f factor %.3f solve %.3f ms)" % (len(x), name, dt * 1e3, st["t_kbuild_ms"], st["t_factor_ms"], st["t_solve_ms"]))
+    t = time.perf_counter(); mm.evaluate(qx[:1], qy[:1], qz[:1], want_v=True); print("  first variance query (builds the inverse factor): %.2f ms" % ((time.perf_counter() - t) * 1e3))
+    mm.close()
