@@ -15,6 +15,8 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -108,6 +110,7 @@ struct gpx_model {
     gpx_options opt{};
     int n = 0, npad = 0, nblk = 0;
     bool ready = false, has_s2 = false, has_inverse = false, has_normals = false;
+    bool inv64 = true;      // F32 modes: assemble the inverse factor in fp64 from the fp32 factor (GPX_INV64=0 disables)
     bool x_packed = false;  // F32_SPLIT: X holds packed hi/lo halves, the 1/D slot holds the scaled weights
     float sk = 1.0f;        // power-of-two scale of the kernel values in the split contraction
     std::vector<double> hx, hy, hz, hlabel, hs2;  // caller order
@@ -161,7 +164,7 @@ struct gpx_model {
     size_t pin_doubles = 0;
     std::mutex mtx;
     gpx_stats stats{};
-    bool stats_create_pending = false, stats_eval_pending = false;
+    bool stats_eval_pending = false;
     bool eval_had_var = false;
 };
 
@@ -397,22 +400,8 @@ static void factorize(gpx_model *m)
 }
 
 // ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
-static int build_inverse(gpx_model *m)
+static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st)
 {
-    if (m->has_inverse)
-        return GPX_OK;
-    const int np = m->npad;
-    const size_t e = m->esz;
-    if (!m->X)
-        HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
-    void *Tws = nullptr;
-    HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
-    (void)hipEventRecord(m->ev[EV_INV0], m->stream);
-    // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
-    // 128-block of every 256-diagonal block
-    HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
-    launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
-    char *L = (char *)m->Kmat, *X = (char *)m->X, *Tw = (char *)Tws;
     auto off = [&](size_t r, size_t c) { return (r * np + c) * e; };
     for (long b = TILE; b < np; b *= 2) {
         // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
@@ -432,7 +421,7 @@ static int build_inverse(gpx_model *m)
         g1.sA = g1.sB = g1.sC = stride;
         g1.batch = P, g1.M_last = m_last;
         g1.nn = 1, g1.b_lower = 1;
-        launch_gemm(m->prec, g1, m->stream);
+        launch_gemm(prec, g1, st);
         GemmArgs g2;  // X21 = -X22 * T  (A lower)
         g2.A = X + off(b, b), g2.lda = np;
         g2.B = Tw + off(b, 0), g2.ldb = np;
@@ -442,11 +431,54 @@ static int build_inverse(gpx_model *m)
         g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
         g2.nn = 1, g2.a_lower = 1;
         g2.alpha = -1.0;
-        launch_gemm(m->prec, g2, m->stream);
+        launch_gemm(prec, g2, st);
+    }
+}
+
+static int build_inverse(gpx_model *m)
+{
+    if (m->has_inverse)
+        return GPX_OK;
+    const int np = m->npad;
+    const size_t e = m->esz;
+    if (!m->X)
+        HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
+    (void)hipEventRecord(m->ev[EV_INV0], m->stream);
+    void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
+    const bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
+    if (assemble64) {
+        // The fp32 factor is kept (that is what runs on the fp32 MFMA), but its inverse is assembled in fp64 and
+        // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
+        // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
+        // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
+        const size_t nn = (size_t)np * np;
+        HIPCHK(hipMalloc(&L64, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&X64, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&Tws, sizeof(double) * nn));
+        HIPCHK(hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE));
+        launch_cast_f2d(nn, (const float *)m->Kmat, (double *)L64, m->stream);
+        launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, (double *)linv64, m->stream);
+        HIPCHK(hipMemsetAsync(X64, 0, sizeof(double) * nn, m->stream));
+        launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
+        trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
+        launch_cast_d2f(nn, (const double *)X64, (float *)m->X, m->stream);
+    } else {
+        HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
+        // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
+        // 128-block of every 256-diagonal block
+        HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
+        launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
+        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)Tws, np, m->stream);
     }
     (void)hipEventRecord(m->ev[EV_INV1], m->stream);
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipFree(Tws));
+    if (L64)
+        HIPCHK(hipFree(L64));
+    if (X64)
+        HIPCHK(hipFree(X64));
+    if (linv64)
+        HIPCHK(hipFree(linv64));
     float ms = 0;
     if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
         m->stats.t_inverse_ms = ms;
@@ -694,6 +726,8 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     m->npad = (int)gpx_padded_n(n);
     m->nblk = m->npad / TILE;
     set_query_batch(m);
+    if (const char *e64 = std::getenv("GPX_INV64"))
+        m->inv64 = std::atoi(e64) != 0;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");

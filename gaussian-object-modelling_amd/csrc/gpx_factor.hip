@@ -12,99 +12,230 @@
 
 namespace gpx {
 
-constexpr int DLD = TILE + 1;  // LDS leading dimension (conflict-free row and column walks)
-constexpr int DT = 1024;  // threads of the diagonal-block kernel
 
-// One 128 x 128 diagonal block, LDS resident: unblocked right-looking LDL^T (no pivoting inside the
-// block), then the unit-lower inverse of L in place.  1024 threads: the trailing update of step j is
-// spread over a 32 x 32 thread grid (<= 16 dependent LDS read-modify-writes per thread and step), the
-// inverse uses 8 lanes per row.  A fully register-resident variant (rows in registers, both loops
-// unrolled 128x) was tried: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
+constexpr int DT = 512;   // threads of the diagonal-block kernel (2 waves/SIMD: step A needs ~200 registers)
+constexpr int NB = 32;    // sub-block order inside the 128 x 128 diagonal block
+constexpr int PLD = NB + 1;
+
+// value of `v` in lane `src` (wave-uniform, here a compile-time constant after unrolling): v_readlane_b32 puts
+// the result in a SCALAR register, so the 1000 broadcasts of step A cost no vector registers
+// (with __shfl = ds_bpermute the scheduler kept hundreds in flight and spilled 1.3 KB per lane)
+__device__ __forceinline__ float bcast_lane(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double bcast_lane(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// One 128 x 128 diagonal block: LDL^T without pivoting + the inverse of its unit-lower L, blocked by 32.
+//
+//   per 32-column panel  A) the 32 x 32 diagonal sub-block is factorised AND inverted by ONE wave with the rows
+//                           in registers (static indices; pivot rows / columns travel by __shfl, no barrier),
+//                        B) the rows below: W = A21 X11^T (= L21 D), L21 = W D^-1   (all 1024 threads),
+//                        C) the trailing update A22 -= W L21^T on the (L2-resident) global block, panel
+//                           operands in LDS.
+//   then the 128 x 128 inverse is assembled from the four 32 x 32 inverses, block column by block column:
+//        X[i][j] = -Xd[i] * sum_{j<=k<i} L[i][k] X[k][j].
+// ~12 barriers per panel instead of one per column; replaces an unblocked LDS kernel (348 us, then 177 us with
+// 1024 threads) that sat on the critical path of the factorisation 128 times at N = 16384.  A fully
+// register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
 template <typename T>
 __global__ __launch_bounds__(DT) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
                                                       T *__restrict__ d, T *__restrict__ dinv,
                                                       int *__restrict__ info, int blk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *S = reinterpret_cast<T *>(smem_raw);  // [TILE][DLD]
-    __shared__ T tmp[TILE];
-    __shared__ T Ds[TILE];
-    const int tid = threadIdx.x;
+    T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
+    T *Lp = Pa + TILE * PLD;                       // [TILE][PLD]  panel: L
+    T *Xd = Lp + TILE * PLD;                       // [4][NB][PLD] inverses of the diagonal sub-blocks
+    T *Di = Xd + 4 * NB * PLD;                     // [TILE]       1 / D
+    // the inverse assembly re-uses the panel region: Xs = 3 off-diagonal blocks, Tb = 3 product blocks
+    T *Xs = Pa;                                    // [3][NB][PLD]  X(1,0), X(2,0), X(2,1)
+    T *Tb = Pa + 3 * NB * PLD;                     // [3][NB][PLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int idx = tid; idx < TILE * TILE; idx += DT) {
-        const int i = idx >> 7, j = idx & 127;
-        S[i * DLD + j] = A[(size_t)i * lda + j];
-    }
-    // ---- right-looking LDL^T; column j keeps u_ij = l_ij * d_j until the final scaling ----
-    const int ti = tid >> 5, tk = tid & 31;
-    int nneg = 0;
-    for (int j = 0; j < TILE; ++j) {
-        __syncthreads();
-        const T dj = S[j * DLD + j];
-        if (tid == 0) {
-            if (!(fabs((double)dj) > 0.0) || !(fabs((double)dj) < 1e300))
-                atomicCAS(&info[0], 0, blk * TILE + j + 1);
-            if (dj < T(0))
-                ++nneg;
+    for (int jb = 0; jb < 4; ++jb) {
+        const int c0 = NB * jb;
+        const int nrows = TILE - c0;
+        for (int idx = tid; idx < nrows * NB; idx += DT) {
+            const int r_ = idx >> 5, c_ = idx & 31;
+            Pa[(c0 + r_) * PLD + c_] = A[(size_t)(c0 + r_) * lda + c0 + c_];
         }
-        const T inv = T(1) / dj;
-        for (int i = j + 1 + ti; i < TILE; i += 32) {
-            const T lij = S[i * DLD + j] * inv;
-            for (int k = j + 1 + tk; k <= i; k += 32)
-                S[i * DLD + k] -= lij * S[k * DLD + j];
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && nneg)
-        atomicAdd(&info[1], nneg);
-    if (tid < TILE) {
-        const T dj = S[tid * DLD + tid];
-        Ds[tid] = T(1) / dj;
-        d[blk * TILE + tid] = dj;
-        dinv[blk * TILE + tid] = T(1) / dj;
-    }
-    __syncthreads();
-    // scale to the unit-lower L, write L (strict lower) and D (diagonal) back
-    for (int idx = tid; idx < TILE * TILE; idx += DT) {
-        const int i = idx >> 7, j = idx & 127;
-        if (j < i) {
-            const T l = S[i * DLD + j] * Ds[j];
-            S[i * DLD + j] = l;
-            A[(size_t)i * lda + j] = l;
-        } else if (j == i) {
-            A[(size_t)i * lda + j] = S[i * DLD + j];
-        }
-    }
-    // ---- in-place inverse of the unit-lower L:  X L = I, columns from right to left ----
-    //   X[i][j] = -( L[i][j] + sum_{j<k<i} X[i][k] L[k][j] ),  8 lanes per row
-    const int row_off = tid >> 3, h = tid & 7;
-    for (int j = TILE - 2; j >= 0; --j) {
         __syncthreads();
-        if (tid < TILE && tid > j)
-            tmp[tid] = S[tid * DLD + j];
+        // ---- A: diagonal sub-block, one wave, lane l (and its twin l + 32) owns row l ----
+        if (wave == 0) {
+            const int l = lane & 31;
+            T r[NB], x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                r[c] = Pa[(c0 + l) * PLD + c];
+            T dmine = T(1);
+            int nneg = 0;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const T dj = bcast_lane(r[j], j);
+                if (!(fabs((double)dj) > 0.0) || !(fabs((double)dj) < 1e300))
+                    bad = true;
+                if (dj < T(0))
+                    ++nneg;
+                if (l == j)
+                    dmine = dj;
+                const T lij = r[j] * (T(1) / dj);
+#pragma unroll
+                for (int k = j + 1; k < NB; ++k) {
+                    const T akj = bcast_lane(r[j], k);  // a_kj (still un-scaled in lane k)
+                    r[k] -= lij * akj;
+                }
+                if (l > j)
+                    r[j] = lij;
+            }
+            // inverse of the unit-lower L11:  X[l][j] = -( L[l][j] + sum_{j<k<l} X[l][k] L[k][j] )
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                x[c] = T(0);
+#pragma unroll
+            for (int j = NB - 2; j >= 0; --j) {
+                T s0 = T(0), s1 = T(0);
+#pragma unroll
+                for (int k = j + 1; k < NB; ++k) {
+                    const T lkj = bcast_lane(r[j], k);  // L[k][j]
+                    const T t = (k < l) ? x[k] * lkj : T(0);
+                    if (k & 1)
+                        s1 += t;
+                    else
+                        s0 += t;
+                }
+                x[j] = (l > j) ? -(r[j] + s0 + s1) : T(0);
+            }
+            if (lane < NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    Xd[(jb * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
+                    if (c < l)
+                        A[(size_t)(c0 + l) * lda + c0 + c] = r[c];
+                }
+                A[(size_t)(c0 + l) * lda + c0 + l] = dmine;
+                Di[c0 + l] = T(1) / dmine;
+                d[blk * TILE + c0 + l] = dmine;
+                dinv[blk * TILE + c0 + l] = T(1) / dmine;
+                if (l == 0) {
+                    if (bad)
+                        atomicCAS(&info[0], 0, blk * TILE + c0 + 1);
+                    if (nneg)
+                        atomicAdd(&info[1], nneg);
+                }
+            }
+        }
         __syncthreads();
-        const int i = j + 1 + row_off;
-        T s = T(0);
-        if (i < TILE)
-            for (int k = j + 1 + h; k < i; k += 8)
-                s += S[i * DLD + k] * tmp[k];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (i < TILE && h == 0)
-            S[i * DLD + j] = -(tmp[i] + s);
+        const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
+        if (nb_rows > 0) {
+            // ---- B: W[i][c] = sum_{k<=c} A[i][k] X11[c][k]  (WPT entries per thread at most) ----
+            constexpr int WPT = ((TILE - NB) * NB + DT - 1) / DT;
+            T wreg[WPT];
+#pragma unroll
+            for (int e = 0; e < WPT; ++e) {
+                const int idx = tid + DT * e;
+                T w = T(0);
+                if (idx < nb_rows * NB) {
+                    const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
+                    const T *arow = Pa + i_ * PLD;
+                    const T *xrow = Xd + (jb * NB + c_) * PLD;
+                    for (int k = 0; k <= c_; ++k)
+                        w += arow[k] * xrow[k];
+                }
+                wreg[e] = w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < WPT; ++e) {
+                const int idx = tid + DT * e;
+                if (idx < nb_rows * NB) {
+                    const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
+                    const T lv = wreg[e] * Di[c0 + c_];
+                    Pa[i_ * PLD + c_] = wreg[e];
+                    Lp[i_ * PLD + c_] = lv;
+                    A[(size_t)i_ * lda + c0 + c_] = lv;
+                }
+            }
+            __syncthreads();
+            // ---- C: trailing update on the global block: A[i][k] -= sum_c W[i][c] L[k][c], k <= i ----
+            const int r0 = c0 + NB;
+            for (int idx = tid; idx < nb_rows * nb_rows; idx += DT) {
+                const int ii = idx / nb_rows, kk = idx - ii * nb_rows;
+                if (kk > ii)
+                    continue;
+                const T *wrow = Pa + (r0 + ii) * PLD;
+                const T *lrow = Lp + (r0 + kk) * PLD;
+                T s = T(0);
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    s += wrow[c] * lrow[c];
+                A[(size_t)(r0 + ii) * lda + r0 + kk] -= s;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
     }
-    __syncthreads();
+
+    // ---- inverse of the 128 x 128 unit-lower L from the four 32 x 32 inverses ----
+    for (int s_ = 1; s_ < 4; ++s_) {
+        // phase 1: T(i,j) = sum_{k=j}^{i-1} L[i][k] X[k][j]  for the 4 - s_ blocks (i = j + s_, j)
+        const int nblocks = 4 - s_;
+        for (int idx = tid; idx < nblocks * NB * NB; idx += DT) {
+            const int b = idx >> 10, r_ = (idx >> 5) & 31, c_ = idx & 31;
+            const int jj = b, ii = b + s_;
+            T acc = T(0);
+            for (int k = jj; k < ii; ++k) {
+                const T *lrow = A + (size_t)(NB * ii + r_) * lda + NB * k;  // L(ii,k) row r_, from global
+                const T *xb = (k == jj) ? Xd + (jj * NB) * PLD
+                                        : Xs + ((k == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB) * PLD;  // X(1,0) | X(2,0) | X(2,1)
+                for (int t = 0; t < NB; ++t)
+                    acc += lrow[t] * xb[t * PLD + c_];
+            }
+            Tb[(b * NB + r_) * PLD + c_] = acc;
+        }
+        __syncthreads();
+        // phase 2: X(i,j) = -Xd[i] * T(i,j)
+        for (int idx = tid; idx < nblocks * NB * NB; idx += DT) {
+            const int b = idx >> 10, r_ = (idx >> 5) & 31, c_ = idx & 31;
+            const int jj = b, ii = b + s_;
+            const T *xdrow = Xd + (ii * NB + r_) * PLD;
+            T acc = T(0);
+            for (int t = 0; t <= r_; ++t)
+                acc += xdrow[t] * Tb[(b * NB + t) * PLD + c_];
+            const T xv = -acc;
+            linv[(size_t)blk * TILE * TILE + (size_t)(NB * ii + r_) * TILE + NB * jj + c_] = xv;
+            if (ii < 3)  // X(1,0), X(2,0), X(2,1) are operands of later steps
+                Xs[((ii == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB + r_) * PLD + c_] = xv;
+        }
+        __syncthreads();
+    }
+    // diagonal blocks and the zero upper part
     for (int idx = tid; idx < TILE * TILE; idx += DT) {
-        const int i = idx >> 7, j = idx & 127;
-        linv[(size_t)blk * TILE * TILE + idx] = j < i ? S[i * DLD + j] : (j == i ? T(1) : T(0));
+        const int r_ = idx >> 7, c_ = idx & 127;
+        const int bi = r_ >> 5, bj = c_ >> 5;
+        if (bj > bi)
+            linv[(size_t)blk * TILE * TILE + idx] = T(0);
+        else if (bj == bi)
+            linv[(size_t)blk * TILE * TILE + idx] = Xd[(bi * NB + (r_ & 31)) * PLD + (c_ & 31)];
     }
+}
+
+static size_t diag_shmem_bytes(size_t esz)
+{
+    return esz * (size_t)(2 * TILE * PLD + 4 * NB * PLD + TILE);  // Pa + Lp + Xd + Di
 }
 
 template <typename T>
 static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
 {
-    const size_t shmem = (size_t)TILE * DLD * sizeof(T);
+    const size_t shmem = diag_shmem_bytes(sizeof(T));
     hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(DT), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
                        (T *)dinv, info, blk);
 }
@@ -113,10 +244,10 @@ void factor_init(int prec)
 {
     if (prec == GPX_PREC_F64)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TILE * DLD * sizeof(double)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
     else
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(TILE * DLD * sizeof(float)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
 }
 
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,

@@ -77,17 +77,6 @@ struct GemmDev {
     long ldp;
 };
 
-__device__ __forceinline__ void tri_decode_g(int t, int &ti, int &tj)
-{
-    int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > t)
-        --i;
-    while ((i + 1) * (i + 2) / 2 <= t)
-        ++i;
-    ti = i;
-    tj = t - i * (i + 1) / 2;
-}
-
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
@@ -120,7 +109,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     // ---- which tile ----
     int mt, nt;
     if (g.lower_only) {
-        tri_decode_g((int)blockIdx.x, mt, nt);
+        tri_decode((int)blockIdx.x, mt, nt);
     } else {
         nt = blockIdx.x;
         mt = g.a_lower ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;  // heavy row-tiles first

@@ -34,6 +34,18 @@ inline Cov<T> lower_cov(const CovHost &h)
     return Cov<T>{(T)h.a, (T)h.s, (T)h.R, (T)h.R3};
 }
 
+// linear index t of a lower-triangular tile enumeration -> (ti, tj), ti >= tj, t = ti (ti + 1) / 2 + tj
+__device__ __forceinline__ void tri_decode(int t, int &ti, int &tj)
+{
+    int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > t)
+        --i;
+    while ((i + 1) * (i + 2) / 2 <= t)
+        ++i;
+    ti = i;
+    tj = t - i * (i + 1) / 2;
+}
+
 // ---- pairwise (kernel-matrix) stages : gpx_pairwise.hip -----------------------------------
 // K (lower block-triangle, identity on padding), per-tile maxima of the squared distance.
 void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
@@ -69,6 +81,7 @@ void launch_axpy_cast(int prec, int n, int npad, double *alpha_d, const void *de
 void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st);
 void launch_normalize_rows3(long n, double *g, hipStream_t st);
 void launch_cast_d2f(size_t n, const double *src, float *dst, hipStream_t st);
+void launch_cast_f2d(size_t n, const float *src, double *dst, hipStream_t st);
 
 // ---- MFMA GEMM core : gpx_gemm.hip ----------------------------------------------------------
 enum GemmEpi { EPI_STORE = 0, EPI_TRSM = 1, EPI_COLSQ = 2 };

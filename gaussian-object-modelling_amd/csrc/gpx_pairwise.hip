@@ -30,17 +30,6 @@ __device__ __forceinline__ void store4(T *dst, const T (&o)[4])
     }
 }
 
-__device__ __forceinline__ void tri_decode(int t, int &ti, int &tj)
-{
-    int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while (i * (i + 1) / 2 > t)
-        --i;
-    while ((i + 1) * (i + 2) / 2 <= t)
-        ++i;
-    ti = i;
-    tj = t - i * (i + 1) / 2;
-}
-
 template <typename T, int KID>
 __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ x,
                                                      const T *__restrict__ y, const T *__restrict__ z,

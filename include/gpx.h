@@ -177,8 +177,8 @@ int gpx_model_commit(gpx_model *m, int with_variance);
  * kbuild: K[i][j] = k(|p_i-p_j|) + sigma2_i*delta_ij on the lower block-triangle of an
  * n_padded x n_padded row-major matrix of `precision` scalars (identity on the padding);
  * replaces buildEuclideanDistanceMatrix + the kernel loop, gp_regressor.hpp:132-159, :548-557.
- * d_x,d_y,d_z,d_s2: device arrays of `precision` scalars, n_padded long. d_rmax: device float/double
- * receiving max pairwise distance (:135) or NULL. */
+ * d_x,d_y,d_z,d_s2: device arrays of `precision` scalars (GPX_PREC_F32 or _F64), n_padded long.
+ * d_rmax: reserved, pass NULL (Model::R comes from gpx_model_get). */
 int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_x,
                    const void *d_y, const void *d_z, const void *d_s2, void *d_K, void *d_rmax, void *stream);
 size_t gpx_padded_n(size_t n); /* leading dimension / padded order used for n training points */
