@@ -13,7 +13,11 @@
 namespace gpx {
 
 
-constexpr int DT = 512;   // threads of the diagonal-block kernel (2 waves/SIMD: step A needs ~200 registers)
+// threads of the diagonal-block kernel: step A keeps two 32-entry rows in registers (fp32 ~180, fp64 ~300 VGPRs)
+template <typename T>
+struct DiagThreads {
+    static constexpr int value = sizeof(T) == 8 ? 256 : 512;
+};
 constexpr int NB = 32;    // sub-block order inside the 128 x 128 diagonal block
 constexpr int PLD = NB + 1;
 
@@ -45,10 +49,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 // 1024 threads) that sat on the critical path of the factorisation 128 times at N = 16384.  A fully
 // register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
 template <typename T>
-__global__ __launch_bounds__(DT) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
+__global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
                                                       T *__restrict__ d, T *__restrict__ dinv,
                                                       int *__restrict__ info, int blk)
 {
+    constexpr int DT = DiagThreads<T>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
     T *Lp = Pa + TILE * PLD;                       // [TILE][PLD]  panel: L
@@ -236,7 +241,7 @@ template <typename T>
 static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
 {
     const size_t shmem = diag_shmem_bytes(sizeof(T));
-    hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(DT), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
+    hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(DiagThreads<T>::value), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
                        (T *)dinv, info, blk);
 }
 

@@ -104,6 +104,30 @@ def test_non_default_hyper_parameters(gpu, orc, ds, golden, kn, par):
         gm.close()
 
 
+@pytest.mark.parametrize("name", ["bowlA", "bowlB", "containerA", "containerB", "jug", "kettle", "pot", "mugD",
+                                  "kitchenUtensilB"])
+def test_c5_objects_from_pcd(gpu, orc, ds, name):
+    """BASELINE config 5: one GP per object, fp32 Gaussian(1,1); PCD -> node training set on the HOST C++ path
+    (gpx_pcd_read + gpx_node_training_set), 128^3 lattice (oracle on a 700-point sub-sample)."""
+    xyz = gpu.pcd_read(os.path.join(GOLDEN_DIR, "pcd", name + ".pcd"))
+    x, y, z, lab, s2 = gpu.node_training_set(xyz)
+    assert len(x) == len(xyz) + 15
+    gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, precision=gpu.F32)
+    om = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(128)
+    out = gm.evaluate(qx, qy, qz, want_v=True)
+    sel = np.arange(0, 128 ** 3, 2999)
+    ref = om.evaluate(qx[sel], qy[sel], qz[sel], want_v=True)
+    assert nerr(gm.alpha, om.alpha) < 1e-5
+    assert nerr(out["f"][sel], ref["f"]) < 1e-5
+    assert verr(out["v"][sel], ref["v"], 1.0) < 1e-5
+    # the surface the node would extract from this grid
+    surf = gm.sample_surface(qx, qy, qz, f_tol=0.01)
+    keep = np.nonzero(np.abs(out["f"]) <= 0.01)[0]
+    np.testing.assert_array_equal(surf["idx"], keep)
+    gm.close()
+
+
 def test_single_training_point(gpu, orc):
     for prec in (1, 0):
         gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), [0.2], [0.0], [-0.1], [1.0], [0.1], precision=prec)
