@@ -1049,8 +1049,18 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
     gpx_model *m = const_cast<gpx_model *>(cm);
     gpx_pending req{nq, qx, qy, qz, f, v, grad, tx, ty};
     if (nq > COMBINE_MAX_NQ) {
-        std::vector<gpx_pending *> one{&req};
-        return run_requests(m, one);
+        // large host batches go straight to the device, in slices of 2^20 queries so that the pinned / device
+        // staging stays bounded (a 256^3 grid is 16.7M queries = 1.9 GB of staging in one piece)
+        constexpr size_t SLICE = (size_t)1 << 20;
+        for (size_t q0 = 0; q0 < nq; q0 += SLICE) {
+            const size_t nn = std::min(SLICE, nq - q0);
+            gpx_pending part{nn, qx + q0, qy + q0, qz + q0, f + q0, v ? v + q0 : nullptr,
+                             grad ? grad + 3 * q0 : nullptr, tx ? tx + 3 * q0 : nullptr, ty ? ty + 3 * q0 : nullptr};
+            std::vector<gpx_pending *> one{&part};
+            if ((rc = run_requests(m, one)))
+                return rc;
+        }
+        return GPX_OK;
     }
     // flat combining: the calling thread either becomes the leader of a batch or waits for one
     std::unique_lock<std::mutex> lk(m->qmtx);

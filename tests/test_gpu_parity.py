@@ -236,6 +236,22 @@ def test_variance_batching_and_large_query_sets(gpu, orc, ds):
             gm.close()
 
 
+def test_host_batches_larger_than_one_slice(gpu, orc, ds):
+    """Host evaluate slices very large batches (2^20 queries per slice); results do not depend on the slicing."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(64)
+    gm = gpu.Model(gpu.make_kernel("laplace", 1, 1), x, y, z, lab, s2, precision=gpu.F64)
+    om = orc.Model(orc.make_kernel("laplace", 1, 1), x, y, z, lab, s2)
+    rng = np.random.default_rng(11)
+    nq = (1 << 20) + 12345
+    q = rng.uniform(-1.1, 1.1, size=(3, nq))
+    out = gm.evaluate(q[0], q[1], q[2], want_v=True, want_grad=True)
+    sel = np.concatenate([np.arange(0, nq, 40009), [(1 << 20) - 1, 1 << 20, nq - 1]])
+    ref = om.evaluate(q[0][sel], q[1][sel], q[2][sel], want_v=True, want_grad=True)
+    for key in ("f", "v", "grad"):
+        assert nerr(out[key][sel], ref[key]) < 1e-10, key
+    gm.close()
+
+
 def test_concurrent_single_point_evaluate(gpu, orc, ds):
     """fakeDeterministicSampling: hundreds of host threads evaluate ONE point each on the same const
     model (src/gp_node.cpp:1027-1038); the call must be re-entrant."""
