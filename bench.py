@@ -252,7 +252,8 @@ def main():
                     "precision": "f32split (3 fp16 MFMA products on hi/lo halves, fp32 accumulation; opt-in)",
                     "ms_per_step": dt * 1e3, "value": nq / dt, "unit": "query-points/s",
                     "variance_gemm_avg_launch_ms": sst["t_var_gemm_ms"] / max(1, sst["var_gemm_launches"]),
-                    "variance_accuracy": "22-bit operands: ~4x the fp32 rounding (3e-5 k(0) at N=16384, 1e-5 up to N~2000)"}
+                    "variance_accuracy": "hi halves on a shared quantum per MFMA k-group (exact fixed-point product sums): "
+                                         "variance error / k(0) vs fp64 at N=16384 1.9e-6 (native fp32 path: 4.5e-6)"}
             except Exception as e:  # never let the extra line break the contract line
                 out["fast_mode"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:

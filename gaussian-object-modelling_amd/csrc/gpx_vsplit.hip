@@ -1,14 +1,21 @@
-// gpx_vsplit.hip -- the variance contraction on the fp16 matrix cores with fp32-class accuracy
-// (GPX_PREC_F32_SPLIT): every fp32 operand x is carried as two halves,
-//     hi = fp16(s x),   lo = fp16(2^11 (s x - hi))          (s: a power of two bringing max|x| below 1)
-// so that s x = hi + 2^-11 lo to ~2^-22 relative for every entry down to 6e-5 of the largest one (the 2^11
-// keeps lo in the NORMAL fp16 range; without it the small off-diagonal entries of the unit-lower inverse
-// factor would only be resolved to an absolute 2^-25 of its diagonal 1).  Then
+// gpx_vsplit.hip -- the variance contraction on the fp16 matrix cores at fp32 accuracy (GPX_PREC_F32_SPLIT):
+// every fp32 operand x is carried as two halves,
+//     hi = fp16(s x) on a per-group grid,   lo = fp16(2^11 (s x - hi))      (s: a power of two bringing max|x| below 1)
+// and
 //     x y  ~  hi_x hi_y  +  2^-11 (hi_x lo_y + lo_x hi_y)
 // runs as three v_mfma_f32_32x32x16_f16 into TWO fp32 accumulator sets (main, correction) that are combined
 // once in the epilogue; the dropped lo*lo term is below 2^-22 relative.  Three fp16 MFMAs move 16x more
 // flops per cycle than one fp32 MFMA, so the contraction costs ~5x fewer matrix-pipe cycles; what remains
 // is a staging problem (the operands are as many bytes as in fp32).
+//
+// Accuracy hinges on how the matrix core adds: the 8 products one lane feeds (8 consecutive k) are summed in
+// fixed point, aligned to the LARGEST of them and truncated 24 bits below it (scripts/mfma_tree_probe.hip), so the
+// error scales with the largest product, not with the sum -- and the rows of the inverse factor times the kernel
+// values cancel by 2-3 orders of magnitude (sum|x k| / |sum x k| ~ 700 at N = 1500).  With free-floating fp16 hi
+// parts that cost 7x the native fp32 error (3e-5 k(0) at N = 16384).  Therefore the hi parts of each such group of
+// 8 share one quantum (split8 below): all hi*hi products of a group are integer multiples of one power of two
+// within 22 bits of the largest, the group sum is exact, and the result is as accurate as the fp32 MFMA path
+// (measured variance error / k(0) at N = 16384: 1.9e-6 vs 4.5e-6 native for Matern-5/2, 1.8e-5 vs 2.1e-5 thin-plate).
 //
 // Packed layout "P16" of a [rows][K] matrix (K a multiple of 32): per row, per block of 32 k, 64 halves =
 // [hi(32) | lo(32)] = 128 bytes.  A row is exactly as long as in fp32, and one k-tile of a row is one
@@ -61,14 +68,32 @@ __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *
         w[i] = dinv[i] * inv * inv;
 }
 
+// One call = the 8 consecutive k that ONE lane feeds to v_mfma_f32_32x32x16_f16.  The matrix core adds the 8
+// products of such a group in fixed point, aligned to the largest of them and TRUNCATED 24 bits below it
+// (scripts/mfma_tree_probe.hip), i.e. with an error relative to the largest product, not to the (here heavily
+// cancelling) sum.  So the hi halves of a group share one quantum q = ulp_fp16(max |x|): every hi is an integer
+// multiple of q, every hi*hi product of the group is an integer multiple of q_x q_k within 22 bits of the largest
+// one, and the group sum is exact.  What hi loses on the small entries of a group moves into lo.
+__device__ __forceinline__ float group_quantum(float amax)
+{
+    int e;
+    (void)frexpf(amax, &e);  // amax in [2^(e-1), 2^e): fp16 ulp there is 2^(e-11), never below the subnormal 2^-24
+    return ldexpf(1.0f, max(e - 11, -24));
+}
+
 __device__ __forceinline__ void split8(const float (&v)[8], float s, half8 &hi, half8 &lo)
 {
+    float amax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        amax = fmaxf(amax, fabsf(v[c] * s));
+    const float q = group_quantum(amax), qi = 1.0f / q;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float x = v[c] * s;
-        const half_t h = (half_t)x;
-        hi[c] = h;
-        lo[c] = (half_t)((x - (float)h) * 2048.0f);
+        const float h = rintf(x * qi) * q;  // exact: q is a power of two
+        hi[c] = (half_t)h;
+        lo[c] = (half_t)((x - h) * 2048.0f);
     }
 }
 

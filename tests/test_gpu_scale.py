@@ -69,13 +69,15 @@ def test_n16384_properties(gpu, ds, kn, par):
         gmx.close()
     else:
         assert verr(o32["v"], o64["v"], k0) < 1e-5
-        # split-fp16 contraction (3 MFMA products on hi/lo halves = 22-bit operands): ~4x the fp32 rounding,
-        # measured 3e-5 at N = 16384 (1e-5 up to N ~ 2000, tests/test_gpu_parity.py); opt-in fast mode
-        gsp = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32_SPLIT)
-        osp = gsp.evaluate(qx, qy, qz, want_v=True)
-        assert verr(osp["v"], o64["v"], k0) < 5e-5
-        assert nerr(osp["f"], o64["f"]) < 1e-6
-        gsp.close()
+    # split-fp16 contraction (3 fp16 MFMA products on hi/lo halves whose hi parts share one quantum per MFMA
+    # k-group, so that the matrix core's fixed-point product sum is exact): measured 1.9e-6 (Matern) / 1.8e-5
+    # (thin-plate) at N = 16384, i.e. no worse than the native fp32 contraction (4.5e-6 / 2.1e-5)
+    gsp = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32_SPLIT)
+    osp = gsp.evaluate(qx, qy, qz, want_v=True)
+    assert verr(osp["v"], o64["v"], k0) < (5e-5 if kn == "thinplate" else 1e-5)
+    assert verr(osp["v"], o64["v"], k0) < 1.5 * verr(o32["v"], o64["v"], k0) + 1e-6
+    assert nerr(osp["f"], o64["f"]) < 1e-6
+    gsp.close()
     # (3) variance bounds for an SPD prior + noise: 0 <= v <= k(0)
     assert o64["v"].min() > -1e-9 * k0 and o64["v"].max() <= k0 * (1 + 1e-12)
     # (4) linearity of alpha in the labels
