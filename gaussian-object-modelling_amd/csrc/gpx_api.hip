@@ -1145,6 +1145,86 @@ extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const do
     return GPX_OK;
 }
 
+// ---- AtlasBase::project, batched and device-resident (reference include/atlas/atlas.hpp:201-276) -------------
+extern "C" int gpx_model_project(const gpx_model *cm, size_t nq, const double *x, const double *y, const double *z,
+                                 const double *normal, const gpx_project_options *opt, double *out_xyz, double *out_f,
+                                 int32_t *out_iter, int32_t *out_status)
+{
+    if (!out_xyz || !normal)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    int rc = check_query(cm, nq, x, y, z, out_xyz);
+    if (rc)
+        return rc;
+    gpx_project_options o{1e-2, 1e-7, 0.001, 500, {0, 0, 0}};
+    if (opt)
+        o = *opt;
+    if (!(o.f_tol >= 0.0) || !(o.improve_tol >= 0.0) || o.max_iter < 0 || !std::isfinite(o.step_mul))
+        return fail(GPX_E_BAD_ARG, "project options: tolerances and max_iter must be non-negative, step_mul finite");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    // device state: cx cy cz f_cur f_new (nq each) | g grad_new (3 nq each) | iter status (nq ints each) | active
+    const size_t doubles = nq * 5 + nq * 6 + nq + 2;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    double *d = m->ws_host_io;
+    double *cx = d, *cy = d + nq, *cz = d + 2 * nq, *fcur = d + 3 * nq, *fnew = d + 4 * nq;
+    double *g = d + 5 * nq, *gnew = d + 8 * nq;
+    int *iter = (int *)(d + 11 * nq), *status = iter + nq;
+    unsigned *active = (unsigned *)(d + 12 * nq);
+    HIPCHK(hipMemcpyAsync(cx, x, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(cy, y, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(cz, z, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g, normal, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(iter, 0, sizeof(int) * 2 * nq, s));
+    bool fused = true;
+    if (const char *e = std::getenv("GPX_PROJECT_FUSED"))
+        fused = std::atoi(e) != 0;
+    if (fused)  // the whole loop in one launch when the model fits the LDS (N <= 4096)
+        fused = launch_project_fused(m->cov, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, o.f_tol,
+                                     o.improve_tol, o.step_mul, o.max_iter, cx, cy, cz, g, fcur, iter, status, s);
+    if (!fused) {
+        // the mean at the start points (:225 of the first iteration; also the answer when max_iter == 0)
+        if ((rc = evaluate_locked(m, nq, cx, cy, cz, fcur, nullptr, nullptr, nullptr, nullptr, s)))
+            return rc;
+        for (int it = 0; it < o.max_iter; ++it) {
+            HIPCHK(hipMemsetAsync(active, 0, sizeof(unsigned), s));
+            launch_project_pre((long)nq, o.f_tol, o.step_mul, cx, cy, cz, g, fcur, status, s);
+            if ((rc = evaluate_locked(m, nq, cx, cy, cz, fnew, nullptr, gnew, nullptr, nullptr, s)))
+                return rc;
+            launch_project_post((long)nq, o.improve_tol, o.max_iter, fnew, gnew, g, fcur, iter, status, active, s);
+            if ((it & 7) == 7 || it + 1 == o.max_iter) {  // look at the device only every 8 iterations
+                unsigned left = 0;
+                HIPCHK(hipMemcpyAsync(&left, active, sizeof(left), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (left == 0)
+                    break;
+            }
+        }
+    }
+    std::vector<double> hc(3 * nq);
+    std::vector<int> hs(2 * nq);
+    HIPCHK(hipMemcpyAsync(hc.data(), cx, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs.data(), iter, sizeof(int) * 2 * nq, hipMemcpyDeviceToHost, s));
+    if (out_f)
+        HIPCHK(hipMemcpyAsync(out_f, fcur, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < nq; ++i) {
+        out_xyz[3 * i] = hc[i];
+        out_xyz[3 * i + 1] = hc[nq + i];
+        out_xyz[3 * i + 2] = hc[2 * nq + i];
+        int st = hs[nq + i];
+        if (st == 0)
+            st = 3;  // max_iter == 0: the loop of the reference is never entered
+        if (out_iter)
+            out_iter[i] = hs[i];
+        if (out_status)
+            out_status[i] = st;
+    }
+    return GPX_OK;
+}
+
 extern "C" int gpx_model_prepare_variance(gpx_model *m)
 {
     if (!m)

@@ -73,6 +73,15 @@ void launch_surface_select(long nq, const double *f, double tol, unsigned *block
                            size_t capacity, const double *qx, const double *qy, const double *qz, long long *idx,
                            double *fs, double *sx, double *sy, double *sz, hipStream_t st);
 void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st);
+// AtlasBase::project, one iteration = pre (tolerance test + step) -> mean/gradient at the new points -> post
+bool launch_project_fused(const CovHost &h, int npts, const double *px, const double *py, const double *pz,
+                          const double *alpha, long nq, double f_tol, double improve_tol, double step_mul,
+                          int max_iter, double *cx, double *cy, double *cz, const double *g, double *f, int *iter,
+                          int *status, hipStream_t st);
+void launch_project_pre(long nq, double f_tol, double step_mul, double *cx, double *cy, double *cz, const double *g,
+                        const double *f_cur, int *status, hipStream_t st);
+void launch_project_post(long nq, double improve_tol, int max_iter, const double *f_new, const double *grad_new,
+                         double *g, double *f_cur, int *iter, int *status, unsigned *active, hipStream_t st);
 // r = y - f - s2*alpha (all double, n entries); also max|r| -> *rmax (atomic, pre-zeroed)
 void launch_residual(int n, const double *y, const double *f, const double *s2, const double *alpha, double *r,
                      double *rmax, hipStream_t st);

@@ -8,6 +8,7 @@
 //   The library always runs it in fp64 (from the fp64 points and alpha, whatever the precision mode): it
 //   costs 26 ms next to 2.1 s of variance at N = 16384 / 2^20 queries, and the 16384-term alternating
 //   sum of a thin-plate GP is not within 1e-5 in fp32.  The kernel stays templated on the scalar type.
+#include <algorithm>
 #include "gpx_cov.hpp"
 
 namespace gpx {
@@ -257,6 +258,204 @@ __global__ __launch_bounds__(256) void tangent_basis_kernel(long nq, const doubl
         ty[3 * q + 1] = u1;
         ty[3 * q + 2] = u2;
     }
+}
+
+// ---- AtlasBase::project (reference include/atlas/atlas.hpp:201-276), all start points at once ----------------
+// Eigen 3.2 predicates: v.isMuchSmallerThan(1e3, 1e-1) <=> |v|^2 <= 1e4 ; v.isZero(p) <=> |v_i| <= p for all i
+__device__ __forceinline__ bool atlas_vec_ok(double a, double b, double c, double zero_prec)
+{
+    const bool much_smaller = a * a + b * b + c * c <= 1e-1 * 1e-1 * 1e3 * 1e3;
+    const bool is_zero = fabs(a) <= zero_prec && fabs(b) <= zero_prec && fabs(c) <= zero_prec;
+    return much_smaller && !is_zero;
+}
+
+// :225-252 -- f at the current point is known: NaN test, |f| < f_tol, then the step along g
+__global__ __launch_bounds__(256) void project_pre_kernel(long nq, double f_tol, double step_mul,
+                                                          double *__restrict__ cx, double *__restrict__ cy,
+                                                          double *__restrict__ cz, const double *__restrict__ g,
+                                                          const double *__restrict__ f_cur, int *__restrict__ status)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq || status[i] != 0)
+        return;
+    const double fc = f_cur[i];
+    if (isnan(fc) || isinf(fc)) {
+        status[i] = -1;
+        return;
+    }
+    if (fabs(fc) < f_tol) {
+        status[i] = 1;
+        return;
+    }
+    const double s0 = step_mul * fc * g[3 * i], s1 = step_mul * fc * g[3 * i + 1], s2 = step_mul * fc * g[3 * i + 2];
+    if (atlas_vec_ok(s0, s1, s2, 1e-6)) {
+        cx[i] -= s0;
+        cy[i] -= s1;
+        cz[i] -= s2;
+    }
+}
+
+// :260-271 -- mean and gradient at the moved point are known: adopt the gradient, improvement test, count
+__global__ __launch_bounds__(256) void project_post_kernel(long nq, double improve_tol, int max_iter,
+                                                           const double *__restrict__ f_new,
+                                                           const double *__restrict__ grad_new, double *__restrict__ g,
+                                                           double *__restrict__ f_cur, int *__restrict__ iter,
+                                                           int *__restrict__ status, unsigned *__restrict__ active)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq || status[i] != 0)
+        return;
+    const double n0 = grad_new[3 * i], n1 = grad_new[3 * i + 1], n2 = grad_new[3 * i + 2];
+    if (atlas_vec_ok(n0, n1, n2, 1e-5)) {
+        g[3 * i] = n0;
+        g[3 * i + 1] = n1;
+        g[3 * i + 2] = n2;
+    }
+    const double fo = f_new[i], fc = f_cur[i];
+    f_cur[i] = fo;  // the mean at the (moved) current point, also what is reported with the result
+    if (fabs(fo - fc) < improve_tol) {
+        status[i] = 2;
+        return;
+    }
+    const int it = iter[i] + 1;
+    iter[i] = it;
+    if (it >= max_iter)
+        status[i] = 3;
+    else
+        atomicAdd(active, 1u);
+}
+
+// The whole loop of AtlasBase::project in ONE launch, for models whose points and weights fit the LDS
+// (32 bytes per training point): one wave per start point, the lanes share the sum over the training points
+// (butterfly reduction, so every lane holds the same f and gradient and takes the same branches), and the
+// iteration runs in registers.  Replaces 4 launches per iteration of the generic path below: the reference's
+// defaults (step_mul 0.001, max_iter 500) make almost every call run the full 500 iterations.
+template <int KID>
+__global__ __launch_bounds__(256) void project_fused_kernel(Cov<double> cov, int npts, const double *__restrict__ px,
+                                                            const double *__restrict__ py,
+                                                            const double *__restrict__ pz,
+                                                            const double *__restrict__ alpha, long nq, double f_tol,
+                                                            double improve_tol, double step_mul, int max_iter,
+                                                            double *__restrict__ cx, double *__restrict__ cy,
+                                                            double *__restrict__ cz, const double *__restrict__ g_in,
+                                                            double *__restrict__ f_out, int *__restrict__ iter_out,
+                                                            int *__restrict__ status_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char proj_smem[];
+    double *sx = reinterpret_cast<double *>(proj_smem), *sy = sx + npts, *sz = sy + npts, *sa = sz + npts;
+    for (int j = threadIdx.x; j < npts; j += 256) {
+        sx[j] = px[j];
+        sy[j] = py[j];
+        sz[j] = pz[j];
+        sa[j] = alpha[j];  // zero on the padding
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long q = wave_global; q < nq; q += nwaves) {
+        double c0 = cx[q], c1 = cy[q], c2 = cz[q];
+        double g0 = g_in[3 * q], g1 = g_in[3 * q + 1], g2 = g_in[3 * q + 2];
+        // mean and un-normalised gradient at (c0, c1, c2), identical in every lane
+        auto eval = [&](double &f, double &n0, double &n1, double &n2) {
+            double af = 0, a0 = 0, a1 = 0, a2 = 0;
+            for (int j = lane; j < npts; j += 64) {
+                const double dx = c0 - sx[j], dy = c1 - sy[j], dz = c2 - sz[j];
+                double k, kd;
+                cov_k_diff<double, KID>(cov, dx * dx + dy * dy + dz * dz, k, kd);
+                const double w = sa[j] * kd;
+                af += sa[j] * k;
+                a0 += w * dx;
+                a1 += w * dy;
+                a2 += w * dz;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                af += __shfl_xor(af, off);
+                a0 += __shfl_xor(a0, off);
+                a1 += __shfl_xor(a1, off);
+                a2 += __shfl_xor(a2, off);
+            }
+            f = af, n0 = a0, n1 = a1, n2 = a2;
+        };
+        double fc, t0, t1, t2;
+        eval(fc, t0, t1, t2);  // :225 of the first iteration (the gradient is not used)
+        int it = 0, status = 3;
+        while (it < max_iter) {
+            if (isnan(fc) || isinf(fc)) {
+                status = -1;
+                break;
+            }
+            if (fabs(fc) < f_tol) {
+                status = 1;
+                break;
+            }
+            const double s0 = step_mul * fc * g0, s1 = step_mul * fc * g1, s2 = step_mul * fc * g2;
+            if (atlas_vec_ok(s0, s1, s2, 1e-6)) {
+                c0 -= s0;
+                c1 -= s1;
+                c2 -= s2;
+            }
+            double fo, n0, n1, n2;
+            eval(fo, n0, n1, n2);
+            if (atlas_vec_ok(n0, n1, n2, 1e-5)) {
+                g0 = n0;
+                g1 = n1;
+                g2 = n2;
+            }
+            const double df = fabs(fo - fc);
+            fc = fo;
+            if (df < improve_tol) {
+                status = 2;
+                break;
+            }
+            ++it;
+        }
+        if (lane == 0) {
+            cx[q] = c0;
+            cy[q] = c1;
+            cz[q] = c2;
+            f_out[q] = fc;
+            iter_out[q] = it;
+            status_out[q] = status;
+        }
+    }
+}
+
+size_t project_fused_lds_bytes(int npts) { return sizeof(double) * 4 * (size_t)npts; }
+
+// false: the model does not fit the LDS, use the per-iteration path
+bool launch_project_fused(const CovHost &h, int npts, const double *px, const double *py, const double *pz,
+                          const double *alpha, long nq, double f_tol, double improve_tol, double step_mul,
+                          int max_iter, double *cx, double *cy, double *cz, const double *g, double *f, int *iter,
+                          int *status, hipStream_t st)
+{
+    const size_t shmem = project_fused_lds_bytes(npts);
+    if (shmem > 128 * 1024)
+        return false;
+    Cov<double> c = lower_cov<double>(h);
+    const long blocks = std::min<long>((nq + 3) / 4, 256L * 8);
+    GPX_DISPATCH_KID(h.id, {
+        auto kern = project_fused_kernel<KID>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), shmem, st, c, npts, px, py, pz, alpha, nq, f_tol,
+                           improve_tol, step_mul, max_iter, cx, cy, cz, g, f, iter, status);
+    });
+    return true;
+}
+
+void launch_project_pre(long nq, double f_tol, double step_mul, double *cx, double *cy, double *cz, const double *g,
+                        const double *f_cur, int *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(project_pre_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, f_tol, step_mul,
+                       cx, cy, cz, g, f_cur, status);
+}
+
+void launch_project_post(long nq, double improve_tol, int max_iter, const double *f_new, const double *grad_new,
+                         double *g, double *f_cur, int *iter, int *status, unsigned *active, hipStream_t st)
+{
+    hipLaunchKernelGGL(project_post_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, improve_tol,
+                       max_iter, f_new, grad_new, g, f_cur, iter, status, active);
 }
 
 void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st)

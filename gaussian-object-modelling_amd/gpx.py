@@ -43,6 +43,11 @@ class Options(C.Structure):
                 ("reserved", C.c_int32 * 6)]
 
 
+class ProjectOptions(C.Structure):
+    _fields_ = [("f_tol", C.c_double), ("improve_tol", C.c_double), ("step_mul", C.c_double),
+                ("max_iter", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class Stats(C.Structure):
     _fields_ = [("t_kbuild_ms", C.c_double), ("t_factor_ms", C.c_double), ("t_solve_ms", C.c_double),
                 ("t_inverse_ms", C.c_double), ("t_normals_ms", C.c_double), ("t_mean_ms", C.c_double),
@@ -59,8 +64,8 @@ class Stats(C.Structure):
 # every symbol include/gpx.h declares
 EXPORTS = [
     "gpx_last_error", "gpx_version", "gpx_device_count", "gpx_model_create", "gpx_model_update",
-    "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_prepare_variance",
-    "gpx_model_get",
+    "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
+    "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
@@ -118,6 +123,9 @@ def lib():
     L.gpx_model_sample_surface.restype = C.c_int
     L.gpx_model_sample_surface.argtypes = [vp, C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t,
                                            C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_size_t)]
+    L.gpx_model_project.restype = C.c_int
+    L.gpx_model_project.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, C.POINTER(ProjectOptions), dp, dp,
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.gpx_model_prepare_variance.restype = C.c_int
     L.gpx_model_prepare_variance.argtypes = [vp]
     L.gpx_model_get.restype = C.c_int
@@ -326,6 +334,19 @@ class Model:
         if v is not None:
             out["v"] = v[:k]
         return out
+
+    def project(self, x, y, z, normal, f_tol=1e-2, improve_tol=1e-7, max_iter=500, step_mul=0.001):
+        """Batched AtlasBase::project (atlas.hpp:201-276): dict(xyz, f, iter, status) for every start point."""
+        x, y, z = _as_d(x), _as_d(y), _as_d(z)
+        nq = len(x)
+        nrm = np.ascontiguousarray(np.asarray(normal, dtype=np.float64).reshape(nq, 3))
+        opt = ProjectOptions(float(f_tol), float(improve_tol), float(step_mul), int(max_iter), (C.c_int32 * 3)())
+        out = np.empty((nq, 3)); f = np.empty(nq)
+        it = np.empty(nq, dtype=np.int32); st = np.empty(nq, dtype=np.int32)
+        i32 = C.POINTER(C.c_int32)
+        _check(self._L.gpx_model_project(self._h, nq, _dptr(x), _dptr(y), _dptr(z), _dptr(nrm), C.byref(opt),
+                                         _dptr(out), _dptr(f), it.ctypes.data_as(i32), st.ctypes.data_as(i32)))
+        return {"xyz": out, "f": f, "iter": it, "status": st}
 
     def evaluate_device(self, nq, d_qx, d_qy, d_qz, d_f, d_v=None, d_grad=None, d_tx=None, d_ty=None, stream=None):
         """Raw device pointers (ints, e.g. torch.Tensor.data_ptr()) of fp64 arrays; asynchronous."""

@@ -271,6 +271,43 @@ public:
         v.resize(n);
     }
 
+    // Batched form of AtlasBase::project (include/atlas/atlas.hpp:201-276): every start point of `start` descends
+    // onto f = 0 along its gradient, with the reference's tolerances, step rule and stopping criteria; `normals`
+    // holds the un-normalised start directions (3 per point, row-major).  `out` receives the projected points
+    // (coord_x/y/z), `status` 1 / 2 / 3 for the f_tol / improve_tol / max_iter exit.  Throws like the reference
+    // ("f is nan or inf", atlas.hpp:230) if any point hits a NaN.  New entry.
+    void project(Model::ConstPtr gp, Data::ConstPtr start, const std::vector<double> &normals, Data::Ptr out,
+                 std::vector<int> &status, const double f_tol = 1e-2, const double improve_tol = 1e-7,
+                 const unsigned int max_iter = 500, const double step_mul = 0.001)
+    {
+        if (!gp || !gp->handle_)
+            throw GPRegressionException("Empty Model pointer");
+        assertData(start);
+        if (!out)
+            throw GPRegressionException("Empty data pointer");
+        const size_t nq = start->coord_x.size();
+        if (start->coord_y.size() != nq || start->coord_z.size() != nq || normals.size() != 3 * nq)
+            throw GPRegressionException("Input data vectors have different lengths");
+        gpx_project_options o{};
+        o.f_tol = f_tol, o.improve_tol = improve_tol, o.step_mul = step_mul, o.max_iter = (int32_t)max_iter;
+        std::vector<double> xyz(3 * nq);
+        std::vector<int32_t> st(nq);
+        const int rc = gpx_model_project(gp->handle_, nq, start->coord_x.data(), start->coord_y.data(),
+                                         start->coord_z.data(), normals.data(), &o, xyz.data(), nullptr, nullptr,
+                                         st.data());
+        if (rc != GPX_OK)
+            throw GPRegressionException(message(rc));
+        out->clear();
+        status.assign(st.begin(), st.end());
+        for (size_t i = 0; i < nq; ++i) {
+            if (st[i] < 0)
+                throw GPRegressionException("f is nan or inf");
+            out->coord_x.push_back(xyz[3 * i]);
+            out->coord_y.push_back(xyz[3 * i + 1]);
+            out->coord_z.push_back(xyz[3 * i + 2]);
+        }
+    }
+
     // update<withNormals>(new_data, gp), :367-479
     template <bool withNormals>
     void update(Data::ConstPtr new_data, Model::Ptr gp)

@@ -147,6 +147,27 @@ int gpx_model_evaluate_device(const gpx_model *m, size_t nq, const void *d_qx, c
                               const void *d_qz, void *d_f, void *d_v, void *d_grad, void *d_tx, void *d_ty,
                               void *stream);
 
+/* Batched form of AtlasBase::project (reference include/atlas/atlas.hpp:201-276; called per chart by
+ * atlas_variance.hpp:124 and atlas_collision.hpp:55): gradient descent of nq start points onto the surface f = 0.
+ * Per iteration and point, exactly as the reference: stop with status 1 if |f| < f_tol (:236); step by
+ * step_mul * f * g unless the step is longer than 100 or all its components are within 1e-6 (:245-252); evaluate
+ * mean and gradient at the new point (:260); adopt the new gradient unless it is longer than 100 or within 1e-5 of
+ * zero (:261-266); stop with status 2 if |f_new - f| < improve_tol (:267); status 3 after max_iter iterations
+ * (:272); status -1 where the reference throws "f is nan or inf" (:227-231).  The reference also computes the
+ * variance in every iteration, for a log line only; it is not computed here.  The whole loop runs on the device
+ * (one mean+gradient pass over the still unconverged points per iteration).
+ * normal: 3*nq row-major, the un-normalised start directions (the chart gradients, atlas_variance.hpp:122).
+ * out_xyz: 3*nq row-major.  out_f (mean at the returned point), out_iter, out_status: nq each, or NULL.
+ * opt == NULL: the reference's defaults f_tol 1e-2, improve_tol 1e-7, max_iter 500, step_mul 0.001. */
+typedef struct gpx_project_options {
+    double f_tol, improve_tol, step_mul;
+    int32_t max_iter;
+    int32_t reserved[3];
+} gpx_project_options;
+int gpx_model_project(const gpx_model *m, size_t nq, const double *x, const double *y, const double *z,
+                      const double *normal, const gpx_project_options *opt, double *out_xyz, double *out_f,
+                      int32_t *out_iter, int32_t *out_status);
+
 /* Iso-surface sampling: the batched form of the node's fakeDeterministicSampling / samplePoint
  * (src/gp_node.cpp:998-1100): evaluate the mean on all nq queries, keep those with |f| <= f_tol
  * (the node's 0.01, :1075) and compute the variance ONLY for the survivors -- the step right after

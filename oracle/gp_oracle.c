@@ -595,6 +595,74 @@ void orc_evaluate_fullcov(const orc_model *m, int nq, const double *qx, const do
 }
 
 /* ---- accessors ---------------------------------------------------------------------------- */
+/* Eigen predicates used by the atlas (Eigen 3.2 DenseBase): v.isMuchSmallerThan(other, prec) for a vector
+ * against a scalar is |v|^2 <= prec^2 other^2; v.isZero(prec) is |v_i| <= prec for every coefficient. */
+static int vec_much_smaller(const double v[3], double other, double prec)
+{
+    return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] <= prec * prec * other * other;
+}
+static int vec_is_zero(const double v[3], double prec)
+{
+    return fabs(v[0]) <= prec && fabs(v[1]) <= prec && fabs(v[2]) <= prec;
+}
+
+/* AtlasBase::project, reference include/atlas/atlas.hpp:201-276, one start point at a time: gradient descent
+ * onto f = 0 along the (un-normalised) gradient.  Per iteration the reference evaluates the mean at the
+ * current point (:225), tests |f| < f_tol (:236), steps by step_mul f g unless the step is "wrong" (:246-252),
+ * evaluates mean + variance + gradient at the new point (:260; the variance only feeds a log line and is not
+ * computed here), adopts the new gradient unless it is "wrong" (:261-266) and tests |f_new - f| < improve_tol
+ * (:267).  status: 1 f_tol, 2 improve_tol, 3 max_iter, -1 f is NaN/Inf (the reference throws, :227-231).
+ * out_f is the mean at the returned point. */
+void orc_project(const orc_model *m, int n, const double *x, const double *y, const double *z, const double *normal,
+                 double f_tol, double improve_tol, int max_iter, double step_mul, double *out_xyz, double *out_f,
+                 int *out_iter, int *out_status)
+{
+    for (int i = 0; i < n; ++i) {
+        double cur[3] = {x[i], y[i], z[i]};
+        double g[3] = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+        int iter = 0, status = 3;
+        double f_here = 0.0;
+        while (iter < max_iter) {
+            double fc;
+            orc_evaluate(m, 1, &cur[0], &cur[1], &cur[2], &fc, NULL, NULL, NULL, NULL); /* :225 */
+            f_here = fc;
+            if (isnan(fc) || isinf(fc)) { /* :227 */
+                status = -1;
+                break;
+            }
+            if (fabs(fc) < f_tol) { /* :236 */
+                status = 1;
+                break;
+            }
+            double step[3] = {step_mul * fc * g[0], step_mul * fc * g[1], step_mul * fc * g[2]}; /* :245 */
+            if (!(!vec_much_smaller(step, 1e3, 1e-1) || vec_is_zero(step, 1e-6))) /* :246-251 */
+                for (int c = 0; c < 3; ++c)
+                    cur[c] -= step[c];
+            double fo, N[3];
+            orc_evaluate(m, 1, &cur[0], &cur[1], &cur[2], &fo, NULL, N, NULL, NULL); /* :260 */
+            f_here = fo;
+            if (!(!vec_much_smaller(N, 1e3, 1e-1) || vec_is_zero(N, 1e-5))) /* :261-266 */
+                for (int c = 0; c < 3; ++c)
+                    g[c] = N[c];
+            if (fabs(fo - fc) < improve_tol) { /* :267 */
+                status = 2;
+                break;
+            }
+            ++iter;
+        }
+        if (max_iter <= 0) /* loop never entered: report the mean at the start point */
+            orc_evaluate(m, 1, &cur[0], &cur[1], &cur[2], &f_here, NULL, NULL, NULL, NULL);
+        for (int c = 0; c < 3; ++c)
+            out_xyz[3 * i + c] = cur[c];
+        if (out_f)
+            out_f[i] = f_here;
+        if (out_iter)
+            out_iter[i] = iter;
+        if (out_status)
+            out_status[i] = status;
+    }
+}
+
 int orc_n(const orc_model *m) { return m->n; }
 double orc_R(const orc_model *m) { return m->R; }
 int orc_ldlt_info(const orc_model *m) { return m->ldlt_info; }

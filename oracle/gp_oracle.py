@@ -63,6 +63,9 @@ def _lib(omp=False):
     L.orc_update.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
     L.orc_evaluate.restype = None
     L.orc_evaluate.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.orc_project.restype = None
+    L.orc_project.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int, C.c_double, dp,
+                              dp, ip, ip]
     L.orc_evaluate_fullcov.restype = None
     L.orc_evaluate_fullcov.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
     L.orc_tangent_basis.restype = None
@@ -252,6 +255,20 @@ class Model:
             out["tx"] = tx
             out["ty"] = ty
         return out
+
+    def project(self, x, y, z, normal, f_tol=1e-2, improve_tol=1e-7, max_iter=500, step_mul=0.001):
+        """AtlasBase::project (atlas.hpp:201-276) for every start point; returns dict(xyz, f, iter, status)."""
+        x, px = _d(x); y, py = _d(y); z, pz = _d(z)
+        n = len(x)
+        nrm = np.ascontiguousarray(np.asarray(normal, dtype=np.float64).reshape(n, 3))
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        out = np.empty((n, 3)); f = np.empty(n)
+        it = np.empty(n, dtype=np.int32); st = np.empty(n, dtype=np.int32)
+        self._L.orc_project(self._h, n, px, py, pz, nrm.ctypes.data_as(dp), f_tol, improve_tol, int(max_iter),
+                            step_mul, out.ctypes.data_as(dp), f.ctypes.data_as(dp), it.ctypes.data_as(ip),
+                            st.ctypes.data_as(ip))
+        return {"xyz": out, "f": f, "iter": it, "status": st}
 
     def evaluate_fullcov(self, qx, qy, qz):
         qx, px = _d(qx); qy, py = _d(qy); qz, pz = _d(qz)

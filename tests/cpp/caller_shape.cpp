@@ -138,6 +138,19 @@ int main(int argc, char **argv)
     reg_->evaluate(obj_gp, c, f1);
     EXPECT(f1.size() == 2 && std::fabs(f1[0] - f[0]) < 1e-12 * (1 + std::fabs(f[0])), "evaluate(f) == evaluate(f,v,...)");
 
+    // ---- atlas_variance.hpp:122-124 : project the chosen sample along the chart gradient (batched form) ----
+    {
+        Data::Ptr proj = std::make_shared<Data>();
+        std::vector<int> st;
+        reg_->project(obj_gp, c, gg, proj, st, 1e-2, 1e-7, 80, 0.5);
+        EXPECT(proj->coord_x.size() == 2 && st.size() == 2, "project output sizes");
+        std::vector<double> fp;
+        reg_->evaluate(obj_gp, proj, fp);
+        EXPECT(st[0] == 1 && std::fabs(fp[0]) < 1e-2, "project reaches |f| < f_tol from a point off the surface");
+        EXPECT(thrown([&] { reg_->project(obj_gp, c, std::vector<double>(3), proj, st); }) ==
+                   "Input data vectors have different lengths", "project: normals length");
+    }
+
     // ---- the four reference exceptions, verbatim (gp_regressor.hpp:198/:231/:374/:566/:570) ----
     Data::Ptr labelled = std::make_shared<Data>(*c);
     labelled->label = {0.0, 0.0};

@@ -236,6 +236,35 @@ def test_variance_batching_and_large_query_sets(gpu, orc, ds):
             gm.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("prec", [1, 0])
+def test_project_matches_atlas_restatement(gpu, orc, ds, golden, prec, fused, monkeypatch):
+    """SURVEY 8f.3: the batched device-side AtlasBase::project (atlas.hpp:201-276) against the oracle's per-point
+    restatement on the node's own model (mugD, ThinPlate(2.0)): same exits, same iteration counts, same points.
+    fused = the whole loop in one launch (models that fit the LDS); otherwise one mean+gradient pass per iteration."""
+    monkeypatch.setenv("GPX_PROJECT_FUSED", fused)
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    om = orc.Model(orc.make_kernel("thinplate", 2.0), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=prec)
+    rng = np.random.default_rng(17)
+    surf = np.stack([x, y, z], 1)[lab == 0]
+    P = surf[rng.integers(0, len(surf), 300)] * rng.uniform(0.8, 1.3, size=(300, 1)) + rng.normal(0, 0.02, (300, 3))
+    g0 = om.evaluate(P[:, 0], P[:, 1], P[:, 2], want_grad=True)["grad"]
+    g0[:5] = 0.0                      # "wrong" start directions (atlas.hpp:246-249)
+    tol_pos = 1e-9 if prec == 1 else 1e-4
+    for kw in (dict(step_mul=0.5, max_iter=80), dict(max_iter=24), dict(step_mul=0.5, max_iter=0)):
+        ref = om.project(P[:, 0], P[:, 1], P[:, 2], g0, **kw)
+        out = gm.project(P[:, 0], P[:, 1], P[:, 2], g0, **kw)
+        same = (out["status"] == ref["status"]) & (out["iter"] == ref["iter"])
+        # a tolerance test can flip where |f| sits within rounding of f_tol; in fp64 that does not happen here
+        assert same.mean() >= (1.0 if prec == 1 else 0.97), kw
+        assert np.max(np.abs(out["xyz"][same] - ref["xyz"][same])) < tol_pos, kw
+        assert np.max(np.abs(out["f"][same] - ref["f"][same])) < (1e-9 if prec == 1 else 1e-4), kw
+        if kw["max_iter"] > 0 and kw.get("step_mul", 0) == 0.5:
+            assert (ref["status"] == 1).mean() > 0.9
+    gm.close()
+
+
 def test_host_batches_larger_than_one_slice(gpu, orc, ds):
     """Host evaluate slices very large batches (2^20 queries per slice); results do not depend on the slicing."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(64)

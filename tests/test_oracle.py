@@ -175,3 +175,32 @@ def test_oracle_normals(orc, golden):
     g = m.evaluate(x, y, z, want_grad=True)["grad"]
     g /= np.linalg.norm(g, axis=1, keepdims=True)
     assert nerr(m.normals, g) < 1e-12
+
+
+def test_project_restatement_properties(orc, ds):
+    """orc_project follows AtlasBase::project (atlas.hpp:201-276): exits and their invariants."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(150)
+    om = orc.Model(orc.make_kernel("thinplate", 2.0), x, y, z, lab, s2)
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(24, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    P = d * rng.uniform(0.85, 1.25, size=(24, 1))
+    g = om.evaluate(P[:, 0], P[:, 1], P[:, 2], want_grad=True)["grad"]
+    r = om.project(P[:, 0], P[:, 1], P[:, 2], g, step_mul=0.5, max_iter=60)
+    f_at = om.evaluate(r["xyz"][:, 0], r["xyz"][:, 1], r["xyz"][:, 2])["f"]
+    np.testing.assert_allclose(r["f"], f_at, rtol=0, atol=1e-12)          # out_f is the mean at the returned point
+    assert np.all(np.abs(r["f"][r["status"] == 1]) < 1e-2)                 # first criterion
+    assert np.all(r["iter"][r["status"] == 3] == 60)
+    assert np.all(r["status"] == 1) and np.all(r["iter"] < 60)             # this start set converges
+    # the reference's defaults (step_mul 0.001) barely move: most points run into max_iter, as in the node's logs
+    r0 = om.project(P[:, 0], P[:, 1], P[:, 2], g, max_iter=40)
+    far = np.abs(om.evaluate(P[:, 0], P[:, 1], P[:, 2])["f"]) >= 2e-2
+    assert np.all(r0["status"][far] == 3)
+    assert np.max(np.linalg.norm(r0["xyz"] - P, axis=1)) < 40 * 0.001 * np.max(np.abs(r["f"]) + 1) * np.max(np.linalg.norm(g, axis=1)) + 1
+    # max_iter = 0: nothing happens, f is the mean at the start point
+    rz = om.project(P[:, 0], P[:, 1], P[:, 2], g, max_iter=0)
+    np.testing.assert_array_equal(rz["xyz"], P)
+    assert np.all(rz["status"] == 3) and np.all(rz["iter"] == 0)
+    # a zero start direction is a "wrong step" (atlas.hpp:246-249): the point stays until a gradient is adopted
+    r1 = om.project(P[:1, 0], P[:1, 1], P[:1, 2], np.zeros((1, 3)), step_mul=0.5, max_iter=60)
+    assert r1["status"][0] == 1
