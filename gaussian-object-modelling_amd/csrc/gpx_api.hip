@@ -150,6 +150,7 @@ struct gpx_model {
     size_t ws_partial_bytes = 0;
     double *ws_grad = nullptr;
     size_t ws_grad_doubles = 0;
+    void *ws_small = nullptr;      // partial sums + counters of the one-launch path for a handful of queries
     double *ws_host_io = nullptr;  // device staging for the host-pointer evaluate
     size_t ws_host_io_doubles = 0;
     int qbatch = 8192;
@@ -189,6 +190,8 @@ static void free_dev(gpx_model *m)
     F(m->ws_partial);
     F(m->ws_grad);
     F(m->ws_host_io);
+    F(m->ws_small);
+    m->ws_small = nullptr;
     F(m->d_normals);
     if (m->pin)
         (void)hipHostFree(m->pin);
@@ -972,6 +975,8 @@ extern "C" int gpx_model_evaluate_device(const gpx_model *cm, size_t nq, const v
 
 // One device batch for a list of host requests: queries are concatenated into pinned staging, evaluated
 // once (the union of the requested outputs), and the results scattered back.
+constexpr size_t SMALL_EVAL_MAX_NQ = 64;  // a handful of queries on a small model: one launch (gpx_predict.hip)
+
 static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
 {
     size_t total = 0;
@@ -1009,6 +1014,43 @@ static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
     double *dqx = d, *dqy = d + total, *dqz = d + 2 * total, *df = d + 3 * total, *dv = d + 4 * total,
            *dg = d + 5 * total, *dtx = d + 8 * total, *dty = d + 11 * total;
     hipStream_t s = m->stream;
+    // a handful of queries on a small model: one launch that reads and writes the pinned buffer directly
+    static const bool small_on = [] {
+        const char *e = std::getenv("GPX_SMALL_EVAL");
+        return !e || std::atoi(e) != 0;
+    }();
+    if (small_on && total <= SMALL_EVAL_MAX_NQ && m->npad <= SMALL_EVAL_NP_MAX &&
+        !(wv && m->opt.precision == GPX_PREC_F32_SPLIT)) {
+        if (wv && (rc = build_inverse(m)))
+            return rc;
+        if (!m->ws_small) {
+            const size_t sb = small_eval_scratch_bytes((int)SMALL_EVAL_MAX_NQ, SMALL_EVAL_NP_MAX);
+            HIPCHK(hipMalloc(&m->ws_small, sb));
+            HIPCHK(hipMemsetAsync(m->ws_small, 0, sb, s));
+        }
+        launch_small_eval(m->prec, m->cov, m->n, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, m->X, m->t_dinv,
+                          (int)total, (int)SMALL_EVAL_MAX_NQ, h, h + 3 * total, wv ? h + 4 * total : nullptr,
+                          wg ? h + 5 * total : nullptr, wtx ? h + 8 * total : nullptr,
+                          wty ? h + 11 * total : nullptr, m->ws_small, s);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            return fail(GPX_E_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        HIPCHK(hipStreamSynchronize(s));
+        off = 0;
+        for (const gpx_pending *r : reqs) {
+            std::memcpy(r->f, h + 3 * total + off, sizeof(double) * r->nq);
+            if (r->v)
+                std::memcpy(r->v, h + 4 * total + off, sizeof(double) * r->nq);
+            if (r->grad)
+                std::memcpy(r->grad, h + 5 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            if (r->tx)
+                std::memcpy(r->tx, h + 8 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            if (r->ty)
+                std::memcpy(r->ty, h + 11 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            off += r->nq;
+        }
+        return GPX_OK;
+    }
     HIPCHK(hipMemcpyAsync(d, h, sizeof(double) * 3 * total, hipMemcpyHostToDevice, s));
     rc = evaluate_locked(m, total, dqx, dqy, dqz, df, wv ? dv : nullptr, wg ? dg : nullptr, wtx ? dtx : nullptr,
                          wty ? dty : nullptr, s);

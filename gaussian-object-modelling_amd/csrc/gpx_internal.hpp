@@ -74,6 +74,12 @@ void launch_surface_select(long nq, const double *f, double tol, unsigned *block
                            double *fs, double *sx, double *sy, double *sz, hipStream_t st);
 void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st);
 // AtlasBase::project, one iteration = pre (tolerance test + step) -> mean/gradient at the new points -> post
+constexpr int SMALL_EVAL_NP_MAX = 1024;  // one launch for a handful of queries: models up to this padded size
+size_t small_eval_scratch_bytes(int nq_max, int npts_max);
+void launch_small_eval(int prec, const CovHost &cov, int n, int npts, const double *px, const double *py,
+                       const double *pz, const double *alpha, const void *X, const void *dinv, int nq, int nq_max,
+                       const double *q, double *f, double *v, double *grad, double *tx, double *ty, void *scratch,
+                       hipStream_t st);
 bool launch_project_fused(const CovHost &h, int npts, const double *px, const double *py, const double *pz,
                           const double *alpha, long nq, double f_tol, double improve_tol, double step_mul,
                           int max_iter, double *cx, double *cy, double *cz, const double *g, double *f, int *iter,

@@ -219,13 +219,8 @@ void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *pa
 }
 
 // ---- computeTangentBasis per row (reference gp_regressor.hpp:29-44, :204-211) ---------------
-__global__ __launch_bounds__(256) void tangent_basis_kernel(long nq, const double *__restrict__ grad,
-                                                            double *__restrict__ tx, double *__restrict__ ty)
+__device__ __forceinline__ void tangent_basis_dev(double g0, double g1, double g2, double (&t)[3], double (&u)[3])
 {
-    long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq)
-        return;
-    double g0 = grad[3 * q], g1 = grad[3 * q + 1], g2 = grad[3 * q + 2];
     double nrm = sqrt(g0 * g0 + g1 * g1 + g2 * g2);
     double n0 = nrm > 0 ? g0 / nrm : g0, n1 = nrm > 0 ? g1 / nrm : g1, n2 = nrm > 0 ? g2 / nrm : g2;
     // Eigen isApprox(UnitX, 1e-3): |N - e_x|^2 <= 1e-6 * min(|N|^2, 1)
@@ -248,16 +243,186 @@ __global__ __launch_bounds__(256) void tangent_basis_kernel(long nq, const doubl
         u1 /= un;
         u2 /= un;
     }
+    t[0] = t0, t[1] = t1, t[2] = t2;
+    u[0] = u0, u[1] = u1, u[2] = u2;
+}
+
+__global__ __launch_bounds__(256) void tangent_basis_kernel(long nq, const double *__restrict__ grad,
+                                                            double *__restrict__ tx, double *__restrict__ ty)
+{
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq)
+        return;
+    double t[3], u[3];
+    tangent_basis_dev(grad[3 * q], grad[3 * q + 1], grad[3 * q + 2], t, u);
     if (tx) {
-        tx[3 * q] = t0;
-        tx[3 * q + 1] = t1;
-        tx[3 * q + 2] = t2;
+        tx[3 * q] = t[0];
+        tx[3 * q + 1] = t[1];
+        tx[3 * q + 2] = t[2];
     }
     if (ty) {
-        ty[3 * q] = u0;
-        ty[3 * q + 1] = u1;
-        ty[3 * q + 2] = u2;
+        ty[3 * q] = u[0];
+        ty[3 * q + 1] = u[1];
+        ty[3 * q + 2] = u[2];
     }
+}
+
+// ---- a handful of queries on a small model: everything in ONE launch -------------------------------------------
+// The node and the atlas call evaluate() with one query point at a time (src/gp_node.cpp:1069-1074 from hundreds of
+// threads, atlas_variance.hpp:72-78, :201).  The general path needs ~7 stream operations for such a call (copy in,
+// mean, K tile, GEMM, finish, copies out: 170 us); here one workgroup per query reads the point from the pinned
+// staging buffer, forms k(q, .) in LDS, reduces mean and gradient, contracts k with the rows of the inverse factor
+// (a wave per row, lanes along k) and writes the results back to pinned host memory.  Mean, gradient and the kernel
+// values are fp64; X and 1/D are read in the model's precision.
+constexpr int SE_ROWS = 64;  // rows of the inverse factor per workgroup
+
+template <typename TX, int KID>
+__global__ __launch_bounds__(256) void small_eval_kernel(Cov<double> cov, double k0, int n, int npts,
+                                                         const double *__restrict__ px, const double *__restrict__ py,
+                                                         const double *__restrict__ pz,
+                                                         const double *__restrict__ alpha, const TX *__restrict__ X,
+                                                         const TX *__restrict__ dinv, int nq,
+                                                         const double *__restrict__ q, double *__restrict__ f,
+                                                         double *__restrict__ v, double *__restrict__ grad,
+                                                         double *__restrict__ tx, double *__restrict__ ty,
+                                                         double *__restrict__ part, unsigned *__restrict__ done)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char se_smem[];
+    double *kq = reinterpret_cast<double *>(se_smem);  // [npts]
+    __shared__ double red[4][5];
+    __shared__ bool last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int iq = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x;
+    const double c0 = q[iq], c1 = q[nq + iq], c2 = q[2 * nq + iq];
+    double af = 0, a0 = 0, a1 = 0, a2 = 0;
+    // every row block needs k(q, .) up to its last row; block 0 also reduces the mean and the gradient
+    const int kmax = v ? min(npts, (rb + 1) * SE_ROWS) : 0;
+    for (int j = tid; j < (rb == 0 ? npts : kmax); j += 256) {
+        const double dx = c0 - px[j], dy = c1 - py[j], dz = c2 - pz[j];
+        double k, kd;
+        cov_k_diff<double, KID>(cov, dx * dx + dy * dy + dz * dz, k, kd);
+        kq[j] = j < n ? k : 0.0;  // the padding rows of X are identity rows: they must see zeros
+        if (rb == 0) {
+            const double a = alpha[j];  // zero on the padding
+            const double w = a * kd;
+            af += a * k;
+            a0 += w * dx;
+            a1 += w * dy;
+            a2 += w * dz;
+        }
+    }
+    if (rb == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            af += __shfl_xor(af, off);
+            a0 += __shfl_xor(a0, off);
+            a1 += __shfl_xor(a1, off);
+            a2 += __shfl_xor(a2, off);
+        }
+        if (lane == 0) {
+            red[wave][0] = af;
+            red[wave][1] = a0;
+            red[wave][2] = a1;
+            red[wave][3] = a2;
+        }
+    }
+    __syncthreads();  // publishes kq (and red)
+    if (rb == 0 && tid == 0) {
+        const double fs = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        const double g0 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        const double g1 = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+        const double g2 = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+        f[iq] = fs;
+        if (grad) {
+            grad[3 * iq] = g0;
+            grad[3 * iq + 1] = g1;
+            grad[3 * iq + 2] = g2;
+        }
+        if (tx || ty) {
+            double t[3], u[3];
+            tangent_basis_dev(g0, g1, g2, t, u);
+            for (int c = 0; c < 3; ++c) {
+                if (tx)
+                    tx[3 * iq + c] = t[c];
+                if (ty)
+                    ty[3 * iq + c] = u[c];
+            }
+        }
+    }
+    if (!v)
+        return;
+    // ---- rows [rb * 64, rb * 64 + 64): a wave per row, four rows in flight per wave (the loop is latency-bound) ----
+    double acc = 0.0;
+    const int j0 = rb * SE_ROWS + wave * (SE_ROWS / 4);
+    for (int jj = 0; jj < SE_ROWS / 4; jj += 4) {
+        double w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + jj + u;
+            const TX *row = X + (size_t)j * npts;
+            double wj = 0.0;
+            for (int k = lane; k <= j; k += 64)
+                wj += (double)row[k] * kq[k];
+            w4[u] = wj;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double wj = w4[u];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                wj += __shfl_xor(wj, off);
+            acc += wj * wj * (double)dinv[j0 + jj + u];
+        }
+    }
+    if (lane == 0)
+        red[wave][4] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        part[(size_t)iq * nrb + rb] = red[0][4] + red[1][4] + red[2][4] + red[3][4];
+        __threadfence();
+        last = atomicAdd(&done[iq], 1u) == (unsigned)(nrb - 1);
+        if (last) {  // the last row block of this query adds the partial sums in a fixed order
+            __threadfence();
+            double s = 0.0;
+            for (int r = 0; r < nrb; ++r)
+                s += __hip_atomic_load(&part[(size_t)iq * nrb + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[iq] = k0 - s;
+            done[iq] = 0;  // ready for the next launch
+        }
+    }
+}
+
+size_t small_eval_scratch_bytes(int nq_max, int npts_max)
+{
+    return sizeof(double) * (size_t)nq_max * (npts_max / SE_ROWS) + sizeof(unsigned) * (size_t)nq_max;
+}
+
+template <typename TX>
+static void small_eval_t(const CovHost &h, int n, int npts, const double *px, const double *py, const double *pz,
+                         const double *alpha, const void *X, const void *dinv, int nq, int nq_max, const double *q,
+                         double *f, double *v, double *grad, double *tx, double *ty, void *scratch, hipStream_t st)
+{
+    Cov<double> c = lower_cov<double>(h);
+    const size_t shmem = sizeof(double) * (size_t)npts;
+    const int nrb = v ? npts / SE_ROWS : 1;
+    double *part = (double *)scratch;
+    unsigned *done = (unsigned *)(part + (size_t)nq_max * (SMALL_EVAL_NP_MAX / SE_ROWS));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((small_eval_kernel<TX, KID>), dim3((unsigned)nrb, (unsigned)nq), dim3(256),
+                                              shmem, st, c, h.k0, n, npts, px, py, pz, alpha, (const TX *)X,
+                                              (const TX *)dinv, nq, q, f, v, grad, tx, ty, part, done));
+}
+
+// q: qx | qy | qz (nq each); q and the outputs may be pinned host memory; v == NULL: no variance (X, dinv unused).
+// scratch: small_eval_scratch_bytes(nq_max, SMALL_EVAL_NP_MAX) bytes of device memory, zeroed once.
+void launch_small_eval(int prec, const CovHost &cov, int n, int npts, const double *px, const double *py,
+                       const double *pz, const double *alpha, const void *X, const void *dinv, int nq, int nq_max,
+                       const double *q, double *f, double *v, double *grad, double *tx, double *ty, void *scratch,
+                       hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)
+        small_eval_t<double>(cov, n, npts, px, py, pz, alpha, X, dinv, nq, nq_max, q, f, v, grad, tx, ty, scratch, st);
+    else
+        small_eval_t<float>(cov, n, npts, px, py, pz, alpha, X, dinv, nq, nq_max, q, f, v, grad, tx, ty, scratch, st);
 }
 
 // ---- AtlasBase::project (reference include/atlas/atlas.hpp:201-276), all start points at once ----------------

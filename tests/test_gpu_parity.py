@@ -265,6 +265,37 @@ def test_project_matches_atlas_restatement(gpu, orc, ds, golden, prec, fused, mo
     gm.close()
 
 
+@pytest.mark.parametrize("prec", [1, 0, 2])
+def test_small_batch_path_agrees_with_general_path(gpu, orc, ds, golden, prec):
+    """Up to 64 queries on a model of N <= 1024 take the one-launch path (a workgroup per query, pinned I/O);
+    the same queries inside a larger batch take the general path.  Both agree with each other and the oracle."""
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    kn, par = "thinplate", (2.0,)
+    om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+    rng = np.random.default_rng(5)
+    Q = rng.uniform(-1.1, 1.1, size=(300, 3))
+    Q[:4] = np.stack([x, y, z], 1)[:4]                       # on training points
+    big = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True, want_basis=True)
+    ref = om.evaluate(Q[:40, 0], Q[:40, 1], Q[:40, 2], want_v=True, want_grad=True, want_basis=True)
+    tol = 1e-10 if prec == 1 else 5e-5
+    for lo, hi in ((0, 1), (1, 40), (40, 104)):
+        small = gm.evaluate(Q[lo:hi, 0], Q[lo:hi, 1], Q[lo:hi, 2], want_v=True, want_grad=True, want_basis=True)
+        for key in ("f", "grad"):
+            assert nerr(small[key], big[key][lo:hi]) < 1e-12 * (1 if prec == 1 else 1e4), key
+        assert verr(small["v"], big["v"][lo:hi], 8.0) < tol
+        gn = np.linalg.norm(big["grad"][lo:hi], axis=1)
+        ok = gn > 1e-2 * gn.max()
+        for key in ("tx", "ty"):
+            assert np.max(np.abs(small[key][ok] - big[key][lo:hi][ok])) < 1e-6, key
+        if hi <= 40:
+            assert nerr(small["f"], ref["f"][lo:hi]) < (1e-10 if prec == 1 else 1e-5)
+            assert verr(small["v"], ref["v"][lo:hi], 8.0) < tol
+    f_only = gm.evaluate(Q[:3, 0], Q[:3, 1], Q[:3, 2])["f"]      # mean only: no inverse factor needed
+    assert nerr(f_only, big["f"][:3]) < 1e-12 * (1 if prec == 1 else 1e4)
+    gm.close()
+
+
 def test_host_batches_larger_than_one_slice(gpu, orc, ds):
     """Host evaluate slices very large batches (2^20 queries per slice); results do not depend on the slicing."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(64)
