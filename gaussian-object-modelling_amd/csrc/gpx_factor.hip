@@ -10,8 +10,12 @@
 //   fwd / bwd  : one launch per block step of L y = b / L^T x = y using the inverse blocks.
 #include "gpx_internal.hpp"
 
-namespace gpx {
+// phase timing of diag_ldl_kernel for scripts/diag_bench.hip (which defines GPX_STAMP); nothing in the library build
+#ifndef GPX_STAMP
+#define GPX_STAMP(i)
+#endif
 
+namespace gpx {
 
 // threads of the diagonal-block kernel: step A keeps two 32-entry rows in registers (fp32 ~180, fp64 ~300 VGPRs)
 template <typename T>
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
     T *Tb = Pa + 3 * NB * PLD;                     // [3][NB][PLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    GPX_STAMP(0);
     for (int jb = 0; jb < 4; ++jb) {
         const int c0 = NB * jb;
         const int nrows = TILE - c0;
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
             Pa[(c0 + r_) * PLD + c_] = A[(size_t)(c0 + r_) * lda + c0 + c_];
         }
         __syncthreads();
+        GPX_STAMP(1 + 4 * jb);
         // ---- A: diagonal sub-block, one wave, lane l (and its twin l + 32) owns row l ----
         if (wave == 0) {
             const int l = lane & 31;
@@ -110,11 +116,11 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
 #pragma unroll
                 for (int k = j + 1; k < NB; ++k) {
                     const T lkj = bcast_lane(r[j], k);  // L[k][j]
-                    const T t = (k < l) ? x[k] * lkj : T(0);
+                    // x[k] is still 0 for k >= l (set below only when l > k), so no select is needed
                     if (k & 1)
-                        s1 += t;
+                        s1 += x[k] * lkj;
                     else
-                        s0 += t;
+                        s0 += x[k] * lkj;
                 }
                 x[j] = (l > j) ? -(r[j] + s0 + s1) : T(0);
             }
@@ -138,6 +144,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
             }
         }
         __syncthreads();
+        GPX_STAMP(2 + 4 * jb);
         const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
         if (nb_rows > 0) {
             // ---- B: W[i][c] = sum_{k<=c} A[i][k] X11[c][k]  (WPT entries per thread at most) ----
@@ -169,23 +176,42 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 }
             }
             __syncthreads();
+            GPX_STAMP(3 + 4 * jb);
             // ---- C: trailing update on the global block: A[i][k] -= sum_c W[i][c] L[k][c], k <= i ----
+            // lower-triangle entries only, CPT per thread; all global loads are issued before the first use (as a
+            // read-modify-write inside the loop every entry paid its own L2 round trip: ~18 in a row for jb = 0)
             const int r0 = c0 + NB;
-            for (int idx = tid; idx < nb_rows * nb_rows; idx += DT) {
-                const int ii = idx / nb_rows, kk = idx - ii * nb_rows;
-                if (kk > ii)
-                    continue;
-                const T *wrow = Pa + (r0 + ii) * PLD;
-                const T *lrow = Lp + (r0 + kk) * PLD;
-                T s = T(0);
+            constexpr int CPT = ((TILE - NB) * (TILE - NB + 1) / 2 + DT - 1) / DT;
+            const int ntri = nb_rows * (nb_rows + 1) / 2;
+            T creg[CPT];
+            int cpos[CPT];
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    s += wrow[c] * lrow[c];
-                A[(size_t)(r0 + ii) * lda + r0 + kk] -= s;
+            for (int e = 0; e < CPT; ++e) {
+                const int t = tid + DT * e;
+                int ii = 0, kk = 0;
+                if (t < ntri)
+                    tri_decode(t, ii, kk);
+                cpos[e] = (ii << 8) | kk;
+                creg[e] = t < ntri ? A[(size_t)(r0 + ii) * lda + r0 + kk] : T(0);
+            }
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+                const int t = tid + DT * e;
+                if (t < ntri) {
+                    const int ii = cpos[e] >> 8, kk = cpos[e] & 255;
+                    const T *wrow = Pa + (r0 + ii) * PLD;
+                    const T *lrow = Lp + (r0 + kk) * PLD;
+                    T s = T(0);
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                        s += wrow[c] * lrow[c];
+                    A[(size_t)(r0 + ii) * lda + r0 + kk] = creg[e] - s;
+                }
             }
         }
         __threadfence_block();
         __syncthreads();
+        GPX_STAMP(4 + 4 * jb);
     }
 
     // ---- inverse of the 128 x 128 unit-lower L from the four 32 x 32 inverses ----
@@ -220,6 +246,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 Xs[((ii == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB + r_) * PLD + c_] = xv;
         }
         __syncthreads();
+        GPX_STAMP(16 + s_);
     }
     // diagonal blocks and the zero upper part
     for (int idx = tid; idx < TILE * TILE; idx += DT) {
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         else if (bj == bi)
             linv[(size_t)blk * TILE * TILE + idx] = Xd[(bi * NB + (r_ & 31)) * PLD + (c_ & 31)];
     }
+    GPX_STAMP(20);
 }
 
 static size_t diag_shmem_bytes(size_t esz)

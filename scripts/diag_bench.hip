@@ -1,0 +1,57 @@
+// diag_bench.hip -- development harness: phase timing (s_memtime) of the 128 x 128 diagonal-block kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/diag_bench.hip -I gaussian-object-modelling_amd/csrc -I include -o scripts/diag_bench.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+__device__ long long gpx_dbg_stamps[32];
+#define GPX_STAMP(i)                                            \
+    do {                                                        \
+        if (threadIdx.x == 0)                                   \
+            gpx_dbg_stamps[(i)] = (long long)wall_clock64();    \
+    } while (0)
+#include "../gaussian-object-modelling_amd/csrc/gpx_factor.hip"
+using namespace gpx;
+
+template <typename T>
+static void run(const char *name, int prec)
+{
+    const int n = 128;
+    std::vector<T> A((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            A[(size_t)i * n + j] = (T)(std::exp(-0.05 * std::fabs((double)(i - j))) + (i == j ? 0.5 : 0.0));
+    T *dA, *dL, *dd, *ddi;
+    int *info;
+    hipMalloc(&dA, sizeof(T) * n * n), hipMalloc(&dL, sizeof(T) * n * n), hipMalloc(&dd, sizeof(T) * n), hipMalloc(&ddi, sizeof(T) * n);
+    hipMalloc(&info, 64), hipMemset(info, 0, 64);
+    long long st[32];
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(dA, A.data(), sizeof(T) * n * n, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0), hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        launch_diag_ldl(prec, dA, n, dL, dd, ddi, info, 0, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(gpx_dbg_stamps), sizeof(st));
+        if (rep == 2) {
+            printf("%s: event %.1f us; phases in us (100 MHz wall clock):\n", name, ms * 1e3);
+            auto us = [&](int a, int b) { return (st[b] - st[a]) / 100.0; };
+            for (int jb = 0; jb < 4; ++jb)
+                printf("  panel %d: load %.1f  A(diag 32x32 LDL+inv, 1 wave) %.1f  B(W, L21) %.1f  C(trailing) %.1f\n", jb,
+                       us(jb ? 4 * jb : 0, 1 + 4 * jb), us(1 + 4 * jb, 2 + 4 * jb), jb < 3 ? us(2 + 4 * jb, 3 + 4 * jb) : 0.0,
+                       jb < 3 ? us(3 + 4 * jb, 4 + 4 * jb) : us(2 + 4 * jb, 4 + 4 * jb));
+            printf("  inverse assembly: %.1f %.1f %.1f  final copy %.1f   total %.1f\n", us(16, 17), us(17, 18), us(18, 19),
+                   us(19, 20), us(0, 20));
+        }
+    }
+}
+int main()
+{
+    run<float>("fp32", 0);
+    run<double>("fp64", 1);
+    return 0;
+}
