@@ -1,5 +1,5 @@
 """Build profiles/<out>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 def main(fetch_dir, write_dir, out, cmd):
     res = {"cmd": cmd,
@@ -9,7 +9,7 @@ def main(fetch_dir, write_dir, out, cmd):
            "kernels": {}}
     vals = collections.defaultdict(dict)
     for d, ctr in ((fetch_dir, "FETCH_SIZE"), (write_dir, "WRITE_SIZE")):
-        f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+        f = max(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)  # newest run
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == ctr and "gpx" in r["Kernel_Name"]:

@@ -5,6 +5,7 @@ def main(src, dst, note=""):
     ks = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
     if not ks:
         raise SystemExit("no kernel_stats.csv under " + src)
+    ks.sort(key=os.path.getmtime, reverse=True)  # newest run first
     rows = list(csv.DictReader(open(ks[0])))
     with open(dst, "w") as fh:
         fh.write("# rocprofv3 --kernel-trace --stats summary\n# source: %s\n# %s\n" % (os.path.basename(ks[0]), note))
