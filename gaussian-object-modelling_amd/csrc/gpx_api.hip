@@ -91,7 +91,7 @@ CovHost make_cov(const gpx_kernel &k)
 }  // namespace gpx
 
 // ------------------------------------------------------------------------------------------------
-enum { EV_T0 = 0, EV_KBUILD, EV_FACTOR, EV_SOLVE, EV_NORMALS, EV_INV0, EV_INV1, EV_M0, EV_M1, EV_V1, EV_COUNT };
+enum { EV_T0 = 0, EV_KBUILD, EV_FACTOR, EV_SOLVE, EV_NORMALS, EV_INV0, EV_INV1, EV_M0, EV_M1, EV_V1, EV_WS, EV_COUNT };
 
 struct gpx_pending {
     size_t nq;
@@ -167,6 +167,7 @@ struct gpx_model {
     gpx_stats stats{};
     bool stats_eval_pending = false;
     bool eval_had_var = false;
+    bool ws_in_flight = false;  // ev[EV_WS] marks the end of the last evaluation that used the shared workspaces
 };
 
 static void free_dev(gpx_model *m)
@@ -878,6 +879,10 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
         if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
             return rc;
     }
+    // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
+    // which may be enqueued on different streams (gpx_model_evaluate_device): order them behind the previous user.
+    if (m->ws_in_flight)
+        (void)hipStreamWaitEvent(s, m->ev[EV_WS], 0);
     (void)hipEventRecord(m->ev[EV_M0], s);
     // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
     // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
@@ -935,6 +940,8 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
         m->gemm_ev_used_var = gi;
     }
     (void)hipEventRecord(m->ev[EV_V1], s);
+    (void)hipEventRecord(m->ev[EV_WS], s);
+    m->ws_in_flight = true;
     m->stats_eval_pending = true;
     m->eval_had_var = v != nullptr;
     hipError_t le = hipGetLastError();

@@ -364,6 +364,36 @@ def test_device_resident_evaluate(gpu, orc, ds):
     gm.close()
 
 
+def test_device_evaluate_on_two_caller_streams(gpu, ds):
+    """Evaluations enqueued on different caller streams share the model's workspaces; the library orders them
+    (an event after each evaluation), so overlapping submissions give the same results as sequential ones."""
+    torch = pytest.importorskip("torch")
+    x, y, z, lab, s2 = ds.fibonacci_training_set(1500)
+    gm = gpu.Model(gpu.make_kernel("matern52", 1, 1), x, y, z, lab, s2, precision=gpu.F32, prepare_variance=True)
+    rng = np.random.default_rng(23)
+    nq = 40000
+    qs = [torch.from_numpy(rng.uniform(-1.1, 1.1, size=(3, nq))).cuda() for _ in range(2)]
+    outs = [(torch.empty(nq, dtype=torch.float64, device="cuda"), torch.empty(nq, dtype=torch.float64, device="cuda"))
+            for _ in range(2)]
+    refs = []
+    for q in qs:  # sequential reference on the model's own stream
+        f, v = torch.empty(nq, dtype=torch.float64, device="cuda"), torch.empty(nq, dtype=torch.float64, device="cuda")
+        gm.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+        gm.sync()
+        refs.append((f.cpu().numpy(), v.cpu().numpy()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(3):  # back-to-back submissions, no synchronisation in between
+        for q, (f, v), st in zip(qs, outs, streams):
+            gm.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr(),
+                               stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    for (f, v), (rf, rv) in zip(outs, refs):
+        np.testing.assert_array_equal(f.cpu().numpy(), rf)
+        np.testing.assert_array_equal(v.cpu().numpy(), rv)
+    gm.close()
+
+
 def test_shell_broadcast_commit_roundtrip(gpu, orc, ds):
     """Sharded-grid path on one GPU: copy the state blobs of a factorised model into a shell
     (stand-in for the RCCL broadcast), commit, and evaluate."""
