@@ -346,7 +346,8 @@ static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 }
 
 // ---- blocked right-looking LDL^T -----------------------------------------------------------------
-static void factorize(gpx_model *m)
+// Columns before c_start (a multiple of 128) are taken as already factorised and applied (rank-n update).
+static void factorize(gpx_model *m, int c_start = 0)
 {
     const int np = m->npad;
     const size_t e = m->esz;
@@ -355,52 +356,96 @@ static void factorize(gpx_model *m)
     auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
     auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * PANEL + c) * e); };
     size_t gemm_idx = 0;
-    for (int c0 = 0; c0 < np; c0 += PANEL) {
-        const int blk = c0 / TILE;
-        for (int half = 0; half < 2; ++half) {
-            const int cc = c0 + half * TILE;  // first column of this 128-wide half panel
-            const int r0 = cc + TILE;         // first row below the diagonal block
-            launch_diag_ldl(m->prec, Kp(cc, cc), np, m->linv, m->t_d, m->t_dinv, m->d_info, blk + half, m->stream);
-            if (r0 >= np)
-                continue;
-            GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
-            t.A = Kp(r0, cc), t.lda = np;
-            t.B = (char *)m->linv + (size_t)(blk + half) * TILE * TILE * e, t.ldb = TILE;
-            t.C = Kp(r0, cc), t.ldc = np;
-            t.M = np - r0, t.N = TILE, t.K = TILE;
-            t.b_lower = 1;
-            t.epi = EPI_TRSM;
-            t.W = Wpp(r0, half * TILE), t.ldw = PANEL;
-            t.colscale = (char *)m->t_dinv + (size_t)cc * e;
-            launch_gemm(m->prec, t, m->stream);
-            if (half == 0) {
-                GemmArgs s;  // second half panel (incl. its diagonal block) -= W_a * L_a^T
-                s.A = Wpp(r0, 0), s.lda = PANEL;
-                s.B = Kp(r0, cc), s.ldb = np;
-                s.C = Kp(r0, r0), s.ldc = np;
-                s.M = np - r0, s.N = TILE, s.K = TILE;
-                s.alpha = -1.0, s.beta = 1;
-                launch_gemm(m->prec, s, m->stream);
-            } else {
-                GemmArgs s;  // trailing matrix -= [W_a W_b] * [L_a L_b]^T, lower tiles only, K = 256
-                s.A = Wpp(r0, 0), s.lda = PANEL;
-                s.B = Kp(r0, c0), s.ldb = np;
-                s.C = Kp(r0, r0), s.ldc = np;
-                s.M = np - r0, s.N = np - r0, s.K = PANEL;
-                s.alpha = -1.0, s.beta = 1;
-                s.lower_only = 1;
-                hipEvent_t *ev = gemm_events(m, gemm_idx);
-                if (ev)
-                    (void)hipEventRecord(ev[0], m->stream);
-                launch_gemm(m->prec, s, m->stream);
-                if (ev) {
-                    (void)hipEventRecord(ev[1], m->stream);
-                    ++gemm_idx;
-                }
-            }
+    // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
+    auto half_step = [&](int cc, int wcol) {
+        const int r0 = cc + TILE;
+        launch_diag_ldl(m->prec, Kp(cc, cc), np, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
+        if (r0 >= np)
+            return;
+        GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
+        t.A = Kp(r0, cc), t.lda = np;
+        t.B = (char *)m->linv + (size_t)(cc / TILE) * TILE * TILE * e, t.ldb = TILE;
+        t.C = Kp(r0, cc), t.ldc = np;
+        t.M = np - r0, t.N = TILE, t.K = TILE;
+        t.b_lower = 1;
+        t.epi = EPI_TRSM;
+        t.W = Wpp(r0, wcol), t.ldw = PANEL;
+        t.colscale = (char *)m->t_dinv + (size_t)cc * e;
+        launch_gemm(m->prec, t, m->stream);
+    };
+    // trailing matrix from row / column r0 on -= W[:, 0:kw] * L[:, c0:c0+kw]^T, lower tiles only
+    auto trailing = [&](int c0, int r0, int kw) {
+        GemmArgs s;
+        s.A = Wpp(r0, 0), s.lda = PANEL;
+        s.B = Kp(r0, c0), s.ldb = np;
+        s.C = Kp(r0, r0), s.ldc = np;
+        s.M = np - r0, s.N = np - r0, s.K = kw;
+        s.alpha = -1.0, s.beta = 1;
+        s.lower_only = 1;
+        hipEvent_t *ev = gemm_events(m, gemm_idx);
+        if (ev)
+            (void)hipEventRecord(ev[0], m->stream);
+        launch_gemm(m->prec, s, m->stream);
+        if (ev) {
+            (void)hipEventRecord(ev[1], m->stream);
+            ++gemm_idx;
         }
+    };
+    int c0 = c_start;
+    if (c0 % PANEL) {  // start in the middle of a 256-panel: a lone 128-wide step
+        half_step(c0, 0);
+        if (c0 + TILE < np)
+            trailing(c0, c0 + TILE, TILE);
+        c0 += TILE;
+    }
+    for (; c0 < np; c0 += PANEL) {
+        half_step(c0, 0);
+        const int r0 = c0 + TILE;
+        if (r0 < np) {
+            GemmArgs s;  // second half panel (incl. its diagonal block) -= W_a * L_a^T
+            s.A = Wpp(r0, 0), s.lda = PANEL;
+            s.B = Kp(r0, c0), s.ldb = np;
+            s.C = Kp(r0, r0), s.ldc = np;
+            s.M = np - r0, s.N = TILE, s.K = TILE;
+            s.alpha = -1.0, s.beta = 1;
+            launch_gemm(m->prec, s, m->stream);
+        }
+        half_step(r0, TILE);
+        if (c0 + PANEL < np)
+            trailing(c0, c0 + PANEL, PANEL);
     }
     m->gemm_ev_used_factor = gemm_idx;
+}
+
+// Rank-n update, rows [t0, npad): the kernel rows have just been built; the columns [0, t0) hold the old factor.
+// Column block by column block: W = A_rows,j Linv_j^T (to the workspace), L_rows,j = W D_j^-1 (in place), then
+// every later column of these rows -= W L_{later rows, j}^T.  2 launches per old column block.
+static void factor_append_rows(gpx_model *m, int t0)
+{
+    const int np = m->npad;
+    const size_t e = m->esz;
+    char *K = (char *)m->Kmat;
+    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
+    void *Wrows = (char *)m->Wp + ((size_t)t0 * PANEL) * e;
+    for (int cc = 0; cc < t0; cc += TILE) {
+        GemmArgs t;
+        t.A = Kp(t0, cc), t.lda = np;
+        t.B = (char *)m->linv + (size_t)(cc / TILE) * TILE * TILE * e, t.ldb = TILE;
+        t.C = Kp(t0, cc), t.ldc = np;
+        t.M = np - t0, t.N = TILE, t.K = TILE;
+        t.b_lower = 1;
+        t.epi = EPI_TRSM;
+        t.W = Wrows, t.ldw = PANEL;
+        t.colscale = (char *)m->t_dinv + (size_t)cc * e;
+        launch_gemm(m->prec, t, m->stream);
+        GemmArgs s;  // columns [cc + 128, np) of the new rows
+        s.A = Wrows, s.lda = PANEL;
+        s.B = Kp(cc + TILE, cc), s.ldb = np;
+        s.C = Kp(t0, cc + TILE), s.ldc = np;
+        s.M = np - t0, s.N = np - (cc + TILE), s.K = TILE;
+        s.alpha = -1.0, s.beta = 1;
+        launch_gemm(m->prec, s, m->stream);
+    }
 }
 
 // ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
@@ -541,8 +586,23 @@ static int demote_to_f32(gpx_model *m)
     return GPX_OK;
 }
 
+// What a rank-n update carries over from the previous factorisation (device buffers of the OLD padded size)
+struct kept_factor {
+    int t0 = 0;        // rows / columns [0, t0) of L, D and the inverse diagonal blocks stay valid
+    int np_old = 0;
+    int n_neg = 0;     // negative pivots among the kept ones
+    void *K = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;  // d, dinv: t0 entries each
+    void release()
+    {
+        for (void *p : {K, linv, d, dinv})
+            if (p)
+                (void)hipFree(p);
+        K = linv = d = dinv = nullptr;
+    }
+};
+
 // ---- create: everything after the host arrays are in place ---------------------------------------
-static int build_model(gpx_model *m)
+static int build_model(gpx_model *m, kept_factor *keep = nullptr)
 {
     const int n = m->n, np = m->npad;
     const size_t e = m->esz;
@@ -596,11 +656,25 @@ static int build_model(gpx_model *m)
     // ---- kernel matrix ----
     (void)hipEventRecord(m->ev[EV_T0], s);
     const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
-    launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
-    launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
-    (void)hipEventRecord(m->ev[EV_KBUILD], s);
-    // ---- factorisation ----
-    factorize(m);
+    if (keep && keep->t0 > 0) {
+        // rank-n update: the old factor goes back into the (possibly larger) matrix, only the new rows are built
+        const size_t t0 = (size_t)keep->t0;
+        HIPCHK(hipMemcpy2DAsync(m->Kmat, e * np, keep->K, e * keep->np_old, e * t0, t0, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->linv, keep->linv, e * (t0 / TILE) * TILE * TILE, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->t_d, keep->d, e * t0, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->t_dinv, keep->dinv, e * t0, hipMemcpyDeviceToDevice, s));
+        launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s,
+                      keep->t0 / TILE);
+        (void)hipEventRecord(m->ev[EV_KBUILD], s);
+        factor_append_rows(m, keep->t0);
+        factorize(m, keep->t0);
+    } else {
+        launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
+        launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
+        (void)hipEventRecord(m->ev[EV_KBUILD], s);
+        // ---- factorisation ----
+        factorize(m);
+    }
     (void)hipEventRecord(m->ev[EV_FACTOR], s);
     // ---- alpha = K^-1 y with fp64-residual refinement ----
     int ir = m->opt.ir_steps >= 0 ? m->opt.ir_steps : (m->prec == GPX_PREC_F64 ? 1 : 2);
@@ -653,13 +727,13 @@ static int build_model(gpx_model *m)
     m->stats.factor_gemm_launches = (int64_t)m->gemm_ev_used_factor;
     m->stats.n = n;
     m->stats.n_padded = np;
-    m->stats.n_negative_pivots = info[1];
+    m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);
     m->stats.ir_steps_done = ir;
     m->stats.alpha_residual = rmax;
     if (info[0] != 0)
         return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(info[0] - 1));
     // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64
-    {
+    if (!(keep && keep->t0 > 0)) {
         const int a = info[2], b = info[3];
         if (a >= 0 && a < n && b >= 0 && b < n) {
             const int ia = m->perm[a], ib = m->perm[b];
@@ -823,6 +897,7 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipStreamSynchronize(m->stream));
     const double keepR = m->R;  // update() does not refresh R (gp_regressor.hpp:454-455)
+    const int n_old = m->n;
     m->hx.insert(m->hx.end(), x, x + n_new);
     m->hy.insert(m->hy.end(), y, y + n_new);
     m->hz.insert(m->hz.end(), z, z + n_new);
@@ -832,6 +907,45 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
         m->has_s2 = true;
     } else {
         m->hs2.insert(m->hs2.end(), n_new, 0.0);
+    }
+    // Rank-n append instead of the reference's refactorisation from scratch (:457-459) when the old
+    // factor is still there in the training precision and the pivot order of the grown set (Eigen's rule on the
+    // diagonal k(0) + sigma2) keeps the old points first, in their old order.  Results agree with a rebuild to
+    // rounding; anything else falls back to the rebuild.
+    kept_factor keep;
+    const char *app_env = std::getenv("GPX_UPDATE_APPEND");  // 0: always rebuild (tests compare the two)
+    const bool append_on = !app_env || std::atoi(app_env) != 0;
+    if (append_on && m->ready && m->Kmat && m->linv && !m->x_packed && m->opt.precision != GPX_PREC_MIXED &&
+        n_old >= TILE) {
+        const int n_tot = (int)m->hx.size();
+        std::vector<double> diag(n_tot);
+        for (int i = 0; i < n_tot; ++i)
+            diag[i] = m->cov.k0 + (m->has_s2 ? m->hs2[i] : 0.0);
+        std::vector<int> perm_new;
+        eigen_pivot_order(diag, perm_new);
+        bool prefix = true;
+        for (int k = 0; k < n_old && prefix; ++k)
+            prefix = perm_new[k] == m->perm[k];
+        if (prefix) {
+            const int t0 = n_old / TILE * TILE;
+            const size_t e = m->esz;
+            keep.t0 = t0;
+            keep.np_old = m->npad;
+            keep.K = m->Kmat, keep.linv = m->linv;  // detached: free_dev must not release them
+            m->Kmat = m->linv = nullptr;
+            if (hipMalloc(&keep.d, e * t0) != hipSuccess || hipMalloc(&keep.dinv, e * t0) != hipSuccess ||
+                hipMemcpy(keep.d, m->t_d, e * t0, hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(keep.dinv, m->t_dinv, e * t0, hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                keep.release();  // out of memory for the carry-over: rebuild instead
+                keep = kept_factor{};
+            } else {
+                std::vector<char> hd(e * t0);
+                HIPCHK(hipMemcpy(hd.data(), keep.d, e * t0, hipMemcpyDeviceToHost));
+                for (int i = 0; i < t0; ++i)
+                    keep.n_neg += (e == 8 ? ((const double *)hd.data())[i] : (double)((const float *)hd.data())[i]) < 0.0;
+            }
+        }
     }
     free_dev(m);
     m->ready = m->has_inverse = m->has_normals = false;
@@ -844,7 +958,8 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     m->npad = (int)gpx_padded_n(m->n);
     m->nblk = m->npad / TILE;
     set_query_batch(m);
-    rc = build_model(m);  // refactor from scratch, as :457-459
+    rc = build_model(m, keep.t0 > 0 ? &keep : nullptr);  // :457-459 refactors from scratch; same results
+    keep.release();
     m->R = keepR;
     return rc;
 }

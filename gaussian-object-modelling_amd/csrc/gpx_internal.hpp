@@ -49,7 +49,8 @@ __device__ __forceinline__ void tri_decode(int t, int &ti, int &tj)
 // ---- pairwise (kernel-matrix) stages : gpx_pairwise.hip -----------------------------------
 // K (lower block-triangle, identity on padding), per-tile maxima of the squared distance.
 void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
-                   const void *s2, void *K, float *tile_max_d2, int *tile_max_ij, hipStream_t st);
+                   const void *s2, void *K, float *tile_max_d2, int *tile_max_ij, hipStream_t st,
+                   int first_tile_row = 0);  // > 0: only the tile rows from that row block on (rank-n update)
 // picks the global maximum of the per-tile maxima -> out_ij[2]
 void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile_max_ij, int *out_ij,
                            hipStream_t st);

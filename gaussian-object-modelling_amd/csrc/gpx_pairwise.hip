@@ -34,13 +34,14 @@ template <typename T, int KID>
 __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ x,
                                                      const T *__restrict__ y, const T *__restrict__ z,
                                                      const T *__restrict__ s2, T *__restrict__ K,
-                                                     float *__restrict__ tmax, int *__restrict__ tij)
+                                                     float *__restrict__ tmax, int *__restrict__ tij, int tile0)
 {
     __shared__ T rx[TILE], ry[TILE], rz[TILE], rs[TILE];
     __shared__ float wbest[4];
     __shared__ int wbi[4], wbj[4];
     int ti, tj;
-    tri_decode((int)blockIdx.x, ti, tj);
+    const int tile = (int)blockIdx.x + tile0;  // tile0 > 0: only the tile rows from some row block on (update)
+    tri_decode(tile, ti, tj);
     const int tid = threadIdx.x;
     if (tid < TILE) {
         int gi = ti * TILE + tid;
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad
                 bi = wbi[w];
                 bj = wbj[w];
             }
-        tmax[blockIdx.x] = best;
-        tij[2 * blockIdx.x] = bi;
-        tij[2 * blockIdx.x + 1] = bj;
+        tmax[tile] = best;
+        tij[2 * tile] = bi;
+        tij[2 * tile + 1] = bj;
     }
 }
 
@@ -192,23 +193,26 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, c
 
 template <typename T>
 static void kbuild_t(const CovHost &h, int n, int npad, const void *x, const void *y, const void *z,
-                     const void *s2, void *K, float *tmax, int *tij, hipStream_t st)
+                     const void *s2, void *K, float *tmax, int *tij, int first_tile_row, hipStream_t st)
 {
     const int nt = npad / TILE;
     const int ntiles = nt * (nt + 1) / 2;
+    const int tile0 = first_tile_row * (first_tile_row + 1) / 2;  // row-major enumeration of the lower tiles
+    if (tile0 >= ntiles)
+        return;
     Cov<T> c = lower_cov<T>(h);
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_kernel<T, KID>), dim3(ntiles), dim3(256), 0, st, c, n, npad,
-                                              (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K,
-                                              tmax, tij));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_kernel<T, KID>), dim3(ntiles - tile0), dim3(256), 0, st, c, n,
+                                              npad, (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K,
+                                              tmax, tij, tile0));
 }
 
 void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
-                   const void *s2, void *K, float *tmax, int *tij, hipStream_t st)
+                   const void *s2, void *K, float *tmax, int *tij, hipStream_t st, int first_tile_row)
 {
     if (prec == GPX_PREC_F64)
-        kbuild_t<double>(cov, n, npad, x, y, z, s2, K, tmax, tij, st);
+        kbuild_t<double>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
     else
-        kbuild_t<float>(cov, n, npad, x, y, z, s2, K, tmax, tij, st);
+        kbuild_t<float>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
 }
 
 void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *out_ij, hipStream_t st)

@@ -128,8 +128,12 @@ int gpx_device_count(void);       /* number of HIP devices, 0 if none / no drive
 int gpx_model_create(const gpx_kernel *kernel, size_t n, const double *x, const double *y, const double *z,
                      const double *label, const double *sigma2, const gpx_options *opt, gpx_model **out);
 
-/* GPRegressor<Cov>::update<withNormals>(new_data, gp), gp_regressor.hpp:367-479: append n_new
- * points and refactor from scratch (:457-459).  Model::R is not refreshed (:454-455). */
+/* GPRegressor<Cov>::update<withNormals>(new_data, gp), gp_regressor.hpp:367-479: append n_new points.  The
+ * reference refactors from scratch (:457-459); here the existing factor is extended (new kernel rows, their
+ * update against the old column blocks, factorisation of the new trailing block, new solve) whenever the old
+ * points stay first in Eigen's pivot order on the diagonal k(0) + sigma2 -- e.g. for one common sigma2 -- and the
+ * old factor is still held in the training precision; otherwise the model is rebuilt.  Either way the results
+ * equal a fresh create on the concatenated data to rounding.  Model::R is not refreshed (:454-455). */
 int gpx_model_update(gpx_model *m, size_t n_new, const double *x, const double *y, const double *z,
                      const double *label, const double *sigma2);
 

@@ -207,6 +207,53 @@ def test_update_appends_and_refactors(gpu, orc, ds, golden):
         gm.close()
 
 
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("n0,n1", [(1500, 40), (1408, 700), (300, 1300), (1000, 24)])
+def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, monkeypatch):
+    """update() appends to the existing factor (new kernel rows, left-looking row update against the old
+    column blocks, factorisation of the new trailing block) instead of refactoring from scratch.  Same alpha, D,
+    inertia and predictions as a rebuild (GPX_UPDATE_APPEND=0) and as a fresh model; cases: inside the last padded
+    tile, across the padding (larger matrix), old N a multiple of 128, first tile partially filled."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n0 + n1)
+    kern = gpu.make_kernel("thinplate", 2.0)  # indefinite: negative pivots on both sides of the split
+    qx, qy, qz = ds.query_grid(5)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPX_UPDATE_APPEND", mode)
+        gm = gpu.Model(kern, x[:n0], y[:n0], z[:n0], lab[:n0], s2[:n0], precision=prec)
+        gm.update(x[n0:], y[n0:], z[n0:], lab[n0:], s2[n0:])
+        o = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+        res[mode] = (gm.alpha.copy(), gm.D.copy(), o, gm.stats["n_negative_pivots"], gm.stats["alpha_residual"])
+        gm.close()
+    fresh = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+    of = fresh.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    assert res["1"][3] == res["0"][3] == fresh.stats["n_negative_pivots"] > 0
+    tol = 1e-9 if prec == 1 else 2e-5
+    for other_alpha, other_D, other_o in ((res["0"][0], res["0"][1], res["0"][2]), (fresh.alpha, fresh.D, of)):
+        assert nerr(res["1"][0], other_alpha) < tol
+        assert nerr(res["1"][1], other_D) < (1e-9 if prec == 1 else 1e-3)
+        for key in ("f", "grad"):
+            assert nerr(res["1"][2][key], other_o[key]) < tol, key
+        assert verr(res["1"][2]["v"], other_o["v"], 8.0) < (1e-9 if prec == 1 else 5e-5)
+    assert res["1"][4] < (1e-9 if prec == 1 else 1e-6)
+    fresh.close()
+
+
+def test_update_with_a_different_noise_level_falls_back_to_rebuild(gpu, orc, ds):
+    """Appended points with a larger sigma2 come FIRST in Eigen's pivot order: not an append, the model is rebuilt."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(400)
+    s2b = s2.copy()
+    s2b[300:] = 0.5
+    kern = ("matern52", (1.0, 1.0))
+    gm = gpu.Model(gpu.make_kernel(kern[0], *kern[1]), x[:300], y[:300], z[:300], lab[:300], s2b[:300], precision=gpu.F64)
+    gm.update(x[300:], y[300:], z[300:], lab[300:], s2b[300:])
+    om = orc.Model(orc.make_kernel(kern[0], *kern[1]), x, y, z, lab, s2b)
+    assert nerr(gm.alpha, om.alpha) < 1e-10
+    qx, qy, qz = ds.query_grid(4)
+    assert nerr(gm.evaluate(qx, qy, qz)["f"], om.evaluate(qx, qy, qz)["f"]) < 1e-10
+    gm.close()
+
+
 def test_kpp_accessor(gpu, orc, golden):
     x, y, z, lab, s2 = (golden["sphere64/" + k] for k in ("x", "y", "z", "label", "sigma2"))
     om = orc.Model(orc.make_kernel("laplace", 1, 1), x, y, z, lab, s2)
