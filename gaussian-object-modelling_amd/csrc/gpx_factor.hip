@@ -325,15 +325,30 @@ __device__ __forceinline__ void block_matvec(const T *__restrict__ M, long ldm, 
         m0[rr] = row[lane];
         m1[rr] = row[lane + 64];
     }
+    // 32 row sums over 64 lanes by recursive halving: a lane gives away the half of the rows its partner keeps, so
+    // the wave needs 16 + 8 + 4 + 2 + 1 + 1 = 32 shuffles instead of 32 x 6 for one butterfly per row; afterwards
+    // lane l holds row l >> 1
+    T s[32];
 #pragma unroll
-    for (int rr = 0; rr < 32; ++rr) {
-        T s = m0[rr] * v0 + m1[rr] * v1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            s += __shfl_xor(s, off);
-        if (lane == 0)
-            out_lds[wave * 32 + rr] = s;
+    for (int rr = 0; rr < 32; ++rr)
+        s[rr] = m0[rr] * v0 + m1[rr] * v1;
+#define GPX_HALVE(N, OFF)                                       \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i)             \
+    {                                                           \
+        const bool up = (lane & (OFF)) != 0;                    \
+        const T send = up ? s[i] : s[i + (N)];                  \
+        const T keep = up ? s[i + (N)] : s[i];                  \
+        s[i] = keep + __shfl_xor(send, (OFF));                  \
     }
+    GPX_HALVE(16, 32)
+    GPX_HALVE(8, 16)
+    GPX_HALVE(4, 8)
+    GPX_HALVE(2, 4)
+    GPX_HALVE(1, 2)
+#undef GPX_HALVE
+    s[0] += __shfl_xor(s[0], 1);
+    if ((lane & 1) == 0)
+        out_lds[wave * 32 + (lane >> 1)] = s[0];
 }
 
 // y[c] = sum_r M[r][c] v[r]; threads 0..127 own a column, two halves of r combined through LDS.
