@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--precision", choices=["f32", "f64", "mixed", "f32split"], default="f32")
     ap.add_argument("--kernel", default=KERNEL[0])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--query-batch", type=int, default=0, help="queries per variance batch (0 = library default)")
     ap.add_argument("--mean-only", action="store_true", help="diagnostic: skip the variance")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra F32_SPLIT line (not part of value)")
     return ap.parse_args()
@@ -153,7 +154,8 @@ def main():
             model[0].close()
         if shard:
             if rank == 0:
-                m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank)
+                m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank,
+                              query_batch=args.query_batch)
             else:
                 m = gpx.Model.shell(kern, n_train, precision=prec, device=local_rank)
             bufs = [sharding.device_blob_as_tensor(torch, *m.state_blob(part), dev)
@@ -163,7 +165,8 @@ def main():
             if rank != 0:
                 m.commit(with_variance=want_v)
         else:
-            m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank)
+            m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank,
+                          query_batch=args.query_batch)
         model[0] = m
         m.evaluate_device(nq_local, qx.data_ptr(), qy.data_ptr(), qz.data_ptr(), f.data_ptr(),
                           v.data_ptr() if want_v else None)
