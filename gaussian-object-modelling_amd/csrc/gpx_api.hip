@@ -136,7 +136,7 @@ struct gpx_model {
     std::vector<double> hD;  // D kept on the host once the factor has been released (mixed precision)
     void *Kmat = nullptr;  // npad x npad, L D L^T in place
     void *linv = nullptr;  // nblk x 128 x 128
-    void *Wp = nullptr;    // npad x 256 panel workspace
+    void *Wp = nullptr;    // npad x 512 panel workspace
     void *X = nullptr;     // npad x npad inverse factor (state blob part 1)
     int *d_info = nullptr; // [0] first bad pivot (1-based), [1] negative pivots, [2..3] argmax pair
     float *d_tmax = nullptr;
@@ -346,6 +346,12 @@ static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 }
 
 // ---- blocked right-looking LDL^T -----------------------------------------------------------------
+// Outer panels of 256 columns = 2 diagonal blocks of 128 (GPX_PANEL=512: 4 blocks): per block the diagonal LDL^T
+// (+ inverse), the panel solve as a GEMM with the inverse block (W = A21 Linv^T to the workspace, L21 = W D^-1 in
+// place) and the update of the remaining columns of the panel; then ONE trailing update with K = panel width.
+// Measured at N = 16384 fp32: 512-wide panels give a trailing tile 16 k-tiles instead of 8 (100.6 -> 112 TFLOP/s,
+// LDL^T 31.8 -> 30.8 ms), but the longer fp32 accumulations cost the ill-conditioned thin-plate system accuracy
+// (alpha after two refinement steps 2.9e-5 instead of < 1e-5 of the fp64 result), so 256 stays the default.
 // Columns before c_start (a multiple of 128) are taken as already factorised and applied (rank-n update).
 static void factorize(gpx_model *m, int c_start = 0)
 {
@@ -354,10 +360,10 @@ static void factorize(gpx_model *m, int c_start = 0)
     char *K = (char *)m->Kmat;
     char *W = (char *)m->Wp;
     auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
-    auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * PANEL + c) * e); };
+    auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * WIDE_PANEL + c) * e); };
     size_t gemm_idx = 0;
     // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
-    auto half_step = [&](int cc, int wcol) {
+    auto block_step = [&](int cc, int wcol) {
         const int r0 = cc + TILE;
         launch_diag_ldl(m->prec, Kp(cc, cc), np, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
         if (r0 >= np)
@@ -369,14 +375,14 @@ static void factorize(gpx_model *m, int c_start = 0)
         t.M = np - r0, t.N = TILE, t.K = TILE;
         t.b_lower = 1;
         t.epi = EPI_TRSM;
-        t.W = Wpp(r0, wcol), t.ldw = PANEL;
+        t.W = Wpp(r0, wcol), t.ldw = WIDE_PANEL;
         t.colscale = (char *)m->t_dinv + (size_t)cc * e;
         launch_gemm(m->prec, t, m->stream);
     };
     // trailing matrix from row / column r0 on -= W[:, 0:kw] * L[:, c0:c0+kw]^T, lower tiles only
     auto trailing = [&](int c0, int r0, int kw) {
         GemmArgs s;
-        s.A = Wpp(r0, 0), s.lda = PANEL;
+        s.A = Wpp(r0, 0), s.lda = WIDE_PANEL;
         s.B = Kp(r0, c0), s.ldb = np;
         s.C = Kp(r0, r0), s.ldc = np;
         s.M = np - r0, s.N = np - r0, s.K = kw;
@@ -392,27 +398,34 @@ static void factorize(gpx_model *m, int c_start = 0)
         }
     };
     int c0 = c_start;
-    if (c0 % PANEL) {  // start in the middle of a 256-panel: a lone 128-wide step
-        half_step(c0, 0);
+    if (c0 % PANEL) {  // start in the middle of a 256-column unit: a lone 128-wide step
+        block_step(c0, 0);
         if (c0 + TILE < np)
             trailing(c0, c0 + TILE, TILE);
         c0 += TILE;
     }
-    for (; c0 < np; c0 += PANEL) {
-        half_step(c0, 0);
-        const int r0 = c0 + TILE;
-        if (r0 < np) {
-            GemmArgs s;  // second half panel (incl. its diagonal block) -= W_a * L_a^T
-            s.A = Wpp(r0, 0), s.lda = PANEL;
-            s.B = Kp(r0, c0), s.ldb = np;
-            s.C = Kp(r0, r0), s.ldc = np;
-            s.M = np - r0, s.N = TILE, s.K = TILE;
-            s.alpha = -1.0, s.beta = 1;
-            launch_gemm(m->prec, s, m->stream);
+    static const int wide = [] {
+        const char *e = std::getenv("GPX_PANEL");
+        return e && std::atoi(e) == WIDE_PANEL ? WIDE_PANEL : PANEL;
+    }();
+    while (c0 < np) {
+        const int pw = std::min(wide, np - c0), nb = pw / TILE;
+        for (int h = 0; h < nb; ++h) {
+            const int cc = c0 + h * TILE, r0 = cc + TILE;
+            block_step(cc, h * TILE);
+            if (h + 1 < nb && r0 < np) {
+                GemmArgs s;  // the remaining columns of the panel (incl. the next diagonal block) -= W_h * L_h^T
+                s.A = Wpp(r0, h * TILE), s.lda = WIDE_PANEL;
+                s.B = Kp(r0, cc), s.ldb = np;
+                s.C = Kp(r0, r0), s.ldc = np;
+                s.M = np - r0, s.N = c0 + pw - r0, s.K = TILE;
+                s.alpha = -1.0, s.beta = 1;
+                launch_gemm(m->prec, s, m->stream);
+            }
         }
-        half_step(r0, TILE);
-        if (c0 + PANEL < np)
-            trailing(c0, c0 + PANEL, PANEL);
+        if (c0 + pw < np)
+            trailing(c0, c0 + pw, pw);
+        c0 += pw;
     }
     m->gemm_ev_used_factor = gemm_idx;
 }
@@ -426,7 +439,7 @@ static void factor_append_rows(gpx_model *m, int t0)
     const size_t e = m->esz;
     char *K = (char *)m->Kmat;
     auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
-    void *Wrows = (char *)m->Wp + ((size_t)t0 * PANEL) * e;
+    void *Wrows = (char *)m->Wp + ((size_t)t0 * WIDE_PANEL) * e;
     for (int cc = 0; cc < t0; cc += TILE) {
         GemmArgs t;
         t.A = Kp(t0, cc), t.lda = np;
@@ -435,11 +448,11 @@ static void factor_append_rows(gpx_model *m, int t0)
         t.M = np - t0, t.N = TILE, t.K = TILE;
         t.b_lower = 1;
         t.epi = EPI_TRSM;
-        t.W = Wrows, t.ldw = PANEL;
+        t.W = Wrows, t.ldw = WIDE_PANEL;
         t.colscale = (char *)m->t_dinv + (size_t)cc * e;
         launch_gemm(m->prec, t, m->stream);
         GemmArgs s;  // columns [cc + 128, np) of the new rows
-        s.A = Wrows, s.lda = PANEL;
+        s.A = Wrows, s.lda = WIDE_PANEL;
         s.B = Kp(cc + TILE, cc), s.ldb = np;
         s.C = Kp(t0, cc + TILE), s.ldc = np;
         s.M = np - t0, s.N = np - (cc + TILE), s.K = TILE;
@@ -629,7 +642,7 @@ static int build_model(gpx_model *m, kept_factor *keep = nullptr)
             return rc;
         HIPCHK(hipMalloc(&m->Kmat, e * (size_t)np * np));
         HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
-        HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * PANEL));
+        HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
         const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
         HIPCHK(hipMalloc((void **)&m->d_tmax, sizeof(float) * ntiles));
         HIPCHK(hipMalloc((void **)&m->d_tij, sizeof(int) * 2 * ntiles));

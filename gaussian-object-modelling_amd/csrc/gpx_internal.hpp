@@ -10,7 +10,8 @@
 namespace gpx {
 
 constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
-constexpr int PANEL = 256;  // outer panel of the factorisation = 2 diagonal blocks
+constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
+constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
 
 // Host-side description of a covariance function, lowered to Cov<T> for the device.
