@@ -507,17 +507,28 @@ static int build_inverse(gpx_model *m)
         HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
     (void)hipEventRecord(m->ev[EV_INV0], m->stream);
     void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
-    const bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
+    bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
+    if (assemble64) {
+        // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
+        const size_t nn = (size_t)np * np;
+        if (hipMalloc(&L64, sizeof(double) * nn) != hipSuccess || hipMalloc(&X64, sizeof(double) * nn) != hipSuccess ||
+            hipMalloc(&Tws, sizeof(double) * nn) != hipSuccess ||
+            hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void **q : {&L64, &X64, &Tws, &linv64}) {
+                if (*q)
+                    (void)hipFree(*q);
+                *q = nullptr;
+            }
+            assemble64 = false;
+        }
+    }
     if (assemble64) {
         // The fp32 factor is kept (that is what runs on the fp32 MFMA), but its inverse is assembled in fp64 and
         // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
         // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
         // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
         const size_t nn = (size_t)np * np;
-        HIPCHK(hipMalloc(&L64, sizeof(double) * nn));
-        HIPCHK(hipMalloc(&X64, sizeof(double) * nn));
-        HIPCHK(hipMalloc(&Tws, sizeof(double) * nn));
-        HIPCHK(hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE));
         launch_cast_f2d(nn, (const float *)m->Kmat, (double *)L64, m->stream);
         launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, (double *)linv64, m->stream);
         HIPCHK(hipMemsetAsync(X64, 0, sizeof(double) * nn, m->stream));
