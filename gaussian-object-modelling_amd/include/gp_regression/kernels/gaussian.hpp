@@ -15,8 +15,10 @@ public:
     const double length_;
     Gaussian() : sigma_(1.0), length_(1.0) {}
     Gaussian(double sigma, double length) : sigma_(sigma), length_(length) {}
-    double compute(double &d) const { return sigma_ * sigma_ * std::exp(-d / (length_ * length_)); }
-    double computediff(double &d) const { return -compute(d) / (length_ * length_); }
+    // the operation order of the reference (products with the reciprocal 1 / length^2), so that host-side
+    // evaluations agree with it bit for bit (tests/test_reference_pin.py)
+    double compute(double &d) const { return (sigma_ * sigma_) * std::exp(-1 * d * (1.0 / (length_ * length_))); }
+    double computediff(double &d) const { return -1 * (1.0 / (length_ * length_)) * compute(d); }
     double computediffdiff(double &) const { return 0.0; }
 };
 }  // namespace gp_regression

@@ -13,8 +13,9 @@ public:
     const double length_;
     Laplace() : sigma_(1.0), length_(1.0) {}
     Laplace(double sigma, double length) : sigma_(sigma), length_(length) {}
-    double compute(double &d) const { return 2.0 * sigma_ * std::exp(-d / length_); }
-    double computediff(double &d) const { return -compute(d) / length_; }
+    // the operation order of the reference (products with the reciprocal 1 / length): bit-identical host results
+    double compute(double &d) const { return 2 * sigma_ * std::exp(-1 * d * (1.0 / length_)); }
+    double computediff(double &d) const { return -1 * (1.0 / length_) * compute(d); }
     double computediffdiff(double &) const { return 0.0; }
 };
 }  // namespace gp_regression

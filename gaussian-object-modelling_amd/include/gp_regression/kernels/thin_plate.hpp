@@ -10,8 +10,10 @@ class ThinPlate
 public:
     ThinPlate() : R_(1.0) {}
     explicit ThinPlate(double R) : R_(R) {}
-    double compute(double d) const { return d * d * (2.0 * d - 3.0 * R_) + R_ * R_ * R_; }
-    double computediff(double d) const { return -6.0 * (R_ - d); }
+    // the monomial form and operation order of the reference: bit-identical host results (the device evaluates
+    // the factored form (d - R)^2 (2d + R), csrc/gpx_cov.hpp)
+    double compute(double d) const { return 2 * d * d * d - 3 * R_ * d * d + R_ * R_ * R_; }
+    double computediff(double d) const { return -6 * (R_ - d); }
     double computediffdiff(double) const { return 0.0; }
     double R() const { return R_; }  // accessor added for the GPU hand-off (the reference keeps R_ private)
 

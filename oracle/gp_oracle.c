@@ -6,18 +6,25 @@
  * load this library, and only as the checker / reported CPU baseline.  The
  * product path (libgpx.so) never links, loads or calls it.
  *
- * PARITY UNPINNED.  The reference's own tests hold no golden values and no
- * assertions for this path (tests/test_gaussian.cpp, tests/test_gp.cpp and
- * tests/test_eigen.cpp only print), and the reference itself cannot be built
- * here: its arithmetic lives in Eigen 3 (find_package(Eigen), CMakeLists.txt:25,
- * no version pin, not vendored, not installed, no network).  This file therefore
- * restates, function by function,
+ * PARITY: PINNED for the covariance functions, UNPINNED for the rest.
+ *   pinned   -- orc_k / orc_kdiff / orc_kdiffdiff for Gaussian, Laplace and ThinPlate are bit-identical to the
+ *               reference's own classes: kernels/{gaussian,laplace,thin_plate}.hpp are plain C++ over <cmath>
+ *               and are compiled from /root/reference into oracle/_ref/libref_kernels.so (oracle/Makefile,
+ *               wrapper oracle/ref_kernels_wrap.cpp); their outputs are committed as tests/golden/ref_kernels.npz
+ *               (tests/golden/make_ref_kernel_golden.py) and checked by tests/test_reference_pin.py.
+ *   unpinned -- everything that goes through Eigen (distance matrix, LDLT, solves, tangent basis): PARITY
+ *               UNPINNED.  The reference's own tests hold no golden values and no assertions for this path
+ *               (tests/test_gaussian.cpp, tests/test_gp.cpp and tests/test_eigen.cpp only print), and
+ *               gp_regressor.hpp cannot be built here: its arithmetic lives in Eigen 3 (find_package(Eigen),
+ *               CMakeLists.txt:25, no version pin, not vendored, not installed, no network).
+ * This file restates, function by function,
  *     include/gp_regression/gp_regressor.hpp      (create / evaluate x4 / update)
  *     include/gp_regression/kernels/{gaussian,laplace,thin_plate}.hpp
  *     matlab_src/test_gp_regression_3Dsurf.m:117-123   (Matern closed forms)
+ *     include/atlas/atlas.hpp:201-276               (AtlasBase::project)
  * and, for Eigen::LDLT (gp_regressor.hpp:81,:161-163), the published algorithm
  * of Eigen 3.2.x LDLT.h (ldlt_inplace<Lower>::unblocked + LDLT::solve), written
- * from its public description.  What pins it instead: analytic known-answer
+ * from its public description.  What pins the unpinned part instead: analytic known-answer
  * tests, GP identities and an independent NumPy/SciPy computation committed as
  * fixtures under tests/golden/ (tests/golden/make_golden.py).
  *

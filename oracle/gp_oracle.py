@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY -- see the header of gp_oracle.c.  Imported by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
-PARITY UNPINNED: the reference holds no golden vectors for this path.
+Parity: the covariance functions are pinned bit-exactly to the reference's own classes (oracle/_ref,
+tests/golden/ref_kernels.npz); the Eigen-dependent rest is PARITY UNPINNED (no golden vectors in the reference).
 """
 import ctypes as C
 import os
