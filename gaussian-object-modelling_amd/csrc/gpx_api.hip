@@ -701,7 +701,17 @@ static int build_model(gpx_model *m, kept_factor *keep = nullptr)
     }
     (void)hipEventRecord(m->ev[EV_FACTOR], s);
     // ---- alpha = K^-1 y with fp64-residual refinement ----
-    int ir = m->opt.ir_steps >= 0 ? m->opt.ir_steps : (m->prec == GPX_PREC_F64 ? 1 : 2);
+    // ir_steps >= 0: exactly that many steps.  Default: adaptive -- at least one step, then until the fp64 residual
+    // max|y - K alpha| is below 1e-9 max|y| (at most 4 steps).  Measured at N = 16384 with an fp32 factor, alpha
+    // error vs fp64 after 1 / 2 / 3 steps: Matern-5/2 2e-9 / 7e-13 / 3e-14 (stops after 1), thin-plate R=4
+    // 2e-4 / 8e-6 / 2e-7 (runs 3); each step costs one substitution pair + one matrix-free residual (2.3 ms).
+    const bool ir_adaptive = m->opt.ir_steps < 0;
+    const int ir_max = ir_adaptive ? 4 : m->opt.ir_steps;
+    double ymax = 0.0;
+    for (int i = 0; i < n; ++i)
+        ymax = std::max(ymax, std::fabs(m->hlabel[i]));
+    const double ir_tol = 1e-9 * std::max(ymax, 1e-300);
+    int ir = 0;
     for (int it = 0;; ++it) {
         // right-hand side: y (first pass) or the fp64 residual
         launch_cast_vec(m->prec, n, np, it == 0 ? m->d_lab : m->d_r, m->t_b, s);
@@ -712,8 +722,16 @@ static int build_model(gpx_model *m, kept_factor *keep = nullptr)
                        m->d_f, nullptr, m->ws_pred, s);
         HIPCHK(hipMemsetAsync(m->d_rmax, 0, sizeof(double), s));
         launch_residual(n, m->d_lab, m->d_f, m->d_s2, m->d_alpha, m->d_r, m->d_rmax, s);
-        if (it >= ir)
+        ir = it;
+        if (it >= ir_max)
             break;
+        if (ir_adaptive && it >= 1) {
+            double r_now = 0.0;
+            HIPCHK(hipMemcpyAsync(&r_now, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!(r_now > ir_tol))
+                break;
+        }
     }
     m->stats.ir_steps_done = ir;
     (void)hipEventRecord(m->ev[EV_SOLVE], s);

@@ -81,7 +81,8 @@ typedef struct gpx_options {
     int32_t precision;     /* gpx_precision */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     int32_t with_normals;  /* create<true>: normals at the training points (gp_regressor.hpp:166-181) */
-    int32_t ir_steps;      /* refinement steps for alpha; -1 = default (2 for F32, 1 for F64) */
+    int32_t ir_steps;      /* refinement steps for alpha (fp64 residuals); -1 = adaptive: at least 1, then until
+                              max|y - K alpha| <= 1e-9 max|y|, at most 4 */
     int32_t prepare_variance; /* 1: build the inverse factor inside create (else lazily at first variance query) */
     int32_t query_batch;   /* queries per variance batch (multiple of 128); 0 = default */
     int32_t reserved[6];
