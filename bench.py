@@ -105,6 +105,11 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL prints
+    # its version block at the first communicator), so everything but the result line goes to stderr from here on.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -261,7 +266,7 @@ def main():
                 out["fast_mode"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_train, nq, args.kernel, kpar)
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if model[0] is not None:
         model[0].close()
     if dist is not None:
