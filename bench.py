@@ -264,6 +264,19 @@ def main():
                                          "variance error / k(0) vs fp64 at N=16384 1.9e-6 (native fp32 path: 4.5e-6)"}
             except Exception as e:  # never let the extra line break the contract line
                 out["fast_mode"] = {"error": str(e)}
+        if world == 1 and want_v and not shard and not args.no_fast_mode and model[0] is not None:
+            # informative only (never `value`): the same prediction through the HOST-pointer entry gpx_model_evaluate,
+            # i.e. including the PCIe copies of 3 x 8 B in and 2 x 8 B out per query (1 MiB-query slices)
+            try:
+                hq = [t.cpu().numpy() for t in (qx, qy, qz)]
+                model[0].evaluate(hq[0][:4096], hq[1][:4096], hq[2][:4096], want_v=True)
+                t1 = time.perf_counter()
+                model[0].evaluate(hq[0], hq[1], hq[2], want_v=True)
+                dt = time.perf_counter() - t1
+                out["host_api"] = {"what": "gpx_model_evaluate(f, v) on host arrays of the trained model (predict only, PCIe copies included)",
+                                   "ms": dt * 1e3, "value": nq_local / dt, "unit": "query-points/s"}
+            except Exception as e:
+                out["host_api"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_train, nq, args.kernel, kpar)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
