@@ -388,6 +388,45 @@ def test_concurrent_single_point_evaluate(gpu, orc, ds):
     gm.close()
 
 
+def test_independent_models_from_concurrent_threads(gpu, orc, ds):
+    """C5 shape on one GPU: eight independent models created, evaluated and destroyed from eight host threads at the
+    same time (each model has its own stream; the launchers' one-time function attributes are process-wide)."""
+    import threading
+    sizes = [266, 481, 466, 724, 447, 712, 354, 277]  # the eight reference objects + 15 exterior points each
+    kerns = [("thinplate", (2.0,)), ("matern52", (1.0, 1.0)), ("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0))]
+    qx, qy, qz = ds.query_grid(9)
+    errs, lock = [], threading.Lock()
+
+    def work(i):
+        try:
+            n = sizes[i]
+            x, y, z, lab, s2 = ds.fibonacci_training_set(n, seed=100 + i)
+            kn, par = kerns[i % len(kerns)]
+            for rep in range(3):
+                prec = gpu.F64 if (i + rep) % 2 == 0 else gpu.F32
+                gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+                out = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+                one = gm.evaluate(qx[:3], qy[:3], qz[:3], want_v=True)     # the one-launch path as well
+                gm.close()
+                om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+                ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+                k0 = float(orc.k(orc.make_kernel(kn, *par), 0.0)[0])
+                tol = 1e-9 if prec == gpu.F64 else 5e-5
+                assert nerr(out["f"], ref["f"]) < tol and verr(out["v"], ref["v"], k0) < tol
+                assert nerr(out["grad"], ref["grad"]) < tol
+                assert nerr(one["f"], ref["f"][:3]) < tol and verr(one["v"], ref["v"][:3], k0) < tol
+        except Exception as e:  # noqa: BLE001 -- reported below
+            with lock:
+                errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+
+
 def test_device_resident_evaluate(gpu, orc, ds):
     """gpx_model_evaluate_device: inputs/outputs stay in HBM (torch only provides the memory)."""
     torch = pytest.importorskip("torch")
