@@ -42,3 +42,17 @@ def test_reference_shaped_caller(gpu, orc, tmp_path):
     om.update([0.05, -0.4, 0.7], [0.9, 0.1, -0.3], [-0.2, 0.85, 0.55], [0.0, 0.0, 0.0], [0.1, 0.1, 0.1])
     ru = om.evaluate(c[:, 0], c[:, 1], c[:, 2], want_v=True)
     assert nerr([fvu[0], fvu[2]], ru["f"]) < 1e-10 and nerr([fvu[1], fvu[3]], ru["v"]) < 1e-10
+
+
+def test_plain_c_caller_of_the_c_abi(gpu, tmp_path):
+    """include/gpx.h is C99: examples/c_abi_example.c (create, evaluate, project, update from plain C) builds with
+    gcc -std=c99 -pedantic and runs against libgpx.so."""
+    exe = str(tmp_path / "c_abi_example")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", os.path.join(ROOT, "examples", "c_abi_example.c"),
+           "-I", os.path.join(ROOT, "include"), "-L", os.path.join(PKG, "lib"), "-lgpx",
+           "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "projected to" in r.stdout and "(status 1)" in r.stdout and "after update (+16 points)" in r.stdout
