@@ -84,11 +84,12 @@ def pmc_traffic(args, n_train, q_per_launch):
     """HBM bytes per launch of the variance GEMM from the committed PMC passes (FETCH_SIZE doubled as the
     MI355X guide prescribes, + WRITE_SIZE); only valid for the shape those passes were taken on."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (os.path.exists(path) and args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192):
+    if not (os.path.exists(path) and args.precision in ("f32", "f32split") and n_train == N_TRAIN and q_per_launch == 8192):
         return None
+    prefix = "gpx::vsplit_gemm_kernel" if args.precision == "f32split" else "gpx::gemm_kernel<float, false, 2"  # <f32, NT, EPI_COLSQ, ...>
     try:
         for name, k in json.load(open(path))["kernels"].items():
-            if name.startswith("gpx::gemm_kernel<float, false, 2"):  # <f32, NT, EPI_COLSQ, ...>
+            if name.startswith(prefix):
                 return k["hbm_bytes_per_dispatch"]
         return None
     except Exception:
