@@ -427,6 +427,37 @@ def test_independent_models_from_concurrent_threads(gpu, orc, ds):
     assert not errs, errs
 
 
+def test_no_device_memory_leak_over_model_lifecycles(gpu, ds):
+    """create / evaluate (general + one-launch paths) / sample_surface / project / update / destroy, 60 times in every
+    precision mode: the free device memory returns to where it started (hipFree of every workspace, temporary and
+    kept factor)."""
+    torch = pytest.importorskip("torch")
+    x, y, z, lab, s2 = ds.fibonacci_training_set(420)
+    qx, qy, qz = ds.query_grid(7)
+
+    def cycle(prec):
+        gm = gpu.Model(gpu.make_kernel("matern52", 1, 1), x[:300], y[:300], z[:300], lab[:300], s2[:300], precision=prec)
+        gm.evaluate(qx, qy, qz, want_v=True, want_grad=True, want_basis=True)
+        gm.evaluate(qx[:2], qy[:2], qz[:2], want_v=True)
+        gm.sample_surface(qx, qy, qz, f_tol=0.05)
+        g = gm.evaluate(qx[:8], qy[:8], qz[:8], want_grad=True)["grad"]
+        gm.project(qx[:8], qy[:8], qz[:8], g, step_mul=0.5, max_iter=20)
+        gm.update(x[300:], y[300:], z[300:], lab[300:], s2[300:])
+        gm.evaluate(qx, qy, qz, want_v=True)
+        gm.close()
+
+    for prec in (gpu.F64, gpu.F32, gpu.MIXED, gpu.F32_SPLIT):
+        cycle(prec)  # first use: one-time allocations of the runtime
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rep in range(15):
+        for prec in (gpu.F64, gpu.F32, gpu.MIXED, gpu.F32_SPLIT):
+            cycle(prec)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 60 model lifecycles" % ((free0 - free1) / 2**20)
+
+
 def test_device_resident_evaluate(gpu, orc, ds):
     """gpx_model_evaluate_device: inputs/outputs stay in HBM (torch only provides the memory)."""
     torch = pytest.importorskip("torch")
