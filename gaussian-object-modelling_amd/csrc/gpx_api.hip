@@ -355,23 +355,29 @@ static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 // Columns before c_start (a multiple of 128) are taken as already factorised and applied (rank-n update).
 static void factorize(gpx_model *m, int c_start = 0)
 {
-    const int np = m->npad;
+    // The kernel matrix is the identity on the padding (N is padded to a multiple of 256): 128-blocks that lie
+    // entirely in it are already factorised (L = I, D = 1) and are only given their identity inverse, so the loops
+    // below stop at the last block that holds a training point -- N = 277 factorises 3 diagonal blocks, not 4.
+    const int np_full = m->npad;
+    const int np = std::min(np_full, (m->n + TILE - 1) / TILE * TILE);
+    launch_identity_blocks(m->prec, np / TILE, m->nblk, m->linv, m->t_d, m->t_dinv, m->stream);
+    const int ldk = np_full;
     const size_t e = m->esz;
     char *K = (char *)m->Kmat;
     char *W = (char *)m->Wp;
-    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
+    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * ldk + c) * e); };
     auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * WIDE_PANEL + c) * e); };
     size_t gemm_idx = 0;
     // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
     auto block_step = [&](int cc, int wcol) {
         const int r0 = cc + TILE;
-        launch_diag_ldl(m->prec, Kp(cc, cc), np, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
+        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
         if (r0 >= np)
             return;
         GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
-        t.A = Kp(r0, cc), t.lda = np;
+        t.A = Kp(r0, cc), t.lda = ldk;
         t.B = (char *)m->linv + (size_t)(cc / TILE) * TILE * TILE * e, t.ldb = TILE;
-        t.C = Kp(r0, cc), t.ldc = np;
+        t.C = Kp(r0, cc), t.ldc = ldk;
         t.M = np - r0, t.N = TILE, t.K = TILE;
         t.b_lower = 1;
         t.epi = EPI_TRSM;
@@ -383,8 +389,8 @@ static void factorize(gpx_model *m, int c_start = 0)
     auto trailing = [&](int c0, int r0, int kw) {
         GemmArgs s;
         s.A = Wpp(r0, 0), s.lda = WIDE_PANEL;
-        s.B = Kp(r0, c0), s.ldb = np;
-        s.C = Kp(r0, r0), s.ldc = np;
+        s.B = Kp(r0, c0), s.ldb = ldk;
+        s.C = Kp(r0, r0), s.ldc = ldk;
         s.M = np - r0, s.N = np - r0, s.K = kw;
         s.alpha = -1.0, s.beta = 1;
         s.lower_only = 1;
@@ -416,8 +422,8 @@ static void factorize(gpx_model *m, int c_start = 0)
             if (h + 1 < nb && r0 < np) {
                 GemmArgs s;  // the remaining columns of the panel (incl. the next diagonal block) -= W_h * L_h^T
                 s.A = Wpp(r0, h * TILE), s.lda = WIDE_PANEL;
-                s.B = Kp(r0, cc), s.ldb = np;
-                s.C = Kp(r0, r0), s.ldc = np;
+                s.B = Kp(r0, cc), s.ldb = ldk;
+                s.C = Kp(r0, r0), s.ldc = ldk;
                 s.M = np - r0, s.N = c0 + pw - r0, s.K = TILE;
                 s.alpha = -1.0, s.beta = 1;
                 launch_gemm(m->prec, s, m->stream);

@@ -292,6 +292,32 @@ void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *
         diag_t<float>(Ablk, lda, linv, d, dinv, info, blk, st);
 }
 
+// Diagonal blocks that lie entirely in the padding (the kernel matrix is the identity there): L = I, D = 1, inverse = I
+template <typename T>
+__global__ __launch_bounds__(256) void identity_blocks_kernel(int blk0, T *__restrict__ linv, T *__restrict__ d,
+                                                              T *__restrict__ dinv)
+{
+    const int blk = blk0 + blockIdx.x;
+    for (int idx = threadIdx.x; idx < TILE * TILE; idx += 256)
+        linv[(size_t)blk * TILE * TILE + idx] = (idx >> 7) == (idx & 127) ? T(1) : T(0);
+    if (threadIdx.x < TILE) {
+        d[blk * TILE + threadIdx.x] = T(1);
+        dinv[blk * TILE + threadIdx.x] = T(1);
+    }
+}
+
+void launch_identity_blocks(int prec, int blk0, int nblk, void *linv, void *d, void *dinv, hipStream_t st)
+{
+    if (blk0 >= nblk)
+        return;
+    if (prec == GPX_PREC_F64)
+        hipLaunchKernelGGL(identity_blocks_kernel<double>, dim3(nblk - blk0), dim3(256), 0, st, blk0, (double *)linv,
+                           (double *)d, (double *)dinv);
+    else
+        hipLaunchKernelGGL(identity_blocks_kernel<float>, dim3(nblk - blk0), dim3(256), 0, st, blk0, (float *)linv,
+                           (float *)d, (float *)dinv);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void place_diag_kernel(const T *__restrict__ linv, T *__restrict__ X, long ldx)
 {

@@ -146,6 +146,8 @@ void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, con
 // inverse to linv (TILE x TILE, row-major, zeros above the diagonal), d / 1/d vectors, info.
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
                      hipStream_t st);
+// diagonal blocks blk0 .. nblk-1 lie in the identity padding: linv = I, d = dinv = 1
+void launch_identity_blocks(int prec, int blk0, int nblk, void *linv, void *d, void *dinv, hipStream_t st);
 void launch_place_diag(int prec, int nblk, const void *linv_blocks, void *X, long ldx, hipStream_t st);
 // forward/backward block substitution steps on a vector (T), see gpx_factor.hip
 // fwd: step kb of L y = b (b is consumed, y receives block kb); bwd: step kb of L^T x = y.
