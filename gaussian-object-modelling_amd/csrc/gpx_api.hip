@@ -1057,6 +1057,7 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
     m->gemm_ev_used_var = 0;
     if (v) {
         const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
         size_t gi = 0;
         for (size_t q0 = 0; q0 < nq; q0 += qb) {
             const size_t nv = std::min(qb, nq - q0);
@@ -1068,25 +1069,25 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
                 launch_vsplit_gemm(m->X, m->ws_kqp, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
-                                   (long)qb, 2, s);
+                                   (long)qb, 2, s, np_rows);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
                 }
-                launch_var_finish(m->prec, m->cov.k0, np / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+                launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
             launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                       qz + q0, m->ws_kqp, s);
+                       qz + q0, m->ws_kqp, s, np_rows);
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
             a.B = m->ws_kqp, a.ldb = np;
-            a.M = np, a.N = (int)ntile, a.K = np;
+            a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
             // 256 x 256 tiles (fp32) halve the L2-miss traffic at equal speed, but only when there are enough of
             // them to fill 256 CUs; small models use 128 x 128 tiles
-            a.cfg = ((size_t)(np / 256) * (ntile / 256) >= 1024) ? 2 : 0;
+            a.cfg = (np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : 0;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
@@ -1098,7 +1099,7 @@ static int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const doub
                 ++gi;
             }
             const int bm = gemm_rows_per_partial(m->prec, a);
-            launch_var_finish(m->prec, m->cov.k0, np / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+            launch_var_finish(m->prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
         }
         m->gemm_ev_used_var = gi;
     }

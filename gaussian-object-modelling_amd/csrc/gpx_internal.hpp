@@ -58,7 +58,8 @@ void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile
 // Kqp[q][j] = k(|q - p_j|), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st);
+                hipStream_t st,
+                int ncols = 0);  // > 0: only the first ncols columns are written (columns in the padding are never read)
 
 // ---- prediction : gpx_predict.hip -----------------------------------------------------------
 // f[q] = sum_j k(|q-p_j|) alpha_j ; grad[q] = sum_j alpha_j k'(.)(q-p_j)  (double outputs).
@@ -139,7 +140,7 @@ void launch_kqp_split(const CovHost &cov, float sk, int n, int npad, const void 
                       long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
                       hipStream_t st);
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial, long ldp,
-                        int prefetch, hipStream_t st);
+                        int prefetch, hipStream_t st, int m_rows = 0);
 
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower

@@ -223,10 +223,10 @@ void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *o
 template <typename T>
 static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz,
                   long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                  hipStream_t st)
+                  hipStream_t st, int ncols)
 {
     Cov<T> c = lower_cov<T>(h);
-    dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
+    dim3 grid((ncols > 0 ? ncols : npad) / TILE, (unsigned)(nq_tile / TILE));
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<T, KID>), grid, dim3(256), 0, st, c, n, npad,
                                               (const T *)px, (const T *)py, (const T *)pz, nq_valid, qx, qy, qz,
                                               (T *)Kqp));
@@ -234,12 +234,12 @@ static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void 
 
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st)
+                hipStream_t st, int ncols)
 {
     if (prec == GPX_PREC_F64)
-        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st);
+        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols);
     else
-        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st);
+        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols);
 }
 
 }  // namespace gpx

@@ -370,7 +370,7 @@ void launch_kqp_split(const CovHost &h, float sk, int n, int npad, const void *p
 }
 
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial,
-                        long ldp, int prefetch, hipStream_t st)
+                        long ldp, int prefetch, hipStream_t st, int m_rows)
 {
     VsplitDev g;
     g.A = (const unsigned char *)Xp;
@@ -387,7 +387,7 @@ void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_done = true;
     }
-    dim3 grid(nq_tile / TILE, np / TILE);
+    dim3 grid(nq_tile / TILE, (m_rows > 0 ? m_rows : np) / TILE);  // rows in the identity padding contribute nothing
     if (prefetch >= 2)
         hipLaunchKernelGGL(vsplit_gemm_kernel<2>, grid, dim3(256), shmem, st, g);
     else
