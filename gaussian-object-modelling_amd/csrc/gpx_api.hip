@@ -163,6 +163,9 @@ struct gpx_model {
     bool leader_active = false;
     double *pin = nullptr;  // pinned host staging of the combiner
     size_t pin_doubles = 0;
+    double *pin2[2] = {nullptr, nullptr};  // pinned double buffer of the pipelined large-batch path
+    size_t pin2_doubles = 0;
+    hipEvent_t pin2_done[2] = {nullptr, nullptr};
     std::mutex mtx;
     gpx_stats stats{};
     bool stats_eval_pending = false;
@@ -198,6 +201,15 @@ static void free_dev(gpx_model *m)
         (void)hipHostFree(m->pin);
     m->pin = nullptr;
     m->pin_doubles = 0;
+    for (int b = 0; b < 2; ++b) {
+        if (m->pin2[b])
+            (void)hipHostFree(m->pin2[b]);
+        m->pin2[b] = nullptr;
+        if (m->pin2_done[b])
+            (void)hipEventDestroy(m->pin2_done[b]);
+        m->pin2_done[b] = nullptr;
+    }
+    m->pin2_doubles = 0;
     m->dvecs = nullptr;
     m->blob0 = m->tvecs = m->Kmat = m->linv = m->Wp = m->X = nullptr;
     m->d_info = nullptr;
@@ -1251,6 +1263,87 @@ static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
     return GPX_OK;
 }
 
+// Large host batches: slices of 2^18 queries through a pinned double buffer on the model's stream.  The stream runs
+// copy-in / kernels / copy-out of slice i while the host fills the other buffer with slice i+1 and, once slice i-1 has
+// signalled, hands its results to the caller -- so the pageable <-> pinned copies (the larger part of the PCIe-side
+// cost) hide behind the device work, and the staging stays bounded (a 256^3 grid would be 1.9 GB in one piece).
+static int run_large(gpx_model *m, const gpx_pending &r)
+{
+    constexpr size_t SLICE = (size_t)1 << 18;
+    const size_t per_q = 3 + 1 + 1 + 3 + 3 + 3;  // qx qy qz | f | v | grad | tx | ty
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    const size_t S = std::min(SLICE, r.nq);
+    int rc;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * S * per_q)))
+        return rc;
+    if (m->pin2_doubles < S * per_q) {
+        for (int b = 0; b < 2; ++b) {
+            if (m->pin2[b])
+                HIPCHK(hipHostFree(m->pin2[b]));
+            m->pin2[b] = nullptr;
+        }
+        m->pin2_doubles = 0;
+        for (int b = 0; b < 2; ++b)
+            HIPCHK(hipHostMalloc((void **)&m->pin2[b], sizeof(double) * S * per_q, hipHostMallocDefault));
+        m->pin2_doubles = S * per_q;
+    }
+    for (int b = 0; b < 2; ++b)
+        if (!m->pin2_done[b])
+            HIPCHK(hipEventCreateWithFlags(&m->pin2_done[b], hipEventDisableTiming));
+    hipStream_t s = m->stream;
+    double *d = m->ws_host_io;
+    const size_t nslices = (r.nq + S - 1) / S;
+    // results of slice i (already in pinned buffer i & 1 once its event has fired) -> the caller's arrays
+    auto deliver = [&](size_t i) -> int {
+        const int b = (int)(i & 1);
+        const size_t q0 = i * S, nn = std::min(S, r.nq - q0);
+        HIPCHK(hipEventSynchronize(m->pin2_done[b]));
+        const double *h = m->pin2[b];
+        std::memcpy(r.f + q0, h + 3 * S, sizeof(double) * nn);
+        if (r.v)
+            std::memcpy(r.v + q0, h + 4 * S, sizeof(double) * nn);
+        if (r.grad)
+            std::memcpy(r.grad + 3 * q0, h + 5 * S, sizeof(double) * 3 * nn);
+        if (r.tx)
+            std::memcpy(r.tx + 3 * q0, h + 8 * S, sizeof(double) * 3 * nn);
+        if (r.ty)
+            std::memcpy(r.ty + 3 * q0, h + 11 * S, sizeof(double) * 3 * nn);
+        return GPX_OK;
+    };
+    for (size_t i = 0; i < nslices; ++i) {
+        const int b = (int)(i & 1);
+        const size_t q0 = i * S, nn = std::min(S, r.nq - q0);
+        if (i >= 2 && (rc = deliver(i - 2)))  // frees pinned buffer b; the device is busy with slice i-1 meanwhile
+            break;
+        double *h = m->pin2[b];
+        std::memcpy(h, r.qx + q0, sizeof(double) * nn);
+        std::memcpy(h + S, r.qy + q0, sizeof(double) * nn);
+        std::memcpy(h + 2 * S, r.qz + q0, sizeof(double) * nn);
+        HIPCHK(hipMemcpyAsync(d, h, sizeof(double) * 3 * S, hipMemcpyHostToDevice, s));
+        if ((rc = evaluate_locked(m, nn, d, d + S, d + 2 * S, d + 3 * S, r.v ? d + 4 * S : nullptr,
+                                  r.grad ? d + 5 * S : nullptr, r.tx ? d + 8 * S : nullptr,
+                                  r.ty ? d + 11 * S : nullptr, s)))
+            break;
+        HIPCHK(hipMemcpyAsync(h + 3 * S, d + 3 * S, sizeof(double) * S * (r.v ? 2 : 1), hipMemcpyDeviceToHost, s));
+        if (r.grad)
+            HIPCHK(hipMemcpyAsync(h + 5 * S, d + 5 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        if (r.tx)
+            HIPCHK(hipMemcpyAsync(h + 8 * S, d + 8 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        if (r.ty)
+            HIPCHK(hipMemcpyAsync(h + 11 * S, d + 11 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(m->pin2_done[b], s));
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    for (size_t i = nslices >= 2 ? nslices - 2 : 0; i < nslices; ++i)
+        if ((rc = deliver(i)))
+            return rc;
+    return GPX_OK;
+}
+
 constexpr size_t COMBINE_MAX_NQ = 4096;  // larger calls fill the device on their own
 
 extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
@@ -1261,20 +1354,8 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
         return rc;
     gpx_model *m = const_cast<gpx_model *>(cm);
     gpx_pending req{nq, qx, qy, qz, f, v, grad, tx, ty};
-    if (nq > COMBINE_MAX_NQ) {
-        // large host batches go straight to the device, in slices of 2^20 queries so that the pinned / device
-        // staging stays bounded (a 256^3 grid is 16.7M queries = 1.9 GB of staging in one piece)
-        constexpr size_t SLICE = (size_t)1 << 20;
-        for (size_t q0 = 0; q0 < nq; q0 += SLICE) {
-            const size_t nn = std::min(SLICE, nq - q0);
-            gpx_pending part{nn, qx + q0, qy + q0, qz + q0, f + q0, v ? v + q0 : nullptr,
-                             grad ? grad + 3 * q0 : nullptr, tx ? tx + 3 * q0 : nullptr, ty ? ty + 3 * q0 : nullptr};
-            std::vector<gpx_pending *> one{&part};
-            if ((rc = run_requests(m, one)))
-                return rc;
-        }
-        return GPX_OK;
-    }
+    if (nq > COMBINE_MAX_NQ)
+        return run_large(m, req);
     // flat combining: the calling thread either becomes the leader of a batch or waits for one
     std::unique_lock<std::mutex> lk(m->qmtx);
     m->pending.push_back(&req);
