@@ -1,0 +1,627 @@
+// gpx_build.hip -- everything between the host arrays and a ready model: device buffers, the kernel matrix, the
+// blocked right-looking LDL^T (replaces Eigen::LDLT::compute, gp_regressor.hpp:161-162), alpha by block
+// substitution with fp64 matrix-free residual refinement (:163), normals (:166-181), the inverse factor X = L^-1 by
+// recursive doubling, the rank-n append of update() and the MIXED-precision demotion.
+#include "gpx_model.hpp"
+
+namespace gpxh {
+
+void free_dev(gpx_model *m)
+{
+    auto F = [](void *p) {
+        if (p)
+            (void)hipFree(p);
+    };
+    F(m->dvecs);
+    F(m->blob0);
+    F(m->tvecs);
+    F(m->Kmat);
+    F(m->linv);
+    F(m->Wp);
+    F(m->X);
+    F(m->d_info);
+    F(m->d_tmax);
+    F(m->d_tij);
+    F(m->ws_pred);
+    F(m->ws_kqp);
+    F(m->ws_partial);
+    F(m->ws_grad);
+    F(m->ws_host_io);
+    F(m->ws_small);
+    m->ws_small = nullptr;
+    F(m->d_normals);
+    if (m->pin)
+        (void)hipHostFree(m->pin);
+    m->pin = nullptr;
+    m->pin_doubles = 0;
+    for (int b = 0; b < 2; ++b) {
+        if (m->pin2[b])
+            (void)hipHostFree(m->pin2[b]);
+        m->pin2[b] = nullptr;
+        if (m->pin2_done[b])
+            (void)hipEventDestroy(m->pin2_done[b]);
+        m->pin2_done[b] = nullptr;
+    }
+    m->pin2_doubles = 0;
+    m->dvecs = nullptr;
+    m->blob0 = m->tvecs = m->Kmat = m->linv = m->Wp = m->X = nullptr;
+    m->d_info = nullptr;
+    m->d_tmax = nullptr;
+    m->d_tij = nullptr;
+    m->ws_pred = nullptr;
+    m->ws_kqp = m->ws_partial = nullptr;
+    m->ws_grad = nullptr;
+    m->ws_host_io = nullptr;
+    m->d_normals = nullptr;
+    m->ws_pred_doubles = m->ws_kqp_bytes = m->ws_partial_bytes = m->ws_grad_doubles = m->ws_host_io_doubles = 0;
+    for (auto &e : m->gemm_ev)
+        (void)hipEventDestroy(e);
+    m->gemm_ev.clear();
+}
+
+
+int ensure(void **p, size_t *have, size_t need)
+{
+    if (*have >= need && *p)
+        return GPX_OK;
+    if (*p)
+        HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIPCHK(hipMalloc(p, need));
+    *have = need;
+    return GPX_OK;
+}
+
+// Eigen 3.2 LDLT pivot rule restated: at step k pick the FIRST largest |diagonal| among the
+// not-yet-eliminated rows and swap it to k.  The left-looking algorithm never updates the
+// trailing diagonal before it is chosen, so the sequence depends on diag(K) only.
+void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
+{
+    const int n = (int)diag.size();
+    perm.resize(n);
+    for (int i = 0; i < n; ++i)
+        perm[i] = i;
+    bool uniform = true;
+    for (int i = 1; i < n && uniform; ++i)
+        uniform = std::fabs(diag[i]) == std::fabs(diag[0]);
+    if (uniform)
+        return;
+    std::vector<double> d(diag);
+    for (int k = 0; k < n; ++k) {
+        int big = k;
+        double bv = std::fabs(d[k]);
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(d[i]) > bv) {
+                bv = std::fabs(d[i]);
+                big = i;
+            }
+        if (big != k) {
+            std::swap(d[k], d[big]);
+            std::swap(perm[k], perm[big]);
+        }
+    }
+}
+
+int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
+{
+    const size_t np = (size_t)m->npad;
+    *bytes = sizeof(double) * np * 4 + esz * np * 4;
+    HIPCHK(hipMalloc(blob, *bytes));
+    return GPX_OK;
+}
+
+void carve_blob0(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad, e = m->esz;
+    m->d_x = (double *)m->blob0;
+    m->d_y = m->d_x + np;
+    m->d_z = m->d_y + np;
+    m->d_alpha = m->d_z + np;
+    char *b = (char *)(m->d_alpha + np);
+    m->t_x = b;
+    m->t_y = b + e * np;
+    m->t_z = b + 2 * e * np;
+    m->t_dinv = b + 3 * e * np;
+}
+
+int alloc_model(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad, e = m->esz;
+    int rc = alloc_blob0(m, e, &m->blob0, &m->blob0_bytes);
+    if (rc)
+        return rc;
+    carve_blob0(m);
+    HIPCHK(hipMalloc((void **)&m->dvecs, sizeof(double) * (np * 4 + 8)));
+    m->d_lab = m->dvecs;
+    m->d_s2 = m->d_lab + np;
+    m->d_r = m->d_s2 + np;
+    m->d_f = m->d_r + np;
+    m->d_rmax = m->d_f + np;
+    HIPCHK(hipMalloc(&m->tvecs, e * np * 6));
+    char *b = (char *)m->tvecs;
+    m->t_s2 = b;
+    m->t_d = b + e * np;
+    m->t_b = b + 2 * e * np;
+    m->t_yv = b + 3 * e * np;
+    m->t_xs = b + 4 * e * np;
+    m->t_alpha = b + 5 * e * np;
+    HIPCHK(hipMalloc((void **)&m->d_info, sizeof(int) * 8));
+    return GPX_OK;
+}
+
+hipEvent_t *gemm_events(gpx_model *m, size_t idx)
+{
+    while (m->gemm_ev.size() < 2 * (idx + 1)) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess)
+            return nullptr;
+        m->gemm_ev.push_back(e);
+    }
+    return &m->gemm_ev[2 * idx];
+}
+
+// ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
+static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
+{
+    for (int kb = 0; kb < m->nblk; ++kb)
+        launch_fwd_step(m->prec, kb, m->nblk, m->Kmat, m->npad, m->linv, b, ytmp, m->stream);
+    launch_scale_vec(m->prec, m->npad, ytmp, m->t_dinv, m->stream);
+    for (int kb = m->nblk - 1; kb >= 0; --kb)
+        launch_bwd_step(m->prec, kb, m->Kmat, m->npad, m->linv, ytmp, x, m->stream);
+}
+
+// ---- blocked right-looking LDL^T -----------------------------------------------------------------
+// Outer panels of 256 columns = 2 diagonal blocks of 128 (GPX_PANEL=512: 4 blocks): per block the diagonal LDL^T
+// (+ inverse), the panel solve as a GEMM with the inverse block (W = A21 Linv^T to the workspace, L21 = W D^-1 in
+// place) and the update of the remaining columns of the panel; then ONE trailing update with K = panel width.
+// Measured at N = 16384 fp32: 512-wide panels give a trailing tile 16 k-tiles instead of 8 (100.6 -> 112 TFLOP/s,
+// LDL^T 31.8 -> 30.8 ms), but the longer fp32 accumulations cost the ill-conditioned thin-plate system accuracy
+// (alpha after two refinement steps 2.9e-5 instead of < 1e-5 of the fp64 result), so 256 stays the default.
+// Columns before c_start (a multiple of 128) are taken as already factorised and applied (rank-n update).
+static void factorize(gpx_model *m, int c_start = 0)
+{
+    // The kernel matrix is the identity on the padding (N is padded to a multiple of 256): 128-blocks that lie
+    // entirely in it are already factorised (L = I, D = 1) and are only given their identity inverse, so the loops
+    // below stop at the last block that holds a training point -- N = 277 factorises 3 diagonal blocks, not 4.
+    const int np_full = m->npad;
+    const int np = std::min(np_full, (m->n + TILE - 1) / TILE * TILE);
+    launch_identity_blocks(m->prec, np / TILE, m->nblk, m->linv, m->t_d, m->t_dinv, m->stream);
+    const int ldk = np_full;
+    const size_t e = m->esz;
+    char *K = (char *)m->Kmat;
+    char *W = (char *)m->Wp;
+    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * ldk + c) * e); };
+    auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * WIDE_PANEL + c) * e); };
+    size_t gemm_idx = 0;
+    // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
+    auto block_step = [&](int cc, int wcol) {
+        const int r0 = cc + TILE;
+        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
+        if (r0 >= np)
+            return;
+        GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
+        t.A = Kp(r0, cc), t.lda = ldk;
+        t.B = (char *)m->linv + (size_t)(cc / TILE) * TILE * TILE * e, t.ldb = TILE;
+        t.C = Kp(r0, cc), t.ldc = ldk;
+        t.M = np - r0, t.N = TILE, t.K = TILE;
+        t.b_lower = 1;
+        t.epi = EPI_TRSM;
+        t.W = Wpp(r0, wcol), t.ldw = WIDE_PANEL;
+        t.colscale = (char *)m->t_dinv + (size_t)cc * e;
+        launch_gemm(m->prec, t, m->stream);
+    };
+    // trailing matrix from row / column r0 on -= W[:, 0:kw] * L[:, c0:c0+kw]^T, lower tiles only
+    auto trailing = [&](int c0, int r0, int kw) {
+        GemmArgs s;
+        s.A = Wpp(r0, 0), s.lda = WIDE_PANEL;
+        s.B = Kp(r0, c0), s.ldb = ldk;
+        s.C = Kp(r0, r0), s.ldc = ldk;
+        s.M = np - r0, s.N = np - r0, s.K = kw;
+        s.alpha = -1.0, s.beta = 1;
+        s.lower_only = 1;
+        hipEvent_t *ev = gemm_events(m, gemm_idx);
+        if (ev)
+            (void)hipEventRecord(ev[0], m->stream);
+        launch_gemm(m->prec, s, m->stream);
+        if (ev) {
+            (void)hipEventRecord(ev[1], m->stream);
+            ++gemm_idx;
+        }
+    };
+    int c0 = c_start;
+    if (c0 % PANEL) {  // start in the middle of a 256-column unit: a lone 128-wide step
+        block_step(c0, 0);
+        if (c0 + TILE < np)
+            trailing(c0, c0 + TILE, TILE);
+        c0 += TILE;
+    }
+    static const int wide = [] {
+        const char *e = std::getenv("GPX_PANEL");
+        return e && std::atoi(e) == WIDE_PANEL ? WIDE_PANEL : PANEL;
+    }();
+    while (c0 < np) {
+        const int pw = std::min(wide, np - c0), nb = pw / TILE;
+        for (int h = 0; h < nb; ++h) {
+            const int cc = c0 + h * TILE, r0 = cc + TILE;
+            block_step(cc, h * TILE);
+            if (h + 1 < nb && r0 < np) {
+                GemmArgs s;  // the remaining columns of the panel (incl. the next diagonal block) -= W_h * L_h^T
+                s.A = Wpp(r0, h * TILE), s.lda = WIDE_PANEL;
+                s.B = Kp(r0, cc), s.ldb = ldk;
+                s.C = Kp(r0, r0), s.ldc = ldk;
+                s.M = np - r0, s.N = c0 + pw - r0, s.K = TILE;
+                s.alpha = -1.0, s.beta = 1;
+                launch_gemm(m->prec, s, m->stream);
+            }
+        }
+        if (c0 + pw < np)
+            trailing(c0, c0 + pw, pw);
+        c0 += pw;
+    }
+    m->gemm_ev_used_factor = gemm_idx;
+}
+
+// Rank-n update, rows [t0, npad): the kernel rows have just been built; the columns [0, t0) hold the old factor.
+// Column block by column block: W = A_rows,j Linv_j^T (to the workspace), L_rows,j = W D_j^-1 (in place), then
+// every later column of these rows -= W L_{later rows, j}^T.  2 launches per old column block.
+static void factor_append_rows(gpx_model *m, int t0)
+{
+    const int np = m->npad;
+    const size_t e = m->esz;
+    char *K = (char *)m->Kmat;
+    auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * np + c) * e); };
+    void *Wrows = (char *)m->Wp + ((size_t)t0 * WIDE_PANEL) * e;
+    for (int cc = 0; cc < t0; cc += TILE) {
+        GemmArgs t;
+        t.A = Kp(t0, cc), t.lda = np;
+        t.B = (char *)m->linv + (size_t)(cc / TILE) * TILE * TILE * e, t.ldb = TILE;
+        t.C = Kp(t0, cc), t.ldc = np;
+        t.M = np - t0, t.N = TILE, t.K = TILE;
+        t.b_lower = 1;
+        t.epi = EPI_TRSM;
+        t.W = Wrows, t.ldw = WIDE_PANEL;
+        t.colscale = (char *)m->t_dinv + (size_t)cc * e;
+        launch_gemm(m->prec, t, m->stream);
+        GemmArgs s;  // columns [cc + 128, np) of the new rows
+        s.A = Wrows, s.lda = WIDE_PANEL;
+        s.B = Kp(cc + TILE, cc), s.ldb = np;
+        s.C = Kp(t0, cc + TILE), s.ldc = np;
+        s.M = np - t0, s.N = np - (cc + TILE), s.K = TILE;
+        s.alpha = -1.0, s.beta = 1;
+        launch_gemm(m->prec, s, m->stream);
+    }
+}
+
+// ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
+static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st)
+{
+    auto off = [&](size_t r, size_t c) { return (r * np + c) * e; };
+    for (long b = TILE; b < np; b *= 2) {
+        // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
+        int P = 0;
+        for (long base = 0; base + b < np; base += 2 * b)
+            ++P;
+        if (P == 0)
+            break;
+        const long last_base = (long)(P - 1) * 2 * b;
+        const int m_last = (int)std::min<long>(b, np - (last_base + b));
+        const long stride = 2 * b * (long)np + 2 * b;
+        GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
+        g1.A = L + off(b, 0), g1.lda = np;
+        g1.B = X + off(0, 0), g1.ldb = np;
+        g1.C = Tw + off(b, 0), g1.ldc = np;
+        g1.M = (int)b, g1.N = (int)b, g1.K = (int)b;
+        g1.sA = g1.sB = g1.sC = stride;
+        g1.batch = P, g1.M_last = m_last;
+        g1.nn = 1, g1.b_lower = 1;
+        launch_gemm(prec, g1, st);
+        GemmArgs g2;  // X21 = -X22 * T  (A lower)
+        g2.A = X + off(b, b), g2.lda = np;
+        g2.B = Tw + off(b, 0), g2.ldb = np;
+        g2.C = X + off(b, 0), g2.ldc = np;
+        g2.M = (int)b, g2.N = (int)b, g2.K = (int)b;
+        g2.sA = g2.sB = g2.sC = stride;
+        g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
+        g2.nn = 1, g2.a_lower = 1;
+        g2.alpha = -1.0;
+        launch_gemm(prec, g2, st);
+    }
+}
+
+int build_inverse(gpx_model *m)
+{
+    if (m->has_inverse)
+        return GPX_OK;
+    const int np = m->npad;
+    const size_t e = m->esz;
+    if (!m->X)
+        HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
+    (void)hipEventRecord(m->ev[EV_INV0], m->stream);
+    void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
+    bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
+    if (assemble64) {
+        // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
+        const size_t nn = (size_t)np * np;
+        if (hipMalloc(&L64, sizeof(double) * nn) != hipSuccess || hipMalloc(&X64, sizeof(double) * nn) != hipSuccess ||
+            hipMalloc(&Tws, sizeof(double) * nn) != hipSuccess ||
+            hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
+            (void)hipGetLastError();
+            for (void **q : {&L64, &X64, &Tws, &linv64}) {
+                if (*q)
+                    (void)hipFree(*q);
+                *q = nullptr;
+            }
+            assemble64 = false;
+        }
+    }
+    if (assemble64) {
+        // The fp32 factor is kept (that is what runs on the fp32 MFMA), but its inverse is assembled in fp64 and
+        // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
+        // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
+        // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
+        const size_t nn = (size_t)np * np;
+        launch_cast_f2d(nn, (const float *)m->Kmat, (double *)L64, m->stream);
+        launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, (double *)linv64, m->stream);
+        HIPCHK(hipMemsetAsync(X64, 0, sizeof(double) * nn, m->stream));
+        launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
+        trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
+        launch_cast_d2f(nn, (const double *)X64, (float *)m->X, m->stream);
+    } else {
+        HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
+        // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
+        // 128-block of every 256-diagonal block
+        HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
+        launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
+        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)Tws, np, m->stream);
+    }
+    (void)hipEventRecord(m->ev[EV_INV1], m->stream);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipFree(Tws));
+    if (L64)
+        HIPCHK(hipFree(L64));
+    if (X64)
+        HIPCHK(hipFree(X64));
+    if (linv64)
+        HIPCHK(hipFree(linv64));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
+        m->stats.t_inverse_ms = ms;
+    if (m->opt.precision == GPX_PREC_F32_SPLIT && !m->x_packed) {
+        if (!m->hD.size()) {  // keep D readable (GPX_FIELD_D) -- the 1/D slot is about to hold the weights
+            std::vector<float> t((size_t)m->n);
+            HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * (size_t)m->n, hipMemcpyDeviceToHost));
+            m->hD.assign(t.begin(), t.end());
+        }
+        int e2 = 0;
+        (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
+        m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
+        launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        m->x_packed = true;
+    }
+    m->has_inverse = true;
+    return GPX_OK;
+}
+
+// ---- MIXED precision: round the fp64 state once to fp32 and release the fp64 factor -----------------
+static int demote_to_f32(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad;
+    hipStream_t s = m->stream;
+    m->hD.resize((size_t)m->n);
+    HIPCHK(hipMemcpy(m->hD.data(), m->t_d, sizeof(double) * (size_t)m->n, hipMemcpyDeviceToHost));
+    void *nb = nullptr, *nX = nullptr;
+    size_t nbytes = 0;
+    int rc = alloc_blob0(m, 4, &nb, &nbytes);
+    if (rc)
+        return rc;
+    HIPCHK(hipMalloc(&nX, sizeof(float) * np * np));
+    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
+    float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
+    launch_cast_d2f(np, (const double *)m->t_x, tf, s);
+    launch_cast_d2f(np, (const double *)m->t_y, tf + np, s);
+    launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
+    launch_cast_d2f(np, (const double *)m->t_dinv, tf + 3 * np, s);
+    launch_cast_d2f(np * np, (const double *)m->X, (float *)nX, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(m->blob0));
+    HIPCHK(hipFree(m->X));
+    HIPCHK(hipFree(m->Kmat));
+    HIPCHK(hipFree(m->linv));
+    HIPCHK(hipFree(m->Wp));
+    HIPCHK(hipFree(m->tvecs));
+    m->Kmat = m->linv = m->Wp = m->tvecs = nullptr;
+    m->t_s2 = m->t_d = m->t_b = m->t_yv = m->t_xs = m->t_alpha = nullptr;
+    m->blob0 = nb;
+    m->blob0_bytes = nbytes;
+    m->X = nX;
+    m->prec = GPX_PREC_F32;
+    m->esz = 4;
+    carve_blob0(m);
+    return GPX_OK;
+}
+
+// ---- create: everything after the host arrays are in place ---------------------------------------
+int build_model(gpx_model *m, kept_factor *keep)
+{
+    const int n = m->n, np = m->npad;
+    const size_t e = m->esz;
+    HIPCHK(hipSetDevice(m->device));
+    factor_init(m->prec);
+    // Eigen's pivot order from the original diagonal k(0) + sigma2_i
+    std::vector<double> diag(n);
+    for (int i = 0; i < n; ++i)
+        diag[i] = m->cov.k0 + (m->has_s2 ? m->hs2[i] : 0.0);
+    eigen_pivot_order(diag, m->perm);
+    // host staging (internal order, zero padded)
+    std::vector<double> st((size_t)np * 5, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const int i = m->perm[k];
+        st[k] = m->hx[i];
+        st[np + k] = m->hy[i];
+        st[2 * (size_t)np + k] = m->hz[i];
+        st[3 * (size_t)np + k] = m->hlabel[i];
+        st[4 * (size_t)np + k] = m->has_s2 ? m->hs2[i] : 0.0;
+    }
+    if (!m->dvecs) {
+        int rc = alloc_model(m);
+        if (rc)
+            return rc;
+        HIPCHK(hipMalloc(&m->Kmat, e * (size_t)np * np));
+        HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
+        HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
+        const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
+        HIPCHK(hipMalloc((void **)&m->d_tmax, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc((void **)&m->d_tij, sizeof(int) * 2 * ntiles));
+    }
+    {  // workspace of the matrix-free residual / normals passes (n queries against npad points)
+        size_t need = predict_ws_doubles(n, np, m->opt.with_normals != 0) * sizeof(double);
+        if (need) {
+            int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+            if (rc)
+                return rc;
+        }
+    }
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 3, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(m->d_lab, st.data() + 3 * (size_t)np, sizeof(double) * (size_t)np * 2,
+                          hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
+    HIPCHK(hipMemsetAsync(m->d_r, 0, sizeof(double) * (size_t)np * 2 + 64, s));
+    HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
+    launch_cast_vec(m->prec, np, np, m->d_x, m->t_x, s);
+    launch_cast_vec(m->prec, np, np, m->d_y, m->t_y, s);
+    launch_cast_vec(m->prec, np, np, m->d_z, m->t_z, s);
+    launch_cast_vec(m->prec, np, np, m->d_s2, m->t_s2, s);
+    // ---- kernel matrix ----
+    (void)hipEventRecord(m->ev[EV_T0], s);
+    const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
+    if (keep && keep->t0 > 0) {
+        // rank-n update: the old factor goes back into the (possibly larger) matrix, only the new rows are built
+        const size_t t0 = (size_t)keep->t0;
+        HIPCHK(hipMemcpy2DAsync(m->Kmat, e * np, keep->K, e * keep->np_old, e * t0, t0, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->linv, keep->linv, e * (t0 / TILE) * TILE * TILE, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->t_d, keep->d, e * t0, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(m->t_dinv, keep->dinv, e * t0, hipMemcpyDeviceToDevice, s));
+        launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s,
+                      keep->t0 / TILE);
+        (void)hipEventRecord(m->ev[EV_KBUILD], s);
+        factor_append_rows(m, keep->t0);
+        factorize(m, keep->t0);
+    } else {
+        launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
+        launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
+        (void)hipEventRecord(m->ev[EV_KBUILD], s);
+        // ---- factorisation ----
+        factorize(m);
+    }
+    (void)hipEventRecord(m->ev[EV_FACTOR], s);
+    // ---- alpha = K^-1 y with fp64-residual refinement ----
+    // ir_steps >= 0: exactly that many steps.  Default: adaptive -- at least one step, then until the fp64 residual
+    // max|y - K alpha| is below 1e-9 max|y| (at most 4 steps).  Measured at N = 16384 with an fp32 factor, alpha
+    // error vs fp64 after 1 / 2 / 3 steps: Matern-5/2 2e-9 / 7e-13 / 3e-14 (stops after 1), thin-plate R=4
+    // 2e-4 / 8e-6 / 2e-7 (runs 3); each step costs one substitution pair + one matrix-free residual (2.3 ms).
+    const bool ir_adaptive = m->opt.ir_steps < 0;
+    const int ir_max = ir_adaptive ? 4 : m->opt.ir_steps;
+    double ymax = 0.0;
+    for (int i = 0; i < n; ++i)
+        ymax = std::max(ymax, std::fabs(m->hlabel[i]));
+    const double ir_tol = 1e-9 * std::max(ymax, 1e-300);
+    int ir = 0;
+    for (int it = 0;; ++it) {
+        // right-hand side: y (first pass) or the fp64 residual
+        launch_cast_vec(m->prec, n, np, it == 0 ? m->d_lab : m->d_r, m->t_b, s);
+        solve_ldl(m, m->t_b, m->t_yv, m->t_xs);
+        launch_axpy_cast(m->prec, n, np, m->d_alpha, m->t_xs, m->t_alpha, s);
+        // r = y - K alpha in fp64, matrix-free from the fp64 points
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z,
+                       m->d_f, nullptr, m->ws_pred, s);
+        HIPCHK(hipMemsetAsync(m->d_rmax, 0, sizeof(double), s));
+        launch_residual(n, m->d_lab, m->d_f, m->d_s2, m->d_alpha, m->d_r, m->d_rmax, s);
+        ir = it;
+        if (it >= ir_max)
+            break;
+        if (ir_adaptive && it >= 1) {
+            double r_now = 0.0;
+            HIPCHK(hipMemcpyAsync(&r_now, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!(r_now > ir_tol))
+                break;
+        }
+    }
+    m->stats.ir_steps_done = ir;
+    (void)hipEventRecord(m->ev[EV_SOLVE], s);
+    // ---- normals at the training points (create<true>, gp_regressor.hpp:166-181) ----
+    if (m->opt.with_normals) {
+        if (!m->d_normals)
+            HIPCHK(hipMalloc((void **)&m->d_normals, sizeof(double) * 3 * (size_t)n));
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z, m->d_f,
+                       m->d_normals, m->ws_pred, s);
+        launch_normalize_rows3(n, m->d_normals, s);
+        m->has_normals = true;
+    }
+    (void)hipEventRecord(m->ev[EV_NORMALS], s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    int info[4];
+    double rmax = 0;
+    HIPCHK(hipMemcpy(info, m->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&rmax, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost));
+    float ms;
+    m->stats = gpx_stats{};
+    if (hipEventElapsedTime(&ms, m->ev[EV_T0], m->ev[EV_KBUILD]) == hipSuccess)
+        m->stats.t_kbuild_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_KBUILD], m->ev[EV_FACTOR]) == hipSuccess)
+        m->stats.t_factor_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_FACTOR], m->ev[EV_SOLVE]) == hipSuccess)
+        m->stats.t_solve_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_SOLVE], m->ev[EV_NORMALS]) == hipSuccess)
+        m->stats.t_normals_ms = ms;
+    double tg = 0;
+    for (size_t i = 0; i < m->gemm_ev_used_factor; ++i)
+        if (hipEventElapsedTime(&ms, m->gemm_ev[2 * i], m->gemm_ev[2 * i + 1]) == hipSuccess)
+            tg += ms;
+    m->stats.t_factor_gemm_ms = tg;
+    m->stats.factor_gemm_launches = (int64_t)m->gemm_ev_used_factor;
+    m->stats.n = n;
+    m->stats.n_padded = np;
+    m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);
+    m->stats.ir_steps_done = ir;
+    m->stats.alpha_residual = rmax;
+    if (info[0] != 0)
+        return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(info[0] - 1));
+    // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64
+    if (!(keep && keep->t0 > 0)) {
+        const int a = info[2], b = info[3];
+        if (a >= 0 && a < n && b >= 0 && b < n) {
+            const int ia = m->perm[a], ib = m->perm[b];
+            const double dx = m->hx[ia] - m->hx[ib], dy = m->hy[ia] - m->hy[ib], dz = m->hz[ia] - m->hz[ib];
+            m->R = std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    m->ready = true;
+    if (m->opt.prepare_variance || m->opt.precision == GPX_PREC_MIXED) {
+        int rc = build_inverse(m);
+        if (rc)
+            return rc;
+    }
+    if (m->opt.precision == GPX_PREC_MIXED)
+        return demote_to_f32(m);
+    return GPX_OK;
+}
+
+void set_query_batch(gpx_model *m)
+{
+    if (m->opt.query_batch > 0) {
+        m->qbatch = m->opt.query_batch;
+        return;
+    }
+    // ~512 MiB of Kqp per batch: 8192 queries at N = 16384, more for small models so that one variance
+    // launch still fills the chip (N = 724: 131072 queries -> 6 x 1024 tiles)
+    size_t qb = ((size_t)512 << 20) / ((size_t)m->npad * 4);
+    qb = std::min<size_t>(std::max<size_t>(qb, 8192), 131072);
+    m->qbatch = (int)(qb / 256 * 256);
+}
+
+}  // namespace gpxh

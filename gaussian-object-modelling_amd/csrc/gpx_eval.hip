@@ -1,0 +1,545 @@
+// gpx_eval.hip -- prediction on a ready model (gp_regressor.hpp:194-357): mean / gradient / tangent basis, the
+// variance as one fused GEMM per query batch, the host-pointer paths (flat combining of small concurrent calls, the
+// one-launch path for a handful of queries, the pipelined large-batch path), iso-surface sampling and the batched
+// AtlasBase::project.
+#include "gpx_model.hpp"
+
+namespace gpxh {
+
+// ---- evaluate ------------------------------------------------------------------------------------
+int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
+                           double *f, double *v, double *grad, double *tx, double *ty, hipStream_t s)
+{
+    const int np = m->npad;
+    const size_t e = m->esz;
+    const bool want_basis = tx || ty;
+    double *g = grad;
+    if (want_basis && !g) {
+        int rc = ensure((void **)&m->ws_grad, &m->ws_grad_doubles, sizeof(double) * 3 * nq);
+        if (rc)
+            return rc;
+        g = m->ws_grad;
+    }
+    size_t need = predict_ws_doubles((long)nq, np, g != nullptr) * sizeof(double);
+    if (need) {
+        int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+        if (rc)
+            return rc;
+    }
+    if (v) {
+        int rc = build_inverse(m);
+        if (rc)
+            return rc;
+        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        if ((rc = ensure(&m->ws_kqp, &m->ws_kqp_bytes, e * qb * np)))
+            return rc;
+        if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
+            return rc;
+    }
+    // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
+    // which may be enqueued on different streams (gpx_model_evaluate_device): order them behind the previous user.
+    if (m->ws_in_flight)
+        (void)hipStreamWaitEvent(s, m->ev[EV_WS], 0);
+    (void)hipEventRecord(m->ev[EV_M0], s);
+    // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
+    // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
+    launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g,
+                   m->ws_pred, s);
+    if (want_basis)
+        launch_tangent_basis((long)nq, g, tx, ty, s);
+    (void)hipEventRecord(m->ev[EV_M1], s);
+    m->gemm_ev_used_var = 0;
+    if (v) {
+        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
+        size_t gi = 0;
+        for (size_t q0 = 0; q0 < nq; q0 += qb) {
+            const size_t nv = std::min(qb, nq - q0);
+            const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
+            if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
+                launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
+                                 qy + q0, qz + q0, m->ws_kqp, s);
+                hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
+                if (ev2)
+                    (void)hipEventRecord(ev2[0], s);
+                launch_vsplit_gemm(m->X, m->ws_kqp, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
+                                   (long)qb, 2, s, np_rows);
+                if (ev2) {
+                    (void)hipEventRecord(ev2[1], s);
+                    ++gi;
+                }
+                launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+                continue;
+            }
+            launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
+                       qz + q0, m->ws_kqp, s, np_rows);
+            GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
+            a.A = m->X, a.lda = np;
+            a.B = m->ws_kqp, a.ldb = np;
+            a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
+            a.a_lower = 1;
+            a.epi = EPI_COLSQ;
+            // 256 x 256 tiles (fp32) halve the L2-miss traffic at equal speed, but only when there are enough of
+            // them to fill 256 CUs; small models use 128 x 128 tiles
+            a.cfg = (np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : 0;
+            a.rowweight = m->t_dinv;
+            a.partial = m->ws_partial, a.ldp = (long)qb;
+            hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
+            if (ev)
+                (void)hipEventRecord(ev[0], s);
+            launch_gemm(m->prec, a, s);
+            if (ev) {
+                (void)hipEventRecord(ev[1], s);
+                ++gi;
+            }
+            const int bm = gemm_rows_per_partial(m->prec, a);
+            launch_var_finish(m->prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+        }
+        m->gemm_ev_used_var = gi;
+    }
+    (void)hipEventRecord(m->ev[EV_V1], s);
+    (void)hipEventRecord(m->ev[EV_WS], s);
+    m->ws_in_flight = true;
+    m->stats_eval_pending = true;
+    m->eval_had_var = v != nullptr;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    return GPX_OK;
+}
+
+int check_query(const gpx_model *m, size_t nq, const void *qx, const void *qy, const void *qz, const void *f)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!m->ready)
+        return fail(GPX_E_STATE, "model is not ready (shell not committed or create failed)");
+    if (nq == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    if (!qx || !qy || !qz)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (!f)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_evaluate_device(const gpx_model *cm, size_t nq, const void *d_qx, const void *d_qy,
+                                         const void *d_qz, void *d_f, void *d_v, void *d_grad, void *d_tx,
+                                         void *d_ty, void *stream)
+{
+    int rc = check_query(cm, nq, d_qx, d_qy, d_qz, d_f);
+    if (rc)
+        return rc;
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = stream ? (hipStream_t)stream : m->stream;
+    return evaluate_locked(m, nq, (const double *)d_qx, (const double *)d_qy, (const double *)d_qz, (double *)d_f,
+                           (double *)d_v, (double *)d_grad, (double *)d_tx, (double *)d_ty, s);
+}
+
+// One device batch for a list of host requests: queries are concatenated into pinned staging, evaluated
+// once (the union of the requested outputs), and the results scattered back.
+
+static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
+{
+    size_t total = 0;
+    bool wv = false, wg = false, wtx = false, wty = false;
+    for (const gpx_pending *r : reqs) {
+        total += r->nq;
+        wv |= r->v != nullptr;
+        wg |= r->grad != nullptr;
+        wtx |= r->tx != nullptr;
+        wty |= r->ty != nullptr;
+    }
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    // layout (host pinned and device alike): qx qy qz | f | v | grad | tx | ty
+    const size_t doubles = total * (3 + 1 + 1 + 3 + 3 + 3);
+    int rc;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    if (m->pin_doubles < doubles) {
+        if (m->pin)
+            HIPCHK(hipHostFree(m->pin));
+        m->pin = nullptr;
+        m->pin_doubles = 0;
+        HIPCHK(hipHostMalloc((void **)&m->pin, sizeof(double) * doubles, hipHostMallocDefault));
+        m->pin_doubles = doubles;
+    }
+    double *h = m->pin, *d = m->ws_host_io;
+    size_t off = 0;
+    for (const gpx_pending *r : reqs) {
+        std::memcpy(h + off, r->qx, sizeof(double) * r->nq);
+        std::memcpy(h + total + off, r->qy, sizeof(double) * r->nq);
+        std::memcpy(h + 2 * total + off, r->qz, sizeof(double) * r->nq);
+        off += r->nq;
+    }
+    double *dqx = d, *dqy = d + total, *dqz = d + 2 * total, *df = d + 3 * total, *dv = d + 4 * total,
+           *dg = d + 5 * total, *dtx = d + 8 * total, *dty = d + 11 * total;
+    hipStream_t s = m->stream;
+    // a handful of queries on a small model: one launch that reads and writes the pinned buffer directly
+    static const bool small_on = [] {
+        const char *e = std::getenv("GPX_SMALL_EVAL");
+        return !e || std::atoi(e) != 0;
+    }();
+    if (small_on && total <= SMALL_EVAL_MAX_NQ && m->npad <= SMALL_EVAL_NP_MAX &&
+        !(wv && m->opt.precision == GPX_PREC_F32_SPLIT)) {
+        if (wv && (rc = build_inverse(m)))
+            return rc;
+        if (!m->ws_small) {
+            const size_t sb = small_eval_scratch_bytes((int)SMALL_EVAL_MAX_NQ, SMALL_EVAL_NP_MAX);
+            HIPCHK(hipMalloc(&m->ws_small, sb));
+            HIPCHK(hipMemsetAsync(m->ws_small, 0, sb, s));
+        }
+        launch_small_eval(m->prec, m->cov, m->n, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, m->X, m->t_dinv,
+                          (int)total, (int)SMALL_EVAL_MAX_NQ, h, h + 3 * total, wv ? h + 4 * total : nullptr,
+                          wg ? h + 5 * total : nullptr, wtx ? h + 8 * total : nullptr,
+                          wty ? h + 11 * total : nullptr, m->ws_small, s);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess)
+            return fail(GPX_E_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+        HIPCHK(hipStreamSynchronize(s));
+        off = 0;
+        for (const gpx_pending *r : reqs) {
+            std::memcpy(r->f, h + 3 * total + off, sizeof(double) * r->nq);
+            if (r->v)
+                std::memcpy(r->v, h + 4 * total + off, sizeof(double) * r->nq);
+            if (r->grad)
+                std::memcpy(r->grad, h + 5 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            if (r->tx)
+                std::memcpy(r->tx, h + 8 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            if (r->ty)
+                std::memcpy(r->ty, h + 11 * total + 3 * off, sizeof(double) * 3 * r->nq);
+            off += r->nq;
+        }
+        return GPX_OK;
+    }
+    HIPCHK(hipMemcpyAsync(d, h, sizeof(double) * 3 * total, hipMemcpyHostToDevice, s));
+    rc = evaluate_locked(m, total, dqx, dqy, dqz, df, wv ? dv : nullptr, wg ? dg : nullptr, wtx ? dtx : nullptr,
+                         wty ? dty : nullptr, s);
+    if (rc)
+        return rc;
+    HIPCHK(hipMemcpyAsync(h + 3 * total, df, sizeof(double) * total * (wv ? 2 : 1), hipMemcpyDeviceToHost, s));
+    if (wg)
+        HIPCHK(hipMemcpyAsync(h + 5 * total, dg, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    if (wtx)
+        HIPCHK(hipMemcpyAsync(h + 8 * total, dtx, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    if (wty)
+        HIPCHK(hipMemcpyAsync(h + 11 * total, dty, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    off = 0;
+    for (const gpx_pending *r : reqs) {
+        std::memcpy(r->f, h + 3 * total + off, sizeof(double) * r->nq);
+        if (r->v)
+            std::memcpy(r->v, h + 4 * total + off, sizeof(double) * r->nq);
+        if (r->grad)
+            std::memcpy(r->grad, h + 5 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        if (r->tx)
+            std::memcpy(r->tx, h + 8 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        if (r->ty)
+            std::memcpy(r->ty, h + 11 * total + 3 * off, sizeof(double) * 3 * r->nq);
+        off += r->nq;
+    }
+    return GPX_OK;
+}
+
+// Large host batches: slices of 2^18 queries through a pinned double buffer on the model's stream.  The stream runs
+// copy-in / kernels / copy-out of slice i while the host fills the other buffer with slice i+1 and, once slice i-1 has
+// signalled, hands its results to the caller -- so the pageable <-> pinned copies (the larger part of the PCIe-side
+// cost) hide behind the device work, and the staging stays bounded (a 256^3 grid would be 1.9 GB in one piece).
+static int run_large(gpx_model *m, const gpx_pending &r)
+{
+    constexpr size_t SLICE = (size_t)1 << 18;
+    const size_t per_q = 3 + 1 + 1 + 3 + 3 + 3;  // qx qy qz | f | v | grad | tx | ty
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    const size_t S = std::min(SLICE, r.nq);
+    int rc;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * S * per_q)))
+        return rc;
+    if (m->pin2_doubles < S * per_q) {
+        for (int b = 0; b < 2; ++b) {
+            if (m->pin2[b])
+                HIPCHK(hipHostFree(m->pin2[b]));
+            m->pin2[b] = nullptr;
+        }
+        m->pin2_doubles = 0;
+        for (int b = 0; b < 2; ++b)
+            HIPCHK(hipHostMalloc((void **)&m->pin2[b], sizeof(double) * S * per_q, hipHostMallocDefault));
+        m->pin2_doubles = S * per_q;
+    }
+    for (int b = 0; b < 2; ++b)
+        if (!m->pin2_done[b])
+            HIPCHK(hipEventCreateWithFlags(&m->pin2_done[b], hipEventDisableTiming));
+    hipStream_t s = m->stream;
+    double *d = m->ws_host_io;
+    const size_t nslices = (r.nq + S - 1) / S;
+    // results of slice i (already in pinned buffer i & 1 once its event has fired) -> the caller's arrays
+    auto deliver = [&](size_t i) -> int {
+        const int b = (int)(i & 1);
+        const size_t q0 = i * S, nn = std::min(S, r.nq - q0);
+        HIPCHK(hipEventSynchronize(m->pin2_done[b]));
+        const double *h = m->pin2[b];
+        std::memcpy(r.f + q0, h + 3 * S, sizeof(double) * nn);
+        if (r.v)
+            std::memcpy(r.v + q0, h + 4 * S, sizeof(double) * nn);
+        if (r.grad)
+            std::memcpy(r.grad + 3 * q0, h + 5 * S, sizeof(double) * 3 * nn);
+        if (r.tx)
+            std::memcpy(r.tx + 3 * q0, h + 8 * S, sizeof(double) * 3 * nn);
+        if (r.ty)
+            std::memcpy(r.ty + 3 * q0, h + 11 * S, sizeof(double) * 3 * nn);
+        return GPX_OK;
+    };
+    for (size_t i = 0; i < nslices; ++i) {
+        const int b = (int)(i & 1);
+        const size_t q0 = i * S, nn = std::min(S, r.nq - q0);
+        if (i >= 2 && (rc = deliver(i - 2)))  // frees pinned buffer b; the device is busy with slice i-1 meanwhile
+            break;
+        double *h = m->pin2[b];
+        std::memcpy(h, r.qx + q0, sizeof(double) * nn);
+        std::memcpy(h + S, r.qy + q0, sizeof(double) * nn);
+        std::memcpy(h + 2 * S, r.qz + q0, sizeof(double) * nn);
+        HIPCHK(hipMemcpyAsync(d, h, sizeof(double) * 3 * S, hipMemcpyHostToDevice, s));
+        if ((rc = evaluate_locked(m, nn, d, d + S, d + 2 * S, d + 3 * S, r.v ? d + 4 * S : nullptr,
+                                  r.grad ? d + 5 * S : nullptr, r.tx ? d + 8 * S : nullptr,
+                                  r.ty ? d + 11 * S : nullptr, s)))
+            break;
+        HIPCHK(hipMemcpyAsync(h + 3 * S, d + 3 * S, sizeof(double) * S * (r.v ? 2 : 1), hipMemcpyDeviceToHost, s));
+        if (r.grad)
+            HIPCHK(hipMemcpyAsync(h + 5 * S, d + 5 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        if (r.tx)
+            HIPCHK(hipMemcpyAsync(h + 8 * S, d + 8 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        if (r.ty)
+            HIPCHK(hipMemcpyAsync(h + 11 * S, d + 11 * S, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(m->pin2_done[b], s));
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    for (size_t i = nslices >= 2 ? nslices - 2 : 0; i < nslices; ++i)
+        if ((rc = deliver(i)))
+            return rc;
+    return GPX_OK;
+}
+
+
+extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
+                                  const double *qz, double *f, double *v, double *grad, double *tx, double *ty)
+{
+    int rc = check_query(cm, nq, qx, qy, qz, f);
+    if (rc)
+        return rc;
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    gpx_pending req{nq, qx, qy, qz, f, v, grad, tx, ty};
+    if (nq > COMBINE_MAX_NQ)
+        return run_large(m, req);
+    // flat combining: the calling thread either becomes the leader of a batch or waits for one
+    std::unique_lock<std::mutex> lk(m->qmtx);
+    m->pending.push_back(&req);
+    while (!req.done) {
+        if (!m->leader_active) {
+            m->leader_active = true;
+            std::vector<gpx_pending *> batch;
+            batch.swap(m->pending);
+            lk.unlock();
+            const int brc = run_requests(m, batch);
+            const std::string berr = brc ? g_err : std::string();
+            lk.lock();
+            for (gpx_pending *p : batch) {
+                p->rc = brc;
+                p->err = berr;
+                p->done = true;
+            }
+            m->leader_active = false;
+            m->qcv.notify_all();
+        } else {
+            m->qcv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (req.rc)
+        g_err = req.err;
+    return req.rc;
+}
+
+extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
+                                        const double *qz, double f_tol, size_t capacity, int64_t *idx, double *f,
+                                        double *v, size_t *n_out)
+{
+    if (!n_out || !idx)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    *n_out = 0;
+    int rc = check_query(cm, nq, qx, qy, qz, f);
+    if (rc)
+        return rc;
+    if (!(f_tol >= 0.0))
+        return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t cap = std::min(capacity, nq);
+    const size_t nb = (nq + 255) / 256;
+    // device staging: qx qy qz f_all | compacted sx sy sz fs vs (cap each) | idx (cap int64) | block counters | total
+    const size_t doubles = nq * 4 + cap * 5 + cap + nb / 2 + 4;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    double *d = m->ws_host_io;
+    double *dqx = d, *dqy = d + nq, *dqz = d + 2 * nq, *dfa = d + 3 * nq;
+    double *sx = d + 4 * nq, *sy = sx + cap, *sz = sy + cap, *fs = sz + cap, *vs = fs + cap;
+    long long *didx = (long long *)(vs + cap);
+    unsigned *bc = (unsigned *)(didx + cap);
+    unsigned long long *dtotal = (unsigned long long *)(d + doubles - 2);
+    HIPCHK(hipMemcpyAsync(dqx, qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqy, qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dqz, qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s)))
+        return rc;
+    launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, cap, dqx, dqy, dqz, didx, fs, sx, sy, sz, s);
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_out = (size_t)total;
+    const size_t ns = std::min((size_t)total, cap);
+    if (ns > 0) {
+        if (v) {  // variance of the survivors only (their mean is recomputed by the same call; it is cheap)
+            if ((rc = evaluate_locked(m, ns, sx, sy, sz, fs, vs, nullptr, nullptr, nullptr, s)))
+                return rc;
+            HIPCHK(hipMemcpyAsync(v, vs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipMemcpyAsync(f, fs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(idx, didx, sizeof(int64_t) * ns, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (total > cap)
+        return fail(GPX_E_SIZE_MISMATCH, "more surface points than capacity");
+    return GPX_OK;
+}
+
+// ---- AtlasBase::project, batched and device-resident (reference include/atlas/atlas.hpp:201-276) -------------
+extern "C" int gpx_model_project(const gpx_model *cm, size_t nq, const double *x, const double *y, const double *z,
+                                 const double *normal, const gpx_project_options *opt, double *out_xyz, double *out_f,
+                                 int32_t *out_iter, int32_t *out_status)
+{
+    if (!out_xyz || !normal)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    int rc = check_query(cm, nq, x, y, z, out_xyz);
+    if (rc)
+        return rc;
+    gpx_project_options o{1e-2, 1e-7, 0.001, 500, {0, 0, 0}};
+    if (opt)
+        o = *opt;
+    if (!(o.f_tol >= 0.0) || !(o.improve_tol >= 0.0) || o.max_iter < 0 || !std::isfinite(o.step_mul))
+        return fail(GPX_E_BAD_ARG, "project options: tolerances and max_iter must be non-negative, step_mul finite");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    // device state: cx cy cz f_cur f_new (nq each) | g grad_new (3 nq each) | iter status (nq ints each) | active
+    const size_t doubles = nq * 5 + nq * 6 + nq + 2;
+    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+        return rc;
+    double *d = m->ws_host_io;
+    double *cx = d, *cy = d + nq, *cz = d + 2 * nq, *fcur = d + 3 * nq, *fnew = d + 4 * nq;
+    double *g = d + 5 * nq, *gnew = d + 8 * nq;
+    int *iter = (int *)(d + 11 * nq), *status = iter + nq;
+    unsigned *active = (unsigned *)(d + 12 * nq);
+    HIPCHK(hipMemcpyAsync(cx, x, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(cy, y, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(cz, z, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g, normal, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(iter, 0, sizeof(int) * 2 * nq, s));
+    bool fused = true;
+    if (const char *e = std::getenv("GPX_PROJECT_FUSED"))
+        fused = std::atoi(e) != 0;
+    if (fused)  // the whole loop in one launch when the model fits the LDS (N <= 4096)
+        fused = launch_project_fused(m->cov, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, o.f_tol,
+                                     o.improve_tol, o.step_mul, o.max_iter, cx, cy, cz, g, fcur, iter, status, s);
+    if (!fused) {
+        // the mean at the start points (:225 of the first iteration; also the answer when max_iter == 0)
+        if ((rc = evaluate_locked(m, nq, cx, cy, cz, fcur, nullptr, nullptr, nullptr, nullptr, s)))
+            return rc;
+        for (int it = 0; it < o.max_iter; ++it) {
+            HIPCHK(hipMemsetAsync(active, 0, sizeof(unsigned), s));
+            launch_project_pre((long)nq, o.f_tol, o.step_mul, cx, cy, cz, g, fcur, status, s);
+            if ((rc = evaluate_locked(m, nq, cx, cy, cz, fnew, nullptr, gnew, nullptr, nullptr, s)))
+                return rc;
+            launch_project_post((long)nq, o.improve_tol, o.max_iter, fnew, gnew, g, fcur, iter, status, active, s);
+            if ((it & 7) == 7 || it + 1 == o.max_iter) {  // look at the device only every 8 iterations
+                unsigned left = 0;
+                HIPCHK(hipMemcpyAsync(&left, active, sizeof(left), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (left == 0)
+                    break;
+            }
+        }
+    }
+    std::vector<double> hc(3 * nq);
+    std::vector<int> hs(2 * nq);
+    HIPCHK(hipMemcpyAsync(hc.data(), cx, sizeof(double) * 3 * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs.data(), iter, sizeof(int) * 2 * nq, hipMemcpyDeviceToHost, s));
+    if (out_f)
+        HIPCHK(hipMemcpyAsync(out_f, fcur, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < nq; ++i) {
+        out_xyz[3 * i] = hc[i];
+        out_xyz[3 * i + 1] = hc[nq + i];
+        out_xyz[3 * i + 2] = hc[2 * nq + i];
+        int st = hs[nq + i];
+        if (st == 0)
+            st = 3;  // max_iter == 0: the loop of the reference is never entered
+        if (out_iter)
+            out_iter[i] = hs[i];
+        if (out_status)
+            out_status[i] = st;
+    }
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_prepare_variance(gpx_model *m)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!m->ready)
+        return fail(GPX_E_STATE, "model is not ready");
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    return build_inverse(m);
+}
+
+extern "C" int gpx_model_sync(const gpx_model *m)
+{
+    if (!m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return GPX_OK;
+}
+
+void resolve_eval_stats(gpx_model *m)
+{
+    if (!m->stats_eval_pending)
+        return;
+    if (hipStreamSynchronize(m->stream) != hipSuccess)
+        return;
+    float ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_M0], m->ev[EV_M1]) == hipSuccess)
+        m->stats.t_mean_ms = ms;
+    m->stats.t_var_ms = 0;
+    if (m->eval_had_var && hipEventElapsedTime(&ms, m->ev[EV_M1], m->ev[EV_V1]) == hipSuccess)
+        m->stats.t_var_ms = ms;
+    double tg = 0;
+    for (size_t i = 0; i < m->gemm_ev_used_var; ++i) {
+        const size_t k = m->gemm_ev_used_factor + i;
+        if (hipEventElapsedTime(&ms, m->gemm_ev[2 * k], m->gemm_ev[2 * k + 1]) == hipSuccess)
+            tg += ms;
+    }
+    m->stats.t_var_gemm_ms = tg;
+    m->stats.var_gemm_launches = (int64_t)m->gemm_ev_used_var;
+    m->stats_eval_pending = false;
+}
+
+}  // namespace gpxh

@@ -1,0 +1,157 @@
+// gpx_model.hpp -- host-side internals of libgpx.so shared by gpx_api.hip (C entry points, model life cycle),
+// gpx_build.hip (kernel matrix, blocked LDL^T, solves, inverse factor) and gpx_eval.hip (prediction paths).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gpx_internal.hpp"
+
+
+#include "gpx_internal.hpp"
+
+using namespace gpx;
+
+// Host internals live in namespace gpxh so that libgpx.so exports nothing un-prefixed besides the gpx_* C entries.
+namespace gpxh {
+// ---- error state (thread-local message behind gpx_last_error) --------------------------------------
+extern thread_local std::string g_err;
+int fail(int code, const std::string &msg);
+}  // namespace gpxh
+using namespace gpxh;
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            int code__ = (e__ == hipErrorOutOfMemory) ? GPX_E_OOM : GPX_E_HIP;                         \
+            return fail(code__, std::string(#expr) + ": " + hipGetErrorString(e__));                   \
+        }                                                                                              \
+    } while (0)
+
+
+// ------------------------------------------------------------------------------------------------
+enum { EV_T0 = 0, EV_KBUILD, EV_FACTOR, EV_SOLVE, EV_NORMALS, EV_INV0, EV_INV1, EV_M0, EV_M1, EV_V1, EV_WS, EV_COUNT };
+
+struct gpx_pending {
+    size_t nq;
+    const double *qx, *qy, *qz;
+    double *f, *v, *grad, *tx, *ty;
+    int rc = GPX_OK;
+    bool done = false;
+    std::string err;
+};
+
+struct gpx_model {
+    int device = 0, prec = 0;
+    size_t esz = 4;
+    gpx_kernel kern{};
+    CovHost cov{};
+    gpx_options opt{};
+    int n = 0, npad = 0, nblk = 0;
+    bool ready = false, has_s2 = false, has_inverse = false, has_normals = false;
+    bool inv64 = true;      // F32 modes: assemble the inverse factor in fp64 from the fp32 factor (GPX_INV64=0 disables)
+    bool x_packed = false;  // F32_SPLIT: X holds packed hi/lo halves, the 1/D slot holds the scaled weights
+    float sk = 1.0f;        // power-of-two scale of the kernel values in the split contraction
+    std::vector<double> hx, hy, hz, hlabel, hs2;  // caller order
+    std::vector<int> perm;                        // internal position -> caller index
+    double R = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
+    size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;
+
+    // state blob part 0 = everything evaluate() reads besides X, internal order, npad each:
+    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | T x y z 1/D
+    void *blob0 = nullptr;
+    size_t blob0_bytes = 0;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;
+    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr;
+    // other fp64 vectors (npad each): label s2 r f, then one double for max|r|
+    double *dvecs = nullptr;
+    double *d_lab = nullptr, *d_s2 = nullptr, *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
+    // other T vectors: s2 d b y xs alpha
+    void *tvecs = nullptr;
+    void *t_s2 = nullptr, *t_d = nullptr, *t_b = nullptr, *t_yv = nullptr, *t_xs = nullptr, *t_alpha = nullptr;
+    std::vector<double> hD;  // D kept on the host once the factor has been released (mixed precision)
+    void *Kmat = nullptr;  // npad x npad, L D L^T in place
+    void *linv = nullptr;  // nblk x 128 x 128
+    void *Wp = nullptr;    // npad x 512 panel workspace
+    void *X = nullptr;     // npad x npad inverse factor (state blob part 1)
+    int *d_info = nullptr; // [0] first bad pivot (1-based), [1] negative pivots, [2..3] argmax pair
+    float *d_tmax = nullptr;
+    int *d_tij = nullptr;
+    // evaluation workspaces (grown on demand, guarded by mtx)
+    double *ws_pred = nullptr;
+    size_t ws_pred_doubles = 0;
+    void *ws_kqp = nullptr;
+    size_t ws_kqp_bytes = 0;
+    void *ws_partial = nullptr;
+    size_t ws_partial_bytes = 0;
+    double *ws_grad = nullptr;
+    size_t ws_grad_doubles = 0;
+    void *ws_small = nullptr;      // partial sums + counters of the one-launch path for a handful of queries
+    double *ws_host_io = nullptr;  // device staging for the host-pointer evaluate
+    size_t ws_host_io_doubles = 0;
+    int qbatch = 8192;
+    // flat combining of concurrent small evaluate() calls (the node issues one call per grid point from
+    // hundreds of threads, src/gp_node.cpp:1027-1038): whoever finds no leader takes every pending request
+    // and runs them as ONE device batch
+    std::mutex qmtx;
+    std::condition_variable qcv;
+    std::vector<struct gpx_pending *> pending;
+    bool leader_active = false;
+    double *pin = nullptr;  // pinned host staging of the combiner
+    size_t pin_doubles = 0;
+    double *pin2[2] = {nullptr, nullptr};  // pinned double buffer of the pipelined large-batch path
+    size_t pin2_doubles = 0;
+    hipEvent_t pin2_done[2] = {nullptr, nullptr};
+    std::mutex mtx;
+    gpx_stats stats{};
+    bool stats_eval_pending = false;
+    bool eval_had_var = false;
+    bool ws_in_flight = false;  // ev[EV_WS] marks the end of the last evaluation that used the shared workspaces
+};
+
+namespace gpxh {
+// What a rank-n update carries over from the previous factorisation (device buffers of the OLD padded size)
+struct kept_factor {
+    int t0 = 0;        // rows / columns [0, t0) of L, D and the inverse diagonal blocks stay valid
+    int np_old = 0;
+    int n_neg = 0;     // negative pivots among the kept ones
+    void *K = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;  // d, dinv: t0 entries each
+    void release()
+    {
+        for (void *p : {K, linv, d, dinv})
+            if (p)
+                (void)hipFree(p);
+        K = linv = d = dinv = nullptr;
+    }
+};
+
+constexpr size_t SMALL_EVAL_MAX_NQ = 64;  // a handful of queries on a small model: one launch (gpx_predict.hip)
+constexpr size_t COMBINE_MAX_NQ = 4096;   // larger host calls fill the device on their own
+
+// ---- gpx_build.hip ----------------------------------------------------------------------------------
+void free_dev(gpx_model *m);
+int ensure(void **p, size_t *have, size_t need);
+void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm);
+int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes);
+void carve_blob0(gpx_model *m);
+int alloc_model(gpx_model *m);
+hipEvent_t *gemm_events(gpx_model *m, size_t idx);
+int build_inverse(gpx_model *m);
+int build_model(gpx_model *m, kept_factor *keep = nullptr);
+void set_query_batch(gpx_model *m);
+// ---- gpx_eval.hip -----------------------------------------------------------------------------------
+int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz, double *f, double *v,
+                    double *grad, double *tx, double *ty, hipStream_t s);
+int check_query(const gpx_model *m, size_t nq, const void *qx, const void *qy, const void *qz, const void *f);
+void resolve_eval_stats(gpx_model *m);
+}  // namespace gpxh
