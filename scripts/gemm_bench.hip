@@ -38,9 +38,9 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dinv, e * N));
     CK(hipMalloc(&partial, e * (size_t)NQ * (N / 128)));
     CK(hipMalloc(&C, e * (size_t)N * N));
-    CK(hipMalloc(&W, e * (size_t)N * 256));
-    if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*256, 4, 1e-2); }
-    else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*256, 4, 1e-2); }
+    CK(hipMalloc(&W, e * (size_t)N * 2048));
+    if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
+    else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
     CK(hipMemset(C, 0, e * (size_t)N * N));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -59,10 +59,11 @@ int main(int argc, char **argv)
         double flop = (double)N * N * NQ;
         printf("VAR  cfg%d prec%d N=%d NQ=%d : %.3f ms  %.1f TFLOP/s (algorithmic N^2 per query)\n", cfg, prec, N, NQ, ms, flop / ms / 1e9);
     }
-    for (int cfg = 0; cfg < 3; cfg += 2) {
+    for (int KK : {128, 256, 512, 1024, 2048})
+    for (int cfg = 0; cfg < 1; cfg += 2) {
         const int M = N - 256;
         GemmArgs s;
-        s.A = W, s.lda = 256; s.B = X, s.ldb = N; s.C = C, s.ldc = N; s.M = M, s.N = M, s.K = 256; s.alpha = -1, s.beta = 1; s.lower_only = 1; s.cfg = cfg;
+        s.A = W, s.lda = 2048; s.B = X, s.ldb = N; s.C = C, s.ldc = N; s.M = M, s.N = M, s.K = KK; s.alpha = -1, s.beta = 1; s.lower_only = 1; s.cfg = cfg;
         launch_gemm(prec, s, st);
         CK(hipStreamSynchronize(st));
         const int reps = 5;
@@ -71,8 +72,9 @@ int main(int argc, char **argv)
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        double flop = (double)M * M * 256;  // lower triangle only: M^2/2 * K * 2
-        printf("SYRK cfg%d prec%d M=%d K=256 : %.3f ms  %.1f TFLOP/s\n", cfg, prec, M, ms, flop / ms / 1e9);
+        double flop = (double)M * M * KK;  // lower triangle only: M^2/2 * K * 2
+        const double tiles = (M / 128) * (M / 128 + 1) / 2.0;
+        printf("SYRK cfg%d prec%d M=%d K=%d : %.3f ms  %.1f TFLOP/s   %.2f us per tile-slot (512 slots)\n", cfg, prec, M, KK, ms, flop / ms / 1e9, ms * 1e3 / (tiles / 512.0));
     }
     return 0;
 }
