@@ -2,11 +2,12 @@
 // triangular solves (gfx950).  Replaces Eigen::LDLT<MatrixXd>::compute / ::solve as used by the
 // reference (gp_regressor.hpp:161-163); the O(N^3) work is in gpx_gemm.hip.
 //
-//   diag_ldl   : one 128 x 128 diagonal block, LDS resident: unblocked right-looking LDL^T
-//                (no pivoting inside the block: the Eigen rule picks pivots from the ORIGINAL
-//                diagonal, so the permutation is applied to the points before kbuild), then the
-//                unit-lower inverse of L in place.  The inverse blocks turn every panel solve
-//                and every block substitution into matrix products.
+//   diag_ldl   : one 128 x 128 diagonal block by one workgroup: right-looking LDL^T blocked by 32 (the 32 x 32
+//                sub-block is factorised and inverted by one wave in registers), no pivoting inside the block
+//                (the Eigen rule picks pivots from the ORIGINAL diagonal, so the permutation is applied to the
+//                points before kbuild), then the unit-lower inverse of L assembled from the four 32 x 32
+//                inverses.  The inverse blocks turn every panel solve and every block substitution into
+//                matrix products.  identity_blocks: the same result for blocks that lie in the padding.
 //   fwd / bwd  : one launch per block step of L y = b / L^T x = y using the inverse blocks.
 #include "gpx_internal.hpp"
 

@@ -1,4 +1,5 @@
-// gpx_predict.hip -- batched GP mean / gradient evaluation and small vector kernels (gfx950).
+// gpx_predict.hip -- batched GP mean / gradient evaluation, the one-launch paths (a handful of queries; the
+// AtlasBase::project loop), iso-surface compaction and small vector kernels (gfx950).
 //
 //   predict : f_i = sum_j k(|q_i - p_j|) alpha_j                 (reference gp_regressor.hpp:300-305, :347-353)
 //             g_i = sum_j alpha_j k'(d_ij) (q_i - p_j)           (:243-249, zero-initialised)
