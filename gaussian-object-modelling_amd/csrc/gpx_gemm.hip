@@ -59,6 +59,15 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
     static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
 
+// 16-byte chunks of padding per staged [row][k] LDS row.  One chunk (144-byte rows) leaves 2-way bank conflicts in the
+// fragment reads: a ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, ... -- and with a row
+// stride of 9 chunks the rows 4..11 of the second k sub-block fall on the banks of rows 0-3 / 12-15 of the first
+// (SQ_LDS_BANK_CONFLICT = 37 % of the LDS cycles of the variance GEMM).  Two chunks (160-byte rows) are
+// conflict-free for every group; the 128 x 128 tile then needs exactly 80 KiB, so two workgroups still fit 160 KiB.
+#ifndef GEMM_KPAD
+#define GEMM_KPAD 2
+#endif
+
 template <typename T>
 struct GemmDev {
     const T *A, *B;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     constexpr int BK = KBYTES / sizeof(T);      // k-tile: KBYTES bytes of k per staged row
     constexpr int CPRW = KBYTES / 16;           // 16-byte chunks per staged [row][k] row
     constexpr int EPC = 16 / sizeof(T);         // elements per 16-byte chunk
-    constexpr int BKP = BK + EPC;               // padded k extent of a [row][k] LDS tile
+    constexpr int BKP = BK + GEMM_KPAD * EPC;   // padded k extent of a [row][k] LDS tile
     constexpr int BNP = BN + EPC;               // padded n extent of a [k][n] LDS tile (NN)
     constexpr int A_TILE = BM * BKP;
     constexpr int B_TILE = NN ? BK * BNP : BN * BKP;
@@ -356,7 +365,7 @@ static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t 
     constexpr int FR = M32 ? 32 : 16;
     constexpr int BM = WGM * FM * FR, BN = WGN * FN * FR;
     constexpr int EPC = 16 / sizeof(T), BK = KBYTES / sizeof(T);
-    constexpr int BKP = BK + EPC, BNP = BN + EPC;
+    constexpr int BKP = BK + GEMM_KPAD * EPC, BNP = BN + EPC;
     constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? BK * BNP : BN * BKP));
     static bool attr_done = false;  // one process drives one device
     auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN, KBYTES, M32>;
