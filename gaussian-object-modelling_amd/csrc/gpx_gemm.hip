@@ -203,8 +203,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     }
 
     const int fr = lane % FR, fg = lane / FR;
-    const int a_frag_off = (wm * FM * FR + fr) * BKP + 4 * fg;
-    const int b_frag_off = NN ? (4 * fg) * BNP + wn * FN * FR + fr : (wn * FN * FR + fr) * BKP + 4 * fg;
+    // k owned by lane group fg inside a 16-deep chunk.  fp32: the 4 consecutive k of ONE 16-byte LDS chunk (4 fg + s).
+    // fp64: TWO 16-byte chunks, fg and fg + 4, i.e. k = 2 fg + (s & 1) + 8 (s >> 1) -- with the natural 4 fg + s a
+    // lane group would step 32 bytes per fg and the 16-lane service groups of ds_read_b128 would collide on the
+    // banks whatever the row padding; stepping ONE chunk per fg is conflict-free with 160-byte rows, as in fp32.
+    constexpr int FGS = sizeof(T) == 8 ? 2 : 4;  // elements per lane-group step
+    const int a_frag_off = (wm * FM * FR + fr) * BKP + FGS * fg;
+    const int b_frag_off = NN ? (sizeof(T) == 8 ? 2 * fg : 4 * fg) * BNP + wn * FN * FR + fr
+                              : (wn * FN * FR + fr) * BKP + FGS * fg;
 
     // ---- EPI_STORE: fetch the C tile NOW, in fragment layout, so that its latency hides under the k-loop
     // (the trailing update of the factorisation has only 8 k-tiles per tile; a read-modify-write epilogue
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                             a[f][0] = v.x, a[f][1] = v.y, a[f][2] = v.z, a[f][3] = v.w;
                         } else {
                             double2 v0 = *reinterpret_cast<const double2 *>(p);
-                            double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
+                            double2 v1 = *reinterpret_cast<const double2 *>(p + 8);
                             a[f][0] = v0.x, a[f][1] = v0.y, a[f][2] = v1.x, a[f][3] = v1.y;
                         }
                     }
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                         if constexpr (NN) {
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
-                                b[f][s] = bs[(kc * KCH + s) * BNP + f * FR];
+                                b[f][s] = bs[(kc * KCH + (sizeof(T) == 8 ? (s & 1) + 8 * (s >> 1) : s)) * BNP + f * FR];
                         } else {
                             const T *p = bs + f * FR * BKP + kc * KCH;
                             if constexpr (sizeof(T) == 4) {
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
                                 b[f][0] = v.x, b[f][1] = v.y, b[f][2] = v.z, b[f][3] = v.w;
                             } else {
                                 double2 v0 = *reinterpret_cast<const double2 *>(p);
-                                double2 v1 = *reinterpret_cast<const double2 *>(p + 2);
+                                double2 v1 = *reinterpret_cast<const double2 *>(p + 8);
                                 b[f][0] = v0.x, b[f][1] = v0.y, b[f][2] = v1.x, b[f][3] = v1.y;
                             }
                         }
