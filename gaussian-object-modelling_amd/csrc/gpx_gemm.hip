@@ -67,6 +67,12 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_KPAD
 #define GEMM_KPAD 2
 #endif
+// 1: give the fp32 instantiations named staging registers and a structured scheduling hint (VMEM reads, then per
+// 16-deep chunk the LDS reads and the MFMAs) as well.  Measured: variance 256^2 tile 137.8 (unhinted 138.2), 128^2
+// tile 131 (136), trailing-update tile 91 (104-107) TFLOP/s -- the fp32 code is better left to the scheduler.
+#ifndef GEMM_F32_HINT
+#define GEMM_F32_HINT 0
+#endif
 
 template <typename T>
 struct GemmDev {
@@ -178,10 +184,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
     // Staging registers.  fp32: small arrays (fully unrolled accesses; the compiler schedules that form best).  fp64:
     // NAMED scalars, because its main loop carries scheduling hints and with those hipcc keeps arrays in scratch
     // memory (at most 2 + 2 chunks per thread there); the fp32 tiles lose ~5 % with named scalars.
-    constexpr bool NAMED = sizeof(T) == 8;
-    static_assert(!NAMED || (A_CH <= 2 && B_CH <= 2), "named staging is written out for 2 chunks per operand");
+    constexpr bool NAMED = sizeof(T) == 8 || GEMM_F32_HINT;
+    static_assert(!NAMED || (A_CH <= 4 && B_CH <= 4), "named staging is written out for 4 chunks per operand");
     uint4 ra[NAMED ? 1 : A_CH], rb[NAMED ? 1 : B_CH];
-    uint4 ra0, ra1, rb0, rb1;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define GPX_A_PTR(I) (a_src + (size_t)(ROWS_PER_PASS * (I)) * g.lda + k0_)
 #define GPX_B_PTR(I) (NN ? b_src + (k0_ + KROWS_PER_PASS * (I)) * g.ldb : b_src + (size_t)(ROWS_PER_PASS * (I)) * g.ldb + k0_)
 #define GPX_GLOAD(KT)                                                                                       \
@@ -192,6 +198,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
             rb0 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(0));                                           \
             if constexpr (A_CH > 1) ra1 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(1));                   \
             if constexpr (B_CH > 1) rb1 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(1));                   \
+            if constexpr (A_CH > 2) ra2 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(2));                   \
+            if constexpr (B_CH > 2) rb2 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(2));                   \
+            if constexpr (A_CH > 3) ra3 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(3));                   \
+            if constexpr (B_CH > 3) rb3 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(3));                   \
         } else {                                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < A_CH; ++i_)                                             \
                 ra[i_] = *reinterpret_cast<const uint4 *>(GPX_A_PTR(i_));                                   \
@@ -208,6 +218,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
             *reinterpret_cast<uint4 *>(GPX_B_LDS(0, BUF)) = rb0;                                            \
             if constexpr (A_CH > 1) *reinterpret_cast<uint4 *>(GPX_A_LDS(1, BUF)) = ra1;                    \
             if constexpr (B_CH > 1) *reinterpret_cast<uint4 *>(GPX_B_LDS(1, BUF)) = rb1;                    \
+            if constexpr (A_CH > 2) *reinterpret_cast<uint4 *>(GPX_A_LDS(2, BUF)) = ra2;                    \
+            if constexpr (B_CH > 2) *reinterpret_cast<uint4 *>(GPX_B_LDS(2, BUF)) = rb2;                    \
+            if constexpr (A_CH > 3) *reinterpret_cast<uint4 *>(GPX_A_LDS(3, BUF)) = ra3;                    \
+            if constexpr (B_CH > 3) *reinterpret_cast<uint4 *>(GPX_B_LDS(3, BUF)) = rb3;                    \
         } else {                                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < A_CH; ++i_)                                             \
                 *reinterpret_cast<uint4 *>(GPX_A_LDS(i_, BUF)) = ra[i_];                                    \
@@ -261,6 +275,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
             if constexpr (sizeof(T) == 8) {
                 __builtin_amdgcn_sched_group_barrier(0x020, A_CH + B_CH, 0);  // the VMEM reads first ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);            // ... then (at least) the first MFMAs
+            } else if (GEMM_F32_HINT) {
+                __builtin_amdgcn_sched_group_barrier(0x020, A_CH + B_CH, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN * 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN * 4, 0);
             }
             {
                 const T *as = As + buf * A_TILE + a_frag_off;
