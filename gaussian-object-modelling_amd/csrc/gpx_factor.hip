@@ -43,16 +43,67 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 
 // One 128 x 128 diagonal block: LDL^T without pivoting + the inverse of its unit-lower L, blocked by 32.
 //
-//   per 32-column panel  A) the 32 x 32 diagonal sub-block is factorised AND inverted by ONE wave with the rows
-//                           in registers (static indices; pivot rows / columns travel by __shfl, no barrier),
-//                        B) the rows below: W = A21 X11^T (= L21 D), L21 = W D^-1   (all 1024 threads),
+//   per 32-column panel  A) the 32 x 32 diagonal sub-block is factorised by wave 0 with the rows in registers
+//                           (static indices; pivot rows / columns travel by v_readlane, no barrier); in the same
+//                           interval wave 1 inverts the PREVIOUS sub-block's L the same way, so the inverses --
+//                           needed only by the assembly at the end -- are off the critical path,
+//                        B) the rows below: W L11^T = A21 by forward substitution, one thread per row with the
+//                           row in registers (L11 is read as LDS broadcasts); L21 = W D^-1,
 //                        C) the trailing update A22 -= W L21^T on the (L2-resident) global block, panel
 //                           operands in LDS.
 //   then the 128 x 128 inverse is assembled from the four 32 x 32 inverses, block column by block column:
 //        X[i][j] = -Xd[i] * sum_{j<=k<i} L[i][k] X[k][j].
-// ~12 barriers per panel instead of one per column; replaces an unblocked LDS kernel (348 us, then 177 us with
+// ~8 barriers per panel instead of one per column; replaces an unblocked LDS kernel (348 us, then 177 us with
 // 1024 threads) that sat on the critical path of the factorisation 128 times at N = 16384.  A fully
 // register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
+// Until the sub-block inverse moved to the second wave and B became a substitution (it was W = A21 X11^T, which
+// needed X11 first) the kernel took 105 us (fp32) / 190 us (fp64).
+
+// step C_ of the row substitution of phase B: prefetch column C_ + 1 of L11, eliminate with column C_
+template <typename T, int C_>
+struct SubstStep {
+    static __device__ __forceinline__ void run(T (&a)[NB], T (&lc)[NB], T (&ln)[NB], const T *lt)
+    {
+        if constexpr (C_ < NB - 1) {
+            constexpr int Q0 = ((C_ + 2) / 4) * 4;  // first aligned quad of column C_ + 1 that is still needed
+#pragma unroll
+            for (int c2 = Q0; c2 < NB; ++c2)
+                ln[c2] = lt[(C_ + 1) * NB + c2];
+            const T w = a[C_];
+#pragma unroll
+            for (int c2 = C_ + 1; c2 < NB; ++c2)
+                a[c2] -= w * lc[c2];
+            constexpr int NREAD = (NB - Q0) / 4 * (sizeof(T) == 8 ? 2 : 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);       // DS reads of the next column first
+            __builtin_amdgcn_sched_group_barrier(0x002, NB - 1 - C_, 0);  // then this column's FMAs
+            SubstStep<T, C_ + 1>::run(a, ln, lc, lt);
+        }
+    }
+};
+
+// unit-lower inverse of a 32 x 32 L held as r[c] = L[l][c] in lane l:  X[l][j] = -( L[l][j] + sum_{j<k<l} X[l][k] L[k][j] )
+template <typename T>
+__device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
+{
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+        x[c] = T(0);
+#pragma unroll
+    for (int j = NB - 2; j >= 0; --j) {
+        T s0 = T(0), s1 = T(0);
+#pragma unroll
+        for (int k = j + 1; k < NB; ++k) {
+            const T lkj = bcast_lane(r[j], k);  // L[k][j]
+            // x[k] is still 0 for k >= l (set below only when l > k), so no select is needed
+            if (k & 1)
+                s1 += x[k] * lkj;
+            else
+                s0 += x[k] * lkj;
+        }
+        x[j] = (l > j) ? -(r[j] + s0 + s1) : T(0);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
                                                       T *__restrict__ d, T *__restrict__ dinv,
@@ -64,13 +115,14 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
     T *Lp = Pa + TILE * PLD;                       // [TILE][PLD]  panel: L
     T *Xd = Lp + TILE * PLD;                       // [4][NB][PLD] inverses of the diagonal sub-blocks
     T *Di = Xd + 4 * NB * PLD;                     // [TILE]       1 / D
+    T *Lt = Di + TILE;                             // [2][NB][NB]  L11 of the current / previous panel, TRANSPOSED
     // the inverse assembly re-uses the panel region: Xs = 3 off-diagonal blocks, Tb = 3 product blocks
     T *Xs = Pa;                                    // [3][NB][PLD]  X(1,0), X(2,0), X(2,1)
     T *Tb = Pa + 3 * NB * PLD;                     // [3][NB][PLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     GPX_STAMP(0);
-    for (int jb = 0; jb < 4; ++jb) {
+    for (int jb = 0; jb <= 4; ++jb) {
         const int c0 = NB * jb;
         const int nrows = TILE - c0;
         for (int idx = tid; idx < nrows * NB; idx += DT) {
@@ -79,10 +131,11 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         }
         __syncthreads();
         GPX_STAMP(1 + 4 * jb);
-        // ---- A: diagonal sub-block, one wave, lane l (and its twin l + 32) owns row l ----
-        if (wave == 0) {
+        // ---- A: wave 0 factorises sub-block jb, wave 1 inverts L of sub-block jb - 1; lane l (and its twin
+        //         l + 32) owns row l ----
+        if (wave == 0 && jb < 4) {
             const int l = lane & 31;
-            T r[NB], x[NB];
+            T r[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c)
                 r[c] = Pa[(c0 + l) * PLD + c];
@@ -107,28 +160,11 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 if (l > j)
                     r[j] = lij;
             }
-            // inverse of the unit-lower L11:  X[l][j] = -( L[l][j] + sum_{j<k<l} X[l][k] L[k][j] )
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                x[c] = T(0);
-#pragma unroll
-            for (int j = NB - 2; j >= 0; --j) {
-                T s0 = T(0), s1 = T(0);
-#pragma unroll
-                for (int k = j + 1; k < NB; ++k) {
-                    const T lkj = bcast_lane(r[j], k);  // L[k][j]
-                    // x[k] is still 0 for k >= l (set below only when l > k), so no select is needed
-                    if (k & 1)
-                        s1 += x[k] * lkj;
-                    else
-                        s0 += x[k] * lkj;
-                }
-                x[j] = (l > j) ? -(r[j] + s0 + s1) : T(0);
-            }
             if (lane < NB) {
+                T *lt = Lt + (jb & 1) * NB * NB;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    Xd[(jb * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
+                    lt[c * NB + l] = c < l ? r[c] : T(0);  // L11[l][c], column c contiguous
                     if (c < l)
                         A[(size_t)(c0 + l) * lda + c0 + c] = r[c];
                 }
@@ -143,41 +179,51 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                         atomicAdd(&info[1], nneg);
                 }
             }
+        } else if (wave == 1 && jb > 0) {
+            const int l = lane & 31;
+            const T *lt = Lt + ((jb - 1) & 1) * NB * NB;
+            T r[NB], x[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                r[c] = lt[c * NB + l];
+            sub_inverse(r, x, l);
+            if (lane < NB) {
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    Xd[((jb - 1) * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
+            }
         }
         __syncthreads();
         GPX_STAMP(2 + 4 * jb);
         const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
         if (nb_rows > 0) {
-            // ---- B: W[i][c] = sum_{k<=c} A[i][k] X11[c][k]  (WPT entries per thread at most) ----
-            constexpr int WPT = ((TILE - NB) * NB + DT - 1) / DT;
-            T wreg[WPT];
+            // ---- B: row i of W solves W L11^T = A21:  w_c = a_ic - sum_{k<c} w_k L11[c][k] ----
+            if (tid < nb_rows) {
+                const int i_ = c0 + NB + tid;
+                const T *lt = Lt + (jb & 1) * NB * NB;
+                T a[NB];
 #pragma unroll
-            for (int e = 0; e < WPT; ++e) {
-                const int idx = tid + DT * e;
-                T w = T(0);
-                if (idx < nb_rows * NB) {
-                    const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
-                    const T *arow = Pa + i_ * PLD;
-                    const T *xrow = Xd + (jb * NB + c_) * PLD;
-                    for (int k = 0; k <= c_; ++k)
-                        w += arow[k] * xrow[k];
-                }
-                wreg[e] = w;
-            }
-            __syncthreads();
+                for (int c = 0; c < NB; ++c)
+                    a[c] = Pa[i_ * PLD + c];
+                // column c of L11 (contiguous in Lt) is fetched whole, one column ahead of its use: left to itself
+                // the compiler issued every LDS read just before its FMA and waited for it (7 us for this loop)
+                T lc[NB], ln[NB];
 #pragma unroll
-            for (int e = 0; e < WPT; ++e) {
-                const int idx = tid + DT * e;
-                if (idx < nb_rows * NB) {
-                    const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
-                    const T lv = wreg[e] * Di[c0 + c_];
-                    Pa[i_ * PLD + c_] = wreg[e];
-                    Lp[i_ * PLD + c_] = lv;
-                    A[(size_t)i_ * lda + c0 + c_] = lv;
+                for (int c2 = 0; c2 < NB; ++c2)
+                    lc[c2] = lt[c2];
+                SubstStep<T, 0>::run(a, lc, ln, lt);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    Pa[i_ * PLD + c] = a[c];
+                    Lp[i_ * PLD + c] = a[c] * Di[c0 + c];
                 }
             }
             __syncthreads();
             GPX_STAMP(3 + 4 * jb);
+            for (int idx = tid; idx < nb_rows * NB; idx += DT) {
+                const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
+                A[(size_t)i_ * lda + c0 + c_] = Lp[i_ * PLD + c_];
+            }
             // ---- C: trailing update on the global block: A[i][k] -= sum_c W[i][c] L[k][c], k <= i ----
             // lower-triangle entries only, CPT per thread; all global loads are issued before the first use (as a
             // read-modify-write inside the loop every entry paid its own L2 round trip: ~18 in a row for jb = 0)
@@ -247,7 +293,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 Xs[((ii == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB + r_) * PLD + c_] = xv;
         }
         __syncthreads();
-        GPX_STAMP(16 + s_);
+        GPX_STAMP(20 + s_);
     }
     // diagonal blocks and the zero upper part
     for (int idx = tid; idx < TILE * TILE; idx += DT) {
@@ -258,12 +304,12 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         else if (bj == bi)
             linv[(size_t)blk * TILE * TILE + idx] = Xd[(bi * NB + (r_ & 31)) * PLD + (c_ & 31)];
     }
-    GPX_STAMP(20);
+    GPX_STAMP(24);
 }
 
 static size_t diag_shmem_bytes(size_t esz)
 {
-    return esz * (size_t)(2 * TILE * PLD + 4 * NB * PLD + TILE);  // Pa + Lp + Xd + Di
+    return esz * (size_t)(2 * TILE * PLD + 4 * NB * PLD + TILE + 2 * NB * NB);  // Pa + Lp + Xd + Di + Lt
 }
 
 template <typename T>

@@ -17,6 +17,7 @@ template <typename T>
 static void run(const char *name, int prec)
 {
     const int n = 128;
+    factor_init(prec);
     std::vector<T> A((size_t)n * n);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j)
@@ -41,11 +42,30 @@ static void run(const char *name, int prec)
             printf("%s: event %.1f us; phases in us (100 MHz wall clock):\n", name, ms * 1e3);
             auto us = [&](int a, int b) { return (st[b] - st[a]) / 100.0; };
             for (int jb = 0; jb < 4; ++jb)
-                printf("  panel %d: load %.1f  A(diag 32x32 LDL+inv, 1 wave) %.1f  B(W, L21) %.1f  C(trailing) %.1f\n", jb,
+                printf("  panel %d: load %.1f  A(LDL wave 0 | inv wave 1) %.1f  B(W, L21) %.1f  C(trailing) %.1f\n", jb,
                        us(jb ? 4 * jb : 0, 1 + 4 * jb), us(1 + 4 * jb, 2 + 4 * jb), jb < 3 ? us(2 + 4 * jb, 3 + 4 * jb) : 0.0,
                        jb < 3 ? us(3 + 4 * jb, 4 + 4 * jb) : us(2 + 4 * jb, 4 + 4 * jb));
-            printf("  inverse assembly: %.1f %.1f %.1f  final copy %.1f   total %.1f\n", us(16, 17), us(17, 18), us(18, 19),
-                   us(19, 20), us(0, 20));
+            printf("  last sub-block inverse %.1f  inverse assembly: %.1f %.1f %.1f  final copy %.1f   total %.1f\n", us(16, 20),
+                   us(20, 21), us(21, 22), us(22, 23), us(23, 24), us(0, 24));
+            // correctness: L D L^T = A and linv L = I, in double on the host
+            std::vector<T> F((size_t)n * n), X((size_t)n * n);
+            hipMemcpy(F.data(), dA, sizeof(T) * n * n, hipMemcpyDeviceToHost);
+            hipMemcpy(X.data(), dL, sizeof(T) * n * n, hipMemcpyDeviceToHost);
+            double e1 = 0, e2 = 0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double s = 0, t = 0;
+                    for (int k = 0; k <= j; ++k) {
+                        const double lik = k == i ? 1.0 : (double)F[(size_t)i * n + k];
+                        const double ljk = k == j ? 1.0 : (double)F[(size_t)j * n + k];
+                        s += lik * (double)F[(size_t)k * n + k] * ljk;
+                    }
+                    for (int k = j; k <= i; ++k)
+                        t += (double)X[(size_t)i * n + k] * (k == j ? 1.0 : (double)F[(size_t)k * n + j]);
+                    e1 = std::fmax(e1, std::fabs(s - (double)A[(size_t)i * n + j]));
+                    e2 = std::fmax(e2, std::fabs(t - (i == j ? 1.0 : 0.0)));
+                }
+            printf("  max |L D L^T - A| = %.3e   max |linv L - I| = %.3e\n", e1, e2);
         }
     }
 }
