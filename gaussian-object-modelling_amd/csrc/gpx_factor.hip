@@ -51,13 +51,15 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 //                           row in registers (L11 is read as LDS broadcasts); L21 = W D^-1,
 //                        C) the trailing update A22 -= W L21^T on the (L2-resident) global block, panel
 //                           operands in LDS.
-//   then the 128 x 128 inverse is assembled from the four 32 x 32 inverses, block column by block column:
-//        X[i][j] = -Xd[i] * sum_{j<=k<i} L[i][k] X[k][j].
-// ~8 barriers per panel instead of one per column; replaces an unblocked LDS kernel (348 us, then 177 us with
-// 1024 threads) that sat on the critical path of the factorisation 128 times at N = 16384.  A fully
+//   then the 128 x 128 inverse X of L is assembled from the four 32 x 32 inverses Xd and the six L blocks (all
+//   kept in LDS) by recursive doubling, every 32 x 32 x 32 product on MFMA (one wave per output block):
+//        X10 = -Xd1 (L10 Xd0),  X32 = -Xd3 (L32 Xd2)                        [first product beside the last inverse]
+//        T   = L_BA X_A   (64 x 64: L20 L21 / L30 L31  times  Xd0 0 / X10 Xd1)
+//        X_BA = -X_B T    (X_B = Xd2 0 / X32 Xd3).
+// History: unblocked LDS kernel 348 us, 177 us with 1024 threads; blocked by 32 with the sub-block factorised AND
+// inverted by one wave, B as W = A21 X11^T and the assembly as scalar loops: 105 us (fp32) / 190 us (fp64); inverse
+// on the second wave + substitution: 90 / 159 us; assembly on MFMA: see DESIGN.md section 4.  A fully
 // register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
-// Until the sub-block inverse moved to the second wave and B became a substitution (it was W = A21 X11^T, which
-// needed X11 first) the kernel took 105 us (fp32) / 190 us (fp64).
 
 // step C_ of the row substitution of phase B: prefetch column C_ + 1 of L11, eliminate with column C_
 template <typename T, int C_>
@@ -91,9 +93,15 @@ __device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
 #pragma unroll
     for (int j = NB - 2; j >= 0; --j) {
         T s0 = T(0), s1 = T(0);
+        // L is known up front, so nothing orders its 496 broadcasts: the compiler emitted all of them first and
+        // spilled the SGPRs to VGPR lanes (writelane + readlane each).  The empty asm ties column j to the result of
+        // the previous step.
+        T rj = r[j];
+        if (j < NB - 2)
+            asm("" : "+v"(rj) : "v"(x[j + 1]));
 #pragma unroll
         for (int k = j + 1; k < NB; ++k) {
-            const T lkj = bcast_lane(r[j], k);  // L[k][j]
+            const T lkj = bcast_lane(rj, k);  // L[k][j]
             // x[k] is still 0 for k >= l (set below only when l > k), so no select is needed
             if (k & 1)
                 s1 += x[k] * lkj;
@@ -104,25 +112,116 @@ __device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
     }
 }
 
+// 32 x 32 x 32 block product of two LDS operands (leading dimension PLD) by one wave on the 16x16x4 MFMA:
+// four 16 x 16 accumulator tiles.  A operand: lane supplies A[i = lane & 15][k = lane >> 4]; B: B[k][j = lane & 15].
+template <typename T>
+struct BlkMma;
+template <>
+struct BlkMma<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+template <>
+struct BlkMma<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <typename T>
+struct BlkAcc {
+    typename BlkMma<T>::acc_t t[2][2];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                t[i][j] = typename BlkMma<T>::acc_t{T(0), T(0), T(0), T(0)};
+    }
+    // += Ab (32 x 32) * Bb (32 x 32)
+    __device__ __forceinline__ void mac(const T *Ab, const T *Bb, int lane)
+    {
+        const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const int k = 4 * kk + kq;
+            const T a0 = Ab[i * PLD + k], a1 = Ab[(16 + i) * PLD + k];
+            const T b0 = Bb[k * PLD + i], b1 = Bb[k * PLD + 16 + i];
+            t[0][0] = BlkMma<T>::mma(a0, b0, t[0][0]);
+            t[0][1] = BlkMma<T>::mma(a0, b1, t[0][1]);
+            t[1][0] = BlkMma<T>::mma(a1, b0, t[1][0]);
+            t[1][1] = BlkMma<T>::mma(a1, b1, t[1][1]);
+        }
+    }
+    // -= Ab (32 x 32) * Bb^T  (Bb row-major [j][k])
+    __device__ __forceinline__ void msub_nt(const T *Ab, const T *Bb, int lane)
+    {
+        const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const int k = 4 * kk + kq;
+            const T a0 = -Ab[i * PLD + k], a1 = -Ab[(16 + i) * PLD + k];
+            const T b0 = Bb[i * PLD + k], b1 = Bb[(16 + i) * PLD + k];
+            t[0][0] = BlkMma<T>::mma(a0, b0, t[0][0]);
+            t[0][1] = BlkMma<T>::mma(a0, b1, t[0][1]);
+            t[1][0] = BlkMma<T>::mma(a1, b0, t[1][0]);
+            t[1][1] = BlkMma<T>::mma(a1, b1, t[1][1]);
+        }
+    }
+    __device__ __forceinline__ void load(const T *g, long ldg, int lane)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    t[i][j][r] = g[(size_t)(16 * i + BlkMma<T>::crow(lane, r)) * ldg + 16 * j + (lane & 15)];
+    }
+    // sign * block -> LDS block (ld PLD, may be null) and / or global (ld ldg, may be null)
+    __device__ __forceinline__ void store(T sign, T *lds, T *g, long ldg, int lane) const
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + BlkMma<T>::crow(lane, r), col = 16 * j + (lane & 15);
+                    const T v = sign * t[i][j][r];
+                    if (lds)
+                        lds[row * PLD + col] = v;
+                    if (g)
+                        g[(size_t)row * ldg + col] = v;
+                }
+    }
+};
+
 template <typename T>
 __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
                                                       T *__restrict__ d, T *__restrict__ dinv,
                                                       int *__restrict__ info, int blk)
 {
     constexpr int DT = DiagThreads<T>::value;
+    constexpr int BLK = NB * PLD;                  // one 32 x 32 LDS block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
-    T *Lp = Pa + TILE * PLD;                       // [TILE][PLD]  panel: L
-    T *Xd = Lp + TILE * PLD;                       // [4][NB][PLD] inverses of the diagonal sub-blocks
-    T *Di = Xd + 4 * NB * PLD;                     // [TILE]       1 / D
-    T *Lt = Di + TILE;                             // [2][NB][NB]  L11 of the current / previous panel, TRANSPOSED
-    // the inverse assembly re-uses the panel region: Xs = 3 off-diagonal blocks, Tb = 3 product blocks
-    T *Xs = Pa;                                    // [3][NB][PLD]  X(1,0), X(2,0), X(2,1)
-    T *Tb = Pa + 3 * NB * PLD;                     // [3][NB][PLD]
+    T *Lt = Pa + TILE * PLD;                       // [2][NB][NB]  L11 of the current / previous panel, TRANSPOSED
+    T *Di = Lt + 2 * NB * NB;                      // [TILE]       1 / D
+    T *Ls = Di + TILE;                             // [6][NB][PLD] L blocks (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2)
+    T *Xd = Ls + 6 * BLK;                          // [4][NB][PLD] inverses of the diagonal sub-blocks
+    // the inverse assembly re-uses Pa | Lt | Di (6400 elements) as six blocks R0 .. R5
+    T *R = Pa;
+    static_assert(6 * BLK <= TILE * PLD + 2 * NB * NB + TILE, "assembly blocks must fit the panel region");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T *Xg = linv + (size_t)blk * TILE * TILE;
+    constexpr int NCW = DT / 64 - 2;             // waves that carry the trailing update (all but the two of step A)
+    constexpr int MAXB = (6 + NCW - 1) / NCW;    // 32 x 32 blocks per such wave (panel 0 has six)
+    BlkAcc<T> cacc[MAXB];
 
     GPX_STAMP(0);
-    for (int jb = 0; jb <= 4; ++jb) {
+    for (int jb = 0; jb < 4; ++jb) {
         const int c0 = NB * jb;
         const int nrows = TILE - c0;
         for (int idx = tid; idx < nrows * NB; idx += DT) {
@@ -133,7 +232,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         GPX_STAMP(1 + 4 * jb);
         // ---- A: wave 0 factorises sub-block jb, wave 1 inverts L of sub-block jb - 1; lane l (and its twin
         //         l + 32) owns row l ----
-        if (wave == 0 && jb < 4) {
+        if (wave == 0) {
             const int l = lane & 31;
             T r[NB];
 #pragma unroll
@@ -192,11 +291,33 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 for (int c = 0; c < NB; ++c)
                     Xd[((jb - 1) * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
             }
+        } else if (wave >= 2) {
+            // the trailing blocks this wave will update in C, in accumulator layout (final since the last barrier)
+#pragma unroll
+            for (int e = 0; e < MAXB; ++e) {
+                const int t = (wave - 2) + NCW * e;
+                if (t < (3 - jb) * (4 - jb) / 2) {
+                    const int bi = t < 1 ? 0 : (t < 3 ? 1 : 2), bj = t - bi * (bi + 1) / 2;
+                    cacc[e].load(A + (size_t)(c0 + NB + NB * bi) * lda + c0 + NB + NB * bj, lda, lane);
+                }
+            }
+            // idle otherwise: the parts of X known by now -- zeros right of the diagonal block in block row jb and
+            // the diagonal block jb - 2 (inverted during the previous interval)
+            for (int idx = tid - 128; idx < NB * (TILE - c0 - NB); idx += DT - 128) {
+                const int w_ = TILE - c0 - NB, r_ = idx / w_, c_ = idx - r_ * w_;
+                Xg[(size_t)(c0 + r_) * TILE + c0 + NB + c_] = T(0);
+            }
+            if (jb >= 2)
+                for (int idx = tid - 128; idx < NB * NB; idx += DT - 128) {
+                    const int b = jb - 2, r_ = idx >> 5, c_ = idx & 31;
+                    Xg[(size_t)(b * NB + r_) * TILE + b * NB + c_] = Xd[(b * NB + r_) * PLD + c_];
+                }
         }
         __syncthreads();
         GPX_STAMP(2 + 4 * jb);
         const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
         if (nb_rows > 0) {
+            T *Lsp = Ls + (jb == 0 ? 0 : (jb == 1 ? 3 : 5)) * BLK;  // L blocks (jb+1 .., jb), rows from c0 + NB
             // ---- B: row i of W solves W L11^T = A21:  w_c = a_ic - sum_{k<c} w_k L11[c][k] ----
             if (tid < nb_rows) {
                 const int i_ = c0 + NB + tid;
@@ -215,44 +336,28 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
                     Pa[i_ * PLD + c] = a[c];
-                    Lp[i_ * PLD + c] = a[c] * Di[c0 + c];
+                    Lsp[tid * PLD + c] = a[c] * Di[c0 + c];
                 }
             }
             __syncthreads();
             GPX_STAMP(3 + 4 * jb);
-            for (int idx = tid; idx < nb_rows * NB; idx += DT) {
-                const int i_ = c0 + NB + (idx >> 5), c_ = idx & 31;
-                A[(size_t)i_ * lda + c0 + c_] = Lp[i_ * PLD + c_];
-            }
-            // ---- C: trailing update on the global block: A[i][k] -= sum_c W[i][c] L[k][c], k <= i ----
-            // lower-triangle entries only, CPT per thread; all global loads are issued before the first use (as a
-            // read-modify-write inside the loop every entry paid its own L2 round trip: ~18 in a row for jb = 0)
-            const int r0 = c0 + NB;
-            constexpr int CPT = ((TILE - NB) * (TILE - NB + 1) / 2 + DT - 1) / DT;
-            const int ntri = nb_rows * (nb_rows + 1) / 2;
-            T creg[CPT];
-            int cpos[CPT];
+            if (wave < 2)
+                for (int idx = tid; idx < nb_rows * NB; idx += 128) {
+                    const int r_ = idx >> 5, c_ = idx & 31;
+                    A[(size_t)(c0 + NB + r_) * lda + c0 + c_] = Lsp[r_ * PLD + c_];
+                }
+            // ---- C: trailing update A22 -= W L21^T, one 32 x 32 block per wave on MFMA (lower blocks; a diagonal
+            //         block is updated whole, its upper half is never read).  The blocks were fetched during A. ----
+            if (wave >= 2) {
+                const int r0 = c0 + NB;
 #pragma unroll
-            for (int e = 0; e < CPT; ++e) {
-                const int t = tid + DT * e;
-                int ii = 0, kk = 0;
-                if (t < ntri)
-                    tri_decode(t, ii, kk);
-                cpos[e] = (ii << 8) | kk;
-                creg[e] = t < ntri ? A[(size_t)(r0 + ii) * lda + r0 + kk] : T(0);
-            }
-#pragma unroll
-            for (int e = 0; e < CPT; ++e) {
-                const int t = tid + DT * e;
-                if (t < ntri) {
-                    const int ii = cpos[e] >> 8, kk = cpos[e] & 255;
-                    const T *wrow = Pa + (r0 + ii) * PLD;
-                    const T *lrow = Lp + (r0 + kk) * PLD;
-                    T s = T(0);
-#pragma unroll
-                    for (int c = 0; c < NB; ++c)
-                        s += wrow[c] * lrow[c];
-                    A[(size_t)(r0 + ii) * lda + r0 + kk] = creg[e] - s;
+                for (int e = 0; e < MAXB; ++e) {
+                    const int t = (wave - 2) + NCW * e;
+                    if (t < (3 - jb) * (4 - jb) / 2) {
+                        const int bi = t < 1 ? 0 : (t < 3 ? 1 : 2), bj = t - bi * (bi + 1) / 2;
+                        cacc[e].msub_nt(Pa + (r0 + NB * bi) * PLD, Lsp + NB * bj * PLD, lane);
+                        cacc[e].store(T(1), (T *)nullptr, A + (size_t)(r0 + NB * bi) * lda + r0 + NB * bj, lda, lane);
+                    }
                 }
             }
         }
@@ -261,55 +366,84 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         GPX_STAMP(4 + 4 * jb);
     }
 
-    // ---- inverse of the 128 x 128 unit-lower L from the four 32 x 32 inverses ----
-    for (int s_ = 1; s_ < 4; ++s_) {
-        // phase 1: T(i,j) = sum_{k=j}^{i-1} L[i][k] X[k][j]  for the 4 - s_ blocks (i = j + s_, j)
-        const int nblocks = 4 - s_;
-        for (int idx = tid; idx < nblocks * NB * NB; idx += DT) {
-            const int b = idx >> 10, r_ = (idx >> 5) & 31, c_ = idx & 31;
-            const int jj = b, ii = b + s_;
-            T acc = T(0);
-            for (int k = jj; k < ii; ++k) {
-                const T *lrow = A + (size_t)(NB * ii + r_) * lda + NB * k;  // L(ii,k) row r_, from global
-                const T *xb = (k == jj) ? Xd + (jj * NB) * PLD
-                                        : Xs + ((k == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB) * PLD;  // X(1,0) | X(2,0) | X(2,1)
-                for (int t = 0; t < NB; ++t)
-                    acc += lrow[t] * xb[t * PLD + c_];
-            }
-            Tb[(b * NB + r_) * PLD + c_] = acc;
+    // ---- inverse of the 128 x 128 unit-lower L ----
+    const T *L10 = Ls, *L20 = Ls + BLK, *L30 = Ls + 2 * BLK, *L21 = Ls + 3 * BLK, *L31 = Ls + 4 * BLK, *L32 = Ls + 5 * BLK;
+    const T *Xd0 = Xd, *Xd1 = Xd + BLK, *Xd2 = Xd + 2 * BLK, *Xd3 = Xd + 3 * BLK;
+    T *R0 = R, *R1 = R + BLK, *R2 = R + 2 * BLK, *R3 = R + 3 * BLK, *R4 = R + 4 * BLK, *R5 = R + 5 * BLK;
+    BlkAcc<T> &acc = cacc[0];
+    // E: wave 1 inverts the last sub-block (reads the second half of Lt = part of R3 .. R5, which stay untouched
+    //    until phase G); waves 2, 3: R0 = L10 Xd0, R1 = L32 Xd2; the rest writes what is already known of X
+    if (wave == 1) {
+        const int l = lane & 31;
+        const T *lt = Lt + NB * NB;
+        T r[NB], x[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            r[c] = lt[c * NB + l];
+        sub_inverse(r, x, l);
+        if (lane < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                Xd[(3 * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
         }
-        __syncthreads();
-        // phase 2: X(i,j) = -Xd[i] * T(i,j)
-        for (int idx = tid; idx < nblocks * NB * NB; idx += DT) {
-            const int b = idx >> 10, r_ = (idx >> 5) & 31, c_ = idx & 31;
-            const int jj = b, ii = b + s_;
-            const T *xdrow = Xd + (ii * NB + r_) * PLD;
-            T acc = T(0);
-            for (int t = 0; t <= r_; ++t)
-                acc += xdrow[t] * Tb[(b * NB + t) * PLD + c_];
-            const T xv = -acc;
-            linv[(size_t)blk * TILE * TILE + (size_t)(NB * ii + r_) * TILE + NB * jj + c_] = xv;
-            if (ii < 3)  // X(1,0), X(2,0), X(2,1) are operands of later steps
-                Xs[((ii == 1 ? 0 : (jj == 0 ? 1 : 2)) * NB + r_) * PLD + c_] = xv;
+    } else if (wave == 2 || wave == 3) {
+        acc.zero();
+        acc.mac(wave == 2 ? L10 : L32, wave == 2 ? Xd0 : Xd2, lane);
+        acc.store(T(1), wave == 2 ? R0 : R1, (T *)nullptr, 0, lane);
+    } else {
+        // diagonal block 2 of X (blocks 0, 1 and the zeros went out during the panel intervals)
+        const int ft = wave == 0 ? lane : 64 + (tid - 256);
+        constexpr int NF = 64 + (DT > 256 ? DT - 256 : 0);
+        for (int idx = ft; idx < NB * NB; idx += NF)
+            Xg[(size_t)(2 * NB + (idx >> 5)) * TILE + 2 * NB + (idx & 31)] = Xd2[(idx >> 5) * PLD + (idx & 31)];
+    }
+    __syncthreads();
+    GPX_STAMP(20);
+    // F: X10 = -Xd1 R0 -> R2, X32 = -Xd3 R1 -> R3 (needs the second half of Lt no more); diagonal block 3
+    if (wave < 2) {
+        acc.zero();
+        acc.mac(wave == 0 ? Xd1 : Xd3, wave == 0 ? R0 : R1, lane);
+        acc.store(T(-1), wave == 0 ? R2 : R3, wave == 0 ? Xg + (size_t)NB * TILE : Xg + (size_t)3 * NB * TILE + 2 * NB, TILE,
+                  lane);
+    } else {
+        for (int idx = tid - 128; idx < NB * NB; idx += DT - 128)
+            Xg[(size_t)(3 * NB + (idx >> 5)) * TILE + 3 * NB + (idx & 31)] = Xd3[(idx >> 5) * PLD + (idx & 31)];
+    }
+    __syncthreads();
+    GPX_STAMP(21);
+    // G: T = L_BA X_A: T20 = L20 Xd0 + L21 X10 -> R0, T30 = L30 Xd0 + L31 X10 -> R1, T21 = L21 Xd1 -> R4, T31 = L31 Xd1 -> R5
+    if (wave < 4) {
+        acc.zero();
+        if (wave < 2) {
+            acc.mac(wave == 0 ? L20 : L30, Xd0, lane);
+            acc.mac(wave == 0 ? L21 : L31, R2, lane);
+        } else {
+            acc.mac(wave == 2 ? L21 : L31, Xd1, lane);
         }
-        __syncthreads();
-        GPX_STAMP(20 + s_);
+        // R0, R1 were last read in F; R4 / R5 overlap Lt and Di, dead since E / the last panel
+        acc.store(T(1), wave == 0 ? R0 : (wave == 1 ? R1 : (wave == 2 ? R4 : R5)), (T *)nullptr, 0, lane);
     }
-    // diagonal blocks and the zero upper part
-    for (int idx = tid; idx < TILE * TILE; idx += DT) {
-        const int r_ = idx >> 7, c_ = idx & 127;
-        const int bi = r_ >> 5, bj = c_ >> 5;
-        if (bj > bi)
-            linv[(size_t)blk * TILE * TILE + idx] = T(0);
-        else if (bj == bi)
-            linv[(size_t)blk * TILE * TILE + idx] = Xd[(bi * NB + (r_ & 31)) * PLD + (c_ & 31)];
+    __syncthreads();
+    GPX_STAMP(22);
+    // H: X_BA = -X_B T: X20 = -Xd2 T20, X30 = -(X32 T20 + Xd3 T30), X21 = -Xd2 T21, X31 = -(X32 T21 + Xd3 T31)
+    if (wave < 4) {
+        const T *Tt = (wave & 1) ? R4 : R0, *Tb = (wave & 1) ? R5 : R1;  // column 0: waves 0, 2; column 1: waves 1, 3
+        acc.zero();
+        if (wave < 2) {
+            acc.mac(Xd2, Tt, lane);
+        } else {
+            acc.mac(R3, Tt, lane);
+            acc.mac(Xd3, Tb, lane);
+        }
+        acc.store(T(-1), (T *)nullptr, Xg + (size_t)(wave < 2 ? 2 : 3) * NB * TILE + (wave & 1) * NB, TILE, lane);
     }
+    GPX_STAMP(23);
     GPX_STAMP(24);
 }
 
 static size_t diag_shmem_bytes(size_t esz)
 {
-    return esz * (size_t)(2 * TILE * PLD + 4 * NB * PLD + TILE + 2 * NB * NB);  // Pa + Lp + Xd + Di + Lt
+    return esz * (size_t)(TILE * PLD + 2 * NB * NB + TILE + 6 * NB * PLD + 4 * NB * PLD);  // Pa + Lt + Di + Ls + Xd
 }
 
 template <typename T>
