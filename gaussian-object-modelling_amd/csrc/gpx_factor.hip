@@ -18,10 +18,11 @@
 
 namespace gpx {
 
-// threads of the diagonal-block kernel: step A keeps two 32-entry rows in registers (fp32 ~180, fp64 ~300 VGPRs)
+// threads of the diagonal-block kernel: 8 waves -- one factorises a sub-block, one inverts the previous one, six
+// carry the trailing update (one 32 x 32 block each); at most 256 VGPRs per lane (fp64 spills 24 of them)
 template <typename T>
 struct DiagThreads {
-    static constexpr int value = sizeof(T) == 8 ? 256 : 512;
+    static constexpr int value = 512;
 };
 constexpr int NB = 32;    // sub-block order inside the 128 x 128 diagonal block
 constexpr int PLD = NB + 1;
@@ -47,8 +48,8 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 //                           (static indices; pivot rows / columns travel by v_readlane, no barrier); in the same
 //                           interval wave 1 inverts the PREVIOUS sub-block's L the same way, so the inverses --
 //                           needed only by the assembly at the end -- are off the critical path,
-//                        B) the rows below: W L11^T = A21 by forward substitution, one thread per row with the
-//                           row in registers (L11 is read as LDS broadcasts); L21 = W D^-1,
+//                        B) the rows below: W L11^T = A21 by forward substitution, the row in the registers of
+//                           4 (fp64: 2) adjacent lanes, pivots by DPP, L11 from LDS; L21 = W D^-1,
 //                        C) the trailing update A22 -= W L21^T on the (L2-resident) global block, panel
 //                           operands in LDS.
 //   then the 128 x 128 inverse X of L is assembled from the four 32 x 32 inverses Xd and the six L blocks (all
@@ -61,29 +62,74 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 // on the second wave + substitution: 90 / 159 us; assembly on MFMA: see DESIGN.md section 4.  A fully
 // register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
 
-// step C_ of the row substitution of phase B: prefetch column C_ + 1 of L11, eliminate with column C_
-template <typename T, int C_>
+// 1 / x to within an ulp or two by Newton steps on the hardware estimate: the IEEE division sequence (12 fp32 /
+// ~25 fp64 instructions) sat on the dependency chain of every pivot column.  Zero, infinite or NaN pivots give a
+// non-finite result, which the caller has already flagged.
+__device__ __forceinline__ float fast_rcp(float x)
+{
+    float y = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, y, 1.0f), y, y);
+}
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+__device__ __forceinline__ float pivot_huge(float) { return 3.0e38f; }
+__device__ __forceinline__ double pivot_huge(double) { return 1e300; }
+
+// Phase B of diag_ldl: a row of W L11^T = A21 is shared by G adjacent lanes, lane q of the group owning the columns
+// q + G m.  Step C_ takes w_C from its owner by a DPP quad permute and eliminates it from the columns right of it
+// (L11 is stored with zeros on and above the diagonal, so "right of it" needs no per-lane test); the lane's slice
+// of column C_ + 1 of L11 is fetched one step ahead -- left to itself the compiler issued every LDS read just
+// before its FMA and waited for it.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// position of row l of L11 inside a column of Lt: the M rows of one lane slot are contiguous
+template <int G>
+__device__ __forceinline__ int lt_slot(int l)
+{
+    return (l % G) * (NB / G) + l / G;
+}
+template <typename T, int G, int C_>
 struct SubstStep {
-    static __device__ __forceinline__ void run(T (&a)[NB], T (&lc)[NB], T (&ln)[NB], const T *lt)
+    static constexpr int M = NB / G;
+    static __device__ __forceinline__ void run(T (&a)[M], T (&lc)[M], T (&ln)[M], const T *ltq)
     {
         if constexpr (C_ < NB - 1) {
-            constexpr int Q0 = ((C_ + 2) / 4) * 4;  // first aligned quad of column C_ + 1 that is still needed
+            constexpr int MO = C_ / G, QO = C_ % G;        // owner of column C_: slot MO of lane QO
+            constexpr int MN = (C_ + 1) / G;               // first slot column C_ + 1 still needs
+            constexpr int EPV = 16 / sizeof(T);            // elements per 16-byte LDS read
+            constexpr int M0 = MN / EPV * EPV;
 #pragma unroll
-            for (int c2 = Q0; c2 < NB; ++c2)
-                ln[c2] = lt[(C_ + 1) * NB + c2];
-            const T w = a[C_];
+            for (int m = M0; m < M; ++m)
+                ln[m] = ltq[(C_ + 1) * NB + m];
+            constexpr int CTRL = G == 4 ? QO * 0x55 : (QO | (QO << 2) | ((2 + QO) << 4) | ((2 + QO) << 6));
+            const T w = dpp_quad<CTRL>(a[MO]);
 #pragma unroll
-            for (int c2 = C_ + 1; c2 < NB; ++c2)
-                a[c2] -= w * lc[c2];
-            constexpr int NREAD = (NB - Q0) / 4 * (sizeof(T) == 8 ? 2 : 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);       // DS reads of the next column first
-            __builtin_amdgcn_sched_group_barrier(0x002, NB - 1 - C_, 0);  // then this column's FMAs
-            SubstStep<T, C_ + 1>::run(a, ln, lc, lt);
+            for (int m = MO; m < M; ++m)
+                a[m] -= w * lc[m];
+            __builtin_amdgcn_sched_group_barrier(0x100, (M - M0) / EPV, 0);  // DS reads of the next column first
+            __builtin_amdgcn_sched_group_barrier(0x002, M - MO + 1, 0);      // then this column's DPP move and FMAs
+            SubstStep<T, G, C_ + 1>::run(a, ln, lc, ltq);
         }
     }
 };
 
 // unit-lower inverse of a 32 x 32 L held as r[c] = L[l][c] in lane l:  X[l][j] = -( L[l][j] + sum_{j<k<l} X[l][k] L[k][j] )
+// (reading column j of L from Lt as uniform LDS reads instead of v_readlane was measured slower: 5.2 vs 4.2 us)
 template <typename T>
 __device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
 {
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
     constexpr int BLK = NB * PLD;                  // one 32 x 32 LDS block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
-    T *Lt = Pa + TILE * PLD;                       // [2][NB][NB]  L11 of the current / previous panel, TRANSPOSED
+    T *Lt = Pa + TILE * PLD;                       // [2][NB][NB]  L11 of the current / previous panel: [column][lt_slot(row)]
     T *Di = Lt + 2 * NB * NB;                      // [TILE]       1 / D
     T *Ls = Di + TILE;                             // [6][NB][PLD] L blocks (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2)
     T *Xd = Ls + 6 * BLK;                          // [4][NB][PLD] inverses of the diagonal sub-blocks
@@ -216,6 +262,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
     static_assert(6 * BLK <= TILE * PLD + 2 * NB * NB + TILE, "assembly blocks must fit the panel region");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T *Xg = linv + (size_t)blk * TILE * TILE;
+    constexpr int BG = DT / 128;                 // lanes that share a row in phase B
     constexpr int NCW = DT / 64 - 2;             // waves that carry the trailing update (all but the two of step A)
     constexpr int MAXB = (6 + NCW - 1) / NCW;    // 32 x 32 blocks per such wave (panel 0 has six)
     BlkAcc<T> cacc[MAXB];
@@ -224,11 +271,6 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
     for (int jb = 0; jb < 4; ++jb) {
         const int c0 = NB * jb;
         const int nrows = TILE - c0;
-        for (int idx = tid; idx < nrows * NB; idx += DT) {
-            const int r_ = idx >> 5, c_ = idx & 31;
-            Pa[(c0 + r_) * PLD + c_] = A[(size_t)(c0 + r_) * lda + c0 + c_];
-        }
-        __syncthreads();
         GPX_STAMP(1 + 4 * jb);
         // ---- A: wave 0 factorises sub-block jb, wave 1 inverts L of sub-block jb - 1; lane l (and its twin
         //         l + 32) owns row l ----
@@ -237,20 +279,20 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
             T r[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c)
-                r[c] = Pa[(c0 + l) * PLD + c];
+                r[c] = A[(size_t)(c0 + l) * lda + c0 + c];  // straight from global: no staging, no barrier
             T dmine = T(1);
             int nneg = 0;
             bool bad = false;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const T dj = bcast_lane(r[j], j);
-                if (!(fabs((double)dj) > 0.0) || !(fabs((double)dj) < 1e300))
+                if (!(fabs(dj) > T(0)) || !(fabs(dj) < pivot_huge(T(0))))
                     bad = true;
                 if (dj < T(0))
                     ++nneg;
                 if (l == j)
                     dmine = dj;
-                const T lij = r[j] * (T(1) / dj);
+                const T lij = r[j] * fast_rcp(dj);
 #pragma unroll
                 for (int k = j + 1; k < NB; ++k) {
                     const T akj = bcast_lane(r[j], k);  // a_kj (still un-scaled in lane k)
@@ -263,7 +305,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
                 T *lt = Lt + (jb & 1) * NB * NB;
 #pragma unroll
                 for (int c = 0; c < NB; ++c) {
-                    lt[c * NB + l] = c < l ? r[c] : T(0);  // L11[l][c], column c contiguous
+                    lt[c * NB + lt_slot<BG>(l)] = c < l ? r[c] : T(0);  // L11[l][c], zero on / above the diagonal
                     if (c < l)
                         A[(size_t)(c0 + l) * lda + c0 + c] = r[c];
                 }
@@ -284,14 +326,23 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
             T r[NB], x[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c)
-                r[c] = lt[c * NB + l];
+                r[c] = lt[c * NB + lt_slot<BG>(l)];
             sub_inverse(r, x, l);
             if (lane < NB) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c)
                     Xd[((jb - 1) * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
             }
-        } else if (wave >= 2) {
+        }
+        if (wave >= 2 || (wave == 1 && jb == 0)) {
+            // the panel rows below the sub-block -> Pa (they are needed from phase B on)
+            const int first = jb == 0 ? 64 : 128;
+            for (int idx = tid - first; idx < (nrows - NB) * NB; idx += DT - first) {
+                const int r_ = idx >> 5, c_ = idx & 31;
+                Pa[(c0 + NB + r_) * PLD + c_] = A[(size_t)(c0 + NB + r_) * lda + c0 + c_];
+            }
+        }
+        if (wave >= 2) {
             // the trailing blocks this wave will update in C, in accumulator layout (final since the last barrier)
 #pragma unroll
             for (int e = 0; e < MAXB; ++e) {
@@ -318,25 +369,23 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
         if (nb_rows > 0) {
             T *Lsp = Ls + (jb == 0 ? 0 : (jb == 1 ? 3 : 5)) * BLK;  // L blocks (jb+1 .., jb), rows from c0 + NB
-            // ---- B: row i of W solves W L11^T = A21:  w_c = a_ic - sum_{k<c} w_k L11[c][k] ----
-            if (tid < nb_rows) {
-                const int i_ = c0 + NB + tid;
-                const T *lt = Lt + (jb & 1) * NB * NB;
-                T a[NB];
+            // ---- B: row i of W solves W L11^T = A21:  w_c = a_ic - sum_{k<c} w_k L11[c][k]; BG lanes per row ----
+            if (tid < nb_rows * BG) {
+                constexpr int M = NB / BG;
+                const int row = tid / BG, q = tid % BG;
+                const int i_ = c0 + NB + row;
+                const T *ltq = Lt + (jb & 1) * NB * NB + q * M;
+                T a[M], lc[M], ln[M];
 #pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    a[c] = Pa[i_ * PLD + c];
-                // column c of L11 (contiguous in Lt) is fetched whole, one column ahead of its use: left to itself
-                // the compiler issued every LDS read just before its FMA and waited for it (7 us for this loop)
-                T lc[NB], ln[NB];
+                for (int m = 0; m < M; ++m) {
+                    a[m] = Pa[i_ * PLD + q + BG * m];
+                    lc[m] = ltq[m];
+                }
+                SubstStep<T, BG, 0>::run(a, lc, ln, ltq);
 #pragma unroll
-                for (int c2 = 0; c2 < NB; ++c2)
-                    lc[c2] = lt[c2];
-                SubstStep<T, 0>::run(a, lc, ln, lt);
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    Pa[i_ * PLD + c] = a[c];
-                    Lsp[tid * PLD + c] = a[c] * Di[c0 + c];
+                for (int m = 0; m < M; ++m) {
+                    Pa[i_ * PLD + q + BG * m] = a[m];
+                    Lsp[row * PLD + q + BG * m] = a[m] * Di[c0 + q + BG * m];
                 }
             }
             __syncthreads();
@@ -379,7 +428,7 @@ __global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__re
         T r[NB], x[NB];
 #pragma unroll
         for (int c = 0; c < NB; ++c)
-            r[c] = lt[c * NB + l];
+            r[c] = lt[c * NB + lt_slot<BG>(l)];
         sub_inverse(r, x, l);
         if (lane < NB) {
 #pragma unroll

@@ -51,7 +51,7 @@ static void run(const char *name, int prec)
             std::vector<T> F((size_t)n * n), X((size_t)n * n);
             hipMemcpy(F.data(), dA, sizeof(T) * n * n, hipMemcpyDeviceToHost);
             hipMemcpy(X.data(), dL, sizeof(T) * n * n, hipMemcpyDeviceToHost);
-            double e1 = 0, e2 = 0;
+            double err1 = 0, err2 = 0;
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j <= i; ++j) {
                     double s = 0, t = 0;
@@ -62,10 +62,24 @@ static void run(const char *name, int prec)
                     }
                     for (int k = j; k <= i; ++k)
                         t += (double)X[(size_t)i * n + k] * (k == j ? 1.0 : (double)F[(size_t)k * n + j]);
-                    e1 = std::fmax(e1, std::fabs(s - (double)A[(size_t)i * n + j]));
-                    e2 = std::fmax(e2, std::fabs(t - (i == j ? 1.0 : 0.0)));
+                    err1 = std::fmax(err1, std::fabs(s - (double)A[(size_t)i * n + j]));
+                    err2 = std::fmax(err2, std::fabs(t - (i == j ? 1.0 : 0.0)));
                 }
-            printf("  max |L D L^T - A| = %.3e   max |linv L - I| = %.3e\n", e1, e2);
+            printf("  max |L D L^T - A| = %.3e   max |linv L - I| = %.3e\n", err1, err2);
+            // back-to-back launches on fresh copies of the block: average duration incl. dispatch
+            const int NL = 256;
+            T *many;
+            hipMalloc(&many, sizeof(T) * n * n * NL);
+            for (int c = 0; c < NL; ++c)
+                hipMemcpy(many + (size_t)c * n * n, A.data(), sizeof(T) * n * n, hipMemcpyHostToDevice);
+            hipEventRecord(e0, 0);
+            for (int c = 0; c < NL; ++c)
+                launch_diag_ldl(prec, many + (size_t)c * n * n, n, dL, dd, ddi, info, 0, 0);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("  %d back-to-back launches: %.1f us each\n", NL, ms * 1e3 / NL);
+            hipFree(many);
         }
     }
 }
