@@ -164,6 +164,14 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx)
 // ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
 static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 {
+    static const bool by_steps = [] {
+        const char *e = getenv("GPX_SOLVE_STEPS");  // 1: one launch per block step (the older path, kept for A/B runs)
+        return e && atoi(e) != 0;
+    }();
+    if (!by_steps) {
+        launch_tri_solve(m->prec, m->nblk, m->Kmat, m->npad, m->linv, m->t_dinv, b, ytmp, x, m->d_info, m->stream);
+        return;
+    }
     for (int kb = 0; kb < m->nblk; ++kb)
         launch_fwd_step(m->prec, kb, m->nblk, m->Kmat, m->npad, m->linv, b, ytmp, m->stream);
     launch_scale_vec(m->prec, m->npad, ytmp, m->t_dinv, m->stream);
@@ -564,7 +572,7 @@ int build_model(gpx_model *m, kept_factor *keep)
     (void)hipEventRecord(m->ev[EV_NORMALS], s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    int info[4];
+    int info[8];
     double rmax = 0;
     HIPCHK(hipMemcpy(info, m->d_info, sizeof(info), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&rmax, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost));
@@ -589,6 +597,9 @@ int build_model(gpx_model *m, kept_factor *keep)
     m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);
     m->stats.ir_steps_done = ir;
     m->stats.alpha_residual = rmax;
+    if (info[5] != 0)
+        return fail(GPX_E_HIP, "block substitution: a workgroup gave up waiting for its predecessor (GPX_SOLVE_STEPS=1 "
+                               "selects the launch-per-step path)");
     if (info[0] != 0)
         return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(info[0] - 1));
     // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64

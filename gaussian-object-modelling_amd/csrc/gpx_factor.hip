@@ -679,6 +679,210 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(int kb, const T *__restri
         y[cb * TILE + tid] -= upd[tid];
 }
 
+// ---- the whole substitution in one launch per direction ------------------------------------------------------
+// Workgroup i owns block row i of L y = b: it subtracts L(i,k) y_k for k = 0 .. i-1 as the y_k appear and then
+// publishes y_i = Linv_i b_i.  The output vector is filled with a sentinel (all-ones NaN, which arithmetic never
+// produces) before the launch and every consumer polls the entries it needs with cache-bypassing loads until they
+// are no sentinel any more: the data validates itself, no flag, no fence.  Workgroups are dispatched in blockIdx
+// order and wait only for lower ones, so the scheme cannot deadlock even when not all of them are resident.  The
+// 128 x 128 block of the NEXT step (the last one: Linv_i) is loaded into a second register set before the poll of
+// the current one, so a block costs a poll round trip and a register matvec (~2.5 us) -- with the loads behind the
+// poll it was 8 us and the 127 blocks of the last row took as long as 256 step launches.  A poll that exceeds
+// SOLVE_SPIN_LIMIT gives up and raises info[5]: a failed call is better than a hung GPU.
+// The backward direction runs the same scheme bottom-up on L^T, with D^-1 folded into its start.
+constexpr int SOLVE_SPIN_LIMIT = 1 << 21;
+
+template <typename T>
+__device__ __forceinline__ void block_load(const T *__restrict__ M, long ldm, T (&m0)[32], T (&m1)[32])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+        const T *row = M + (size_t)(wave * 32 + rr) * ldm;
+        m0[rr] = row[lane];
+        m1[rr] = row[lane + 64];
+    }
+}
+// out = M v with M in the registers filled by block_load
+template <typename T>
+__device__ __forceinline__ void block_mv_regs(const T (&m0)[32], const T (&m1)[32], const T *v_lds, T *out_lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T v0 = v_lds[lane], v1 = v_lds[lane + 64];
+    T s[32];
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr)
+        s[rr] = m0[rr] * v0 + m1[rr] * v1;
+#define GPX_HALVE(N, OFF)                                       \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i)             \
+    {                                                           \
+        const bool up = (lane & (OFF)) != 0;                    \
+        const T send = up ? s[i] : s[i + (N)];                  \
+        const T keep = up ? s[i + (N)] : s[i];                  \
+        s[i] = keep + __shfl_xor(send, (OFF));                  \
+    }
+    GPX_HALVE(16, 32)
+    GPX_HALVE(8, 16)
+    GPX_HALVE(4, 8)
+    GPX_HALVE(2, 4)
+    GPX_HALVE(1, 2)
+#undef GPX_HALVE
+    s[0] += __shfl_xor(s[0], 1);
+    if ((lane & 1) == 0)
+        out_lds[wave * 32 + (lane >> 1)] = s[0];
+}
+// transposed: thread (c = tid & 127, hh = tid >> 7) holds rows hh*64 .. +63 of column c
+template <typename T>
+__device__ __forceinline__ void block_load_t(const T *__restrict__ M, long ldm, T (&mv)[64])
+{
+    const int c = threadIdx.x & 127, hh = threadIdx.x >> 7;
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+        mv[rr] = M[(size_t)(hh * 64 + rr) * ldm + c];
+}
+template <typename T>
+__device__ __forceinline__ void block_mv_regs_t(const T (&mv)[64], const T *v_lds, T *out_lds, T *scratch_lds)
+{
+    const int c = threadIdx.x & 127, hh = threadIdx.x >> 7;
+    T s = T(0);
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+        s += mv[rr] * v_lds[hh * 64 + rr];
+    if (hh == 1)
+        scratch_lds[c] = s;
+    __syncthreads();
+    if (hh == 0)
+        out_lds[c] = s + scratch_lds[c];
+}
+
+// entry *p of the shared vector once it is no sentinel any more (0 and info[5] = 1 after SOLVE_SPIN_LIMIT polls)
+__device__ __forceinline__ float poll_entry(const float *p, int *info)
+{
+    const unsigned *u = reinterpret_cast<const unsigned *>(p);
+    for (int spins = 0; spins < SOLVE_SPIN_LIMIT; ++spins) {
+        const unsigned b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != 0xffffffffu)
+            return __uint_as_float(b);
+        __builtin_amdgcn_s_sleep(1);
+    }
+    atomicExch(&info[5], 1);
+    return 0.0f;
+}
+__device__ __forceinline__ double poll_entry(const double *p, int *info)
+{
+    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(p);
+    for (int spins = 0; spins < SOLVE_SPIN_LIMIT; ++spins) {
+        const unsigned long long b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b != 0xffffffffffffffffull)
+            return __longlong_as_double((long long)b);
+        __builtin_amdgcn_s_sleep(1);
+    }
+    atomicExch(&info[5], 1);
+    return 0.0;
+}
+__device__ __forceinline__ void publish_entry(float *p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish_entry(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// TRANS = false: L y = b, rows top-down.  TRANS = true: L^T x = D^-1 y, rows bottom-up (scale = 1/D).
+// `out` must hold the sentinel in every entry at launch.
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__restrict__ L, long ld,
+                                                        const T *__restrict__ linv, const T *__restrict__ scale,
+                                                        const T *__restrict__ rhs, T *out, int *info)
+{
+    __shared__ T vk[TILE], upd[TILE], scratch[TILE];
+    constexpr int RS = TRANS ? 64 : 32;  // registers of one half block set
+    const int tid = threadIdx.x;
+    const int i = TRANS ? nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int nprev = TRANS ? nblk - 1 - i : i;  // blocks this row depends on, in the order they get ready
+    T acc = T(0);                                // entry tid of the working right-hand side (tid < TILE)
+    if (tid < TILE)
+        acc = TRANS ? rhs[i * TILE + tid] * scale[i * TILE + tid] : rhs[i * TILE + tid];
+    // block s of the sequence: L(i, s) (TRANS: L(nblk-1-s, i)) for s < nprev, then the inverse diagonal block
+    auto src = [&](int s) -> const T * {
+        if (s >= nprev)
+            return linv + (size_t)i * TILE * TILE;
+        return TRANS ? L + (size_t)(nblk - 1 - s) * TILE * ld + (size_t)i * TILE : L + (size_t)i * TILE * ld + (size_t)s * TILE;
+    };
+    auto ldm = [&](int s) -> long { return s >= nprev ? (long)TILE : ld; };
+    T a0[RS], a1[TRANS ? 1 : 32], b0[RS], b1[TRANS ? 1 : 32];
+    auto load = [&](int s, T(&r0)[RS], T(&r1)[TRANS ? 1 : 32]) {
+        if constexpr (TRANS)
+            block_load_t<T>(src(s), ldm(s), r0);
+        else
+            block_load<T>(src(s), ldm(s), r0, r1);
+    };
+    auto mv = [&](const T(&r0)[RS], const T(&r1)[TRANS ? 1 : 32]) {
+        if constexpr (TRANS)
+            block_mv_regs_t<T>(r0, vk, upd, scratch);
+        else
+            block_mv_regs<T>(r0, r1, vk, upd);
+    };
+    // one step: the block in (r0, r1) times the published vector block of step s
+    auto step = [&](int s, const T(&r0)[RS], const T(&r1)[TRANS ? 1 : 32]) {
+        const int k = TRANS ? nblk - 1 - s : s;
+        if (tid < TILE)
+            vk[tid] = poll_entry(out + k * TILE + tid, info);
+        __syncthreads();
+        mv(r0, r1);
+        __syncthreads();
+        if (tid < TILE)
+            acc -= upd[tid];
+    };
+    load(0, a0, a1);
+    bool last_in_b = false;
+    for (int s = 0; s < nprev; s += 2) {
+        load(s + 1, b0, b1);
+        step(s, a0, a1);
+        if (s + 1 < nprev) {
+            load(s + 2, a0, a1);
+            step(s + 1, b0, b1);
+        } else {
+            last_in_b = true;
+        }
+    }
+    if (tid < TILE)
+        vk[tid] = acc;
+    __syncthreads();
+    if (last_in_b)
+        mv(b0, b1);
+    else
+        mv(a0, a1);
+    __syncthreads();
+    if (tid < TILE)
+        publish_entry(out + i * TILE + tid, upd[tid]);
+}
+
+template <typename T>
+static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b, void *y,
+                        void *x, int *info, hipStream_t st)
+{
+    const size_t words = (size_t)nblk * TILE * (sizeof(T) / 4);
+    (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, words, st);
+    (void)hipMemsetD32Async((hipDeviceptr_t)x, (int)0xffffffff, words, st);
+    hipLaunchKernelGGL((tri_solve_kernel<T, false>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
+                       (const T *)nullptr, (const T *)b, (T *)y, info);
+    hipLaunchKernelGGL((tri_solve_kernel<T, true>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
+                       (const T *)dinv, (const T *)y, (T *)x, info);
+}
+
+// x = (L D L^T)^-1 b (y: scratch of the same length), two launches
+void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b,
+                      void *y, void *x, int *info, hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)
+        tri_solve_t<double>(nblk, L, ld, linv, dinv, b, y, x, info, st);
+    else
+        tri_solve_t<float>(nblk, L, ld, linv, dinv, b, y, x, info, st);
+}
+
 void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const void *linv, void *b, void *y,
                      hipStream_t st)
 {

@@ -156,6 +156,10 @@ void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const v
                      hipStream_t st);
 void launch_bwd_step(int prec, int kb, const void *L, long ld, const void *linv_blocks, void *y, void *x,
                      hipStream_t st);
+// the same substitution, one launch per direction (workgroup per block row, self-validating entries between them):
+// x = (L D L^T)^-1 b, y: scratch of the same length; info[5] = 1 when a wait gave up
+void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv_blocks, const void *dinv,
+                      const void *b, void *y, void *x, int *info, hipStream_t st);
 void factor_init(int prec);  // per-device one-time kernel attributes (LDS size of diag_ldl)
 void launch_scale_vec(int prec, int npad, void *b, const void *dinv, hipStream_t st);
 

@@ -84,7 +84,7 @@ struct gpx_model {
     void *linv = nullptr;  // nblk x 128 x 128
     void *Wp = nullptr;    // npad x 512 panel workspace
     void *X = nullptr;     // npad x npad inverse factor (state blob part 1)
-    int *d_info = nullptr; // [0] first bad pivot (1-based), [1] negative pivots, [2..3] argmax pair
+    int *d_info = nullptr; // [0] first bad pivot (1-based), [1] negative pivots, [2..3] argmax pair; [5] substitution gave up
     float *d_tmax = nullptr;
     int *d_tij = nullptr;
     // evaluation workspaces (grown on demand, guarded by mtx)
