@@ -185,7 +185,8 @@ static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 // place) and the update of the remaining columns of the panel; then ONE trailing update with K = panel width.
 // Measured at N = 16384 fp32: 512-wide panels give a trailing tile 16 k-tiles instead of 8 (100.6 -> 112 TFLOP/s,
 // LDL^T 31.8 -> 30.8 ms), but the longer fp32 accumulations cost the ill-conditioned thin-plate system accuracy
-// (alpha after two refinement steps 2.9e-5 instead of < 1e-5 of the fp64 result), so 256 stays the default.
+// (alpha after two refinement steps 2.9e-5 instead of < 1e-5 of the fp64 result), so 256 stays the fp32 default;
+// fp64 factorisations use 512 (GPX_PANEL=256 / 512 forces either).
 // Columns before c_start (a multiple of 128) are taken as already factorised and applied (rank-n update).
 static void factorize(gpx_model *m, int c_start = 0)
 {
@@ -244,10 +245,13 @@ static void factorize(gpx_model *m, int c_start = 0)
             trailing(c0, c0 + TILE, TILE);
         c0 += TILE;
     }
-    static const int wide = [] {
+    static const int wide_env = [] {
         const char *e = std::getenv("GPX_PANEL");
-        return e && std::atoi(e) == WIDE_PANEL ? WIDE_PANEL : PANEL;
+        return e ? std::atoi(e) : 0;
     }();
+    // fp64 has no accuracy to lose to the longer accumulations: 512-wide panels there (LDL^T at N = 16384: 43.1 -> 40.0 ms)
+    const int wide = wide_env == WIDE_PANEL ? WIDE_PANEL
+                                            : (wide_env == PANEL ? PANEL : (m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL));
     while (c0 < np) {
         const int pw = std::min(wide, np - c0), nb = pw / TILE;
         for (int h = 0; h < nb; ++h) {
