@@ -164,10 +164,8 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx)
 // ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
 static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
 {
-    static const bool by_steps = [] {
-        const char *e = getenv("GPX_SOLVE_STEPS");  // 1: one launch per block step (the older path, kept for A/B runs)
-        return e && atoi(e) != 0;
-    }();
+    const char *e = getenv("GPX_SOLVE_STEPS");  // 1: one launch per block step (the older path, kept for A/B runs)
+    const bool by_steps = e && atoi(e) != 0;
     if (!by_steps) {
         launch_tri_solve(m->prec, m->nblk, m->Kmat, m->npad, m->linv, m->t_dinv, b, ytmp, x, m->d_info, m->stream);
         return;

@@ -2,13 +2,15 @@
 // triangular solves (gfx950).  Replaces Eigen::LDLT<MatrixXd>::compute / ::solve as used by the
 // reference (gp_regressor.hpp:161-163); the O(N^3) work is in gpx_gemm.hip.
 //
-//   diag_ldl   : one 128 x 128 diagonal block by one workgroup: right-looking LDL^T blocked by 32 (the 32 x 32
-//                sub-block is factorised and inverted by one wave in registers), no pivoting inside the block
-//                (the Eigen rule picks pivots from the ORIGINAL diagonal, so the permutation is applied to the
-//                points before kbuild), then the unit-lower inverse of L assembled from the four 32 x 32
-//                inverses.  The inverse blocks turn every panel solve and every block substitution into
-//                matrix products.  identity_blocks: the same result for blocks that lie in the padding.
-//   fwd / bwd  : one launch per block step of L y = b / L^T x = y using the inverse blocks.
+//   diag_ldl   : one 128 x 128 diagonal block by one workgroup of 8 waves: right-looking LDL^T blocked by 32 (the
+//                32 x 32 sub-block is factorised by one wave in registers, the rows below by substitution, the
+//                trailing update on MFMA), no pivoting inside the block (the Eigen rule picks pivots from the
+//                ORIGINAL diagonal, so the permutation is applied to the points before kbuild), then the unit-lower
+//                inverse of L assembled from the four 32 x 32 inverses on MFMA.  The inverse blocks turn every
+//                panel solve and every block substitution into matrix products.  identity_blocks: the same result
+//                for blocks that lie in the padding.
+//   tri_solve  : L y = b and L^T x = D^-1 y in one launch each (a workgroup per block row, results handed on
+//                through self-validating entries); fwd / bwd step kernels: the same, one launch per block step.
 #include "gpx_internal.hpp"
 
 // phase timing of diag_ldl_kernel for scripts/diag_bench.hip (which defines GPX_STAMP); nothing in the library build

@@ -239,6 +239,28 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, monkeyp
     fresh.close()
 
 
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("kname,kpar", [("matern52", (1.0, 1.0)), ("thinplate", (2.0,))])
+@pytest.mark.parametrize("n", [100, 277, 1500, 2305])
+def test_one_launch_substitution_equals_step_launches(gpu, ds, prec, kname, kpar, n, monkeypatch):
+    """LDLT::solve (gp_regressor.hpp:163): the substitution in one launch per direction (workgroup per block row,
+    self-validating hand-over) gives the alpha of the launch-per-block-step path (GPX_SOLVE_STEPS=1); 1 .. 19 block
+    rows, a well-conditioned and an indefinite, ill-conditioned system.  No refinement: the raw solve."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel(kname, *kpar)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GPX_SOLVE_STEPS", mode)
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, ir_steps=0)
+        res[mode] = (gm.alpha.copy(), gm.stats["alpha_residual"])
+        gm.close()
+    # the two paths sum in different orders: equal up to the conditioning of the system times the working precision
+    tol = {("matern52", 1): 1e-11, ("thinplate", 1): 1e-6, ("matern52", 0): 1e-3}.get((kname, prec))
+    if tol is not None:
+        assert nerr(res["0"][0], res["1"][0]) < tol
+    assert res["0"][1] < 20 * res["1"][1] + 1e-12  # and the residual is no worse
+
+
 def test_update_with_a_different_noise_level_falls_back_to_rebuild(gpu, orc, ds):
     """Appended points with a larger sigma2 come FIRST in Eigen's pivot order: not an append, the model is rebuilt."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(400)
