@@ -273,6 +273,10 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
                 HIPCHK(hipMemcpy(hd.data(), keep.d, e * t0, hipMemcpyDeviceToHost));
                 for (int i = 0; i < t0; ++i)
                     keep.n_neg += (e == 8 ? ((const double *)hd.data())[i] : (double)((const float *)hd.data())[i]) < 0.0;
+                if (m->has_inverse && m->X) {  // the inverse factor grows by the new rows too (gpx_build.hip)
+                    keep.X = m->X;
+                    m->X = nullptr;
+                }
             }
         }
     }

@@ -57,6 +57,9 @@ void free_dev(gpx_model *m)
     for (auto &e : m->gemm_ev)
         (void)hipEventDestroy(e);
     m->gemm_ev.clear();
+    // timings of an evaluate() that were not read yet refer to the events just destroyed
+    m->stats_eval_pending = false;
+    m->gemm_ev_used_var = m->gemm_ev_used_factor = 0;
 }
 
 
@@ -304,9 +307,12 @@ static void factor_append_rows(gpx_model *m, int t0)
 }
 
 // ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
-static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st)
+// L, X, Tw point at the top-left corner of an np x np diagonal part of matrices with leading dimension ld.
+static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st, long ld = 0)
 {
-    auto off = [&](size_t r, size_t c) { return (r * np + c) * e; };
+    if (ld == 0)
+        ld = np;
+    auto off = [&](size_t r, size_t c) { return (r * ld + c) * e; };
     for (long b = TILE; b < np; b *= 2) {
         // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
         int P = 0;
@@ -316,20 +322,20 @@ static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np,
             break;
         const long last_base = (long)(P - 1) * 2 * b;
         const int m_last = (int)std::min<long>(b, np - (last_base + b));
-        const long stride = 2 * b * (long)np + 2 * b;
+        const long stride = 2 * b * ld + 2 * b;
         GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
-        g1.A = L + off(b, 0), g1.lda = np;
-        g1.B = X + off(0, 0), g1.ldb = np;
-        g1.C = Tw + off(b, 0), g1.ldc = np;
+        g1.A = L + off(b, 0), g1.lda = ld;
+        g1.B = X + off(0, 0), g1.ldb = ld;
+        g1.C = Tw + off(b, 0), g1.ldc = ld;
         g1.M = (int)b, g1.N = (int)b, g1.K = (int)b;
         g1.sA = g1.sB = g1.sC = stride;
         g1.batch = P, g1.M_last = m_last;
         g1.nn = 1, g1.b_lower = 1;
         launch_gemm(prec, g1, st);
         GemmArgs g2;  // X21 = -X22 * T  (A lower)
-        g2.A = X + off(b, b), g2.lda = np;
-        g2.B = Tw + off(b, 0), g2.ldb = np;
-        g2.C = X + off(b, 0), g2.ldc = np;
+        g2.A = X + off(b, b), g2.lda = ld;
+        g2.B = Tw + off(b, 0), g2.ldb = ld;
+        g2.C = X + off(b, 0), g2.ldc = ld;
         g2.M = (int)b, g2.N = (int)b, g2.K = (int)b;
         g2.sA = g2.sB = g2.sC = stride;
         g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
@@ -412,6 +418,68 @@ int build_inverse(gpx_model *m)
     }
     m->has_inverse = true;
     return GPX_OK;
+}
+
+// ---- rank-n update: the inverse factor grows with the factor --------------------------------------------------
+// X = L^-1 of the grown factor: the leading t0 x t0 part is the old X, the new rows are
+//     X22 = (L22)^-1 (recursive doubling on the small trailing block),   X21 = -X22 (L21 X11),
+// two products with one thin operand (N = 16128 + 256: 2 ms) instead of the 26 ms of a fresh inverse at the next
+// variance query.  Runs in the working precision (the fresh fp32 path assembles in fp64: the appended rows carry
+// fp32 product rounding instead; the update tests hold the variance to the same tolerance as a rebuild).  Any
+// allocation failure just leaves the inverse to be rebuilt lazily.
+static void append_inverse(gpx_model *m, kept_factor *keep)
+{
+    const int np = m->npad, t0 = keep->t0;
+    const size_t e = m->esz;
+    const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);
+    const int m2 = np_rows - t0;
+    if (m2 <= 0 || t0 <= 0 || !keep->X)
+        return;
+    hipStream_t s = m->stream;
+    void *Tw = nullptr;
+    if (hipMalloc(&m->X, e * (size_t)np * np) != hipSuccess || hipMalloc(&Tw, e * (size_t)m2 * np) != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->X)
+            (void)hipFree(m->X);
+        m->X = nullptr;
+        return;
+    }
+    (void)hipEventRecord(m->ev[EV_INV0], s);
+    bool ok = hipMemsetAsync(m->X, 0, e * (size_t)np * np, s) == hipSuccess;
+    ok = ok && hipMemcpy2DAsync(m->X, e * np, keep->X, e * keep->np_old, e * t0, t0, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (ok) {
+        launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, s);
+        auto at = [&](void *base, size_t r, size_t c) { return (char *)base + (r * np + c) * e; };
+        trtri_levels(m->prec, e, at(m->Kmat, t0, t0), at(m->X, t0, t0), (char *)Tw, m2, s, np);
+        GemmArgs g1;  // T = L21 * X11 (B lower-triangular, [k][n])
+        g1.A = at(m->Kmat, t0, 0), g1.lda = np;
+        g1.B = m->X, g1.ldb = np;
+        g1.C = Tw, g1.ldc = np;
+        g1.M = m2, g1.N = t0, g1.K = t0;
+        g1.nn = 1, g1.b_lower = 1;
+        launch_gemm(m->prec, g1, s);
+        GemmArgs g2;  // X21 = -X22 * T (A lower-triangular)
+        g2.A = at(m->X, t0, t0), g2.lda = np;
+        g2.B = Tw, g2.ldb = np;
+        g2.C = at(m->X, t0, 0), g2.ldc = np;
+        g2.M = m2, g2.N = t0, g2.K = m2;
+        g2.nn = 1, g2.a_lower = 1;
+        g2.alpha = -1.0;
+        launch_gemm(m->prec, g2, s);
+    }
+    (void)hipEventRecord(m->ev[EV_INV1], s);
+    ok = ok && hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
+    (void)hipFree(Tw);
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipFree(m->X);
+        m->X = nullptr;
+        return;
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
+        m->stats.t_inverse_ms = ms;
+    m->has_inverse = true;
 }
 
 // ---- MIXED precision: round the fp64 state once to fp32 and release the fp64 factor -----------------
@@ -614,6 +682,8 @@ int build_model(gpx_model *m, kept_factor *keep)
         }
     }
     m->ready = true;
+    if (keep && keep->t0 > 0 && keep->X)
+        append_inverse(m, keep);
     if (m->opt.prepare_variance || m->opt.precision == GPX_PREC_MIXED) {
         int rc = build_inverse(m);
         if (rc)

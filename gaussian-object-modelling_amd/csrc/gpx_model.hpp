@@ -126,12 +126,13 @@ struct kept_factor {
     int np_old = 0;
     int n_neg = 0;     // negative pivots among the kept ones
     void *K = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;  // d, dinv: t0 entries each
+    void *X = nullptr;  // the old inverse factor (leading dimension np_old) when it had been built, else null
     void release()
     {
-        for (void *p : {K, linv, d, dinv})
+        for (void *p : {K, linv, d, dinv, X})
             if (p)
                 (void)hipFree(p);
-        K = linv = d = dinv = nullptr;
+        K = linv = d = dinv = X = nullptr;
     }
 };
 

@@ -207,13 +207,15 @@ def test_update_appends_and_refactors(gpu, orc, ds, golden):
         gm.close()
 
 
+@pytest.mark.parametrize("inv_first", [False, True])
 @pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("n0,n1", [(1500, 40), (1408, 700), (300, 1300), (1000, 24)])
-def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, monkeypatch):
+def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, inv_first, monkeypatch):
     """update() appends to the existing factor (new kernel rows, left-looking row update against the old
     column blocks, factorisation of the new trailing block) instead of refactoring from scratch.  Same alpha, D,
     inertia and predictions as a rebuild (GPX_UPDATE_APPEND=0) and as a fresh model; cases: inside the last padded
-    tile, across the padding (larger matrix), old N a multiple of 128, first tile partially filled."""
+    tile, across the padding (larger matrix), old N a multiple of 128, first tile partially filled.  inv_first: the
+    inverse factor exists before the update (a variance query) and is extended by the new rows instead of rebuilt."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(n0 + n1)
     kern = gpu.make_kernel("thinplate", 2.0)  # indefinite: negative pivots on both sides of the split
     qx, qy, qz = ds.query_grid(5)
@@ -221,7 +223,11 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, monkeyp
     for mode in ("1", "0"):
         monkeypatch.setenv("GPX_UPDATE_APPEND", mode)
         gm = gpu.Model(kern, x[:n0], y[:n0], z[:n0], lab[:n0], s2[:n0], precision=prec)
+        if inv_first:
+            gm.evaluate(qx, qy, qz, want_v=True)
         gm.update(x[n0:], y[n0:], z[n0:], lab[n0:], s2[n0:])
+        if inv_first and mode == "1":
+            assert gm.stats["t_inverse_ms"] > 0  # extended inside update(), not left to the next query
         o = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
         res[mode] = (gm.alpha.copy(), gm.D.copy(), o, gm.stats["n_negative_pivots"], gm.stats["alpha_residual"])
         gm.close()
