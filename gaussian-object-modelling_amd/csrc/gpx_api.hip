@@ -87,6 +87,10 @@ extern "C" void gpx_model_destroy(gpx_model *m)
     for (auto &e : m->ev)
         if (e)
             (void)hipEventDestroy(e);
+    for (auto &e : m->la_ev)
+        (void)hipEventDestroy(e);
+    if (m->stream2)
+        (void)hipStreamDestroy(m->stream2);
     if (m->stream)
         (void)hipStreamDestroy(m->stream);
     if (prev >= 0)

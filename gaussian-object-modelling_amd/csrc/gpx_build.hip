@@ -205,9 +205,9 @@ static void factorize(gpx_model *m, int c_start = 0)
     auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * WIDE_PANEL + c) * e); };
     size_t gemm_idx = 0;
     // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
-    auto block_step = [&](int cc, int wcol) {
+    auto block_step = [&](int cc, int wcol, hipStream_t st) {
         const int r0 = cc + TILE;
-        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, m->stream);
+        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, st, st != m->stream);
         if (r0 >= np)
             return;
         GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
@@ -219,12 +219,23 @@ static void factorize(gpx_model *m, int c_start = 0)
         t.epi = EPI_TRSM;
         t.W = Wpp(r0, wcol), t.ldw = WIDE_PANEL;
         t.colscale = (char *)m->t_dinv + (size_t)cc * e;
-        launch_gemm(m->prec, t, m->stream);
+        launch_gemm(m->prec, t, st);
     };
-    // trailing matrix from row / column r0 on -= W[:, 0:kw] * L[:, c0:c0+kw]^T, lower tiles only
-    auto trailing = [&](int c0, int r0, int kw) {
+    // the remaining columns of a panel [.., pend) (incl. the next diagonal block) -= W_h * L_h^T
+    auto half_update = [&](int cc, int wcol, int pend, hipStream_t st) {
+        const int r0 = cc + TILE;
         GemmArgs s;
-        s.A = Wpp(r0, 0), s.lda = WIDE_PANEL;
+        s.A = Wpp(r0, wcol), s.lda = WIDE_PANEL;
+        s.B = Kp(r0, cc), s.ldb = ldk;
+        s.C = Kp(r0, r0), s.ldc = ldk;
+        s.M = np - r0, s.N = pend - r0, s.K = TILE;
+        s.alpha = -1.0, s.beta = 1;
+        launch_gemm(m->prec, s, st);
+    };
+    // trailing matrix from row / column r0 on -= W[:, wofs:wofs+kw] * L[:, c0:c0+kw]^T, lower tiles only
+    auto trailing = [&](int c0, int r0, int kw, int wofs = 0) {
+        GemmArgs s;
+        s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
         s.B = Kp(r0, c0), s.ldb = ldk;
         s.C = Kp(r0, r0), s.ldc = ldk;
         s.M = np - r0, s.N = np - r0, s.K = kw;
@@ -239,17 +250,89 @@ static void factorize(gpx_model *m, int c_start = 0)
             ++gemm_idx;
         }
     };
+    // ---- look-ahead: panel p+1 is factorised on a second stream while the trailing update of panel p runs ----
+    // Per 256-panel the serial chain (2 diagonal blocks, 2 panel solves, 1 half update: ~130 us at N = 16384) is as
+    // long as the trailing update itself.  The update is split into the 256-column strip the next panel lives in
+    // (main stream, first) and the rest; the chain of panel p+1 starts on the second stream as soon as the strip is
+    // done and the main stream waits for it after the rest.  Two event hops per panel (~15 us each); the two halves
+    // of the 512-wide workspace alternate; bit-identical to the plain order with 256-wide panels.  What it buys is modest -- LDL^T at
+    // N = 16384: fp32 22.8 -> 21.9 ms, fp64 40.0 -> 37.1 ms -- because the chain runs 2.6x slower beside the GEMM
+    // (diagonal block 45 -> 95-145 us, panel solve 18 -> 46 us: they share SIMDs and slots with it), and the
+    // 8-wave diagonal kernel does not even fit on a CU next to a GEMM workgroup (it then waits for the GEMM to
+    // drain: measured 315 us), hence the 4-wave variant for these launches.  Setting CUs aside for the chain with
+    // hipExtStreamCreateWithCUMask was measured twice (this design and an earlier one): 47 ms, i.e. twice as slow
+    // as no look-ahead -- kernels on CU-masked streams pay far more than the 15 us hop; stream priority and
+    // s_setprio in the chain kernels changed nothing.  GPX_LOOKAHEAD=0 selects the plain order.
+    const char *pw_e = std::getenv("GPX_PANEL");
+    const int wide_env = pw_e ? std::atoi(pw_e) : 0;
+    const char *la_e = std::getenv("GPX_LOOKAHEAD");
+    // default: from 8192 rows on (below that the event hops cost what the overlap gains: N = 4096 fp64 3.95 -> 4.15 ms);
+    // GPX_LOOKAHEAD=1 forces it from 512 rows on, 0 switches it off; it works on 256-wide panels
+    const int la_min = la_e && std::atoi(la_e) != 0 ? 2 * PANEL : 32 * PANEL;
+    const bool la_env = (!la_e || std::atoi(la_e) != 0) && wide_env != WIDE_PANEL && np >= la_min;
+    if (la_env && c_start == 0 && !m->stream2 &&
+        hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        m->stream2 = nullptr;
+    }
+    if (la_env && c_start == 0 && m->stream2) {
+        hipStream_t sa = m->stream, sb = m->stream2;
+        size_t ev_used = 0;
+        auto next_event = [&]() -> hipEvent_t {
+            if (ev_used == m->la_ev.size()) {
+                hipEvent_t ev;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                    return nullptr;
+                m->la_ev.push_back(ev);
+            }
+            return m->la_ev[ev_used++];
+        };
+        auto chain = [&](int c0, int wofs, hipStream_t st) {
+            const int nb = std::min(PANEL, np - c0) / TILE;
+            for (int h = 0; h < nb; ++h) {
+                const int cc = c0 + h * TILE;
+                block_step(cc, wofs + h * TILE, st);
+                if (h + 1 < nb)
+                    half_update(cc, wofs + h * TILE, c0 + nb * TILE, st);
+            }
+        };
+        chain(0, 0, sa);
+        int p = 0;
+        for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
+            const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
+            const int sw = std::min(PANEL, np - r0);  // width of the strip = of the next panel
+            GemmArgs s;  // strip: C[r0:, r0:r0+sw] -= W_p L_p^T (the tile above the diagonal is computed too, nobody reads it)
+            s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
+            s.B = Kp(r0, c0), s.ldb = ldk;
+            s.C = Kp(r0, r0), s.ldc = ldk;
+            s.M = np - r0, s.N = sw, s.K = PANEL;
+            s.alpha = -1.0, s.beta = 1;
+            launch_gemm(m->prec, s, sa);
+            hipEvent_t e1 = nullptr, e2 = nullptr;
+            const bool overlap = r0 + sw < np && (e1 = next_event()) && (e2 = next_event());
+            if (overlap) {
+                (void)hipEventRecord(e1, sa);
+                (void)hipStreamWaitEvent(sb, e1, 0);
+                chain(r0, wofs ^ PANEL, sb);
+                (void)hipEventRecord(e2, sb);
+                trailing(c0, r0 + sw, PANEL, wofs);
+                (void)hipStreamWaitEvent(sa, e2, 0);
+            } else {
+                if (r0 + sw < np)
+                    trailing(c0, r0 + sw, PANEL, wofs);
+                chain(r0, wofs ^ PANEL, sa);
+            }
+        }
+        m->gemm_ev_used_factor = gemm_idx;
+        return;
+    }
     int c0 = c_start;
     if (c0 % PANEL) {  // start in the middle of a 256-column unit: a lone 128-wide step
-        block_step(c0, 0);
+        block_step(c0, 0, m->stream);
         if (c0 + TILE < np)
             trailing(c0, c0 + TILE, TILE);
         c0 += TILE;
     }
-    static const int wide_env = [] {
-        const char *e = std::getenv("GPX_PANEL");
-        return e ? std::atoi(e) : 0;
-    }();
     // fp64 has no accuracy to lose to the longer accumulations: 512-wide panels there (LDL^T at N = 16384: 43.1 -> 40.0 ms)
     const int wide = wide_env == WIDE_PANEL ? WIDE_PANEL
                                             : (wide_env == PANEL ? PANEL : (m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL));
@@ -257,16 +340,9 @@ static void factorize(gpx_model *m, int c_start = 0)
         const int pw = std::min(wide, np - c0), nb = pw / TILE;
         for (int h = 0; h < nb; ++h) {
             const int cc = c0 + h * TILE, r0 = cc + TILE;
-            block_step(cc, h * TILE);
-            if (h + 1 < nb && r0 < np) {
-                GemmArgs s;  // the remaining columns of the panel (incl. the next diagonal block) -= W_h * L_h^T
-                s.A = Wpp(r0, h * TILE), s.lda = WIDE_PANEL;
-                s.B = Kp(r0, cc), s.ldb = ldk;
-                s.C = Kp(r0, r0), s.ldc = ldk;
-                s.M = np - r0, s.N = c0 + pw - r0, s.K = TILE;
-                s.alpha = -1.0, s.beta = 1;
-                launch_gemm(m->prec, s, m->stream);
-            }
+            block_step(cc, h * TILE, m->stream);
+            if (h + 1 < nb && r0 < np)
+                half_update(cc, h * TILE, c0 + pw, m->stream);
         }
         if (c0 + pw < np)
             trailing(c0, c0 + pw, pw);

@@ -21,11 +21,10 @@
 namespace gpx {
 
 // threads of the diagonal-block kernel: 8 waves -- one factorises a sub-block, one inverts the previous one, six
-// carry the trailing update (one 32 x 32 block each); at most 256 VGPRs per lane (fp64 spills 24 of them)
-template <typename T>
-struct DiagThreads {
-    static constexpr int value = 512;
-};
+// carry the trailing update (one 32 x 32 block each); at most 256 VGPRs per lane (fp64 spills 24 of them).
+// The 4-wave instantiation (fp32) is the one that fits on a CU BESIDE a workgroup of the trailing-update GEMM
+// (<= 256 VGPRs per SIMD, 68 of the 160 KB of LDS): the 8-wave one needs a whole CU and starves behind a running GEMM.
+constexpr int DIAG_THREADS = 512, DIAG_THREADS_NARROW = 256;
 constexpr int NB = 32;    // sub-block order inside the 128 x 128 diagonal block
 constexpr int PLD = NB + 1;
 
@@ -246,12 +245,11 @@ struct BlkAcc {
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(DiagThreads<T>::value) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
+template <typename T, int DT>
+__global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
                                                       T *__restrict__ d, T *__restrict__ dinv,
                                                       int *__restrict__ info, int blk)
 {
-    constexpr int DT = DiagThreads<T>::value;
     constexpr int BLK = NB * PLD;                  // one 32 x 32 LDS block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
@@ -497,31 +495,37 @@ static size_t diag_shmem_bytes(size_t esz)
     return esz * (size_t)(TILE * PLD + 2 * NB * NB + TILE + 6 * NB * PLD + 4 * NB * PLD);  // Pa + Lt + Di + Ls + Xd
 }
 
-template <typename T>
+template <typename T, int DT>
 static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
 {
     const size_t shmem = diag_shmem_bytes(sizeof(T));
-    hipLaunchKernelGGL(diag_ldl_kernel<T>, dim3(1), dim3(DiagThreads<T>::value), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d,
-                       (T *)dinv, info, blk);
+    hipLaunchKernelGGL((diag_ldl_kernel<T, DT>), dim3(1), dim3(DT), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d, (T *)dinv,
+                       info, blk);
 }
 
 void factor_init(int prec)
 {
-    if (prec == GPX_PREC_F64)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double>),
+    if (prec == GPX_PREC_F64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double, DIAG_THREADS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
-    else
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float>),
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS_NARROW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
+    }
 }
 
+// narrow: the 4-wave instantiation (fp32 only), for launches that run beside a GEMM on another stream
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
-                     hipStream_t st)
+                     hipStream_t st, bool narrow)
 {
     if (prec == GPX_PREC_F64)
-        diag_t<double>(Ablk, lda, linv, d, dinv, info, blk, st);
+        diag_t<double, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
+    else if (narrow)
+        diag_t<float, DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
     else
-        diag_t<float>(Ablk, lda, linv, d, dinv, info, blk, st);
+        diag_t<float, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
 }
 
 // Diagonal blocks that lie entirely in the padding (the kernel matrix is the identity there): L = I, D = 1, inverse = I

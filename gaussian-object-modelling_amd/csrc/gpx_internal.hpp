@@ -146,7 +146,7 @@ void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, con
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower
 // inverse to linv (TILE x TILE, row-major, zeros above the diagonal), d / 1/d vectors, info.
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
-                     hipStream_t st);
+                     hipStream_t st, bool narrow = false);  // narrow: 4-wave variant that fits beside a GEMM workgroup
 // diagonal blocks blk0 .. nblk-1 lie in the identity padding: linv = I, d = dinv = 1
 void launch_identity_blocks(int prec, int blk0, int nblk, void *linv, void *d, void *dinv, hipStream_t st);
 void launch_place_diag(int prec, int nblk, const void *linv_blocks, void *X, long ldx, hipStream_t st);

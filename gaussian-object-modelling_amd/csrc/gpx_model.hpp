@@ -63,6 +63,8 @@ struct gpx_model {
     std::vector<int> perm;                        // internal position -> caller index
     double R = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;         // look-ahead of the factorisation: the next panel beside the trailing update
+    std::vector<hipEvent_t> la_ev;         // its cross-stream events (no timing), reused
     hipEvent_t ev[EV_COUNT] = {};
     std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
     size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;

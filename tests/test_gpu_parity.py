@@ -246,6 +246,29 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, inv_fir
 
 
 @pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("n", [600, 2048, 2305, 3000])
+def test_lookahead_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch):
+    """Eigen::LDLT::compute (gp_regressor.hpp:161-162): with the next panel factorised on a second stream beside the
+    trailing update (GPX_LOOKAHEAD=1 forces it; default from 8192 rows on) every tile sees the same products in the same
+    order: D, alpha and the predictions are bit-identical to the plain order with the same (256-wide) panels.
+    Sizes: 3 panels, exactly 8 panels, a last panel of one block, a ragged end."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel("thinplate", 2.0)
+    qx, qy, qz = ds.query_grid(4)
+    res = {}
+    monkeypatch.setenv("GPX_PANEL", "256")  # the plain fp64 order would use 512-wide panels
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPX_LOOKAHEAD", mode)
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+        o = gm.evaluate(qx, qy, qz, want_v=True)
+        res[mode] = (gm.D.copy(), gm.alpha.copy(), o["f"].copy(), o["v"].copy(), gm.stats["n_negative_pivots"])
+        gm.close()
+    for a, b in zip(res["1"][:4], res["0"][:4]):
+        np.testing.assert_array_equal(a, b)
+    assert res["1"][4] == res["0"][4]
+
+
+@pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("kname,kpar", [("matern52", (1.0, 1.0)), ("thinplate", (2.0,))])
 @pytest.mark.parametrize("n", [100, 277, 1500, 2305])
 def test_one_launch_substitution_equals_step_launches(gpu, ds, prec, kname, kpar, n, monkeypatch):
