@@ -871,8 +871,12 @@ static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, cons
                         void *x, int *info, hipStream_t st)
 {
     const size_t words = (size_t)nblk * TILE * (sizeof(T) / 4);
-    (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, words, st);
-    (void)hipMemsetD32Async((hipDeviceptr_t)x, (int)0xffffffff, words, st);
+    if ((char *)x == (char *)y + words * 4) {  // adjacent (the model's vectors are): one fill
+        (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, 2 * words, st);
+    } else {
+        (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, words, st);
+        (void)hipMemsetD32Async((hipDeviceptr_t)x, (int)0xffffffff, words, st);
+    }
     hipLaunchKernelGGL((tri_solve_kernel<T, false>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
                        (const T *)nullptr, (const T *)b, (T *)y, info);
     hipLaunchKernelGGL((tri_solve_kernel<T, true>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
