@@ -266,10 +266,13 @@ static void factorize(gpx_model *m, int c_start = 0)
     const char *pw_e = std::getenv("GPX_PANEL");
     const int wide_env = pw_e ? std::atoi(pw_e) : 0;
     const char *la_e = std::getenv("GPX_LOOKAHEAD");
-    // default: from 8192 rows on (below that the event hops cost what the overlap gains: N = 4096 fp64 3.95 -> 4.15 ms);
-    // GPX_LOOKAHEAD=1 forces it from 512 rows on, 0 switches it off; it works on 256-wide panels
-    const int la_min = la_e && std::atoi(la_e) != 0 ? 2 * PANEL : 32 * PANEL;
-    const bool la_env = (!la_e || std::atoi(la_e) != 0) && wide_env != WIDE_PANEL && np >= la_min;
+    // Default window, from measurements (LDL^T ms, look-ahead on / off): fp32 N = 8192 6.9 / 6.5, 16384 21.3 / 22.8,
+    // 32768 117 / 125 -> from 16384 rows on; fp64 N = 4096 4.15 / 3.95, 8192 9.7 / 10.5, 16384 36.9 / 40.0,
+    // 32768 239 / 232 (there the 512-wide panels of the plain order win) -> 8192 <= rows < 32768.
+    // GPX_LOOKAHEAD=1 forces it from 512 rows on, 0 switches it off; it works on 256-wide panels.
+    const bool la_forced = la_e && std::atoi(la_e) != 0;
+    const bool la_window = m->prec == GPX_PREC_F64 ? (np >= 32 * PANEL && np < 128 * PANEL) : np >= 64 * PANEL;
+    const bool la_env = (!la_e || la_forced) && wide_env != WIDE_PANEL && (la_forced ? np >= 2 * PANEL : la_window);
     if (la_env && c_start == 0 && !m->stream2 &&
         hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();

@@ -249,7 +249,7 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, inv_fir
 @pytest.mark.parametrize("n", [600, 2048, 2305, 3000])
 def test_lookahead_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch):
     """Eigen::LDLT::compute (gp_regressor.hpp:161-162): with the next panel factorised on a second stream beside the
-    trailing update (GPX_LOOKAHEAD=1 forces it; default from 8192 rows on) every tile sees the same products in the same
+    trailing update (GPX_LOOKAHEAD=1 forces it; by default only at sizes where it pays) every tile sees the same products in the same
     order: D, alpha and the predictions are bit-identical to the plain order with the same (256-wide) panels.
     Sizes: 3 panels, exactly 8 panels, a last panel of one block, a ragged end."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
