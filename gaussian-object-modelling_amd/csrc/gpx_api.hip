@@ -127,18 +127,20 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     HIPCHK(hipSetDevice(dev));
     gpx_model *m = new gpx_model();
     m->device = dev;
-    m->prec = (o.precision == GPX_PREC_F32 || o.precision == GPX_PREC_F32_SPLIT) ? GPX_PREC_F32
-                                                                                  : GPX_PREC_F64;  // MIXED trains in fp64
-    m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
     m->kern = *kernel;
     m->cov = make_cov(*kernel);
     m->opt = o;
     m->n = (int)n;
     m->npad = (int)gpx_padded_n(n);
     m->nblk = m->npad / TILE;
+    set_training_precision(m);  // MIXED and small F32 models train in fp64
     set_query_batch(m);
     if (const char *e64 = std::getenv("GPX_INV64"))
         m->inv64 = std::atoi(e64) != 0;
+    // fp32 variance contraction: take the per-query fit out of the kernel operand (GPX_VAR_FIT=0: plain kernel values)
+    m->var_fit = o.precision != GPX_PREC_F64;
+    if (const char *vf = std::getenv("GPX_VAR_FIT"))
+        m->var_fit = m->var_fit && std::atoi(vf) != 0;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");
@@ -248,8 +250,7 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     kept_factor keep;
     const char *app_env = std::getenv("GPX_UPDATE_APPEND");  // 0: always rebuild (tests compare the two)
     const bool append_on = !app_env || std::atoi(app_env) != 0;
-    if (append_on && m->ready && m->Kmat && m->linv && !m->x_packed && m->opt.precision != GPX_PREC_MIXED &&
-        n_old >= TILE) {
+    if (append_on && m->ready && m->Kmat && m->linv && !m->x_packed && !m->train64 && n_old >= TILE) {
         const int n_tot = (int)m->hx.size();
         std::vector<double> diag(n_tot);
         for (int i = 0; i < n_tot; ++i)
@@ -286,14 +287,12 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     }
     free_dev(m);
     m->ready = m->has_inverse = m->has_normals = false;
-    m->prec = (m->opt.precision == GPX_PREC_F32 || m->opt.precision == GPX_PREC_F32_SPLIT) ? GPX_PREC_F32
-                                                                                              : GPX_PREC_F64;
-    m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
     m->hD.clear();
     m->x_packed = false;
     m->n = (int)m->hx.size();
     m->npad = (int)gpx_padded_n(m->n);
     m->nblk = m->npad / TILE;
+    set_training_precision(m);
     set_query_batch(m);
     rc = build_model(m, keep.t0 > 0 ? &keep : nullptr);  // :457-459 refactors from scratch; same results
     keep.release();
@@ -470,7 +469,7 @@ extern "C" int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const 
     gpx_model *m = nullptr;
     if ((rc = new_model(kernel, n, o, &m)))
         return rc;
-    if (o.precision == GPX_PREC_MIXED) {  // the committed state of a MIXED model is the fp32 layout
+    if (m->train64) {  // the committed state of a model trained in fp64 (MIXED, small F32) is the fp32 layout
         m->prec = GPX_PREC_F32;
         m->esz = 4;
     }
@@ -538,6 +537,106 @@ extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
         }
     }
     return GPX_OK;
+}
+
+// ---- in-library multi-device placement (SURVEY 8b / north star: "host code stays C++") ---------------------------
+// A C++ caller shaped like src/gp_node.cpp (one process, many host threads sharing one model, :1025-1038) puts
+// read-only replicas of a trained model on other GPUs of the node and shards its query grid over them: the source's
+// state (points, alpha, 1/D, cloud moments, correction vectors; the inverse factor) is copied device to device --
+// hipMemcpyPeerAsync, i.e. xGMI when peer access is available, staged through the host otherwise -- into shells and
+// committed.  No RCCL communicator is needed inside one process; the one-process-per-GPU path (bench.py --mode
+// shard) moves the same two blobs with a torch.distributed broadcast.
+extern "C" int gpx_model_replicate(const gpx_model *csrc, int ndev, const int *devs, gpx_model **out)
+{
+    if (!csrc)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!devs || !out)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    if (ndev <= 0)
+        return fail(GPX_E_BAD_ARG, "ndev must be positive");
+    gpx_model *src = const_cast<gpx_model *>(csrc);
+    if (!src->ready)
+        return fail(GPX_E_STATE, "model is not ready");
+    const int have = gpx_device_count();
+    for (int i = 0; i < ndev; ++i) {
+        out[i] = nullptr;
+        if (devs[i] < 0 || devs[i] >= have)
+            return fail(GPX_E_BAD_ARG, "device ordinal out of range");
+    }
+    std::lock_guard<std::mutex> lk(src->mtx);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    HIPCHK(hipSetDevice(src->device));
+    int rc = build_inverse(src);  // replicas carry the inverse factor: they hold no LDL^T to build it from
+    if (rc)
+        return rc;
+    HIPCHK(hipStreamSynchronize(src->stream));
+    const size_t xbytes = src->esz * (size_t)src->npad * src->npad;
+    for (int i = 0; i < ndev && rc == GPX_OK; ++i) {
+        gpx_options o = src->opt;
+        o.device = devs[i];
+        gpx_model *r = nullptr;
+        if ((rc = gpx_model_create_shell(&src->kern, (size_t)src->n, &o, &r)))
+            break;
+        out[i] = r;
+        if (devs[i] != src->device) {  // best effort: direct xGMI copies instead of staging through the host
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[i], src->device) == hipSuccess && can) {
+                (void)hipSetDevice(devs[i]);
+                (void)hipDeviceEnablePeerAccess(src->device, 0);
+                (void)hipGetLastError();  // "already enabled" is fine
+            }
+        }
+        hipError_t e = hipSetDevice(src->device);
+        if (e == hipSuccess)
+            e = hipMemcpyPeerAsync(r->blob0, devs[i], src->blob0, src->device, src->blob0_bytes, src->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyPeerAsync(r->X, devs[i], src->X, src->device, xbytes, src->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(src->stream);
+        if (e != hipSuccess) {
+            rc = fail(e == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
+            break;
+        }
+        // host-side fields (accessors, a later update() by rebuild)
+        r->hx = src->hx, r->hy = src->hy, r->hz = src->hz, r->hlabel = src->hlabel, r->hs2 = src->hs2;
+        r->has_s2 = src->has_s2;
+        r->perm = src->perm;
+        r->R = src->R;
+        r->hD = src->hD;
+        if (r->hD.empty() && src->t_d) {  // replicas hold no factor: keep D readable (GPX_FIELD_D)
+            r->hD.resize((size_t)src->n);
+            if (src->prec == GPX_PREC_F64) {
+                e = hipMemcpy(r->hD.data(), src->t_d, sizeof(double) * (size_t)src->n, hipMemcpyDeviceToHost);
+            } else {
+                std::vector<float> t((size_t)src->n);
+                e = hipMemcpy(t.data(), src->t_d, sizeof(float) * (size_t)src->n, hipMemcpyDeviceToHost);
+                r->hD.assign(t.begin(), t.end());
+            }
+            if (e != hipSuccess) {
+                rc = fail(GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
+                break;
+            }
+        }
+        r->stats = src->stats;
+        r->sk = src->sk;
+        r->var_fit = src->var_fit;
+        if ((rc = gpx_model_commit(r, 1)))
+            break;
+        r->x_packed = src->x_packed;
+    }
+    if (rc) {
+        const std::string keep = g_err;
+        for (int i = 0; i < ndev; ++i) {
+            if (out[i])
+                gpx_model_destroy(out[i]);
+            out[i] = nullptr;
+        }
+        g_err = keep;
+    }
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    return rc;
 }
 
 // ---- stand-alone kbuild (tests / roofline leg) ---------------------------------------------------

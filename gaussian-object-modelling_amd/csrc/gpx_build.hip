@@ -25,6 +25,7 @@ void free_dev(gpx_model *m)
     F(m->ws_pred);
     F(m->ws_kqp);
     F(m->ws_partial);
+    F(m->ws_coef);
     F(m->ws_grad);
     F(m->ws_host_io);
     F(m->ws_small);
@@ -49,7 +50,8 @@ void free_dev(gpx_model *m)
     m->d_tmax = nullptr;
     m->d_tij = nullptr;
     m->ws_pred = nullptr;
-    m->ws_kqp = m->ws_partial = nullptr;
+    m->ws_kqp = m->ws_partial = m->ws_coef = nullptr;
+    m->ws_coef_bytes = 0;
     m->ws_grad = nullptr;
     m->ws_host_io = nullptr;
     m->d_normals = nullptr;
@@ -109,7 +111,7 @@ void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
 int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
 {
     const size_t np = (size_t)m->npad;
-    *bytes = sizeof(double) * np * 4 + esz * np * 4;
+    *bytes = sizeof(double) * (np * 4 + VAR_NMOM) + esz * np * (4 + VAR_NCORR);
     HIPCHK(hipMalloc(blob, *bytes));
     return GPX_OK;
 }
@@ -121,11 +123,37 @@ void carve_blob0(gpx_model *m)
     m->d_y = m->d_x + np;
     m->d_z = m->d_y + np;
     m->d_alpha = m->d_z + np;
-    char *b = (char *)(m->d_alpha + np);
+    m->d_fitmom = m->d_alpha + np;
+    char *b = (char *)(m->d_fitmom + VAR_NMOM);
     m->t_x = b;
     m->t_y = b + e * np;
     m->t_z = b + 2 * e * np;
     m->t_dinv = b + 3 * e * np;
+    m->t_corr = b + 4 * e * np;
+}
+
+// Moments of the point cloud (means over the n training points, fp64 on the host) behind the per-query fit of the
+// variance contraction, see gpx_internal.hpp; uses the working-precision roundings of the coordinates, i.e. the
+// points the kqp kernels see.
+static void cloud_moments(const gpx_model *m, const std::vector<double> &st, int np, double (&mom)[VAR_NMOM])
+{
+    for (double &v : mom)
+        v = 0.0;
+    const int n = m->n;
+    const bool f32 = m->prec != GPX_PREC_F64;
+    for (int k = 0; k < n; ++k) {
+        double x = st[k], y = st[np + k], z = st[2 * (size_t)np + k];
+        if (f32)
+            x = (double)(float)x, y = (double)(float)y, z = (double)(float)z;
+        const double r2 = x * x + y * y + z * z;
+        mom[0] += x, mom[1] += y, mom[2] += z;
+        mom[3] += x * x, mom[4] += x * y, mom[5] += x * z, mom[6] += y * y, mom[7] += y * z, mom[8] += z * z;
+        mom[9] += r2;
+        mom[10] += r2 * x, mom[11] += r2 * y, mom[12] += r2 * z;
+        mom[13] += r2 * r2;
+    }
+    for (double &v : mom)
+        v /= (double)n;
 }
 
 int alloc_model(gpx_model *m)
@@ -165,12 +193,17 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx)
 }
 
 // ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
-static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x)
+// Default: one launch per direction (tri_solve_kernel).  force_steps (or GPX_SOLVE_STEPS=1): one launch per block
+// step -- the path build_model falls back to when a workgroup of the one-launch kernel gave up waiting (info[5]).
+// GPX_SOLVE_SPIN_LIMIT (read per call; tests use it to force the give-up) overrides the spin limit of the polls.
+static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x, bool force_steps)
 {
     const char *e = getenv("GPX_SOLVE_STEPS");  // 1: one launch per block step (the older path, kept for A/B runs)
-    const bool by_steps = e && atoi(e) != 0;
+    const bool by_steps = force_steps || (e && atoi(e) != 0);
     if (!by_steps) {
-        launch_tri_solve(m->prec, m->nblk, m->Kmat, m->npad, m->linv, m->t_dinv, b, ytmp, x, m->d_info, m->stream);
+        const char *sl = getenv("GPX_SOLVE_SPIN_LIMIT");
+        launch_tri_solve(m->prec, m->nblk, m->Kmat, m->npad, m->linv, m->t_dinv, b, ytmp, x, m->d_info, m->stream,
+                         sl ? atoi(sl) : 0);
         return;
     }
     for (int kb = 0; kb < m->nblk; ++kb)
@@ -424,6 +457,29 @@ static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np,
     }
 }
 
+// F32_SPLIT: the fp32 inverse factor becomes packed fp16 hi/lo halves in place, the 1/D slot the scaled weights and
+// the row-correction vectors move to the accumulators' units.  No-op for the other modes, while the model still
+// trains in fp64 (the packing runs on the demoted fp32 state) and when already packed.
+static int pack_split(gpx_model *m)
+{
+    if (m->opt.precision != GPX_PREC_F32_SPLIT || m->x_packed || m->prec != GPX_PREC_F32 || !m->X)
+        return GPX_OK;
+    const int np = m->npad;
+    if (!m->hD.size()) {  // keep D readable (GPX_FIELD_D) -- the 1/D slot is about to hold the weights
+        std::vector<float> t((size_t)m->n);
+        HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * (size_t)m->n, hipMemcpyDeviceToHost));
+        m->hD.assign(t.begin(), t.end());
+    }
+    int e2 = 0;
+    (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
+    m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
+    launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream,
+                         m->var_fit ? (float *)m->t_corr : nullptr);
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->x_packed = true;
+    return GPX_OK;
+}
+
 int build_inverse(gpx_model *m)
 {
     if (m->has_inverse)
@@ -462,6 +518,8 @@ int build_inverse(gpx_model *m)
         launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
         trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
         launch_cast_d2f(nn, (const double *)X64, (float *)m->X, m->stream);
+        if (m->var_fit)  // from the un-rounded rows: the rounding of X then only meets the small fit residual
+            launch_var_rowcorr(true, m->prec, m->n, np, X64, np, m->t_x, m->t_y, m->t_z, m->t_corr, m->stream);
     } else {
         HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
         // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
@@ -469,6 +527,13 @@ int build_inverse(gpx_model *m)
         HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
         launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
         trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)Tws, np, m->stream);
+        if (m->var_fit)
+            launch_var_rowcorr(false, m->prec, m->n, np, m->X, np, m->t_x, m->t_y, m->t_z, m->t_corr, m->stream);
+    }
+    {
+        hipError_t le = hipGetLastError();  // launches are not checked one by one
+        if (le != hipSuccess)
+            return fail(GPX_E_HIP, std::string("inverse factor: kernel launch: ") + hipGetErrorString(le));
     }
     (void)hipEventRecord(m->ev[EV_INV1], m->stream);
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -482,21 +547,8 @@ int build_inverse(gpx_model *m)
     float ms = 0;
     if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
         m->stats.t_inverse_ms = ms;
-    if (m->opt.precision == GPX_PREC_F32_SPLIT && !m->x_packed) {
-        if (!m->hD.size()) {  // keep D readable (GPX_FIELD_D) -- the 1/D slot is about to hold the weights
-            std::vector<float> t((size_t)m->n);
-            HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * (size_t)m->n, hipMemcpyDeviceToHost));
-            m->hD.assign(t.begin(), t.end());
-        }
-        int e2 = 0;
-        (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
-        m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
-        launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream);
-        HIPCHK(hipStreamSynchronize(m->stream));
-        m->x_packed = true;
-    }
     m->has_inverse = true;
-    return GPX_OK;
+    return pack_split(m);
 }
 
 // ---- rank-n update: the inverse factor grows with the factor --------------------------------------------------
@@ -545,6 +597,8 @@ static void append_inverse(gpx_model *m, kept_factor *keep)
         g2.nn = 1, g2.a_lower = 1;
         g2.alpha = -1.0;
         launch_gemm(m->prec, g2, s);
+        if (m->var_fit)  // the cloud (hence its moments) and the rows of X changed: all rows again (N^2/2 reads)
+            launch_var_rowcorr(false, m->prec, m->n, np, m->X, np, m->t_x, m->t_y, m->t_z, m->t_corr, s);
     }
     (void)hipEventRecord(m->ev[EV_INV1], s);
     ok = ok && hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
@@ -574,12 +628,13 @@ static int demote_to_f32(gpx_model *m)
     if (rc)
         return rc;
     HIPCHK(hipMalloc(&nX, sizeof(float) * np * np));
-    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
-    float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
+    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * (np * 4 + VAR_NMOM), hipMemcpyDeviceToDevice, s));
+    float *tf = (float *)((char *)nb + sizeof(double) * (np * 4 + VAR_NMOM));
     launch_cast_d2f(np, (const double *)m->t_x, tf, s);
     launch_cast_d2f(np, (const double *)m->t_y, tf + np, s);
     launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
     launch_cast_d2f(np, (const double *)m->t_dinv, tf + 3 * np, s);
+    launch_cast_d2f(np * VAR_NCORR, (const double *)m->t_corr, tf + 4 * np, s);
     launch_cast_d2f(np * np, (const double *)m->X, (float *)nX, s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(m->blob0));
@@ -644,6 +699,9 @@ int build_model(gpx_model *m, kept_factor *keep)
     HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 3, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m->d_lab, st.data() + 3 * (size_t)np, sizeof(double) * (size_t)np * 2,
                           hipMemcpyHostToDevice, s));
+    double mom[VAR_NMOM];
+    cloud_moments(m, st, np, mom);
+    HIPCHK(hipMemcpyAsync(m->d_fitmom, mom, sizeof(mom), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
     HIPCHK(hipMemsetAsync(m->d_r, 0, sizeof(double) * (size_t)np * 2 + 64, s));
     HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
@@ -686,25 +744,50 @@ int build_model(gpx_model *m, kept_factor *keep)
         ymax = std::max(ymax, std::fabs(m->hlabel[i]));
     const double ir_tol = 1e-9 * std::max(ymax, 1e-300);
     int ir = 0;
-    for (int it = 0;; ++it) {
-        // right-hand side: y (first pass) or the fp64 residual
-        launch_cast_vec(m->prec, n, np, it == 0 ? m->d_lab : m->d_r, m->t_b, s);
-        solve_ldl(m, m->t_b, m->t_yv, m->t_xs);
-        launch_axpy_cast(m->prec, n, np, m->d_alpha, m->t_xs, m->t_alpha, s);
-        // r = y - K alpha in fp64, matrix-free from the fp64 points
-        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z,
-                       m->d_f, nullptr, m->ws_pred, s);
-        HIPCHK(hipMemsetAsync(m->d_rmax, 0, sizeof(double), s));
-        launch_residual(n, m->d_lab, m->d_f, m->d_s2, m->d_alpha, m->d_r, m->d_rmax, s);
-        ir = it;
-        if (it >= ir_max)
-            break;
-        if (ir_adaptive && it >= 1) {
-            double r_now = 0.0;
-            HIPCHK(hipMemcpyAsync(&r_now, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (!(r_now > ir_tol))
+    // by_steps: the launch-per-step substitution.  Returns with the stream synchronised and *gave_up telling whether
+    // a workgroup of the one-launch substitution stopped waiting (its alpha is then invalid).
+    auto compute_alpha = [&](bool by_steps, bool *gave_up) -> int {
+        HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
+        for (int it = 0;; ++it) {
+            // right-hand side: y (first pass) or the fp64 residual
+            launch_cast_vec(m->prec, n, np, it == 0 ? m->d_lab : m->d_r, m->t_b, s);
+            solve_ldl(m, m->t_b, m->t_yv, m->t_xs, by_steps);
+            launch_axpy_cast(m->prec, n, np, m->d_alpha, m->t_xs, m->t_alpha, s);
+            // r = y - K alpha in fp64, matrix-free from the fp64 points
+            launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z,
+                           m->d_f, nullptr, m->ws_pred, s);
+            HIPCHK(hipMemsetAsync(m->d_rmax, 0, sizeof(double), s));
+            launch_residual(n, m->d_lab, m->d_f, m->d_s2, m->d_alpha, m->d_r, m->d_rmax, s);
+            ir = it;
+            if (it >= ir_max)
                 break;
+            if (ir_adaptive && it >= 1) {
+                double r_now = 0.0;
+                HIPCHK(hipMemcpyAsync(&r_now, m->d_rmax, sizeof(double), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (!(r_now > ir_tol))
+                    break;
+            }
+        }
+        int flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, m->d_info + 5, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        *gave_up = flag != 0;
+        return GPX_OK;
+    };
+    int64_t solve_fallbacks = 0;
+    {
+        bool gave_up = false;
+        int rc = compute_alpha(false, &gave_up);
+        if (rc)
+            return rc;
+        if (gave_up) {
+            // the one-launch substitution relies on lower block rows making progress; when a poll ran out of
+            // patience its result is void: clear the flag and redo alpha with one launch per block step
+            HIPCHK(hipMemsetAsync(m->d_info + 5, 0, sizeof(int), s));
+            solve_fallbacks = 1;
+            if ((rc = compute_alpha(true, &gave_up)))
+                return rc;
         }
     }
     m->stats.ir_steps_done = ir;
@@ -746,9 +829,9 @@ int build_model(gpx_model *m, kept_factor *keep)
     m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);
     m->stats.ir_steps_done = ir;
     m->stats.alpha_residual = rmax;
-    if (info[5] != 0)
-        return fail(GPX_E_HIP, "block substitution: a workgroup gave up waiting for its predecessor (GPX_SOLVE_STEPS=1 "
-                               "selects the launch-per-step path)");
+    m->stats.solve_fallbacks = solve_fallbacks;
+    if (info[5] != 0)  // cannot happen: the step kernels never raise it
+        return fail(GPX_E_HIP, "block substitution: give-up flag set after the launch-per-step fallback");
     if (info[0] != 0)
         return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(info[0] - 1));
     // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64
@@ -763,14 +846,33 @@ int build_model(gpx_model *m, kept_factor *keep)
     m->ready = true;
     if (keep && keep->t0 > 0 && keep->X)
         append_inverse(m, keep);
-    if (m->opt.prepare_variance || m->opt.precision == GPX_PREC_MIXED) {
+    if (m->opt.prepare_variance || m->train64) {
         int rc = build_inverse(m);
         if (rc)
             return rc;
     }
-    if (m->opt.precision == GPX_PREC_MIXED)
-        return demote_to_f32(m);
+    if (m->train64) {
+        int rc = demote_to_f32(m);
+        return rc ? rc : pack_split(m);
+    }
     return GPX_OK;
+}
+
+// Arithmetic of the training stage.  MIXED trains in fp64 by definition.  F32 / F32_SPLIT models of up to
+// GPX_TRAIN_F64_MAX padded rows (default 2048; 0 = never) do too: there the whole fp64 create costs under two
+// milliseconds, while an fp32 LDL^T accumulates its Schur complements with errors of ~1e-5 k(0) against pivots that
+// sink to the noise level sigma^2 -- for the thin-plate matrices that alone is 5e-6 .. 1e-5 of max|v| in the variance
+// (measured, scripts/tp_err_survey.py; with the fp64 factor 1e-7 .. 1e-6).  Larger models keep the fp32 MFMA
+// factorisation (N = 4096: 9e-7, N = 16384: 1.1e-6 with the centred contraction).
+void set_training_precision(gpx_model *m)
+{
+    const int p = m->opt.precision;
+    long thr = 2048;
+    if (const char *e = std::getenv("GPX_TRAIN_F64_MAX"))
+        thr = std::atol(e);
+    m->train64 = p == GPX_PREC_MIXED || ((p == GPX_PREC_F32 || p == GPX_PREC_F32_SPLIT) && m->npad <= thr);
+    m->prec = (p == GPX_PREC_F64 || m->train64) ? GPX_PREC_F64 : GPX_PREC_F32;
+    m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
 }
 
 void set_query_batch(gpx_model *m)

@@ -35,6 +35,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             return rc;
         if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
             return rc;
+        if (m->var_fit && (rc = ensure(&m->ws_coef, &m->ws_coef_bytes, e * qb * VAR_NCORR)))
+            return rc;
     }
     // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
     // which may be enqueued on different streams (gpx_model_evaluate_device): order them behind the previous user.
@@ -58,12 +60,14 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
-                                 qy + q0, qz + q0, m->ws_kqp, s);
+                                 qy + q0, qz + q0, m->ws_kqp, s, m->var_fit ? m->d_fitmom : nullptr,
+                                 m->var_fit ? (float *)m->ws_coef : nullptr, (long)qb);
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
                 launch_vsplit_gemm(m->X, m->ws_kqp, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
-                                   (long)qb, 2, s, np_rows);
+                                   (long)qb, 2, s, np_rows, m->var_fit ? (const float *)m->t_corr : nullptr, np,
+                                   m->var_fit ? (const float *)m->ws_coef : nullptr, (long)qb);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
@@ -71,19 +75,29 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
+            // The kernel operand holds k - fit with a per-query fit that is rank 5 in (q, p); the GEMM epilogue adds
+            // X * fit back from the model's five row-correction vectors (gpx_internal.hpp, "low-rank fit").
             launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                       qz + q0, m->ws_kqp, s, np_rows);
+                       qz + q0, m->ws_kqp, s, np_rows, m->var_fit ? m->d_fitmom : nullptr,
+                       m->var_fit ? m->ws_coef : nullptr, (long)qb);
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
             a.B = m->ws_kqp, a.ldb = np;
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
-            // 256 x 256 tiles (fp32) halve the L2-miss traffic at equal speed, but only when there are enough of
-            // them to fill 256 CUs; small models use 128 x 128 tiles
-            a.cfg = (np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : 0;
+            // 128 x 128 tiles, two workgroups per CU (the tile is compiled for <= 256 registers, gpx_gemm.hip): 141 TFLOP/s
+            // on the N = 16384 contraction against 138 for 256 x 256 tiles at one workgroup per CU, which halve the
+            // L2-miss traffic but leave nobody to cover a workgroup's epilogue (GPX_VAR_TILE=2 selects them)
+            static const int var_tile = [] {
+                const char *e = std::getenv("GPX_VAR_TILE");
+                return e ? std::atoi(e) : 0;
+            }();
+            a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : 0;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
+            if (m->var_fit)
+                a.rowcorr = m->t_corr, a.ldrc = np, a.colcoef = m->ws_coef, a.ldcc = (long)qb;
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (ev)
                 (void)hipEventRecord(ev[0], s);

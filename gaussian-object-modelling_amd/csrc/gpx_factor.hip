@@ -275,7 +275,11 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long
         // ---- A: wave 0 factorises sub-block jb, wave 1 inverts L of sub-block jb - 1; lane l (and its twin
         //         l + 32) owns row l ----
         if (wave == 0) {
-            const int l = lane & 31;
+            // l is made opaque once per panel: left loop-invariant, hipcc computes the ~150 lane masks (l == j, l > j,
+            // c < l ...) of all 32 columns at kernel entry, keeps them alive across the four panels and spills
+            // 185-210 SGPRs to VGPR lanes; recomputing a mask next to its use is one v_cmp
+            int l = lane & 31;
+            asm volatile("" : "+v"(l));
             T r[NB];
 #pragma unroll
             for (int c = 0; c < NB; ++c)
@@ -321,7 +325,8 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long
                 }
             }
         } else if (wave == 1 && jb > 0) {
-            const int l = lane & 31;
+            int l = lane & 31;
+            asm volatile("" : "+v"(l));
             const T *lt = Lt + ((jb - 1) & 1) * NB * NB;
             T r[NB], x[NB];
 #pragma unroll
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long
     // E: wave 1 inverts the last sub-block (reads the second half of Lt = part of R3 .. R5, which stay untouched
     //    until phase G); waves 2, 3: R0 = L10 Xd0, R1 = L32 Xd2; the rest writes what is already known of X
     if (wave == 1) {
-        const int l = lane & 31;
+        int l = lane & 31;
+        asm volatile("" : "+v"(l));
         const T *lt = Lt + NB * NB;
         T r[NB], x[NB];
 #pragma unroll
@@ -505,14 +511,19 @@ static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *i
 
 void factor_init(int prec)
 {
+    static PerDeviceOnce once64, once32;  // per device, see gpx_internal.hpp
     if (prec == GPX_PREC_F64) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double, DIAG_THREADS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
+        once64.run([] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double, DIAG_THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
+        });
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS_NARROW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
+        once32.run([] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS_NARROW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
+        });
     }
 }
 
@@ -693,8 +704,11 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(int kb, const T *__restri
 // order and wait only for lower ones, so the scheme cannot deadlock even when not all of them are resident.  The
 // 128 x 128 block of the NEXT step (the last one: Linv_i) is loaded into a second register set before the poll of
 // the current one, so a block costs a poll round trip and a register matvec (~2.5 us) -- with the loads behind the
-// poll it was 8 us and the 127 blocks of the last row took as long as 256 step launches.  A poll that exceeds
-// SOLVE_SPIN_LIMIT gives up and raises info[5]: a failed call is better than a hung GPU.
+// poll it was 8 us and the 127 blocks of the last row took as long as 256 step launches.  In-order dispatch is what
+// the hardware does, not a guarantee of the programming model (other streams, host threads and processes share the
+// GPU): a poll that exceeds the spin limit gives up with 0 and raises info[5], every workgroup still reaches its
+// end, and the host then REDOES the solve with the launch-per-step kernels below (build_model, gpx_build.hip;
+// gpx_stats.solve_fallbacks) -- neither a hung GPU nor a failed call.
 // The backward direction runs the same scheme bottom-up on L^T, with D^-1 folded into its start.
 constexpr int SOLVE_SPIN_LIMIT = 1 << 21;
 
@@ -761,11 +775,11 @@ __device__ __forceinline__ void block_mv_regs_t(const T (&mv)[64], const T *v_ld
         out_lds[c] = s + scratch_lds[c];
 }
 
-// entry *p of the shared vector once it is no sentinel any more (0 and info[5] = 1 after SOLVE_SPIN_LIMIT polls)
-__device__ __forceinline__ float poll_entry(const float *p, int *info)
+// entry *p of the shared vector once it is no sentinel any more (0 and info[5] = 1 after spin_limit polls)
+__device__ __forceinline__ float poll_entry(const float *p, int *info, int spin_limit)
 {
     const unsigned *u = reinterpret_cast<const unsigned *>(p);
-    for (int spins = 0; spins < SOLVE_SPIN_LIMIT; ++spins) {
+    for (int spins = 0; spins < spin_limit; ++spins) {
         const unsigned b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffu)
             return __uint_as_float(b);
@@ -774,10 +788,10 @@ __device__ __forceinline__ float poll_entry(const float *p, int *info)
     atomicExch(&info[5], 1);
     return 0.0f;
 }
-__device__ __forceinline__ double poll_entry(const double *p, int *info)
+__device__ __forceinline__ double poll_entry(const double *p, int *info, int spin_limit)
 {
     const unsigned long long *u = reinterpret_cast<const unsigned long long *>(p);
-    for (int spins = 0; spins < SOLVE_SPIN_LIMIT; ++spins) {
+    for (int spins = 0; spins < spin_limit; ++spins) {
         const unsigned long long b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffffffffffull)
             return __longlong_as_double((long long)b);
@@ -801,7 +815,7 @@ __device__ __forceinline__ void publish_entry(double *p, double v)
 template <typename T, bool TRANS>
 __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__restrict__ L, long ld,
                                                         const T *__restrict__ linv, const T *__restrict__ scale,
-                                                        const T *__restrict__ rhs, T *out, int *info)
+                                                        const T *__restrict__ rhs, T *out, int *info, int spin_limit)
 {
     __shared__ T vk[TILE], upd[TILE], scratch[TILE];
     constexpr int RS = TRANS ? 64 : 32;  // registers of one half block set
@@ -835,7 +849,7 @@ __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__res
     auto step = [&](int s, const T(&r0)[RS], const T(&r1)[TRANS ? 1 : 32]) {
         const int k = TRANS ? nblk - 1 - s : s;
         if (tid < TILE)
-            vk[tid] = poll_entry(out + k * TILE + tid, info);
+            vk[tid] = poll_entry(out + k * TILE + tid, info, spin_limit);
         __syncthreads();
         mv(r0, r1);
         __syncthreads();
@@ -868,8 +882,10 @@ __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__res
 
 template <typename T>
 static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b, void *y,
-                        void *x, int *info, hipStream_t st)
+                        void *x, int *info, hipStream_t st, int spin_limit)
 {
+    if (spin_limit <= 0)
+        spin_limit = SOLVE_SPIN_LIMIT;
     const size_t words = (size_t)nblk * TILE * (sizeof(T) / 4);
     if ((char *)x == (char *)y + words * 4) {  // adjacent (the model's vectors are): one fill
         (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, 2 * words, st);
@@ -878,19 +894,19 @@ static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, cons
         (void)hipMemsetD32Async((hipDeviceptr_t)x, (int)0xffffffff, words, st);
     }
     hipLaunchKernelGGL((tri_solve_kernel<T, false>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
-                       (const T *)nullptr, (const T *)b, (T *)y, info);
+                       (const T *)nullptr, (const T *)b, (T *)y, info, spin_limit);
     hipLaunchKernelGGL((tri_solve_kernel<T, true>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
-                       (const T *)dinv, (const T *)y, (T *)x, info);
+                       (const T *)dinv, (const T *)y, (T *)x, info, spin_limit);
 }
 
 // x = (L D L^T)^-1 b (y: scratch of the same length), two launches
 void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b,
-                      void *y, void *x, int *info, hipStream_t st)
+                      void *y, void *x, int *info, hipStream_t st, int spin_limit)
 {
     if (prec == GPX_PREC_F64)
-        tri_solve_t<double>(nblk, L, ld, linv, dinv, b, y, x, info, st);
+        tri_solve_t<double>(nblk, L, ld, linv, dinv, b, y, x, info, st, spin_limit);
     else
-        tri_solve_t<float>(nblk, L, ld, linv, dinv, b, y, x, info, st);
+        tri_solve_t<float>(nblk, L, ld, linv, dinv, b, y, x, info, st, spin_limit);
 }
 
 void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const void *linv, void *b, void *y,

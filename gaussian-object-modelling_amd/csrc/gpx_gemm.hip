@@ -73,6 +73,13 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_F32_HINT
 #define GEMM_F32_HINT 0
 #endif
+// Waves per SIMD the 4-wave (128 x 128) tiles are compiled for.  Without a bound hipcc budgets 512 registers per lane
+// (252 VGPRs + 80 AGPRs for the read-modify-write tile), which leaves ONE workgroup per CU although two fit its LDS;
+// 2 caps the tile at 256 registers (234 used, nothing spilled) so that two workgroups share a CU and one hides the
+// other's prologue / epilogue -- what the short k-loops of the LDL^T trailing update need.
+#ifndef GEMM_WAVES_PER_EU
+#define GEMM_WAVES_PER_EU 2
+#endif
 
 template <typename T>
 struct GemmDev {
@@ -90,12 +97,14 @@ struct GemmDev {
     const T *rowweight;
     T *partial;
     long ldp;
+    const T *rowcorr, *colcoef;  // EPI_COLSQ: acc[m][n] += sum_c colcoef[c][n] * rowcorr[c][m], c < VAR_NCORR (null: none)
+    long ldrc, ldcc;
 };
 
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_EU : 1) void gemm_kernel(GemmDev<T> g)
 {
     using MF = MfmaT<T, M32>;
     using acc_t = typename MF::acc_t;
@@ -387,20 +396,51 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmDev<T> g)
         }
     } else {  // EPI_COLSQ
         T *red = smem;  // [WGM][BN], re-using the staging buffers (all waves are past the k-loop barrier)
-        T w[FM][NACC];
+        // Low-rank correction of the contraction (gpx_eval.hip, "centred kernel operand"): the B operand holds
+        // k - fit with fit[n][k] = sum_c colcoef[c][n] b_c[k]; the product of A with the fit is added back here from
+        // rowcorr[c][m] = sum_k A[m][k] b_c[k], which was accumulated once per model in fp64.
+        const bool corr = g.colcoef != nullptr;
+        T ca[FN][VAR_NCORR];
+        if (corr) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < NACC; ++r)
-                w[i][r] = g.rowweight[m0 + (wm * FM + i) * FR + MF::crow(lane, r)];
+                for (int c = 0; c < VAR_NCORR; ++c)
+                    ca[j][c] = g.colcoef[(size_t)c * g.ldcc + n0 + (wn * FN + j) * FR + fr];
+        }
+        T colsum[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            colsum[j] = T(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            T w[NACC], sr[VAR_NCORR][NACC];
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                const int row = m0 + (wm * FM + i) * FR + MF::crow(lane, r);
+                w[r] = g.rowweight[row];
+                if (corr) {
+#pragma unroll
+                    for (int c = 0; c < VAR_NCORR; ++c)
+                        sr[c][r] = g.rowcorr[(size_t)c * g.ldrc + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) {
+                    T a = acc[i][j][r];
+                    if (corr) {
+#pragma unroll
+                        for (int c = 0; c < VAR_NCORR; ++c)
+                            a += ca[j][c] * sr[c][r];
+                    }
+                    colsum[j] += a * a * w[r];
+                }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            T s = T(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int r = 0; r < NACC; ++r)
-                    s += acc[i][j][r] * acc[i][j][r] * w[i][r];
+            T s = colsum[j];
             if constexpr (FR == 16)
                 s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
@@ -426,13 +466,12 @@ static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t 
     constexpr int EPC = 16 / sizeof(T), BK = KBYTES / sizeof(T);
     constexpr int BKP = BK + GEMM_KPAD * EPC, BNP = BN + EPC;
     constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? BK * BNP : BN * BKP));
-    static bool attr_done = false;  // one process drives one device
+    static PerDeviceOnce attr_once;  // the LDS-size attribute is per device (one static per instantiation)
     auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN, KBYTES, M32>;
-    if (!attr_done) {
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem);
-        attr_done = true;
-    }
+    });
     const int mt = a.M / BM, nt = a.N / BN;
     if (mt <= 0 || nt <= 0 || a.batch <= 0)
         return;
@@ -493,6 +532,8 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     g.colscale = (const T *)a.colscale;
     g.rowweight = (const T *)a.rowweight;
     g.partial = (T *)a.partial, g.ldp = a.ldp;
+    g.rowcorr = (const T *)a.rowcorr, g.colcoef = (const T *)a.colcoef;
+    g.ldrc = a.ldrc, g.ldcc = a.ldcc;
     const int cfg = pick_cfg(a, sizeof(T));
 #define GPX_GEMM_CFG(NN_, EPI_)                                                \
     do {                                                                       \

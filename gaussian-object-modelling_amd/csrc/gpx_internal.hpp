@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/gpx.h"
 
 namespace gpx {
@@ -13,6 +15,26 @@ constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
 constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
 constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
+// terms of the low-rank fit taken out of the kernel operand of the variance contraction: {1, p_x, p_y, p_z, |p|^2}
+constexpr int VAR_NCORR = 5;
+
+// Kernel attributes such as hipFuncAttributeMaxDynamicSharedMemorySize are PER DEVICE (and per kernel instantiation):
+// one flag per device ordinal, run under std::call_once so that concurrent builders on several host threads (or a
+// process that drives more than one GPU through gpx_options.device / gpx_model_replicate) each set them exactly once.
+constexpr int MAX_DEVICES = 64;
+struct PerDeviceOnce {
+    std::once_flag flag[MAX_DEVICES];
+    template <typename F>
+    void run(F &&f)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+            f();  // unknown ordinal: set the attribute every time (idempotent)
+            return;
+        }
+        std::call_once(flag[dev], f);
+    }
+};
 
 // Host-side description of a covariance function, lowered to Cov<T> for the device.
 struct CovHost {
@@ -55,11 +77,28 @@ void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x,
 // picks the global maximum of the per-tile maxima -> out_ij[2]
 void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile_max_ij, int *out_ij,
                            hipStream_t st);
-// Kqp[q][j] = k(|q - p_j|), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
+// ---- low-rank fit taken out of the kernel operand of the variance contraction (gpx_eval.hip) ----
+// Per query q the B operand holds k(d) - (a_q + b_q d^2): what a polynomial of degree one in
+// d^2 = |q|^2 - 2 q.p + |p|^2 cannot represent.  ANY (a_q, b_q) gives the same variance in exact arithmetic (the fit is
+// rank 5 in (q, p) and its product with the inverse factor is added back in the GEMM epilogue from five per-model
+// vectors); a good one shrinks the operand, and with it the fp32 rounding of the N-term contractions, by an order of
+// magnitude (thin-plate R = 4, N = 16384: variance error 2.0e-5 k(0) -> see DESIGN.md section 6).  (a_q, b_q) is the
+// least-squares line through k at three points of the interval mean +- sqrt(3) sigma of d^2 over the training
+// set, and those two moments follow in O(1) from the moments of the point cloud below (means over the n points).
+constexpr int VAR_NMOM = 16;  // doubles: m1[3] | M2 xx xy xz yy yz zz | s2 = E|p|^2 | s3[3] = E|p|^2 p | s4 = E|p|^4 | pad
+// Kqp[q][j] = k(|q - p_j|) - (a_q + b_q |q - p_j|^2), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
+// fitmom: device pointer to the VAR_NMOM moments, or null for the plain kernel values (a_q = b_q = 0); coef (T,
+// [VAR_NCORR][ldcc]): the fit's query-side coefficients {a_q + b_q |q|^2, -2 b_q q_xyz, b_q} for the GEMM epilogue.
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
                 hipStream_t st,
-                int ncols = 0);  // > 0: only the first ncols columns are written (columns in the padding are never read)
+                int ncols = 0,  // > 0: only the first ncols columns are written (columns in the padding are never read)
+                const double *fitmom = nullptr, void *coef = nullptr, long ldcc = 0);
+
+// out (prec scalars, [VAR_NCORR][np]) = X b_c for b = {1, p_x, p_y, p_z, |p|^2} (fp64 accumulation); X: np x np
+// lower-triangular, fp64 if x_is_f64 (or prec is F64) else fp32; the points are `prec` scalars
+void launch_var_rowcorr(bool x_is_f64, int prec, int n, int np, const void *X, long ldx, const void *px, const void *py,
+                        const void *pz, void *out, hipStream_t st);
 
 // ---- prediction : gpx_predict.hip -----------------------------------------------------------
 // f[q] = sum_j k(|q-p_j|) alpha_j ; grad[q] = sum_j alpha_j k'(.)(q-p_j)  (double outputs).
@@ -126,6 +165,9 @@ struct GemmArgs {
     const void *rowweight = nullptr; // EPI_COLSQ: partial[mt][n] = sum_rows acc^2 * rowweight[m]
     void *partial = nullptr;
     long ldp = 0;
+    const void *rowcorr = nullptr;   // EPI_COLSQ: acc[m][n] += sum_c colcoef[c][n] * rowcorr[c][m] before squaring
+    const void *colcoef = nullptr;   //   (c < VAR_NCORR; leading dimensions ldrc / ldcc; null: no correction)
+    long ldrc = 0, ldcc = 0;
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
@@ -135,12 +177,15 @@ int gemm_tile_n(int cfg);
 // ---- split-fp16 variance contraction : gpx_vsplit.hip ------------------------------------------
 // in place: X (fp32, np x np) -> packed hi/lo halves with a device-chosen power-of-two scale sx;
 // dinv -> w = dinv / (sx sk)^2
-void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st);
+//   rowcorr ([VAR_NCORR][np] or null): the row-correction vectors of the fit, scaled by sx sk in place
+void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st,
+                          float *rowcorr = nullptr);
 void launch_kqp_split(const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st);
+                      hipStream_t st, const double *fitmom = nullptr, float *coef = nullptr, long ldcc = 0);
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial, long ldp,
-                        int prefetch, hipStream_t st, int m_rows = 0);
+                        int prefetch, hipStream_t st, int m_rows = 0, const float *rowcorr = nullptr, long ldrc = 0,
+                        const float *colcoef = nullptr, long ldcc = 0);
 
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower
@@ -157,9 +202,10 @@ void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const v
 void launch_bwd_step(int prec, int kb, const void *L, long ld, const void *linv_blocks, void *y, void *x,
                      hipStream_t st);
 // the same substitution, one launch per direction (workgroup per block row, self-validating entries between them):
-// x = (L D L^T)^-1 b, y: scratch of the same length; info[5] = 1 when a wait gave up
+// x = (L D L^T)^-1 b, y: scratch of the same length; info[5] = 1 when a wait gave up after spin_limit polls
+// (<= 0: the default limit) -- the result is then invalid and the caller redoes the solve with the step kernels
 void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv_blocks, const void *dinv,
-                      const void *b, void *y, void *x, int *info, hipStream_t st);
+                      const void *b, void *y, void *x, int *info, hipStream_t st, int spin_limit = 0);
 void factor_init(int prec);  // per-device one-time kernel attributes (LDS size of diag_ldl)
 void launch_scale_vec(int prec, int npad, void *b, const void *dinv, hipStream_t st);
 

@@ -56,6 +56,7 @@ struct gpx_model {
     gpx_options opt{};
     int n = 0, npad = 0, nblk = 0;
     bool ready = false, has_s2 = false, has_inverse = false, has_normals = false;
+    bool train64 = false;   // MIXED, and F32 / F32_SPLIT models small enough that fp64 training is free (set_training_precision)
     bool inv64 = true;      // F32 modes: assemble the inverse factor in fp64 from the fp32 factor (GPX_INV64=0 disables)
     bool x_packed = false;  // F32_SPLIT: X holds packed hi/lo halves, the 1/D slot holds the scaled weights
     float sk = 1.0f;        // power-of-two scale of the kernel values in the split contraction
@@ -70,11 +71,13 @@ struct gpx_model {
     size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;
 
     // state blob part 0 = everything evaluate() reads besides X, internal order, npad each:
-    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | T x y z 1/D
+    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | VAR_NMOM doubles: moments of the point
+    //   cloud (per-query fit of the variance contraction) | T x y z 1/D | T [VAR_NCORR][npad]: X {1, p, |p|^2}
     void *blob0 = nullptr;
     size_t blob0_bytes = 0;
-    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;
-    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr, *d_fitmom = nullptr;
+    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr, *t_corr = nullptr;
+    bool var_fit = false;  // the low-rank fit is taken out of the kernel operand of the variance GEMM (fp32 modes)
     // other fp64 vectors (npad each): label s2 r f, then one double for max|r|
     double *dvecs = nullptr;
     double *d_lab = nullptr, *d_s2 = nullptr, *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
@@ -96,6 +99,8 @@ struct gpx_model {
     size_t ws_kqp_bytes = 0;
     void *ws_partial = nullptr;
     size_t ws_partial_bytes = 0;
+    void *ws_coef = nullptr;  // [VAR_NCORR][qbatch] query-side coefficients of the fit
+    size_t ws_coef_bytes = 0;
     double *ws_grad = nullptr;
     size_t ws_grad_doubles = 0;
     void *ws_small = nullptr;      // partial sums + counters of the one-launch path for a handful of queries
@@ -152,6 +157,7 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx);
 int build_inverse(gpx_model *m);
 int build_model(gpx_model *m, kept_factor *keep = nullptr);
 void set_query_batch(gpx_model *m);
+void set_training_precision(gpx_model *m);
 // ---- gpx_eval.hip -----------------------------------------------------------------------------------
 int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz, double *f, double *v,
                     double *grad, double *tx, double *ty, hipStream_t s);

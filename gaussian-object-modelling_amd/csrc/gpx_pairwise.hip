@@ -147,22 +147,39 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
     }
 }
 
+// fitmom != null: Kqp holds k(d) - (a_q + b_q d^2), the per-query fit of var_fit_query (gpx_cov.hpp, gpx_internal.hpp);
+// the first column block also writes the fit's query-side coefficients coef[c][q] for b = {1, p_x, p_y, p_z, |p|^2}:
+// {a_q + b_q |q|^2, -2 b_q q_xyz, b_q}.  fitmom == null: the plain kernel values.
 template <typename T, int KID>
 __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ px,
                                                   const T *__restrict__ py, const T *__restrict__ pz,
                                                   long nq_valid, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
-                                                  T *__restrict__ Kqp)
+                                                  T *__restrict__ Kqp, const double *__restrict__ fitmom,
+                                                  T *__restrict__ coef, long ldcc)
 {
-    __shared__ T rx[TILE], ry[TILE], rz[TILE];
+    __shared__ T rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.y * TILE;
     if (tid < TILE) {
         long q = q0 + tid;
         bool ok = q < nq_valid;
-        rx[tid] = ok ? (T)qx[q] : T(0);
-        ry[tid] = ok ? (T)qy[q] : T(0);
-        rz[tid] = ok ? (T)qz[q] : T(0);
+        const T ax = ok ? (T)qx[q] : T(0), ay = ok ? (T)qy[q] : T(0), az = ok ? (T)qz[q] : T(0);
+        rx[tid] = ax;
+        ry[tid] = ay;
+        rz[tid] = az;
+        T fa = T(0), fb = T(0);
+        if (fitmom && ok)
+            var_fit_query<T, KID>(cov, fitmom, ax, ay, az, fa, fb);
+        rfa[tid] = fa;
+        rfb[tid] = fb;
+        if (coef && blockIdx.x == 0) {
+            coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
+            coef[ldcc + q] = T(-2) * fb * ax;
+            coef[2 * ldcc + q] = T(-2) * fb * ay;
+            coef[3 * ldcc + q] = T(-2) * fb * az;
+            coef[4 * ldcc + q] = fb;
+        }
     }
     const int tx = tid & 31, ty = tid >> 5;
     const int gj0 = blockIdx.x * TILE + tx * 4;
@@ -178,17 +195,66 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, c
     for (int r = 0; r < 16; ++r) {
         const int li = ty + 8 * r;
         const long q = q0 + li;
-        const T ax = rx[li], ay = ry[li], az = rz[li];
+        const T ax = rx[li], ay = ry[li], az = rz[li], fa = rfa[li], fb = rfb[li];
         T out[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
             T d2 = dx * dx + dy * dy + dz * dz;
-            T kv = cov_k<T, KID>(cov, d2);
+            T kv = cov_k<T, KID>(cov, d2) - (fa + fb * d2);
             out[c] = (q < nq_valid && gj0 + c < n) ? kv : T(0);
         }
         store4<T>(Kqp + (size_t)q * npad + gj0, out);
     }
+}
+
+// Row-correction vectors of the variance contraction: out[c][j] = sum_l X[j][l] b_c[l], b = {1, p_x, p_y, p_z, |p|^2}
+// over the training points l < n, accumulated in fp64 whatever the types (TX: X, T: points and output).  X is
+// lower-triangular: row j is read up to its diagonal.  One workgroup per row; ~N^2/2 reads once per model.
+template <typename TX, typename T>
+__global__ __launch_bounds__(256) void var_rowcorr_kernel(int n, int np, const TX *__restrict__ X, long ldx,
+                                                          const T *__restrict__ px, const T *__restrict__ py,
+                                                          const T *__restrict__ pz, T *__restrict__ out)
+{
+    __shared__ double red[4][VAR_NCORR];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int lend = min(n, j + 1);
+    double s[VAR_NCORR] = {0, 0, 0, 0, 0};
+    const TX *row = X + (size_t)j * ldx;
+    for (int l = tid; l < lend; l += 256) {
+        const double xv = (double)row[l];
+        const double x = (double)px[l], y = (double)py[l], z = (double)pz[l];
+        s[0] += xv;
+        s[1] = fma(xv, x, s[1]);
+        s[2] = fma(xv, y, s[2]);
+        s[3] = fma(xv, z, s[3]);
+        s[4] = fma(xv, x * x + y * y + z * z, s[4]);
+    }
+#pragma unroll
+    for (int c = 0; c < VAR_NCORR; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s[c] += __shfl_xor(s[c], off);
+        if ((tid & 63) == 0)
+            red[tid >> 6][c] = s[c];
+    }
+    __syncthreads();
+    if (tid < VAR_NCORR)
+        out[(size_t)tid * np + j] = (T)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+void launch_var_rowcorr(bool x_is_f64, int prec, int n, int np, const void *X, long ldx, const void *px, const void *py,
+                        const void *pz, void *out, hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)  // fp64 model: X is fp64 too
+        hipLaunchKernelGGL((var_rowcorr_kernel<double, double>), dim3(np), dim3(256), 0, st, n, np, (const double *)X, ldx,
+                           (const double *)px, (const double *)py, (const double *)pz, (double *)out);
+    else if (x_is_f64)
+        hipLaunchKernelGGL((var_rowcorr_kernel<double, float>), dim3(np), dim3(256), 0, st, n, np, (const double *)X, ldx,
+                           (const float *)px, (const float *)py, (const float *)pz, (float *)out);
+    else
+        hipLaunchKernelGGL((var_rowcorr_kernel<float, float>), dim3(np), dim3(256), 0, st, n, np, (const float *)X, ldx,
+                           (const float *)px, (const float *)py, (const float *)pz, (float *)out);
 }
 
 template <typename T>
@@ -223,23 +289,23 @@ void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *o
 template <typename T>
 static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz,
                   long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                  hipStream_t st, int ncols)
+                  hipStream_t st, int ncols, const double *fitmom, void *coef, long ldcc)
 {
     Cov<T> c = lower_cov<T>(h);
     dim3 grid((ncols > 0 ? ncols : npad) / TILE, (unsigned)(nq_tile / TILE));
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<T, KID>), grid, dim3(256), 0, st, c, n, npad,
                                               (const T *)px, (const T *)py, (const T *)pz, nq_valid, qx, qy, qz,
-                                              (T *)Kqp));
+                                              (T *)Kqp, fitmom, (T *)coef, ldcc));
 }
 
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st, int ncols)
+                hipStream_t st, int ncols, const double *fitmom, void *coef, long ldcc)
 {
     if (prec == GPX_PREC_F64)
-        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols);
+        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fitmom, coef, ldcc);
     else
-        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols);
+        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fitmom, coef, ldcc);
 }
 
 }  // namespace gpx

@@ -57,15 +57,23 @@ __device__ __forceinline__ float pow2_scale_below_one(float amax)
     return ldexpf(1.0f, -e);
 }
 
-// scale_inv2[0] = 1 / (sx * sk)^2 ; w[j] = dinv[j] * scale_inv2
+// scale_inv2[0] = 1 / (sx * sk)^2 ; w[j] = dinv[j] * scale_inv2 ; the VAR_NCORR row-correction vectors of the
+// low-rank fit (rowcorr, n each, may be null) are brought to the accumulators' units: *= sx sk (a power of two)
 __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *dinv,
-                                                            const unsigned *__restrict__ amax_bits, float sk, float *w)
+                                                            const unsigned *__restrict__ amax_bits, float sk, float *w,
+                                                            float *rowcorr)
 {
     const float sx = pow2_scale_below_one(__uint_as_float(*amax_bits));
     const float inv = 1.0f / (sx * sk);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n)
+    if (i < n) {
         w[i] = dinv[i] * inv * inv;
+        if (rowcorr) {
+#pragma unroll
+            for (int c = 0; c < VAR_NCORR; ++c)
+                rowcorr[(size_t)c * n + i] *= sx * sk;
+        }
+    }
 }
 
 // One call = the 8 consecutive k that ONE lane feeds to v_mfma_f32_32x32x16_f16.  The matrix core adds the 8
@@ -132,17 +140,32 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk
                                                         const float *__restrict__ pz, long nq_valid,
                                                         const double *__restrict__ qx,
                                                         const double *__restrict__ qy,
-                                                        const double *__restrict__ qz, half_t *__restrict__ P)
+                                                        const double *__restrict__ qz, half_t *__restrict__ P,
+                                                        const double *__restrict__ fitmom, float *__restrict__ coef,
+                                                        long ldcc)
 {
-    __shared__ float rx[TILE], ry[TILE], rz[TILE];
+    __shared__ float rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.y * TILE;
     if (tid < TILE) {
         const long q = q0 + tid;
         const bool ok = q < nq_valid;
-        rx[tid] = ok ? (float)qx[q] : 0.0f;
-        ry[tid] = ok ? (float)qy[q] : 0.0f;
-        rz[tid] = ok ? (float)qz[q] : 0.0f;
+        const float ax = ok ? (float)qx[q] : 0.0f, ay = ok ? (float)qy[q] : 0.0f, az = ok ? (float)qz[q] : 0.0f;
+        rx[tid] = ax;
+        ry[tid] = ay;
+        rz[tid] = az;
+        float fa = 0.0f, fb = 0.0f;  // per-query fit taken out of the kernel values (see kqp_kernel, gpx_pairwise.hip)
+        if (fitmom && ok)
+            var_fit_query<float, KID>(cov, fitmom, ax, ay, az, fa, fb);
+        rfa[tid] = fa;
+        rfb[tid] = fb;
+        if (coef && blockIdx.x == 0) {
+            coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
+            coef[ldcc + q] = -2.0f * fb * ax;
+            coef[2 * ldcc + q] = -2.0f * fb * ay;
+            coef[3 * ldcc + q] = -2.0f * fb * az;
+            coef[4 * ldcc + q] = fb;
+        }
     }
     const int tx = tid & 15, ty = tid >> 4;  // 16 lanes x 8 columns = 128 training points per row
     const int gj0 = blockIdx.x * TILE + tx * 8;
@@ -158,12 +181,13 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk
     for (int r = 0; r < 8; ++r) {
         const int li = ty + 16 * r;
         const long q = q0 + li;
-        const float ax = rx[li], ay = ry[li], az = rz[li];
+        const float ax = rx[li], ay = ry[li], az = rz[li], fit_a = rfa[li], fit_b = rfb[li];
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
-            const float kv = cov_k<float, KID>(cov, dx * dx + dy * dy + dz * dz);
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float kv = cov_k<float, KID>(cov, d2) - (fit_a + fit_b * d2);
             v[c] = (q < nq_valid && gj0 + c < n) ? kv : 0.0f;
         }
         half8 hi, lo;
@@ -182,6 +206,8 @@ struct VsplitDev {
     const float *w;          // per-row weight (1/D, scales folded in)
     float *partial;
     long ldp;
+    const float *rowcorr, *colcoef;  // low-rank fit added back before squaring (rowcorr pre-scaled by sx sk); null: none
+    long ldrc, ldcc;
 };
 
 // 128 x 128 tile, 4 waves of 64 x 64 = 2 x 2 fragments of v_mfma_f32_32x32x16_f16; k-tile = 32 (one
@@ -321,22 +347,42 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
     // ---- epilogue: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
-    float w[2][16];
+    const bool corr = g.colcoef != nullptr;
+    float ca[2][VAR_NCORR];
+    if (corr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < VAR_NCORR; ++c)
+                ca[j][c] = g.colcoef[(size_t)c * g.ldcc + n0 + wn * 64 + j * 32 + (lane & 31)];
+    }
+    float colsum[2] = {0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            w[i][r] = g.w[m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float wr = g.w[row];
+            float sr[VAR_NCORR];
+            if (corr) {
+#pragma unroll
+                for (int c = 0; c < VAR_NCORR; ++c)
+                    sr[c] = g.rowcorr[(size_t)c * g.ldrc + row];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
+                if (corr) {
+#pragma unroll
+                    for (int c = 0; c < VAR_NCORR; ++c)
+                        wv += ca[j][c] * sr[c];
+                }
+                colsum[j] += wv * wv * wr;
+            }
+        }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
-                s += wv * wv * w[i][r];
-            }
+        float s = colsum[j];
         s += __shfl_xor(s, 32);
         if (lane < 32)
             red[wm * TILE + wn * 64 + j * 32 + lane] = s;
@@ -347,7 +393,8 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------
-void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st)
+void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st,
+                          float *rowcorr)
 {
     // X (fp32) -> P16 in place; dinv -> w = dinv / (sx sk)^2 in place
     (void)hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
@@ -355,38 +402,40 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
     hipLaunchKernelGGL(split_absmax_kernel, dim3(2048), dim3(256), 0, st, X, n, amax_bits);
     hipLaunchKernelGGL(split_pack_kernel, dim3(4096), dim3(256), 0, st, X, n / 32, amax_bits);
     hipLaunchKernelGGL(split_weights_kernel, dim3((np + 255) / 256), dim3(256), 0, st, np, dinv_to_w, amax_bits, sk,
-                       dinv_to_w);
+                       dinv_to_w, rowcorr);
 }
 
 void launch_kqp_split(const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st)
+                      hipStream_t st, const double *fitmom, float *coef, long ldcc)
 {
     Cov<float> c = lower_cov<float>(h);
     dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<KID>), grid, dim3(256), 0, st, c, sk, n, npad,
                                               (const float *)px, (const float *)py, (const float *)pz, nq_valid, qx,
-                                              qy, qz, (half_t *)P));
+                                              qy, qz, (half_t *)P, fitmom, coef, ldcc));
 }
 
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial,
-                        long ldp, int prefetch, hipStream_t st, int m_rows)
+                        long ldp, int prefetch, hipStream_t st, int m_rows, const float *rowcorr, long ldrc,
+                        const float *colcoef, long ldcc)
 {
     VsplitDev g;
+    g.rowcorr = colcoef ? rowcorr : nullptr, g.colcoef = rowcorr ? colcoef : nullptr;
+    g.ldrc = ldrc, g.ldcc = ldcc;
     g.A = (const unsigned char *)Xp;
     g.B = (const unsigned char *)Kp;
     g.M = np, g.N = nq_tile, g.K = np;
     g.w = w;
     g.partial = partial, g.ldp = ldp;
     constexpr size_t shmem = 4 * (size_t)TILE * (128 + 16);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;  // per device, see gpx_internal.hpp
+    attr_once.run([&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_done = true;
-    }
+    });
     dim3 grid(nq_tile / TILE, (m_rows > 0 ? m_rows : np) / TILE);  // rows in the identity padding contribute nothing
     if (prefetch >= 2)
         hipLaunchKernelGGL(vsplit_gemm_kernel<2>, grid, dim3(256), shmem, st, g);

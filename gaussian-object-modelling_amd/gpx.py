@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("n", C.c_int64), ("n_padded", C.c_int64), ("n_negative_pivots", C.c_int64),
                 ("ir_steps_done", C.c_int64), ("alpha_residual", C.c_double),
                 ("var_gemm_launches", C.c_int64), ("factor_gemm_launches", C.c_int64),
-                ("reserved", C.c_double * 4)]
+                ("solve_fallbacks", C.c_int64), ("reserved", C.c_double * 3)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -67,6 +67,7 @@ EXPORTS = [
     "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
+    "gpx_model_replicate",
     "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
@@ -140,6 +141,8 @@ def lib():
     L.gpx_model_state_blob.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gpx_model_commit.restype = C.c_int
     L.gpx_model_commit.argtypes = [vp, C.c_int]
+    L.gpx_model_replicate.restype = C.c_int
+    L.gpx_model_replicate.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.gpx_dev_kbuild.restype = C.c_int
     L.gpx_dev_kbuild.argtypes = [C.POINTER(Kernel), C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.gpx_pcd_read.restype = C.c_long
@@ -362,6 +365,18 @@ class Model:
 
     def commit(self, with_variance=True):
         _check(self._L.gpx_model_commit(self._h, int(bool(with_variance))))
+
+    def replicate(self, devices):
+        """gpx_model_replicate: read-only replicas of this model on the given HIP devices (list of Model)."""
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        outs = (C.c_void_p * len(devices))()
+        _check(self._L.gpx_model_replicate(self._h, len(devices), devs, outs))
+        reps = []
+        for h in outs:
+            r = Model.__new__(Model)
+            r._L, r._h, r.kernel, r.precision = self._L, C.c_void_p(h), self.kernel, self.precision
+            reps.append(r)
+        return reps
 
 
 def pcd_read(path):

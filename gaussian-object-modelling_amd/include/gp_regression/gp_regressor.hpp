@@ -308,6 +308,30 @@ public:
         }
     }
 
+    // Read-only replicas of a trained model on other GPUs of the node, one per entry of `devices` (HIP ordinals):
+    // the caller shards its query grid over them, e.g. one x-slab per replica from its own host threads
+    // (src/gp_node.cpp:1025-1038 shares one model among threads the same way).  evaluate() on a replica returns
+    // the same values as on `gp`.  New entry (gpx_model_replicate), not in the reference header.
+    std::vector<Model::Ptr> replicate(Model::ConstPtr gp, const std::vector<int> &devices)
+    {
+        if (!gp || !gp->handle_)
+            throw GPRegressionException("Empty Model pointer");
+        std::vector<gpx_model *> h(devices.size(), nullptr);
+        if (devices.empty())
+            return {};
+        const int rc = gpx_model_replicate(gp->handle_, (int)devices.size(), devices.data(), h.data());
+        if (rc != GPX_OK)
+            throw GPRegressionException(message(rc));
+        std::vector<Model::Ptr> out;
+        for (gpx_model *r : h) {
+            Model::Ptr m = std::make_shared<Model>();
+            m->handle_ = r;
+            m->R = gp->R;
+            out.push_back(m);
+        }
+        return out;
+    }
+
     // update<withNormals>(new_data, gp), :367-479
     template <bool withNormals>
     void update(Data::ConstPtr new_data, Model::Ptr gp)

@@ -99,7 +99,9 @@ typedef struct gpx_stats {
     int64_t n, n_padded, n_negative_pivots, ir_steps_done;
     double alpha_residual;  /* max |y - K alpha| after refinement (fp64, matrix-free) */
     int64_t var_gemm_launches, factor_gemm_launches;
-    double reserved[4];
+    int64_t solve_fallbacks; /* 1: the one-launch block substitution gave up waiting and alpha was recomputed with
+                                the launch-per-step kernels (same result; see gpx_factor.hip) */
+    double reserved[3];
 } gpx_stats;
 
 typedef enum {
@@ -199,6 +201,15 @@ int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const gpx_options
 int gpx_model_state_blob(gpx_model *m, int part /*0: points, alpha, 1/D; 1: inverse factor*/, void **d_ptr,
                          size_t *bytes);
 int gpx_model_commit(gpx_model *m, int with_variance);
+
+/* In-process multi-device placement for a C++ caller of the reference's shape (one process, host threads sharing a
+ * model: src/gp_node.cpp:1025-1038; no reference equivalent, the reference is single-device CPU code): out[i]
+ * receives a read-only replica of `src` on HIP device devs[i] (state copied device to device, over xGMI where peer
+ * access exists), ready for gpx_model_evaluate* / _sample_surface / _project; evaluate on a replica returns
+ * bit-identical results to `src`.  The inverse factor is built on `src` first if it was not yet.  Replicas are
+ * destroyed with gpx_model_destroy; gpx_model_update on a replica rebuilds it from its host copy of the data.
+ * On failure no replica is left behind. */
+int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_model **out);
 
 /* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------
  * kbuild: K[i][j] = k(|p_i-p_j|) + sigma2_i*delta_ij on the lower block-triangle of an

@@ -1,0 +1,51 @@
+"""CPU-side check of the shipped device code: every gfx950 kernel of libgpx.so is read back from the code-object
+metadata (tests/codeobj.py) and must use no scratch memory and spill no vector registers.  Scratch is what turned the
+first GEMM core into a 79 TFLOP/s kernel and spilled SGPRs sat on the serial pivot chain of the
+diagonal-block kernel, so both are kept out by a test rather than by inspection."""
+import os
+
+import pytest
+
+import codeobj
+
+# SGPRs parked in VGPR lanes (v_writelane / v_readlane, no memory traffic).  Every kernel is at 0 except the
+# diagonal-block kernel: it had 185-210 -- the ~150 lane masks of all 32 pivot columns hoisted to the kernel entry --
+# until the lane index was made opaque per panel; what is left (43-47 fp32, 97 fp64) are kernel arguments and
+# role masks that are parked at entry and fetched at phase boundaries, none inside the pivot recurrence.
+SGPR_SPILL_LIMIT = {"diag_ldl_kernelIf": 48, "diag_ldl_kernelId": 100}
+
+
+@pytest.fixture(scope="module")
+def kernels(gpx, tmp_path_factory):
+    ks = codeobj.kernels(gpx.LIB_PATH, tmp_path_factory.mktemp("codeobj"))
+    assert len(ks) > 50, "could not read the kernels of libgpx.so"
+    return ks
+
+
+def test_no_kernel_uses_scratch(kernels):
+    bad = [(k["name"], k["private_segment_fixed_size"]) for k in kernels if k["private_segment_fixed_size"] != 0]
+    assert not bad, "kernels with a private segment (scratch): %s" % bad
+
+
+def test_no_kernel_spills_vector_registers(kernels):
+    bad = [(k["name"], k["vgpr_spill_count"]) for k in kernels if k["vgpr_spill_count"] != 0]
+    assert not bad, "kernels with VGPR spills: %s" % bad
+
+
+def test_no_kernel_spills_scalar_registers(kernels):
+    def limit(name):
+        return max([v for key, v in SGPR_SPILL_LIMIT.items() if key in name] + [0])
+
+    bad = [(k["name"], k["sgpr_spill_count"]) for k in kernels if k["sgpr_spill_count"] > limit(k["name"])]
+    assert not bad, "kernels with SGPR spills: %s" % bad
+
+
+def test_gemm_tiles_leave_room_for_two_workgroups_per_cu(kernels):
+    """The 4-wave 128 x 128 GEMM tiles are meant to run two workgroups per CU (2 waves per SIMD): at most 256 of the
+    512 registers per lane, arch + accumulator registers together."""
+    seen = 0
+    for k in kernels:
+        if "gemm_kernel" in k["name"] and k["max_flat_workgroup_size"] == 256:
+            seen += 1
+            assert k["vgpr_count"] + k["agpr_count"] <= 256, (k["name"], k["vgpr_count"], k["agpr_count"])
+    assert seen >= 4

@@ -38,10 +38,9 @@ def _check(gm, om, q, prec, basis=True):
     assert nerr(gm.alpha, om.alpha) < mtol
     for key in ("f", "grad"):
         assert nerr(out[key], ref[key]) < mtol, key
-    # With an fp32 LDL^T of the thin-plate matrix (cond 1e5..1e7) the variance, which has no refinement step,
-    # is good to a few 1e-5 k(0); GPX_PREC_MIXED (fp64 factor, fp32 contraction) is tested at 1e-5.
-    vtol = 5e-5 if (prec in (0, 3) and om.kern.id == 2) else tol
-    assert verr(out["v"], ref["v"], _k0(om)) < vtol, "v"
+    # every fp32 mode is held to the north-star 1e-5, thin-plate included: the contraction runs on the centred kernel
+    # operand and models of up to 2048 padded rows are trained in fp64 (set_training_precision)
+    assert verr(out["v"], ref["v"], _k0(om)) < tol, "v"
     if basis:
         # the tangent basis normalises the gradient: compare where the gradient is not tiny
         gn = np.linalg.norm(ref["grad"], axis=1)
@@ -74,8 +73,7 @@ def test_mugd_node_training_set(gpu, orc, ds, golden, kkey, prec):
     assert nerr(gm.alpha, golden[pre + "alpha"]) < max(tol, 1e-9)
     for key in ("f", "grad"):
         assert nerr(out[key], golden[pre + key]) < max(tol, 1e-9), key
-    vtol = 5e-5 if (prec in (0, 3) and kn == "thinplate") else max(tol, 1e-9)
-    assert verr(out["v"], golden[pre + "v"], _k0(om)) < vtol
+    assert verr(out["v"], golden[pre + "v"], _k0(om)) < max(tol, 1e-9)
     gm.close()
 
 
@@ -220,6 +218,7 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, inv_fir
     kern = gpu.make_kernel("thinplate", 2.0)  # indefinite: negative pivots on both sides of the split
     qx, qy, qz = ds.query_grid(5)
     res = {}
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # F32 means an fp32 LDL^T here (small F32 models train in fp64 by default)
     for mode in ("1", "0"):
         monkeypatch.setenv("GPX_UPDATE_APPEND", mode)
         gm = gpu.Model(kern, x[:n0], y[:n0], z[:n0], lab[:n0], s2[:n0], precision=prec)
@@ -240,7 +239,9 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, n0, n1, inv_fir
         assert nerr(res["1"][1], other_D) < (1e-9 if prec == 1 else 1e-3)
         for key in ("f", "grad"):
             assert nerr(res["1"][2][key], other_o[key]) < tol, key
-        assert verr(res["1"][2]["v"], other_o["v"], 8.0) < (1e-9 if prec == 1 else 5e-5)
+        # prec 0 is forced to train in fp32 here: two independent fp32 factorisations of an indefinite matrix (append vs
+        # from scratch) each carry the fp32 LDL^T's backward error in the variance (test_forced_fp32_training_of_small_models)
+        assert verr(res["1"][2]["v"], other_o["v"], 8.0) < (1e-9 if prec == 1 else 4e-5)
     assert res["1"][4] < (1e-9 if prec == 1 else 1e-6)
     fresh.close()
 
@@ -257,6 +258,7 @@ def test_lookahead_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch)
     qx, qy, qz = ds.query_grid(4)
     res = {}
     monkeypatch.setenv("GPX_PANEL", "256")  # the plain fp64 order would use 512-wide panels
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # prec 0: the fp32 factorisation at every size
     for mode in ("1", "0"):
         monkeypatch.setenv("GPX_LOOKAHEAD", mode)
         gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
@@ -266,6 +268,95 @@ def test_lookahead_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch)
     for a, b in zip(res["1"][:4], res["0"][:4]):
         np.testing.assert_array_equal(a, b)
     assert res["1"][4] == res["0"][4]
+
+
+@pytest.mark.parametrize("n", [16, 129, 300, 600, 1500])
+def test_forced_fp32_training_of_small_models(gpu, orc, ds, n, monkeypatch):
+    """GPX_PREC_F32 models of up to 2048 padded rows are trained in fp64 (free at that size).  With the switch off the
+    fp32 kernel matrix / LDL^T / substitution run at these ragged sizes too: alpha, mean and gradient stay at 1e-5
+    (fp64 residual refinement); the variance has no refinement step and shows the backward error of an fp32
+    factorisation whose Schur complements sink to the noise level -- measured up to 9e-6 of max|v| for the
+    thin-plate matrices, hence the fp64 default for these sizes -- and is held to 2e-5 here."""
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    q = _queries(ds, x, y, z, g=5)
+    for kn, par in (("matern52", (1, 1)), ("thinplate", (4.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+        ref = om.evaluate(*q, want_v=True, want_grad=True)
+        for prec in (gpu.F32, gpu.F32_SPLIT):
+            gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+            out = gm.evaluate(*q, want_v=True, want_grad=True)
+            assert nerr(gm.alpha, om.alpha) < 1e-5
+            assert nerr(out["f"], ref["f"]) < 1e-5 and nerr(out["grad"], ref["grad"]) < 1e-5
+            assert verr(out["v"], ref["v"], _k0(om)) < (2e-5 if kn == "thinplate" else 1e-5)
+            gm.close()
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("n", [1500, 2305])
+def test_substitution_give_up_falls_back_to_step_launches(gpu, ds, prec, n, monkeypatch):
+    """The one-launch block substitution hands results from lower to higher block rows through polled entries; a poll
+    that runs out of patience (GPX_SOLVE_SPIN_LIMIT=1 forces that: one look, then give up) voids the solve, and
+    create() then recomputes alpha in-process with the launch-per-step kernels: success, gpx_stats.solve_fallbacks
+    == 1, and exactly the alpha of GPX_SOLVE_STEPS=1."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel("matern52", 1.0, 1.0)
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    monkeypatch.setenv("GPX_SOLVE_STEPS", "1")
+    gs = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+    a_steps, st_steps = gs.alpha.copy(), gs.stats
+    gs.close()
+    monkeypatch.setenv("GPX_SOLVE_STEPS", "0")
+    monkeypatch.setenv("GPX_SOLVE_SPIN_LIMIT", "1")
+    gf = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+    assert gf.stats["solve_fallbacks"] == 1 and st_steps["solve_fallbacks"] == 0
+    np.testing.assert_array_equal(gf.alpha, a_steps)
+    assert gf.stats["alpha_residual"] == st_steps["alpha_residual"]
+    gf.update(x[:5] * 0.5, y[:5] * 0.5, z[:5] * 0.5, lab[:5], s2[:5])  # the update path takes the same fallback
+    assert gf.stats["solve_fallbacks"] == 1
+    gf.close()
+    monkeypatch.delenv("GPX_SOLVE_SPIN_LIMIT")
+    gn = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+    assert gn.stats["solve_fallbacks"] == 0
+    assert nerr(gn.alpha, a_steps) < (1e-10 if prec == 1 else 1e-5)
+    gn.close()
+
+
+@pytest.mark.parametrize("prec", [1, 0, 2, 3])
+def test_replicas_are_bit_identical_to_their_source(gpu, ds, prec):
+    """gpx_model_replicate: read-only copies of a trained model on the listed devices (this box has one GPU, so the
+    replicas land on device 0; across devices the same two blobs travel by hipMemcpyPeer).  Replicas answer
+    evaluate / sample_surface / accessors exactly like the source and outlive it."""
+    n = 2305  # above the fp64-training threshold: F32 keeps its fp32 factor, which replicas do not receive
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel("thinplate", 4.0)
+    src = gpu.Model(kern, x, y, z, lab, s2, precision=prec, device=0)
+    qx, qy, qz = ds.query_grid(9)
+    ref = src.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    reps = src.replicate([0, 0])
+    assert len(reps) == 2
+    a, D, R = src.alpha.copy(), src.D.copy(), src.R
+    surf = src.sample_surface(qx, qy, qz, f_tol=0.05)
+    src.close()  # replicas own their state
+    for r in reps:
+        out = r.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+        for key in ("f", "v", "grad"):
+            np.testing.assert_array_equal(out[key], ref[key])
+        one = r.evaluate(qx[:3], qy[:3], qz[:3], want_v=True)
+        np.testing.assert_array_equal(one["f"], ref["f"][:3])
+        np.testing.assert_array_equal(r.alpha, a)
+        np.testing.assert_array_equal(r.D, D)
+        assert r.R == R and r.n == n
+        s2_ = r.sample_surface(qx, qy, qz, f_tol=0.05)
+        np.testing.assert_array_equal(s2_["idx"], surf["idx"])
+        np.testing.assert_array_equal(s2_["v"], surf["v"])
+    # a replica can still be updated: it rebuilds from its host copy of the data
+    reps[0].update(x[:3] * 0.7, y[:3] * 0.7, z[:3] * 0.7, lab[:3], s2[:3])
+    assert reps[0].n == n + 3
+    for r in reps:
+        r.close()
+    with pytest.raises(gpu.GpxError):
+        gpu.Model(kern, x[:50], y[:50], z[:50], lab[:50], s2[:50], precision=prec).replicate([7])
 
 
 @pytest.mark.parametrize("prec", [1, 0])
@@ -278,6 +369,7 @@ def test_one_launch_substitution_equals_step_launches(gpu, ds, prec, kname, kpar
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     kern = gpu.make_kernel(kname, *kpar)
     res = {}
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # prec 0: the fp32 substitution kernels at every size
     for mode in ("0", "1"):
         monkeypatch.setenv("GPX_SOLVE_STEPS", mode)
         gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, ir_steps=0)
@@ -376,7 +468,7 @@ def test_small_batch_path_agrees_with_general_path(gpu, orc, ds, golden, prec):
     Q[:4] = np.stack([x, y, z], 1)[:4]                       # on training points
     big = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True, want_basis=True)
     ref = om.evaluate(Q[:40, 0], Q[:40, 1], Q[:40, 2], want_v=True, want_grad=True, want_basis=True)
-    tol = 1e-10 if prec == 1 else 5e-5
+    tol = 1e-10 if prec == 1 else 1e-5
     for lo, hi in ((0, 1), (1, 40), (40, 104)):
         small = gm.evaluate(Q[lo:hi, 0], Q[lo:hi, 1], Q[lo:hi, 2], want_v=True, want_grad=True, want_basis=True)
         for key in ("f", "grad"):
@@ -462,7 +554,7 @@ def test_independent_models_from_concurrent_threads(gpu, orc, ds):
                 om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
                 ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
                 k0 = float(orc.k(orc.make_kernel(kn, *par), 0.0)[0])
-                tol = 1e-9 if prec == gpu.F64 else 5e-5
+                tol = 1e-9 if prec == gpu.F64 else 1e-5
                 assert nerr(out["f"], ref["f"]) < tol and verr(out["v"], ref["v"], k0) < tol
                 assert nerr(out["grad"], ref["grad"]) < tol
                 assert nerr(one["f"], ref["f"][:3]) < tol and verr(one["v"], ref["v"][:3], k0) < tol
