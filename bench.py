@@ -34,6 +34,9 @@ KERNEL = ("matern52", (1.0, 1.0))
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 matrix peak (the opt-in split contraction runs three fp16 products per fp32 one)
+# VALU instructions per (query, training point) pair in the inner loop of predict_kernel<double, KID, false> (mean only),
+# counted in the gfx950 ISA of the shipped library (scripts/predict_isa.py -> profiles/r02_predict_isa.txt)
+MEAN_VALU_PER_PAIR = {}
 
 
 def parse():
@@ -54,30 +57,49 @@ def parse():
 
 
 def cpu_baseline(n_train, nq, kernel_name, kernel_par):
-    """Oracle (CPU fp64 port of the reference algorithm) on a bounded sample, 1 core."""
+    """Oracle (CPU fp64 port of the reference algorithm) on bounded samples: one core (the reference's create is
+    single-threaded and its evaluate parallelism is the caller's threads) and all host cores (OpenMP build)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     orc = importlib.import_module("gp_oracle")
     ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
-    ns, nqs = 3072, 1024
-    x, y, z, lab, s2 = ds.fibonacci_training_set(ns)
-    qx, qy, qz = ds.query_grid(11)
-    qx, qy, qz = qx[:nqs], qy[:nqs], qz[:nqs]
     kern = orc.make_kernel(kernel_name, *kernel_par)
-    t0 = time.perf_counter()
-    m = orc.Model(kern, x, y, z, lab, s2, omp=False)
-    t1 = time.perf_counter()
-    m.evaluate(qx, qy, qz, want_v=True)
-    t2 = time.perf_counter()
-    t_create, t_q = t1 - t0, (t2 - t1) / nqs
-    # cost model of the reference algorithm: create ~ N^3 (unblocked LDL^T), evaluate ~ N^2 per query
-    t_full = t_create * (n_train / ns) ** 3 + t_q * (n_train / ns) ** 2 * nq
-    return {
-        "value": nq / t_full, "unit": "query-points/s", "cores": 1, "kind": "port",
+    ncores = os.cpu_count() or 1
+
+    def sample(ns, nqs, omp):
+        x, y, z, lab, s2 = ds.fibonacci_training_set(ns)
+        qx, qy, qz = ds.query_grid(11)
+        qx, qy, qz = qx[:nqs], qy[:nqs], qz[:nqs]
+        t0 = time.perf_counter()
+        m = orc.Model(kern, x, y, z, lab, s2, omp=omp)
+        t1 = time.perf_counter()
+        m.evaluate(qx, qy, qz, want_v=True)
+        t2 = time.perf_counter()
+        t_create, t_q = t1 - t0, (t2 - t1) / nqs
+        # cost model of the reference algorithm: create ~ N^3 (unblocked LDL^T), evaluate ~ N^2 per query
+        t_full = t_create * (n_train / ns) ** 3 + t_q * (n_train / ns) ** 2 * nq
+        return t_create, t_q, t_full
+
+    ns1, nq1 = 3072, 1024
+    c1, q1, full1 = sample(ns1, nq1, False)
+    out = {
+        "value": nq / full1, "unit": "query-points/s", "cores": 1, "kind": "port",
         "sample": ("oracle/gp_oracle.c (fp64 restatement of gp_regressor.hpp, unblocked LDL^T, per-query solve) "
                    "timed at N_train=%d (create %.2fs) and %d queries (%.2f ms/query), scaled by N^3 / N^2 to "
-                   "N_train=%d, N_query=%d -> %.0f s per step" % (ns, t_create, nqs, t_q * 1e3, n_train, nq, t_full)),
+                   "N_train=%d, N_query=%d -> %.0f s per step.  The sample's 72 MiB matrix is cache-resident, the "
+                   "2 GiB one of N_train=%d is not: the scaling flatters the CPU" %
+                   (ns1, c1, nq1, q1 * 1e3, n_train, nq, full1, n_train)),
     }
+    try:
+        nsa, nqa = 6144, 1024
+        ca, qa, fulla = sample(nsa, nqa, True)
+        out["all_cores"] = {
+            "value": nq / fulla, "unit": "query-points/s", "cores": ncores, "kind": "port",
+            "sample": ("oracle/libgp_oracle_omp.so (OpenMP over the rows of each rank-1 update and over the queries) on %d "
+                       "cores, timed at N_train=%d (create %.2fs) and %d queries (%.2f ms/query), scaled by N^3 / N^2 -> "
+                       "%.0f s per step" % (ncores, nsa, ca, nqa, qa * 1e3, fulla))}
+    except Exception as e:  # the one-core figure is the contract; never lose it to the extra sample
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def pmc_traffic(args, n_train, q_per_launch):
@@ -239,11 +261,51 @@ def main():
         if roof:
             out["roofline"] = roof
             fg = st["factor_gemm_launches"]
-            if fg > 0:
+            if fg > 0 and st["t_factor_gemm_ms"] > 0:
+                # two figures: the event-timed trailing-update launches against their OWN flops (lower tiles x 2 x 128^2 x
+                # K; the look-ahead's 256-column strip products and the panel chain are outside these events), and the
+                # whole factorisation, N^3/3 over everything between kbuild and the alpha solve
+                tr = st["factor_gemm_flops"] / (st["t_factor_gemm_ms"] * 1e-3) / 1e12
+                whole = (n_train ** 3 / 3.0) / (st["t_factor_ms"] * 1e-3) / 1e12
                 out["roofline_factor"] = {
-                    "bound": "mfma", "kernel": "gemm_kernel<%s,NT,STORE> (LDL^T trailing update)" % args.precision,
-                    "achieved": (n_train ** 3 / 3.0) / (st["t_factor_gemm_ms"] * 1e-3) / 1e12, "peak": peak,
-                    "unit": "TFLOP/s", "frac": (n_train ** 3 / 3.0) / (st["t_factor_gemm_ms"] * 1e-3) / 1e12 / peak}
+                    "bound": "mfma", "kernel": "gemm_kernel<%s,NT,STORE> (LDL^T trailing update, K = panel width)" % gemm_t,
+                    "achieved": tr, "peak": peak, "unit": "TFLOP/s", "frac": tr / peak,
+                    "timed_launches": fg, "timed_flops": st["factor_gemm_flops"], "timed_ms": st["t_factor_gemm_ms"],
+                    "whole_ldlt": {"what": "N^3/3 flop / t_factor_ms (diagonal blocks, panel solves, strip and trailing updates)",
+                                   "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
+        esz = 8 if prec == gpx.F64 else 4
+        npad = int(st["n_padded"])
+        HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+        if st["t_kbuild_ms"] > 0:
+            nt = npad // 128
+            kb_bytes = nt * (nt + 1) // 2 * 128 * 128 * esz + 4 * npad * esz  # lower block-triangle written + points read
+            bw = kb_bytes / (st["t_kbuild_ms"] * 1e-3)
+            out["roofline_kbuild"] = {"bound": "hbm", "kernel": "kbuild_kernel<%s> (+ the arg-max reduction, same events)" % gemm_t,
+                                      "bytes": kb_bytes, "ms": st["t_kbuild_ms"], "achieved": bw / 1e9, "peak": HBM_PEAK / 1e9,
+                                      "unit": "GB/s", "frac": bw / HBM_PEAK}
+        if want_v and st["var_gemm_launches"] > 0 and st.get("t_var_kqp_ms", 0) > 0:
+            launches = st["var_gemm_launches"]
+            q_per_launch = nq_local / launches
+            np_rows = min(npad, (n_train + 127) // 128 * 128)
+            kq_bytes = q_per_launch * np_rows * 4 + 4 * npad * 4 + q_per_launch * 24  # Kqp written (fp32 or packed halves) + points + queries
+            if prec == gpx.F64:
+                kq_bytes = q_per_launch * np_rows * 8 + 4 * npad * 8 + q_per_launch * 24
+            ms = st["t_var_kqp_ms"] / launches
+            bw = kq_bytes / (ms * 1e-3)
+            out["roofline_kqp"] = {"bound": "hbm", "kernel": "kqp_kernel (kernel operand of one variance batch)",
+                                   "bytes_per_launch": kq_bytes, "avg_launch_ms": ms, "achieved": bw / 1e9,
+                                   "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bw / HBM_PEAK}
+        if st["t_mean_ms"] > 0:
+            pairs = float(nq_local) * npad
+            rate = pairs / (st["t_mean_ms"] * 1e-3)
+            lane_rate = 256 * 4 * 16 * 2.4e9  # lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz
+            out["roofline_mean"] = {
+                "bound": "valu", "kernel": "predict_kernel<f64> (mean; fp64 in every mode)",
+                "pair_evals": pairs, "ms": st["t_mean_ms"], "achieved": rate / 1e9, "unit": "G pair-evals/s",
+                "valu_instr_per_pair": MEAN_VALU_PER_PAIR[args.kernel] if args.kernel in MEAN_VALU_PER_PAIR else None,
+                "frac": (rate * MEAN_VALU_PER_PAIR[args.kernel] / lane_rate) if args.kernel in MEAN_VALU_PER_PAIR else None,
+                "note": "VALU-issue fraction = pair-evals/s x VALU instructions per pair (counted in the ISA of the inner loop, "
+                        "profiles/r02_predict_isa.txt) / 3.93e13 lane-instructions/s; HBM traffic is 32 B per query"}
         if world == 1 and want_v and args.precision == "f32" and not args.no_fast_mode and not shard:
             # informative only, measured AFTER the timed region and never part of `value`: the same step with the
             # variance contraction on the fp16 matrix cores (hi/lo operand halves, GPX_PREC_F32_SPLIT)
@@ -269,6 +331,36 @@ def main():
                                          "variance error / k(0) vs fp64 at N=16384 1.9e-6 (native fp32 path: 4.5e-6)"}
             except Exception as e:  # never let the extra line break the contract line
                 out["fast_mode"] = {"error": str(e)}
+        if world == 1 and want_v and args.precision == "f32" and not args.no_fast_mode and not shard:
+            # informative only, after the timed region, never `value`: the same step in the reference's own arithmetic
+            # (fp64 throughout), driver-visible: ms per step and the fp64 variance GEMM against the fp64 MFMA peak
+            try:
+                def f64_step():
+                    m64 = gpx.Model(kern, x, y, z, lab, s2, precision=gpx.F64, prepare_variance=True, device=local_rank)
+                    m64.evaluate_device(nq_local, qx.data_ptr(), qy.data_ptr(), qz.data_ptr(), f.data_ptr(), v.data_ptr())
+                    m64.sync()
+                    return m64
+                f64_step().close()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sts = []
+                for _ in range(2):
+                    m64 = f64_step()
+                    sts.append(m64.stats)
+                    m64.close()
+                dt = (time.perf_counter() - t1) / 2
+                s64 = {k: float(np.mean([s_[k] for s_ in sts])) for k in sts[0]}
+                l64 = max(1.0, s64["var_gemm_launches"])
+                a64 = float(n_train) ** 2 * (nq_local / l64) / (s64["t_var_gemm_ms"] / l64 * 1e-3) / 1e12
+                out["f64"] = {"what": "the same step with GPX_PREC_F64 (the reference's arithmetic), 2 steps after 1 warm-up",
+                              "ms_per_step": dt * 1e3, "value": nq / dt, "unit": "query-points/s",
+                              "variance_gemm": {"achieved": a64, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": a64 / PEAK_F64_MFMA_TFLOPS, "avg_launch_ms": s64["t_var_gemm_ms"] / l64},
+                              "stages_ms": {k: s64[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_solve_ms", "t_inverse_ms",
+                                                                "t_mean_ms", "t_var_ms")},
+                              "alpha_residual": s64["alpha_residual"]}
+            except Exception as e:
+                out["f64"] = {"error": str(e)}
         if world == 1 and want_v and not shard and not args.no_fast_mode and model[0] is not None:
             # informative only (never `value`): the same prediction through the HOST-pointer entry gpx_model_evaluate,
             # i.e. including the PCIe copies of 3 x 8 B in and 2 x 8 B out per query (1 MiB-query slices)

@@ -59,6 +59,10 @@ void free_dev(gpx_model *m)
     for (auto &e : m->gemm_ev)
         (void)hipEventDestroy(e);
     m->gemm_ev.clear();
+    for (auto &e : m->kqp_ev)
+        (void)hipEventDestroy(e);
+    m->kqp_ev.clear();
+    m->kqp_ev_used = 0;
     // timings of an evaluate() that were not read yet refer to the events just destroyed
     m->stats_eval_pending = false;
     m->gemm_ev_used_var = m->gemm_ev_used_factor = 0;
@@ -111,7 +115,7 @@ void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
 int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
 {
     const size_t np = (size_t)m->npad;
-    *bytes = sizeof(double) * (np * 4 + VAR_NMOM) + esz * np * (4 + VAR_NCORR);
+    *bytes = sizeof(double) * np * 4 + esz * np * (4 + VAR_NCORR);
     HIPCHK(hipMalloc(blob, *bytes));
     return GPX_OK;
 }
@@ -123,37 +127,12 @@ void carve_blob0(gpx_model *m)
     m->d_y = m->d_x + np;
     m->d_z = m->d_y + np;
     m->d_alpha = m->d_z + np;
-    m->d_fitmom = m->d_alpha + np;
-    char *b = (char *)(m->d_fitmom + VAR_NMOM);
+    char *b = (char *)(m->d_alpha + np);
     m->t_x = b;
     m->t_y = b + e * np;
     m->t_z = b + 2 * e * np;
     m->t_dinv = b + 3 * e * np;
     m->t_corr = b + 4 * e * np;
-}
-
-// Moments of the point cloud (means over the n training points, fp64 on the host) behind the per-query fit of the
-// variance contraction, see gpx_internal.hpp; uses the working-precision roundings of the coordinates, i.e. the
-// points the kqp kernels see.
-static void cloud_moments(const gpx_model *m, const std::vector<double> &st, int np, double (&mom)[VAR_NMOM])
-{
-    for (double &v : mom)
-        v = 0.0;
-    const int n = m->n;
-    const bool f32 = m->prec != GPX_PREC_F64;
-    for (int k = 0; k < n; ++k) {
-        double x = st[k], y = st[np + k], z = st[2 * (size_t)np + k];
-        if (f32)
-            x = (double)(float)x, y = (double)(float)y, z = (double)(float)z;
-        const double r2 = x * x + y * y + z * z;
-        mom[0] += x, mom[1] += y, mom[2] += z;
-        mom[3] += x * x, mom[4] += x * y, mom[5] += x * z, mom[6] += y * y, mom[7] += y * z, mom[8] += z * z;
-        mom[9] += r2;
-        mom[10] += r2 * x, mom[11] += r2 * y, mom[12] += r2 * z;
-        mom[13] += r2 * r2;
-    }
-    for (double &v : mom)
-        v /= (double)n;
 }
 
 int alloc_model(gpx_model *m)
@@ -237,6 +216,7 @@ static void factorize(gpx_model *m, int c_start = 0)
     auto Kp = [&](size_t r, size_t c) { return (void *)(K + (r * ldk + c) * e); };
     auto Wpp = [&](size_t r, size_t c) { return (void *)(W + (r * WIDE_PANEL + c) * e); };
     size_t gemm_idx = 0;
+    m->factor_gemm_flops = 0;
     // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
     auto block_step = [&](int cc, int wcol, hipStream_t st) {
         const int r0 = cc + TILE;
@@ -274,6 +254,10 @@ static void factorize(gpx_model *m, int c_start = 0)
         s.M = np - r0, s.N = np - r0, s.K = kw;
         s.alpha = -1.0, s.beta = 1;
         s.lower_only = 1;
+        {
+            const double mt = (double)(s.M / TILE);
+            m->factor_gemm_flops += mt * (mt + 1) * 0.5 * 2.0 * TILE * TILE * kw;
+        }
         hipEvent_t *ev = gemm_events(m, gemm_idx);
         if (ev)
             (void)hipEventRecord(ev[0], m->stream);
@@ -628,8 +612,8 @@ static int demote_to_f32(gpx_model *m)
     if (rc)
         return rc;
     HIPCHK(hipMalloc(&nX, sizeof(float) * np * np));
-    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * (np * 4 + VAR_NMOM), hipMemcpyDeviceToDevice, s));
-    float *tf = (float *)((char *)nb + sizeof(double) * (np * 4 + VAR_NMOM));
+    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
+    float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
     launch_cast_d2f(np, (const double *)m->t_x, tf, s);
     launch_cast_d2f(np, (const double *)m->t_y, tf + np, s);
     launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
@@ -699,9 +683,6 @@ int build_model(gpx_model *m, kept_factor *keep)
     HIPCHK(hipMemcpyAsync(m->d_x, st.data(), sizeof(double) * (size_t)np * 3, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(m->d_lab, st.data() + 3 * (size_t)np, sizeof(double) * (size_t)np * 2,
                           hipMemcpyHostToDevice, s));
-    double mom[VAR_NMOM];
-    cloud_moments(m, st, np, mom);
-    HIPCHK(hipMemcpyAsync(m->d_fitmom, mom, sizeof(mom), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
     HIPCHK(hipMemsetAsync(m->d_r, 0, sizeof(double) * (size_t)np * 2 + 64, s));
     HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
@@ -824,6 +805,7 @@ int build_model(gpx_model *m, kept_factor *keep)
             tg += ms;
     m->stats.t_factor_gemm_ms = tg;
     m->stats.factor_gemm_launches = (int64_t)m->gemm_ev_used_factor;
+    m->stats.factor_gemm_flops = m->factor_gemm_flops;
     m->stats.n = n;
     m->stats.n_padded = np;
     m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);

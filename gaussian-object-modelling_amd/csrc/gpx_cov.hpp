@@ -82,32 +82,6 @@ __device__ __forceinline__ void cov_k_diff(const Cov<T> &c, T d2, T &k, T &kd)
     }
 }
 
-// (a_q, b_q) of the fit k(d) ~ a_q + b_q d^2 for one query (see gpx_internal.hpp): mean and variance of
-// u = |q - p|^2 over the training points from the cloud's moments (double: E[u^2] - E[u]^2 cancels), then the
-// least-squares line through k at u_lo, u_mid, u_hi = mean -+ sqrt(3) sigma (clamped at 0).
-template <typename T, int KID>
-__device__ __forceinline__ void var_fit_query(const Cov<T> &cov, const double *__restrict__ mom, T qx, T qy, T qz,
-                                              T &fa, T &fb)
-{
-    const double x = (double)qx, y = (double)qy, z = (double)qz;
-    const double a = x * x + y * y + z * z;
-    const double bx = -2.0 * x, by = -2.0 * y, bz = -2.0 * z;
-    const double bm1 = bx * mom[0] + by * mom[1] + bz * mom[2];
-    const double s2 = mom[9];
-    const double eu = a + bm1 + s2;
-    const double bMb = bx * (bx * mom[3] + 2.0 * (by * mom[4] + bz * mom[5])) + by * (by * mom[6] + 2.0 * bz * mom[7]) +
-                       bz * bz * mom[8];
-    const double eu2 = a * a + 2.0 * a * (bm1 + s2) + bMb + 2.0 * (bx * mom[10] + by * mom[11] + bz * mom[12]) + mom[13];
-    const double var = fmax(eu2 - eu * eu, 0.0);
-    const double hw = 1.7320508075688772 * sqrt(var);
-    const double ulo = fmax(eu - hw, 0.0), uhi = fmax(eu + hw, 0.0), umid = 0.5 * (ulo + uhi);
-    const T k0 = cov_k<T, KID>(cov, (T)ulo), k1 = cov_k<T, KID>(cov, (T)umid), k2 = cov_k<T, KID>(cov, (T)uhi);
-    const double du = uhi - ulo;
-    const double b = du > 1e-12 * (1.0 + uhi) ? ((double)k2 - (double)k0) / du : 0.0;
-    fb = (T)b;
-    fa = (T)(((double)k0 + (double)k1 + (double)k2) * (1.0 / 3.0) - (double)fb * umid);
-}
-
 // Dispatch a functor templated on <T, KID> from run-time (prec, id).
 #define GPX_DISPATCH_KID(ID, ...)                                              \
     switch (ID) {                                                              \

@@ -35,7 +35,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             return rc;
         if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
             return rc;
-        if (m->var_fit && (rc = ensure(&m->ws_coef, &m->ws_coef_bytes, e * qb * VAR_NCORR)))
+        if (m->var_fit && (rc = ensure(&m->ws_coef, &m->ws_coef_bytes, e * qb * VAR_NCOEF)))
             return rc;
     }
     // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
@@ -58,10 +58,32 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         for (size_t q0 = 0; q0 < nq; q0 += qb) {
             const size_t nv = std::min(qb, nq - q0);
             const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
+            // The kernel operand holds k - fit with a per-query fit that is rank 5 in (q, p); the GEMM epilogue adds
+            // X * fit back from the model's five row-correction vectors (gpx_internal.hpp, "low-rank fit").
+            hipEvent_t *kev = nullptr;  // brackets the Kqp launch of this batch (stats; only on the model's own stream)
+            if (s == m->stream) {
+                while (m->kqp_ev.size() < 2 * (gi + 1)) {
+                    hipEvent_t e_;
+                    if (hipEventCreate(&e_) != hipSuccess)
+                        break;
+                    m->kqp_ev.push_back(e_);
+                }
+                if (m->kqp_ev.size() >= 2 * (gi + 1))
+                    kev = &m->kqp_ev[2 * gi];
+            }
+            const char *fab = nullptr;  // rows a_q, b_q of the batch's coefficient array
+            if (m->var_fit) {
+                launch_var_fit(m->prec, m->cov, m->n, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
+                               qz + q0, m->ws_coef, (long)qb, s);
+                fab = (const char *)m->ws_coef + e * qb * VAR_NCORR;
+            }
+            if (kev)
+                (void)hipEventRecord(kev[0], s);
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
-                                 qy + q0, qz + q0, m->ws_kqp, s, m->var_fit ? m->d_fitmom : nullptr,
-                                 m->var_fit ? (float *)m->ws_coef : nullptr, (long)qb);
+                                 qy + q0, qz + q0, m->ws_kqp, s, (const float *)fab, (long)qb);
+                if (kev)
+                    (void)hipEventRecord(kev[1], s);
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
@@ -75,11 +97,10 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
-            // The kernel operand holds k - fit with a per-query fit that is rank 5 in (q, p); the GEMM epilogue adds
-            // X * fit back from the model's five row-correction vectors (gpx_internal.hpp, "low-rank fit").
             launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                       qz + q0, m->ws_kqp, s, np_rows, m->var_fit ? m->d_fitmom : nullptr,
-                       m->var_fit ? m->ws_coef : nullptr, (long)qb);
+                       qz + q0, m->ws_kqp, s, np_rows, fab, (long)qb);
+            if (kev)
+                (void)hipEventRecord(kev[1], s);
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
             a.B = m->ws_kqp, a.ldb = np;
@@ -110,6 +131,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             launch_var_finish(m->prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
         }
         m->gemm_ev_used_var = gi;
+        m->kqp_ev_used = (s == m->stream) ? gi : 0;
     }
     (void)hipEventRecord(m->ev[EV_V1], s);
     (void)hipEventRecord(m->ev[EV_WS], s);
@@ -553,6 +575,11 @@ void resolve_eval_stats(gpx_model *m)
     }
     m->stats.t_var_gemm_ms = tg;
     m->stats.var_gemm_launches = (int64_t)m->gemm_ev_used_var;
+    double tk = 0;
+    for (size_t i = 0; i < m->kqp_ev_used && 2 * i + 1 < m->kqp_ev.size(); ++i)
+        if (hipEventElapsedTime(&ms, m->kqp_ev[2 * i], m->kqp_ev[2 * i + 1]) == hipSuccess)
+            tk += ms;
+    m->stats.t_var_kqp_ms = tk;
     m->stats_eval_pending = false;
 }
 

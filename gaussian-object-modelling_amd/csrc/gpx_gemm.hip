@@ -80,6 +80,14 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_WAVES_PER_EU
 #define GEMM_WAVES_PER_EU 2
 #endif
+// How the COLSQ epilogue gets this tile's slices of the low-rank correction (5 row vectors, 5 column vectors):
+// 0: scattered global loads in the epilogue; 1: requested before the k-loop (registers), parked in LDS after it;
+// 2: cooperative coalesced loads after the k-loop, through LDS.  Measured (scripts/gemm_bench.hip, N = 16384, 8192
+// queries, 128 x 128 tiles): 15.69 / 16.44 / 16.16 ms -- with two workgroups per CU the other workgroup's MFMAs cover
+// the scattered loads, while the parked registers and the extra barrier of the LDS variants cost more than they save.
+#ifndef GEMM_CORR_STAGE
+#define GEMM_CORR_STAGE 0
+#endif
 
 template <typename T>
 struct GemmDev {
@@ -272,6 +280,27 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
                                         (wn * FN + j) * FR + fr];
     }
 
+    // ---- EPI_COLSQ with the low-rank correction: this tile's slices of the five row vectors and five column
+    // coefficient vectors go through LDS, so that the epilogue does not wait for ~200 scattered global loads per lane
+    constexpr int NPC = (EPI == EPI_COLSQ) ? ((BM + BN) * VAR_NCORR + NT - 1) / NT : 1;
+    T pc[NPC];
+    const bool corr = (EPI == EPI_COLSQ) && g.colcoef != nullptr;
+#define GPX_CORR_LOAD()                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPC; ++i_)                                                               \
+    {                                                                                                                \
+        const int e_ = tid + NT * i_;                                                                                \
+        T v_ = T(0);                                                                                                 \
+        if (e_ < VAR_NCORR * BM)                                                                                     \
+            v_ = g.rowcorr[(size_t)(e_ / BM) * g.ldrc + m0 + e_ % BM];                                               \
+        else if (e_ < VAR_NCORR * (BM + BN))                                                                         \
+            v_ = g.colcoef[(size_t)((e_ - VAR_NCORR * BM) / BN) * g.ldcc + n0 + (e_ - VAR_NCORR * BM) % BN];         \
+        pc[i_] = v_;                                                                                                 \
+    }
+    if constexpr (EPI == EPI_COLSQ && GEMM_CORR_STAGE == 1) {
+        if (corr)
+            GPX_CORR_LOAD();
+    }
+
     // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
     // The last iteration re-loads its own tile (clamped index) so that nothing in the loop is conditional.
     if (kt0 < kt1) {
@@ -399,14 +428,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
         // Low-rank correction of the contraction (gpx_eval.hip, "centred kernel operand"): the B operand holds
         // k - fit with fit[n][k] = sum_c colcoef[c][n] b_c[k]; the product of A with the fit is added back here from
         // rowcorr[c][m] = sum_k A[m][k] b_c[k], which was accumulated once per model in fp64.
-        const bool corr = g.colcoef != nullptr;
+        T *cs = smem + WGM * BN;  // [VAR_NCORR][BM] row vectors | [VAR_NCORR][BN] column coefficients of this tile
+        if (corr && GEMM_CORR_STAGE != 0) {
+            if constexpr (GEMM_CORR_STAGE == 2)
+                GPX_CORR_LOAD();
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int e = tid + NT * i;
+                if (e < VAR_NCORR * (BM + BN))
+                    cs[e] = pc[i];
+            }
+            __syncthreads();
+        }
         T ca[FN][VAR_NCORR];
         if (corr) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int c = 0; c < VAR_NCORR; ++c)
-                    ca[j][c] = g.colcoef[(size_t)c * g.ldcc + n0 + (wn * FN + j) * FR + fr];
+                    ca[j][c] = GEMM_CORR_STAGE != 0 ? cs[VAR_NCORR * BM + c * BN + (wn * FN + j) * FR + fr]
+                                                    : g.colcoef[(size_t)c * g.ldcc + n0 + (wn * FN + j) * FR + fr];
         }
         T colsum[FN];
 #pragma unroll
@@ -417,12 +458,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
             T w[NACC], sr[VAR_NCORR][NACC];
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
-                const int row = m0 + (wm * FM + i) * FR + MF::crow(lane, r);
-                w[r] = g.rowweight[row];
+                const int lrow = (wm * FM + i) * FR + MF::crow(lane, r);
+                w[r] = g.rowweight[m0 + lrow];
                 if (corr) {
 #pragma unroll
                     for (int c = 0; c < VAR_NCORR; ++c)
-                        sr[c][r] = g.rowcorr[(size_t)c * g.ldrc + row];
+                        sr[c][r] = GEMM_CORR_STAGE != 0 ? cs[c * BM + lrow] : g.rowcorr[(size_t)c * g.ldrc + m0 + lrow];
                 }
             }
 #pragma unroll
@@ -456,6 +497,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
             g.partial[(size_t)mt * g.ldp + n0 + c] = s;
         }
     }
+#undef GPX_CORR_LOAD
 }
 
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES = 128, bool M32 = false>

@@ -82,18 +82,23 @@ void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile
 // d^2 = |q|^2 - 2 q.p + |p|^2 cannot represent.  ANY (a_q, b_q) gives the same variance in exact arithmetic (the fit is
 // rank 5 in (q, p) and its product with the inverse factor is added back in the GEMM epilogue from five per-model
 // vectors); a good one shrinks the operand, and with it the fp32 rounding of the N-term contractions, by an order of
-// magnitude (thin-plate R = 4, N = 16384: variance error 2.0e-5 k(0) -> see DESIGN.md section 6).  (a_q, b_q) is the
-// least-squares line through k at three points of the interval mean +- sqrt(3) sigma of d^2 over the training
-// set, and those two moments follow in O(1) from the moments of the point cloud below (means over the n points).
-constexpr int VAR_NMOM = 16;  // doubles: m1[3] | M2 xx xy xz yy yz zz | s2 = E|p|^2 | s3[3] = E|p|^2 p | s4 = E|p|^4 | pad
+// magnitude (thin-plate R = 4, N = 16384: variance error 2.0e-5 k(0) -> 1.1e-6).  (a_q, b_q) is the
+// least-squares line of k against d^2 over a strided sample of ~512 training points (all of them for small models),
+// so it follows the actual distances of the query, outliers such as the node's exterior sphere included.
+constexpr int VAR_FIT_SAMPLES = 512;
+constexpr int VAR_NCOEF = VAR_NCORR + 2;  // rows of the per-batch coefficient array: the 5 epilogue coefficients, a_q, b_q
+// coef (prec scalars, [VAR_NCOEF][ldcc]) for the queries [0, nq_tile) of a batch (zero from nq_valid on); px, py, pz:
+// the n training points as prec scalars
+void launch_var_fit(int prec, const CovHost &cov, int n, const void *px, const void *py, const void *pz, long nq_valid,
+                    long nq_tile, const double *qx, const double *qy, const double *qz, void *coef, long ldcc,
+                    hipStream_t st);
 // Kqp[q][j] = k(|q - p_j|) - (a_q + b_q |q - p_j|^2), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
-// fitmom: device pointer to the VAR_NMOM moments, or null for the plain kernel values (a_q = b_q = 0); coef (T,
-// [VAR_NCORR][ldcc]): the fit's query-side coefficients {a_q + b_q |q|^2, -2 b_q q_xyz, b_q} for the GEMM epilogue.
+// fab: rows a_q, b_q of launch_var_fit's array (prec scalars, stride ldcc), or null for the plain kernel values.
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
                 hipStream_t st,
                 int ncols = 0,  // > 0: only the first ncols columns are written (columns in the padding are never read)
-                const double *fitmom = nullptr, void *coef = nullptr, long ldcc = 0);
+                const void *fab = nullptr, long ldcc = 0);
 
 // out (prec scalars, [VAR_NCORR][np]) = X b_c for b = {1, p_x, p_y, p_z, |p|^2} (fp64 accumulation); X: np x np
 // lower-triangular, fp64 if x_is_f64 (or prec is F64) else fp32; the points are `prec` scalars
@@ -182,7 +187,7 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
                           float *rowcorr = nullptr);
 void launch_kqp_split(const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st, const double *fitmom = nullptr, float *coef = nullptr, long ldcc = 0);
+                      hipStream_t st, const float *fab = nullptr, long ldcc = 0);
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial, long ldp,
                         int prefetch, hipStream_t st, int m_rows = 0, const float *rowcorr = nullptr, long ldrc = 0,
                         const float *colcoef = nullptr, long ldcc = 0);

@@ -69,13 +69,16 @@ struct gpx_model {
     hipEvent_t ev[EV_COUNT] = {};
     std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
     size_t gemm_ev_used_factor = 0, gemm_ev_used_var = 0;
+    std::vector<hipEvent_t> kqp_ev;   // pairs bracketing the Kqp launches of the last evaluate (stats)
+    size_t kqp_ev_used = 0;
+    double factor_gemm_flops = 0;     // algorithmic flops of the event-timed trailing-update launches
 
     // state blob part 0 = everything evaluate() reads besides X, internal order, npad each:
-    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | VAR_NMOM doubles: moments of the point
-    //   cloud (per-query fit of the variance contraction) | T x y z 1/D | T [VAR_NCORR][npad]: X {1, p, |p|^2}
+    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | T x y z 1/D | T [VAR_NCORR][npad]:
+    //   X {1, p_x, p_y, p_z, |p|^2}, the row-correction vectors of the variance contraction
     void *blob0 = nullptr;
     size_t blob0_bytes = 0;
-    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr, *d_fitmom = nullptr;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;
     void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr, *t_corr = nullptr;
     bool var_fit = false;  // the low-rank fit is taken out of the kernel operand of the variance GEMM (fp32 modes)
     // other fp64 vectors (npad each): label s2 r f, then one double for max|r|

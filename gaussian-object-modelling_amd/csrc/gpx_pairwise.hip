@@ -147,16 +147,90 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
     }
 }
 
-// fitmom != null: Kqp holds k(d) - (a_q + b_q d^2), the per-query fit of var_fit_query (gpx_cov.hpp, gpx_internal.hpp);
-// the first column block also writes the fit's query-side coefficients coef[c][q] for b = {1, p_x, p_y, p_z, |p|^2}:
-// {a_q + b_q |q|^2, -2 b_q q_xyz, b_q}.  fitmom == null: the plain kernel values.
+// Per-query fit of the variance contraction, once per query batch: (a_q, b_q) = least-squares line of k against
+// u = d^2 over every `stride`-th training point (sums in fp64: the normal equations cancel).  coef rows 0..4 = the
+// fit's query-side coefficients for b = {1, p_x, p_y, p_z, |p|^2}: {a_q + b_q |q|^2, -2 b_q q_xyz, b_q} (read by the GEMM
+// epilogue), rows 5, 6 = a_q, b_q (read by the kqp kernels).  Queries are rounded to T first: they are the coordinates
+// the kqp kernels use.
+template <typename T, int KID>
+__global__ __launch_bounds__(256) void var_fit_kernel(Cov<T> cov, int n, int stride, const T *__restrict__ px,
+                                                      const T *__restrict__ py, const T *__restrict__ pz, long nq_valid,
+                                                      long nq_tile, const double *__restrict__ qx,
+                                                      const double *__restrict__ qy, const double *__restrict__ qz,
+                                                      T *__restrict__ coef, long ldcc)
+{
+    // 16 lanes share a query: lane `sub` takes the samples sub, sub + 16, ... of the strided list
+    const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    if (q >= nq_tile)
+        return;
+    T fa = T(0), fb = T(0), ax = T(0), ay = T(0), az = T(0);
+    if (q < nq_valid) {
+        ax = (T)qx[q], ay = (T)qy[q], az = (T)qz[q];
+        double s1 = 0, su = 0, suu = 0, sk = 0, suk = 0;
+        for (int l = sub * stride; l < n; l += 16 * stride) {
+            const T dx = ax - px[l], dy = ay - py[l], dz = az - pz[l];
+            const T d2 = dx * dx + dy * dy + dz * dz;
+            const double u = (double)d2, kv = (double)cov_k<T, KID>(cov, d2);
+            s1 += 1.0;
+            su += u;
+            suu = fma(u, u, suu);
+            sk += kv;
+            suk = fma(u, kv, suk);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off);
+            su += __shfl_xor(su, off);
+            suu += __shfl_xor(suu, off);
+            sk += __shfl_xor(sk, off);
+            suk += __shfl_xor(suk, off);
+        }
+        const double det = s1 * suu - su * su;
+        double b = 0.0;
+        if (det > 1e-12 * s1 * suu)
+            b = (s1 * suk - su * sk) / det;
+        fb = (T)b;
+        fa = (T)((sk - (double)fb * su) / s1);
+    }
+    if (sub != 0)
+        return;
+    coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
+    coef[ldcc + q] = T(-2) * fb * ax;
+    coef[2 * ldcc + q] = T(-2) * fb * ay;
+    coef[3 * ldcc + q] = T(-2) * fb * az;
+    coef[4 * ldcc + q] = fb;
+    coef[5 * ldcc + q] = fa;
+    coef[6 * ldcc + q] = fb;
+}
+
+void launch_var_fit(int prec, const CovHost &h, int n, const void *px, const void *py, const void *pz, long nq_valid,
+                    long nq_tile, const double *qx, const double *qy, const double *qz, void *coef, long ldcc,
+                    hipStream_t st)
+{
+    const dim3 grid((unsigned)((nq_tile + 15) / 16));
+    const int stride = (n + VAR_FIT_SAMPLES - 1) / VAR_FIT_SAMPLES;
+    if (prec == GPX_PREC_F64) {
+        Cov<double> c = lower_cov<double>(h);
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<double, KID>), grid, dim3(256), 0, st, c, n, stride,
+                                                  (const double *)px, (const double *)py, (const double *)pz, nq_valid,
+                                                  nq_tile, qx, qy, qz, (double *)coef, ldcc));
+    } else {
+        Cov<float> c = lower_cov<float>(h);
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<float, KID>), grid, dim3(256), 0, st, c, n, stride,
+                                                  (const float *)px, (const float *)py, (const float *)pz, nq_valid,
+                                                  nq_tile, qx, qy, qz, (float *)coef, ldcc));
+    }
+}
+
+// fab != null: Kqp holds k(d) - (a_q + b_q d^2) with the per-query fit (a_q, b_q) = fab[q], fab[ldcc + q] of
+// var_fit_kernel; fab == null: the plain kernel values.
 template <typename T, int KID>
 __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ px,
                                                   const T *__restrict__ py, const T *__restrict__ pz,
                                                   long nq_valid, const double *__restrict__ qx,
                                                   const double *__restrict__ qy, const double *__restrict__ qz,
-                                                  T *__restrict__ Kqp, const double *__restrict__ fitmom,
-                                                  T *__restrict__ coef, long ldcc)
+                                                  T *__restrict__ Kqp, const T *__restrict__ fab, long ldcc)
 {
     __shared__ T rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
     const int tid = threadIdx.x;
@@ -164,22 +238,11 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, c
     if (tid < TILE) {
         long q = q0 + tid;
         bool ok = q < nq_valid;
-        const T ax = ok ? (T)qx[q] : T(0), ay = ok ? (T)qy[q] : T(0), az = ok ? (T)qz[q] : T(0);
-        rx[tid] = ax;
-        ry[tid] = ay;
-        rz[tid] = az;
-        T fa = T(0), fb = T(0);
-        if (fitmom && ok)
-            var_fit_query<T, KID>(cov, fitmom, ax, ay, az, fa, fb);
-        rfa[tid] = fa;
-        rfb[tid] = fb;
-        if (coef && blockIdx.x == 0) {
-            coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
-            coef[ldcc + q] = T(-2) * fb * ax;
-            coef[2 * ldcc + q] = T(-2) * fb * ay;
-            coef[3 * ldcc + q] = T(-2) * fb * az;
-            coef[4 * ldcc + q] = fb;
-        }
+        rx[tid] = ok ? (T)qx[q] : T(0);
+        ry[tid] = ok ? (T)qy[q] : T(0);
+        rz[tid] = ok ? (T)qz[q] : T(0);
+        rfa[tid] = fab ? fab[q] : T(0);
+        rfb[tid] = fab ? fab[ldcc + q] : T(0);
     }
     const int tx = tid & 31, ty = tid >> 5;
     const int gj0 = blockIdx.x * TILE + tx * 4;
@@ -289,23 +352,23 @@ void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *o
 template <typename T>
 static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz,
                   long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                  hipStream_t st, int ncols, const double *fitmom, void *coef, long ldcc)
+                  hipStream_t st, int ncols, const void *fab, long ldcc)
 {
     Cov<T> c = lower_cov<T>(h);
     dim3 grid((ncols > 0 ? ncols : npad) / TILE, (unsigned)(nq_tile / TILE));
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<T, KID>), grid, dim3(256), 0, st, c, n, npad,
                                               (const T *)px, (const T *)py, (const T *)pz, nq_valid, qx, qy, qz,
-                                              (T *)Kqp, fitmom, (T *)coef, ldcc));
+                                              (T *)Kqp, (const T *)fab, ldcc));
 }
 
 void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
                 long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st, int ncols, const double *fitmom, void *coef, long ldcc)
+                hipStream_t st, int ncols, const void *fab, long ldcc)
 {
     if (prec == GPX_PREC_F64)
-        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fitmom, coef, ldcc);
+        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fab, ldcc);
     else
-        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fitmom, coef, ldcc);
+        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fab, ldcc);
 }
 
 }  // namespace gpx

@@ -141,8 +141,7 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk
                                                         const double *__restrict__ qx,
                                                         const double *__restrict__ qy,
                                                         const double *__restrict__ qz, half_t *__restrict__ P,
-                                                        const double *__restrict__ fitmom, float *__restrict__ coef,
-                                                        long ldcc)
+                                                        const float *__restrict__ fab, long ldcc)
 {
     __shared__ float rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
     const int tid = threadIdx.x;
@@ -150,22 +149,11 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk
     if (tid < TILE) {
         const long q = q0 + tid;
         const bool ok = q < nq_valid;
-        const float ax = ok ? (float)qx[q] : 0.0f, ay = ok ? (float)qy[q] : 0.0f, az = ok ? (float)qz[q] : 0.0f;
-        rx[tid] = ax;
-        ry[tid] = ay;
-        rz[tid] = az;
-        float fa = 0.0f, fb = 0.0f;  // per-query fit taken out of the kernel values (see kqp_kernel, gpx_pairwise.hip)
-        if (fitmom && ok)
-            var_fit_query<float, KID>(cov, fitmom, ax, ay, az, fa, fb);
-        rfa[tid] = fa;
-        rfb[tid] = fb;
-        if (coef && blockIdx.x == 0) {
-            coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
-            coef[ldcc + q] = -2.0f * fb * ax;
-            coef[2 * ldcc + q] = -2.0f * fb * ay;
-            coef[3 * ldcc + q] = -2.0f * fb * az;
-            coef[4 * ldcc + q] = fb;
-        }
+        rx[tid] = ok ? (float)qx[q] : 0.0f;
+        ry[tid] = ok ? (float)qy[q] : 0.0f;
+        rz[tid] = ok ? (float)qz[q] : 0.0f;
+        rfa[tid] = fab ? fab[q] : 0.0f;  // per-query fit taken out of the kernel values (var_fit_kernel, gpx_pairwise.hip)
+        rfb[tid] = fab ? fab[ldcc + q] : 0.0f;
     }
     const int tx = tid & 15, ty = tid >> 4;  // 16 lanes x 8 columns = 128 training points per row
     const int gj0 = blockIdx.x * TILE + tx * 8;
@@ -347,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
     // ---- epilogue: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
+    // low-rank correction, as in the COLSQ epilogue of gemm_kernel (gpx_gemm.hip): the B operand holds k - fit, the
+    // product of X with the fit comes back from the model's five row vectors (pre-scaled by sx sk) and the batch's
+    // five column coefficient vectors.  Plain global loads: staging them through LDS was measured slower (971 vs 929 ms
+    // per fast-mode bench step).
     const bool corr = g.colcoef != nullptr;
     float ca[2][VAR_NCORR];
     if (corr) {
@@ -407,13 +399,13 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
 
 void launch_kqp_split(const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st, const double *fitmom, float *coef, long ldcc)
+                      hipStream_t st, const float *fab, long ldcc)
 {
     Cov<float> c = lower_cov<float>(h);
     dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<KID>), grid, dim3(256), 0, st, c, sk, n, npad,
                                               (const float *)px, (const float *)py, (const float *)pz, nq_valid, qx,
-                                              qy, qz, (half_t *)P, fitmom, coef, ldcc));
+                                              qy, qz, (half_t *)P, fab, ldcc));
 }
 
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial,

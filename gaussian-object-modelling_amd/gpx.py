@@ -55,7 +55,8 @@ class Stats(C.Structure):
                 ("n", C.c_int64), ("n_padded", C.c_int64), ("n_negative_pivots", C.c_int64),
                 ("ir_steps_done", C.c_int64), ("alpha_residual", C.c_double),
                 ("var_gemm_launches", C.c_int64), ("factor_gemm_launches", C.c_int64),
-                ("solve_fallbacks", C.c_int64), ("reserved", C.c_double * 3)]
+                ("solve_fallbacks", C.c_int64), ("t_var_kqp_ms", C.c_double), ("factor_gemm_flops", C.c_double),
+                ("reserved", C.c_double * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

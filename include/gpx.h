@@ -101,7 +101,9 @@ typedef struct gpx_stats {
     int64_t var_gemm_launches, factor_gemm_launches;
     int64_t solve_fallbacks; /* 1: the one-launch block substitution gave up waiting and alpha was recomputed with
                                 the launch-per-step kernels (same result; see gpx_factor.hip) */
-    double reserved[3];
+    double t_var_kqp_ms;      /* the kernel-operand (Kqp) launches of the last evaluate only (subset of t_var_ms) */
+    double factor_gemm_flops; /* algorithmic flops of the event-timed trailing-update launches (lower tiles x 2 x 128^2 x K) */
+    double reserved[1];
 } gpx_stats;
 
 typedef enum {

@@ -32,13 +32,18 @@ int main(int argc, char **argv)
     const int NQ = argc > 2 ? atoi(argv[2]) : 8192;  // queries per launch
     const int prec = argc > 3 ? atoi(argv[3]) : 0;
     const size_t e = prec ? 8 : 4;
-    void *X, *Kqp, *dinv, *partial, *C, *W;
+    void *X, *Kqp, *dinv, *partial, *C, *W, *rowcorr, *colcoef;
+    const bool with_corr = argc > 4 ? atoi(argv[4]) != 0 : true;  // the low-rank correction in the COLSQ epilogue
     CK(hipMalloc(&X, e * (size_t)N * N));
     CK(hipMalloc(&Kqp, e * (size_t)NQ * N));
     CK(hipMalloc(&dinv, e * N));
     CK(hipMalloc(&partial, e * (size_t)NQ * (N / 128)));
     CK(hipMalloc(&C, e * (size_t)N * N));
     CK(hipMalloc(&W, e * (size_t)N * 2048));
+    CK(hipMalloc(&rowcorr, e * (size_t)N * VAR_NCORR));
+    CK(hipMalloc(&colcoef, e * (size_t)NQ * VAR_NCORR));
+    if (prec) { fill((double *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2); fill((double *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0); }
+    else { fill((float *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2); fill((float *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0); }
     if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
     else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
     CK(hipMemset(C, 0, e * (size_t)N * N));
@@ -48,6 +53,7 @@ int main(int argc, char **argv)
         GemmArgs a;
         a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
         a.rowweight = dinv; a.partial = partial, a.ldp = NQ; a.cfg = cfg;
+        if (with_corr) { a.rowcorr = rowcorr, a.ldrc = N; a.colcoef = colcoef, a.ldcc = NQ; }
         launch_gemm(prec, a, st);
         CK(hipStreamSynchronize(st));
         const int reps = 3;

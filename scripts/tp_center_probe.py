@@ -41,9 +41,9 @@ p0, b0 = m.state_blob(0)
 p1, b1 = m.state_blob(1)
 t0 = sh.device_blob_as_tensor(torch, p0, b0, dev)
 t1 = sh.device_blob_as_tensor(torch, p1, b1, dev)
-npad = (b0 - 8 * 16) // (4 * 8 + 9 * 4)  # fp64 x y z alpha | 16 moments | T x y z 1/D | T 5 correction vectors
+npad = b0 // (4 * 8 + 9 * 4)  # fp64 x y z alpha | T x y z 1/D | T 5 correction vectors
 d64 = t0[: 4 * 8 * npad].view(torch.float64).view(4, npad)
-tt = t0[8 * (4 * npad + 16):].view(torch.float32).view(9, npad)[:4]
+tt = t0[8 * 4 * npad:].view(torch.float32).view(9, npad)[:4]
 X32 = t1.view(torch.float32).view(npad, npad)
 dinv = tt[3].double()
 P = d64[:3].T.contiguous()

@@ -1,0 +1,91 @@
+"""Generates tests/golden/gp_golden_n16384.npz: an anchor at the HEADLINE size (BASELINE configs 3 / 4: N_train = 16384,
+Matern-5/2(1,1) and thin-plate R = 4, sigma2 = 0.1 on the synthetic Fibonacci cloud of SURVEY 8d), computed with an
+implementation INDEPENDENT of oracle/ and of libgpx: NumPy distances + SciPy/LAPACK Cholesky (dpotrf / dpotrs) in fp64
+on the formulas of the reference (include/gp_regression/gp_regressor.hpp:132-163, :299-319; kernels/thin_plate.hpp:12-20;
+Matern closed form matlab_src/test_gp_regression_3Dsurf.m:121-123).  Stores alpha at 256 sampled training indices and
+f / v / grad at 64 queries (13 KB).  Run in the build container (~4 min on 8 cores, ~7 GiB):
+
+    python tests/golden/make_golden_n16384.py
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.linalg as sl
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+
+N = 16384
+KERNELS = {
+    "matern52": (lambda d: (1 + np.sqrt(5) * d + 5 * d * d / 3) * np.exp(-np.sqrt(5) * d),
+                 lambda d: -(5.0 / 3.0) * (1 + np.sqrt(5) * d) * np.exp(-np.sqrt(5) * d), 1.0),
+    "thinplate4": (lambda d: 2 * d ** 3 - 12.0 * d ** 2 + 64.0, lambda d: -6 * (4.0 - d), 64.0),
+}
+
+
+def pdist(A, B):
+    # direct differences (no norm expansion), blocked over A to bound memory
+    out = np.empty((len(A), len(B)))
+    for i in range(0, len(A), 1024):
+        d = A[i:i + 1024, None, :] - B[None, :, :]
+        out[i:i + 1024] = np.sqrt((d * d).sum(-1))
+    return out
+
+
+def queries(P):
+    g = np.linspace(-1.01, 1.01, 4)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    Q = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    rng = np.random.default_rng(16384)
+    near = P[rng.integers(0, N - 15, 4)] * (1 + 1e-2 * rng.normal(size=(4, 1)))  # just off the surface
+    return np.concatenate([Q[:52], P[[0, 7777, 16368, 16383]], near, [[0.0, 0.0, 0.0], [0.2, -0.7, 0.4], [0.6, 0.6, 0.6],
+                                                                             [1.5, 0.1, -1.2]]], 0)
+
+
+def main():
+    x, y, z, lab, s2 = ds.fibonacci_training_set(N)
+    P = np.stack([x, y, z], 1)
+    Q = queries(P)
+    assert Q.shape == (64, 3)
+    sel = np.arange(0, N, 64)
+    out = {"n": np.array(N), "Q": Q, "alpha_idx": sel}
+    t0 = time.time()
+    D = pdist(P, P)
+    Dq = pdist(Q, P)
+    print("distances %.1fs" % (time.time() - t0), flush=True)
+    for kname, (kf, kd, k0) in KERNELS.items():
+        t0 = time.time()
+        K = kf(D)
+        K[np.diag_indices(N)] += s2
+        c = sl.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+        alpha = sl.cho_solve(c, lab, check_finite=False)
+        Kq = kf(Dq)
+        f = Kq @ alpha
+        S = sl.cho_solve(c, Kq.T, check_finite=False)
+        v = k0 - np.einsum("ij,ji->i", Kq, S)
+        W = kd(Dq) * alpha[None, :]
+        grad = (W[:, :, None] * (Q[:, None, :] - P[None, :, :])).sum(1)
+        del K, c
+        # residual of the solve, matrix-free: max |y - K alpha| (rebuilds K row blocks)
+        res = 0.0
+        for i in range(0, N, 2048):
+            Kb = kf(D[i:i + 2048])
+            r = lab[i:i + 2048] - Kb @ alpha - s2[i:i + 2048] * alpha[i:i + 2048]
+            res = max(res, float(np.abs(r).max()))
+        pre = kname + "/"
+        out[pre + "alpha"], out[pre + "f"], out[pre + "v"], out[pre + "grad"] = alpha[sel], f, v, grad
+        out[pre + "alpha_max"] = np.array(np.abs(alpha).max())
+        out[pre + "residual"] = np.array(res)
+        print("%s: %.1fs  max|alpha| %.4g  residual %.2e  v in [%.3g, %.3g]" % (kname, time.time() - t0, np.abs(alpha).max(),
+                                                                             res, v.min(), v.max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "gp_golden_n16384.npz"), **out)
+    print("wrote gp_golden_n16384.npz (%d arrays)" % len(out))
+
+
+if __name__ == "__main__":
+    main()
