@@ -282,9 +282,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
 
     // ---- EPI_COLSQ with the low-rank correction: this tile's slices of the five row vectors and five column
     // coefficient vectors go through LDS, so that the epilogue does not wait for ~200 scattered global loads per lane
-    constexpr int NPC = (EPI == EPI_COLSQ) ? ((BM + BN) * VAR_NCORR + NT - 1) / NT : 1;
+    // (fp32 only: the fp64 contraction needs no correction, and its hinted main loop is sensitive to every extra
+    // register -- with the correction code compiled in, the fp64 variance product dropped from 72.5 to 64 TFLOP/s)
+    constexpr bool CORR_OK = (EPI == EPI_COLSQ) && sizeof(T) == 4;
+    constexpr int NPC = (CORR_OK && GEMM_CORR_STAGE != 0) ? ((BM + BN) * VAR_NCORR + NT - 1) / NT : 1;
     T pc[NPC];
-    const bool corr = (EPI == EPI_COLSQ) && g.colcoef != nullptr;
+    const bool corr = CORR_OK && g.colcoef != nullptr;
 #define GPX_CORR_LOAD()                                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < NPC; ++i_)                                                               \
     {                                                                                                                \
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
             v_ = g.colcoef[(size_t)((e_ - VAR_NCORR * BM) / BN) * g.ldcc + n0 + (e_ - VAR_NCORR * BM) % BN];         \
         pc[i_] = v_;                                                                                                 \
     }
-    if constexpr (EPI == EPI_COLSQ && GEMM_CORR_STAGE == 1) {
+    if constexpr (CORR_OK && GEMM_CORR_STAGE == 1) {
         if (corr)
             GPX_CORR_LOAD();
     }
@@ -428,8 +431,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
         // Low-rank correction of the contraction (gpx_eval.hip, "centred kernel operand"): the B operand holds
         // k - fit with fit[n][k] = sum_c colcoef[c][n] b_c[k]; the product of A with the fit is added back here from
         // rowcorr[c][m] = sum_k A[m][k] b_c[k], which was accumulated once per model in fp64.
+        if constexpr (!CORR_OK) {
+            // (the fp64 instantiation keeps exactly this form: its main loop's schedule -- 72.5 TFLOP/s -- changed
+            // with every other arrangement of the epilogue, down to 57 TFLOP/s)
+            T w[FM][NACC];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r)
+                    w[i][r] = g.rowweight[m0 + (wm * FM + i) * FR + MF::crow(lane, r)];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                T s = T(0);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < NACC; ++r)
+                        s += acc[i][j][r] * acc[i][j][r] * w[i][r];
+                if constexpr (FR == 16)
+                    s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (fg == 0)
+                    red[wm * BN + (wn * FN + j) * FR + fr] = s;
+            }
+        } else {
+        T colsum[FN];
         T *cs = smem + WGM * BN;  // [VAR_NCORR][BM] row vectors | [VAR_NCORR][BN] column coefficients of this tile
-        if (corr && GEMM_CORR_STAGE != 0) {
+        if constexpr (CORR_OK && GEMM_CORR_STAGE != 0) {
+          if (corr) {
             if constexpr (GEMM_CORR_STAGE == 2)
                 GPX_CORR_LOAD();
 #pragma unroll
@@ -439,6 +468,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
                     cs[e] = pc[i];
             }
             __syncthreads();
+          }
         }
         T ca[FN][VAR_NCORR];
         if (corr) {
@@ -449,7 +479,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
                     ca[j][c] = GEMM_CORR_STAGE != 0 ? cs[VAR_NCORR * BM + c * BN + (wn * FN + j) * FR + fr]
                                                     : g.colcoef[(size_t)c * g.ldcc + n0 + (wn * FN + j) * FR + fr];
         }
-        T colsum[FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j)
             colsum[j] = T(0);
@@ -487,6 +516,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
             s += __shfl_xor(s, 32);
             if (fg == 0)
                 red[wm * BN + (wn * FN + j) * FR + fr] = s;
+        }
         }
         __syncthreads();
         for (int c = tid; c < BN; c += NT) {
