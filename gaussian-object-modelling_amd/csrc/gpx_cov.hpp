@@ -34,20 +34,64 @@ __device__ __forceinline__ double dev_exp<double>(double x)
     return exp(x);
 }
 
-// k(d) given the squared distance d2.
-template <typename T, int KID>
+// ---- fp64 sqrt / exp for the N-term prediction sums (gpx_predict.hip) -------------------------------------------------
+// The mean of 2^20 queries against 16384 points is 1.7e10 kernel evaluations in fp64 and VALU-issue bound; the
+// library's sqrt / exp spend most of their ~45 instructions on ranges this path never sees.  These take
+// x in [0, 1e300) / x <= 0 and stay within ~2 ulp:
+//   sqrt: v_rsq_f64 seed (>= 26 bits) + one coupled Newton step on (g, h) = (x y, y / 2):  error 1.5 eps_seed^2
+//   exp : 2^n e^r, n = rint(x log2 e), r = x - n ln 2 (two-part ln 2), Taylor degree 12 on |r| <= 0.347 (1.7e-16), v_ldexp_f64
+struct MathAcc {  // the compiler library's functions (kernel matrix, Kqp: pinned to the reference classes at 4e-15)
+    template <typename T>
+    static __device__ __forceinline__ T sqrt_(T x) { return dev_sqrt<T>(x); }
+    template <typename T>
+    static __device__ __forceinline__ T exp_(T x) { return dev_exp<T>(x); }
+};
+struct MathFast {
+    static __device__ __forceinline__ float sqrt_(float x) { return dev_sqrt<float>(x); }
+    static __device__ __forceinline__ float exp_(float x) { return dev_exp<float>(x); }
+    static __device__ __forceinline__ double sqrt_(double x)  // x > 0 (callers add 1e-300 to the squared distance)
+    {
+        const double y = __builtin_amdgcn_rsq(x);
+        const double g = x * y, h = 0.5 * y;
+        const double r = fma(-h, g, 0.5);
+        return fma(g, r, g);
+    }
+    static __device__ __forceinline__ double exp_(double x)
+    {
+        const double n = __builtin_rint(x * 1.4426950408889634);
+        const double r = fma(n, -0.6931471805599453, x);  // |n| <= ~1100: n (ln 2 - fl(ln 2)) <= 3e-14 at the far end, 4e-16 for |x| < 12
+        double p = 2.08767569878680989792e-09;  // 1/12!
+        p = fma(p, r, 2.50521083854417187751e-08);
+        p = fma(p, r, 2.75573192239858906526e-07);
+        p = fma(p, r, 2.75573192239858906526e-06);
+        p = fma(p, r, 2.48015873015873015873e-05);
+        p = fma(p, r, 1.98412698412698412698e-04);
+        p = fma(p, r, 1.38888888888888888889e-03);
+        p = fma(p, r, 8.33333333333333333333e-03);
+        p = fma(p, r, 4.16666666666666666667e-02);
+        p = fma(p, r, 1.66666666666666666667e-01);
+        p = fma(p, r, 0.5);
+        p = fma(p, r, 1.0);
+        p = fma(p, r, 1.0);
+        return __builtin_amdgcn_ldexp(p, (int)n);  // deep underflow flushes to 0
+    }
+};
+
+// k(d) given the squared distance d2.  UNIT_A: without the amplitude c.a of the exponential kernels (the caller has
+// folded it into the weights the values are multiplied with); thin-plate has none.
+template <typename T, int KID, typename M = MathAcc, bool UNIT_A = false>
 __device__ __forceinline__ T cov_k(const Cov<T> &c, T d2)
 {
     if constexpr (KID == GPX_KERNEL_THINPLATE) {
         // 2d^3 - 3R d^2 + R^3 == (d - R)^2 (2d + R): the factored form has no cancellation between
         // O(R^3) terms, which matters in fp32 for d > R (k is small there, the monomials are not).
-        T d = dev_sqrt<T>(d2);
+        T d = M::sqrt_(d2);
         T e = d - c.R;
         return e * e * (T(2) * d + c.R);
     } else {
-        T d = dev_sqrt<T>(d2);
+        T d = M::sqrt_(d2);
         T t = c.s * d;
-        T e = c.a * dev_exp<T>(-t);
+        T e = UNIT_A ? M::exp_(-t) : c.a * M::exp_(-t);
         if constexpr (KID == GPX_KERNEL_MATERN32)
             return e * (T(1) + t);
         else if constexpr (KID == GPX_KERNEL_MATERN52)
@@ -58,17 +102,17 @@ __device__ __forceinline__ T cov_k(const Cov<T> &c, T d2)
 }
 
 // k(d) and the reference's "computediff" (multiplies (q - p) in the gradient).
-template <typename T, int KID>
+template <typename T, int KID, typename M = MathAcc, bool UNIT_A = false>
 __device__ __forceinline__ void cov_k_diff(const Cov<T> &c, T d2, T &k, T &kd)
 {
-    T d = dev_sqrt<T>(d2);
+    T d = M::sqrt_(d2);
     if constexpr (KID == GPX_KERNEL_THINPLATE) {
         T e = d - c.R;
         k = e * e * (T(2) * d + c.R);
         kd = T(6) * e;  // -6 (R - d)
     } else {
         T t = c.s * d;
-        T e = c.a * dev_exp<T>(-t);
+        T e = UNIT_A ? M::exp_(-t) : c.a * M::exp_(-t);
         if constexpr (KID == GPX_KERNEL_MATERN32) {
             k = e * (T(1) + t);
             kd = -(c.s * c.s) * e;  // -3 sigma^2 / l^2 e^-t

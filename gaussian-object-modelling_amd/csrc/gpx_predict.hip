@@ -61,9 +61,12 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
     const int j0 = blockIdx.y * chunk_len;
     const int j1 = min(npts, j0 + chunk_len);
     double fa = 0, fb = 0, gax = 0, gay = 0, gaz = 0, gbx = 0, gby = 0, gbz = 0;
+    // the amplitude of the exponential kernels rides on alpha (one multiply per point and tile instead of one per pair)
+    const T amp = KID == GPX_KERNEL_THINPLATE ? T(1) : cov.a;
+    constexpr T TINY = sizeof(T) == 8 ? T(1e-300) : T(0);  // keeps the rsq seed of MathFast::sqrt_ finite at d = 0
     for (int jt = j0; jt < j1; jt += PT) {
         __syncthreads();
-        tile[tid] = P4<T>{px[jt + tid], py[jt + tid], pz[jt + tid], alpha[jt + tid]};
+        tile[tid] = P4<T>{px[jt + tid], py[jt + tid], pz[jt + tid], alpha[jt + tid] * amp};
         __syncthreads();
         T sa = 0, sb = 0, tax = 0, tay = 0, taz = 0, tbx = 0, tby = 0, tbz = 0;
 #pragma unroll 4
@@ -71,12 +74,12 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
             const P4<T> p = tile[jj];
             T dxa = ax - p.x, dya = ay - p.y, dza = az - p.z;
             T dxb = bx - p.x, dyb = by - p.y, dzb = bz - p.z;
-            T d2a = dxa * dxa + dya * dya + dza * dza;
-            T d2b = dxb * dxb + dyb * dyb + dzb * dzb;
+            T d2a = fma(dza, dza, fma(dya, dya, fma(dxa, dxa, TINY)));
+            T d2b = fma(dzb, dzb, fma(dyb, dyb, fma(dxb, dxb, TINY)));
             if constexpr (GRAD) {
                 T ka, kda, kb, kdb;
-                cov_k_diff<T, KID>(cov, d2a, ka, kda);
-                cov_k_diff<T, KID>(cov, d2b, kb, kdb);
+                cov_k_diff<T, KID, MathFast, true>(cov, d2a, ka, kda);
+                cov_k_diff<T, KID, MathFast, true>(cov, d2b, kb, kdb);
                 sa += ka * p.a;
                 sb += kb * p.a;
                 T wa = kda * p.a, wb = kdb * p.a;
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
                 tby += wb * dyb;
                 tbz += wb * dzb;
             } else {
-                sa += cov_k<T, KID>(cov, d2a) * p.a;
-                sb += cov_k<T, KID>(cov, d2b) * p.a;
+                sa += cov_k<T, KID, MathFast, true>(cov, d2a) * p.a;
+                sb += cov_k<T, KID, MathFast, true>(cov, d2b) * p.a;
             }
         }
         fa += (double)sa;
