@@ -26,6 +26,112 @@ int fail(int code, const std::string &msg)
 }
 }  // namespace gpxh
 
+// ---- pool of large device buffers -------------------------------------------------------------------------
+namespace gpxh {
+namespace {
+struct BigBuf {
+    void *p;
+    size_t bytes;
+    int dev;
+};
+std::mutex g_pool_mtx;
+std::vector<BigBuf> g_pool_free;  // parked
+std::vector<BigBuf> g_pool_live;  // handed out through big_alloc (so that big_free knows size and device)
+size_t g_pool_parked = 0;
+size_t pool_cap()
+{
+    static const size_t cap = [] {
+        const char *e = std::getenv("GPX_POOL_MB");
+        return (size_t)(e ? std::atol(e) : 16384) << 20;
+    }();
+    return cap;
+}
+}  // namespace
+
+hipError_t big_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (bytes >= BIG_POOL_MIN) {
+        std::lock_guard<std::mutex> lk(g_pool_mtx);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool_free.size(); ++i) {
+            const BigBuf &b = g_pool_free[i];
+            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 &&
+                (best < 0 || b.bytes < g_pool_free[best].bytes))
+                best = i;
+        }
+        if (best >= 0) {
+            BigBuf b = g_pool_free[best];
+            g_pool_free.erase(g_pool_free.begin() + best);
+            g_pool_parked -= b.bytes;
+            g_pool_live.push_back(b);
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && bytes >= BIG_POOL_MIN) {  // out of memory with buffers parked: release them and retry
+        (void)hipGetLastError();
+        gpx_trim();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && bytes >= BIG_POOL_MIN) {
+        std::lock_guard<std::mutex> lk(g_pool_mtx);
+        g_pool_live.push_back(BigBuf{*p, bytes, dev});
+    }
+    return e;
+}
+
+void big_free(void *p)
+{
+    if (!p)
+        return;
+    BigBuf b{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mtx);
+        for (size_t i = 0; i < g_pool_live.size(); ++i)
+            if (g_pool_live[i].p == p) {
+                b = g_pool_live[i];
+                g_pool_live.erase(g_pool_live.begin() + i);
+                break;
+            }
+    }
+    if (!b.p || g_pool_parked + b.bytes > pool_cap()) {
+        (void)hipFree(p);
+        return;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(b.dev);
+    (void)hipDeviceSynchronize();  // what hipFree would have done: nothing in flight may still use the buffer
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+    std::lock_guard<std::mutex> lk(g_pool_mtx);
+    g_pool_free.push_back(b);
+    g_pool_parked += b.bytes;
+}
+}  // namespace gpxh
+
+extern "C" void gpx_trim(void)
+{
+    std::vector<gpxh::BigBuf> drop;
+    {
+        std::lock_guard<std::mutex> lk(gpxh::g_pool_mtx);
+        drop.swap(gpxh::g_pool_free);
+        gpxh::g_pool_parked = 0;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (const auto &b : drop) {
+        (void)hipSetDevice(b.dev);
+        (void)hipFree(b.p);
+    }
+    if (prev >= 0)
+        (void)hipSetDevice(prev);
+}
+
 extern "C" const char *gpx_last_error(void) { return g_err.c_str(); }
 extern "C" const char *gpx_version(void) { return "gpx 0.1 (gfx950)"; }
 extern "C" int gpx_device_count(void)
@@ -475,7 +581,7 @@ extern "C" int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const 
     }
     rc = alloc_model(m);
     if (rc == GPX_OK) {
-        hipError_t e = hipMalloc(&m->X, m->esz * (size_t)m->npad * m->npad);
+        hipError_t e = big_alloc(&m->X, m->esz * (size_t)m->npad * m->npad);
         if (e != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, hipGetErrorString(e));
     }

@@ -8,10 +8,7 @@ namespace gpxh {
 
 void free_dev(gpx_model *m)
 {
-    auto F = [](void *p) {
-        if (p)
-            (void)hipFree(p);
-    };
+    auto F = [](void *p) { big_free(p); };  // parks buffers of 64 MiB and more, hipFree otherwise
     F(m->dvecs);
     F(m->blob0);
     F(m->tvecs);
@@ -73,11 +70,10 @@ int ensure(void **p, size_t *have, size_t need)
 {
     if (*have >= need && *p)
         return GPX_OK;
-    if (*p)
-        HIPCHK(hipFree(*p));
+    big_free(*p);
     *p = nullptr;
     *have = 0;
-    HIPCHK(hipMalloc(p, need));
+    HIPCHK(big_alloc(p, need));
     *have = need;
     return GPX_OK;
 }
@@ -297,6 +293,9 @@ static void factorize(gpx_model *m, int c_start = 0)
     }
     if (la_env && c_start == 0 && m->stream2) {
         hipStream_t sa = m->stream, sb = m->stream2;
+        int la_tail_rows = 4096;  // GPX_LA_TAIL: remaining rows from which on the plain order is used (0: never)
+        if (const char *te = std::getenv("GPX_LA_TAIL"))
+            la_tail_rows = std::atoi(te);
         size_t ev_used = 0;
         auto next_event = [&]() -> hipEvent_t {
             if (ev_used == m->la_ev.size()) {
@@ -321,6 +320,15 @@ static void factorize(gpx_model *m, int c_start = 0)
         for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
             const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
             const int sw = std::min(PANEL, np - r0);  // width of the strip = of the next panel
+            // Deep in the tail the whole trailing update is shorter than the strip launch plus the two cross-stream
+            // hops that the split costs (timeline at N = 16384: strip 23 us + 2 x ~10 us against a trailing update of
+            // 27 us at 2816 rows): there the plain order -- one trailing update, then the chain on the same stream --
+            // is the faster one.  Same tiles, same k order: bit-identical either way.
+            if (np - r0 <= la_tail_rows) {
+                trailing(c0, r0, PANEL, wofs);
+                chain(r0, wofs ^ PANEL, sa);
+                continue;
+            }
             GemmArgs s;  // strip: C[r0:, r0:r0+sw] -= W_p L_p^T (the tile above the diagonal is computed too, nobody reads it)
             s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
             s.B = Kp(r0, c0), s.ldb = ldk;
@@ -471,22 +479,24 @@ int build_inverse(gpx_model *m)
     const int np = m->npad;
     const size_t e = m->esz;
     if (!m->X)
-        HIPCHK(hipMalloc(&m->X, e * (size_t)np * np));
+        HIPCHK(big_alloc(&m->X, e * (size_t)np * np));
     (void)hipEventRecord(m->ev[EV_INV0], m->stream);
     void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
     bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
     if (assemble64) {
         // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
         const size_t nn = (size_t)np * np;
-        if (hipMalloc(&L64, sizeof(double) * nn) != hipSuccess || hipMalloc(&X64, sizeof(double) * nn) != hipSuccess ||
-            hipMalloc(&Tws, sizeof(double) * nn) != hipSuccess ||
+        if (big_alloc(&L64, sizeof(double) * nn) != hipSuccess || big_alloc(&X64, sizeof(double) * nn) != hipSuccess ||
+            big_alloc(&Tws, sizeof(double) * nn) != hipSuccess ||
             hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
             (void)hipGetLastError();
-            for (void **q : {&L64, &X64, &Tws, &linv64}) {
-                if (*q)
-                    (void)hipFree(*q);
+            for (void **q : {&L64, &X64, &Tws}) {
+                big_free(*q);
                 *q = nullptr;
             }
+            if (linv64)
+                (void)hipFree(linv64);
+            linv64 = nullptr;
             assemble64 = false;
         }
     }
@@ -495,17 +505,18 @@ int build_inverse(gpx_model *m)
         // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
         // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
         // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
-        const size_t nn = (size_t)np * np;
-        launch_cast_f2d(nn, (const float *)m->Kmat, (double *)L64, m->stream);
+        launch_cast_lower_f2d(np, (const float *)m->Kmat, (double *)L64, false, m->stream);  // the upper tiles are never read
         launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, (double *)linv64, m->stream);
-        HIPCHK(hipMemsetAsync(X64, 0, sizeof(double) * nn, m->stream));
+        // (no memset of X64: the assembly reads and writes only tiles on / below the block diagonal -- place_diag
+        // supplies the diagonal tiles, zeros above the diagonal inside them -- and the final cast writes the zeros of
+        // the upper tiles of X without reading them)
         launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
         trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
-        launch_cast_d2f(nn, (const double *)X64, (float *)m->X, m->stream);
+        launch_cast_lower_d2f(np, (const double *)X64, (float *)m->X, true, m->stream);
         if (m->var_fit)  // from the un-rounded rows: the rounding of X then only meets the small fit residual
             launch_var_rowcorr(true, m->prec, m->n, np, X64, np, m->t_x, m->t_y, m->t_z, m->t_corr, m->stream);
     } else {
-        HIPCHK(hipMalloc(&Tws, e * (size_t)np * np));
+        HIPCHK(big_alloc(&Tws, e * (size_t)np * np));
         // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
         // 128-block of every 256-diagonal block
         HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
@@ -521,11 +532,9 @@ int build_inverse(gpx_model *m)
     }
     (void)hipEventRecord(m->ev[EV_INV1], m->stream);
     HIPCHK(hipStreamSynchronize(m->stream));
-    HIPCHK(hipFree(Tws));
-    if (L64)
-        HIPCHK(hipFree(L64));
-    if (X64)
-        HIPCHK(hipFree(X64));
+    big_free(Tws);
+    big_free(L64);
+    big_free(X64);
     if (linv64)
         HIPCHK(hipFree(linv64));
     float ms = 0;
@@ -552,10 +561,9 @@ static void append_inverse(gpx_model *m, kept_factor *keep)
         return;
     hipStream_t s = m->stream;
     void *Tw = nullptr;
-    if (hipMalloc(&m->X, e * (size_t)np * np) != hipSuccess || hipMalloc(&Tw, e * (size_t)m2 * np) != hipSuccess) {
+    if (big_alloc(&m->X, e * (size_t)np * np) != hipSuccess || hipMalloc(&Tw, e * (size_t)m2 * np) != hipSuccess) {
         (void)hipGetLastError();
-        if (m->X)
-            (void)hipFree(m->X);
+        big_free(m->X);
         m->X = nullptr;
         return;
     }
@@ -589,7 +597,7 @@ static void append_inverse(gpx_model *m, kept_factor *keep)
     (void)hipFree(Tw);
     if (!ok) {
         (void)hipGetLastError();
-        (void)hipFree(m->X);
+        big_free(m->X);
         m->X = nullptr;
         return;
     }
@@ -611,7 +619,7 @@ static int demote_to_f32(gpx_model *m)
     int rc = alloc_blob0(m, 4, &nb, &nbytes);
     if (rc)
         return rc;
-    HIPCHK(hipMalloc(&nX, sizeof(float) * np * np));
+    HIPCHK(big_alloc(&nX, sizeof(float) * np * np));
     HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
     float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
     launch_cast_d2f(np, (const double *)m->t_x, tf, s);
@@ -619,11 +627,11 @@ static int demote_to_f32(gpx_model *m)
     launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
     launch_cast_d2f(np, (const double *)m->t_dinv, tf + 3 * np, s);
     launch_cast_d2f(np * VAR_NCORR, (const double *)m->t_corr, tf + 4 * np, s);
-    launch_cast_d2f(np * np, (const double *)m->X, (float *)nX, s);
+    launch_cast_lower_d2f((int)np, (const double *)m->X, (float *)nX, true, s);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(m->blob0));
-    HIPCHK(hipFree(m->X));
-    HIPCHK(hipFree(m->Kmat));
+    big_free(m->X);
+    big_free(m->Kmat);
     HIPCHK(hipFree(m->linv));
     HIPCHK(hipFree(m->Wp));
     HIPCHK(hipFree(m->tvecs));
@@ -664,7 +672,7 @@ int build_model(gpx_model *m, kept_factor *keep)
         int rc = alloc_model(m);
         if (rc)
             return rc;
-        HIPCHK(hipMalloc(&m->Kmat, e * (size_t)np * np));
+        HIPCHK(big_alloc(&m->Kmat, e * (size_t)np * np));
         HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
         HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
         const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;

@@ -39,7 +39,7 @@ __device__ __forceinline__ double dev_exp<double>(double x)
 // library's sqrt / exp spend most of their ~45 instructions on ranges this path never sees.  These take
 // x in [0, 1e300) / x <= 0 and stay within ~2 ulp:
 //   sqrt: v_rsq_f64 seed (>= 26 bits) + one coupled Newton step on (g, h) = (x y, y / 2):  error 1.5 eps_seed^2
-//   exp : 2^n e^r, n = rint(x log2 e), r = x - n ln 2 (two-part ln 2), Taylor degree 12 on |r| <= 0.347 (1.7e-16), v_ldexp_f64
+//   exp : 2^n e^r, n = rint(x log2 e), r = x - n ln 2, Taylor degree 12 on |r| <= 0.347 (1.7e-16), exponent-field add
 struct MathAcc {  // the compiler library's functions (kernel matrix, Kqp: pinned to the reference classes at 4e-15)
     template <typename T>
     static __device__ __forceinline__ T sqrt_(T x) { return dev_sqrt<T>(x); }
@@ -58,8 +58,14 @@ struct MathFast {
     }
     static __device__ __forceinline__ double exp_(double x)
     {
-        const double n = __builtin_rint(x * 1.4426950408889634);
-        const double r = fma(n, -0.6931471805599453, x);  // |n| <= ~1100: n (ln 2 - fl(ln 2)) <= 3e-14 at the far end, 4e-16 for |x| < 12
+        // n = rint(x log2 e) by the 1.5 * 2^52 trick: the integer sits in the low word of the biased sum, so neither
+        // v_rndne_f64 nor v_cvt_i32_f64 (both slower than an FMA) is needed; x is clamped where e^x is ~1e-304
+        constexpr double MAGIC = 6755399441055744.0;
+        x = fmax(x, -700.0);
+        const double nb = fma(x, 1.4426950408889634, MAGIC);
+        const int ni = __double2loint(nb);
+        const double n = nb - MAGIC;
+        const double r = fma(n, -0.6931471805599453, x);  // |n| <= 1010: n (ln 2 - fl(ln 2)) <= 3e-14 at the far end, 4e-16 for |x| < 12
         double p = 2.08767569878680989792e-09;  // 1/12!
         p = fma(p, r, 2.50521083854417187751e-08);
         p = fma(p, r, 2.75573192239858906526e-07);
@@ -73,7 +79,8 @@ struct MathFast {
         p = fma(p, r, 0.5);
         p = fma(p, r, 1.0);
         p = fma(p, r, 1.0);
-        return __builtin_amdgcn_ldexp(p, (int)n);  // deep underflow flushes to 0
+        // p in [0.70, 1.42]: scale by 2^n with one integer add on the exponent field (no underflow: n >= -1010)
+        return __hiloint2double(__double2hiint(p) + (ni << 20), __double2loint(p));
     }
 };
 

@@ -130,6 +130,17 @@ struct gpx_model {
 };
 
 namespace gpxh {
+// ---- large device buffers (gpx_api.hip) ---------------------------------------------------------------
+// hipMalloc / hipFree of the multi-GiB buffers of a big model (kernel matrix, inverse factor, the three fp64
+// temporaries of the inverse assembly) cost 100-700 ms per create() on this stack, and erratically so (measured:
+// scripts/la_check.py, create() wall 49 ms or 300-710 ms for 25 ms of device work).  Buffers of at least
+// BIG_POOL_MIN bytes released by one model are therefore parked in a per-process pool (per device, best fit within
+// 25 %) and handed to the next; GPX_POOL_MB caps the parked bytes (default 16384, 0 disables), gpx_trim() empties
+// the pool.  big_free() synchronises the device before parking, as hipFree would have.
+constexpr size_t BIG_POOL_MIN = (size_t)64 << 20;
+hipError_t big_alloc(void **p, size_t bytes);
+void big_free(void *p);
+
 // What a rank-n update carries over from the previous factorisation (device buffers of the OLD padded size)
 struct kept_factor {
     int t0 = 0;        // rows / columns [0, t0) of L, D and the inverse diagonal blocks stay valid
@@ -139,9 +150,11 @@ struct kept_factor {
     void *X = nullptr;  // the old inverse factor (leading dimension np_old) when it had been built, else null
     void release()
     {
-        for (void *p : {K, linv, d, dinv, X})
+        for (void *p : {linv, d, dinv})
             if (p)
                 (void)hipFree(p);
+        big_free(K);  // from big_alloc, like every kernel matrix / inverse factor
+        big_free(X);
         K = linv = d = dinv = X = nullptr;
     }
 };

@@ -826,6 +826,56 @@ __global__ __launch_bounds__(256) void cast_f2d_kernel(size_t n, const float *__
         dst[i] = (double)src[i];
 }
 
+// Square np x np matrices whose content is lower block-triangular (the factor, its inverse): only the 128 x 128
+// tiles on and below the block diagonal are read and converted; tiles above are skipped or (zero_upper) written as
+// zeros without being read.  4 consecutive elements per lane (16-byte fp32 / 32-byte fp64 accesses).
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_lower_kernel(int np, const TS *__restrict__ src, TD *__restrict__ dst,
+                                                         int zero_upper)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti && !zero_upper)
+        return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 lanes x 4 columns, 8 rows per pass
+#pragma unroll 4
+    for (int r = ty; r < TILE; r += 8) {
+        const size_t off = (size_t)(ti * TILE + r) * np + tj * TILE + tx * 4;
+        TD o[4] = {TD(0), TD(0), TD(0), TD(0)};
+        if (tj <= ti) {
+            TS v[4];
+            if constexpr (sizeof(TS) == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + off);
+                v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+            } else {
+                const double2 t0 = *reinterpret_cast<const double2 *>(src + off);
+                const double2 t1 = *reinterpret_cast<const double2 *>(src + off + 2);
+                v[0] = t0.x, v[1] = t0.y, v[2] = t1.x, v[3] = t1.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                o[c] = (TD)v[c];
+        }
+        if constexpr (sizeof(TD) == 4) {
+            *reinterpret_cast<float4 *>(dst + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            *reinterpret_cast<double2 *>(dst + off) = make_double2(o[0], o[1]);
+            *reinterpret_cast<double2 *>(dst + off + 2) = make_double2(o[2], o[3]);
+        }
+    }
+}
+
+void launch_cast_lower_f2d(int np, const float *src, double *dst, bool zero_upper, hipStream_t st)
+{
+    hipLaunchKernelGGL((cast_lower_kernel<float, double>), dim3(np / TILE, np / TILE), dim3(256), 0, st, np, src, dst,
+                       zero_upper ? 1 : 0);
+}
+
+void launch_cast_lower_d2f(int np, const double *src, float *dst, bool zero_upper, hipStream_t st)
+{
+    hipLaunchKernelGGL((cast_lower_kernel<double, float>), dim3(np / TILE, np / TILE), dim3(256), 0, st, np, src, dst,
+                       zero_upper ? 1 : 0);
+}
+
 void launch_cast_f2d(size_t n, const float *src, double *dst, hipStream_t st)
 {
     size_t blocks = (n + 255) / 256;

@@ -68,7 +68,7 @@ EXPORTS = [
     "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
-    "gpx_model_replicate",
+    "gpx_model_replicate", "gpx_trim",
     "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
@@ -142,6 +142,7 @@ def lib():
     L.gpx_model_state_blob.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gpx_model_commit.restype = C.c_int
     L.gpx_model_commit.argtypes = [vp, C.c_int]
+    L.gpx_trim.restype = None
     L.gpx_model_replicate.restype = C.c_int
     L.gpx_model_replicate.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.gpx_dev_kbuild.restype = C.c_int
@@ -161,6 +162,11 @@ def _check(rc):
 
 def device_count():
     return lib().gpx_device_count()
+
+
+def trim():
+    """Free the pool of parked large device buffers (gpx_trim)."""
+    lib().gpx_trim()
 
 
 def make_kernel(name, *params):

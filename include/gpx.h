@@ -193,6 +193,10 @@ int gpx_model_prepare_variance(gpx_model *m);
 int gpx_model_get(const gpx_model *m, int field, void *dst, size_t bytes);
 int gpx_model_sync(const gpx_model *m); /* hipStreamSynchronize on the model's stream */
 void gpx_model_destroy(gpx_model *m);
+/* Device buffers of 64 MiB and more (kernel matrix, inverse factor, assembly temporaries) are parked in a per-process
+ * pool when a model releases them and handed to the next model, because allocating and freeing multi-GiB buffers costs
+ * hundreds of milliseconds; GPX_POOL_MB (default 16384, 0 = off) caps the parked bytes.  gpx_trim() frees them. */
+void gpx_trim(void);
 
 /* ---- one model, query grid sharded over ranks (one process per GPU) -----------------------
  * The rank that factorised exports its read-only state as ONE contiguous device blob

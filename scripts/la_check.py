@@ -1,16 +1,19 @@
+"""Repeated create() at N = 16384 (wall + stage times) for timelines under rocprofv3 --kernel-trace."""
 import importlib, os, sys, time
-sys.path.insert(0, os.getcwd())
-import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
 ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
-x, y, z, lab, s2 = ds.fibonacci_training_set(16384)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+prec = {"f32": gpx.F32, "f64": gpx.F64}[sys.argv[2] if len(sys.argv) > 2 else "f32"]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+x, y, z, lab, s2 = ds.fibonacci_training_set(n)
 kern = gpx.make_kernel("matern52", 1.0, 1.0)
-for rep in range(5):
+for rep in range(reps):
     t = time.perf_counter()
-    gm = gpx.Model(kern, x, y, z, lab, s2, precision=gpx.F32)
-    w = time.perf_counter() - t
+    gm = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=True)
+    wall = time.perf_counter() - t
     st = gm.stats
-    t = time.perf_counter()
     gm.close()
-    c = time.perf_counter() - t
-    print("rep %d: create %.1f ms wall, LDL %.2f (gemm %.2f) alpha %.2f, close %.1f ms" % (rep, w*1e3, st["t_factor_ms"], st["t_factor_gemm_ms"], st["t_solve_ms"], c*1e3), flush=True)
+    print("create %.2f ms wall; kbuild %.2f LDL^T %.2f (GEMM %.2f) alpha %.2f inverse %.2f" % (
+        wall * 1e3, st["t_kbuild_ms"], st["t_factor_ms"], st["t_factor_gemm_ms"], st["t_solve_ms"], st["t_inverse_ms"]), flush=True)
