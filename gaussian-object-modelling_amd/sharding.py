@@ -48,3 +48,21 @@ def gather_slabs(dist, torch, local, nq, rank, world, dst=0):
     if rank != dst:
         return None
     return torch.cat([bufs[r][: sizes[r]] for r in range(world)])
+
+
+def state_blob_layout(npad, esz):
+    """Byte layout of state blob part 0 of a model (gpx_model_state_blob(m, 0), csrc/gpx_model.hpp): name -> (offset,
+    count, bytes per element).  fp64 x y z alpha (internal = pivot order, zero padded to npad), then in the working
+    type (esz = 4 or 8): x y z 1/D and the five row-correction vectors X {1, p_x, p_y, p_z, |p|^2} of the variance
+    contraction.  Part 1 is the npad x npad inverse factor X = L^-1 (row-major, working type)."""
+    out, off = {}, 0
+    for name in ("x", "y", "z", "alpha"):
+        out[name] = (off, npad, 8)
+        off += 8 * npad
+    for name in ("tx", "ty", "tz", "dinv"):
+        out[name] = (off, npad, esz)
+        off += esz * npad
+    out["corr"] = (off, 5 * npad, esz)
+    off += esz * 5 * npad
+    out["bytes"] = off
+    return out

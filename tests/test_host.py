@@ -179,3 +179,24 @@ def test_pcd_reader_survives_mutated_files_under_sanitizers(tmp_path):
     r = subprocess.run([exe, "100"] + files, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "no crash" in r.stdout
+
+
+def test_eigen_typed_overloads_compile_where_eigen_exists(tmp_path):
+    """SURVEY 8a F14: the Eigen::MatrixXd overloads of evaluate and computeTangentBasis(Eigen::Vector3d...) of the header
+    shim sit behind __has_include(<Eigen/Core>).  Eigen 3 is not in this image, so here the test records
+    that and skips; on a machine that has it the overloads must compile against the calls the reference makes."""
+    import subprocess
+    probe = tmp_path / "probe.cpp"
+    probe.write_text("#if __has_include(<Eigen/Core>)\nint have_eigen = 1;\n#else\n#error no Eigen\n#endif\n")
+    inc = []
+    for cand in ("/usr/include/eigen3", "/usr/local/include/eigen3"):
+        if os.path.isdir(cand):
+            inc += ["-I", cand]
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only"] + inc + [str(probe)], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("<Eigen/Core> not available in this image: the Eigen-typed overloads stay uncompiled here")
+    pkg = os.path.join(ROOT, "gaussian-object-modelling_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + inc + ["-I", os.path.join(pkg, "include"), "-I",
+                        os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "eigen_overloads.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -47,6 +47,99 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _state_worker(rank, world, port, q):
+    """The sharded-grid protocol with the REAL message: rank 0 factorises (oracle) and packs the two state blobs in the
+    byte layout of gpx_model_state_blob (part 0: points, alpha, 1/D, correction vectors; part 1: the inverse factor
+    X = L^-1); both travel as uint8 tensors through sharding.broadcast_state, exactly as bench.py --mode shard moves
+    the device blobs; the other rank "commits" by decoding them and evaluates its slab the way the device does:
+    f = k alpha, v = k(0) - sum_j (X k)_j^2 / D_j.  No rank but 0 ever sees the training labels."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import gp_oracle as orc
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n, npad, g, esz = 300, 512, 6, 8
+        nq = g ** 3
+        lay = sh.state_blob_layout(npad, esz)
+        blob0 = torch.zeros(lay["bytes"], dtype=torch.uint8)
+        blob1 = torch.zeros(esz * npad * npad, dtype=torch.uint8)
+        kern = orc.make_kernel("matern52", 1, 1)
+        model = None
+        if rank == 0:
+            x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+            model = orc.Model(kern, x, y, z, lab, s2)
+            F, tr = model.ldlt()  # Eigen layout: unit-lower L below the diagonal, D on it, transpositions tr
+            L, D = np.tril(F, -1) + np.eye(n), np.diag(F).copy()
+            perm = np.arange(n)
+            for k_ in range(n):  # P K P^T = L D L^T; perm: internal position -> caller index
+                perm[k_], perm[tr[k_]] = perm[tr[k_]], perm[k_]
+            X = np.eye(npad)
+            X[:n, :n] = np.linalg.inv(L)
+            b0 = blob0.numpy()
+
+            def put(name, vals):
+                off, cnt, w = lay[name]
+                a = np.zeros(cnt)
+                a[:len(vals)] = vals
+                b0[off:off + cnt * w] = a.astype(np.float64).view(np.uint8)
+
+            put("x", x[perm]), put("y", y[perm]), put("z", z[perm]), put("alpha", model.alpha[perm])
+            put("tx", x[perm]), put("ty", y[perm]), put("tz", z[perm])
+            dinv = np.ones(npad)
+            dinv[:n] = 1.0 / D
+            put("dinv", dinv)
+            blob1.numpy()[:] = X.astype(np.float64).view(np.uint8).ravel()
+        sh.broadcast_state(dist, [blob0, blob1], src=0)
+        # ---- every rank: decode ("commit") and evaluate its slab from the blobs alone ----
+        b0 = blob0.numpy()
+
+        def get(name):
+            off, cnt, w = lay[name]
+            return b0[off:off + cnt * w].view(np.float64)
+
+        px, py, pz, alpha, dinv = get("x"), get("y"), get("z"), get("alpha"), get("dinv")
+        X = blob1.numpy().view(np.float64).reshape(npad, npad)
+        qx, qy, qz = ds.query_grid(g)
+        lo, hi = sh.slab_range(nq, rank, world)
+        d = np.sqrt((qx[lo:hi, None] - px[None, :n]) ** 2 + (qy[lo:hi, None] - py[None, :n]) ** 2 +
+                    (qz[lo:hi, None] - pz[None, :n]) ** 2)
+        Kq = np.zeros((hi - lo, npad))
+        Kq[:, :n] = orc.k(kern, d.ravel()).reshape(d.shape)
+        f_loc = Kq @ alpha
+        W = Kq @ X.T
+        v_loc = float(orc.k(kern, 0.0)[0]) - (W * W * dinv[None, :]).sum(1)
+        f = sh.gather_slabs(dist, torch, torch.from_numpy(f_loc), nq, rank, world)
+        v = sh.gather_slabs(dist, torch, torch.from_numpy(v_loc), nq, rank, world)
+        if rank == 0:
+            ref = model.evaluate(qx, qy, qz, want_v=True)
+            q.put((float(np.max(np.abs(f.numpy() - ref["f"])) / np.max(np.abs(ref["f"]))),
+                   float(np.max(np.abs(v.numpy() - ref["v"])) / max(1.0, np.max(np.abs(ref["v"])))),
+                   int(blob0.numel() + blob1.numel())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factor_blobs_travel_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_state_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ef, ev, nbytes = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ef < 1e-10 and ev < 1e-10  # the slab of rank 1 was computed from the broadcast blobs alone
+    assert nbytes == 8 * 512 * (4 + 4 + 5) + 8 * 512 * 512
+
+
 def test_sharded_grid_world2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
