@@ -401,21 +401,12 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
     return req.rc;
 }
 
-extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
-                                        const double *qz, double f_tol, size_t capacity, int64_t *idx, double *f,
-                                        double *v, size_t *n_out)
+// mean on all queries -> deterministic compaction of |f| <= f_tol -> variance of the survivors only; the caller holds
+// m->mtx and has set the device
+static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
+                                 double f_tol, size_t capacity, int64_t *idx, double *f, double *v, size_t *n_out)
 {
-    if (!n_out || !idx)
-        return fail(GPX_E_NULL, "Empty output pointer");
-    *n_out = 0;
-    int rc = check_query(cm, nq, qx, qy, qz, f);
-    if (rc)
-        return rc;
-    if (!(f_tol >= 0.0))
-        return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
-    gpx_model *m = const_cast<gpx_model *>(cm);
-    std::lock_guard<std::mutex> lk(m->mtx);
-    HIPCHK(hipSetDevice(m->device));
+    int rc;
     hipStream_t s = m->stream;
     const size_t cap = std::min(capacity, nq);
     const size_t nb = (nq + 255) / 256;
@@ -451,6 +442,214 @@ extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const do
         HIPCHK(hipStreamSynchronize(s));
     }
     if (total > cap)
+        return fail(GPX_E_SIZE_MISMATCH, "more surface points than capacity");
+    return GPX_OK;
+}
+
+extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const double *qx, const double *qy,
+                                        const double *qz, double f_tol, size_t capacity, int64_t *idx, double *f,
+                                        double *v, size_t *n_out)
+{
+    if (!n_out || !idx)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    *n_out = 0;
+    int rc = check_query(cm, nq, qx, qy, qz, f);
+    if (rc)
+        return rc;
+    if (!(f_tol >= 0.0))
+        return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    return sample_surface_locked(m, nq, qx, qy, qz, f_tol, capacity, idx, f, v, n_out);
+}
+
+// ---- the surface-following sampler of the node (src/gp_node.cpp:1102-1291: marchingSampling + marchingCubes) -------
+// The reference walks from cube to cube with one std::thread per neighbour and one single-point evaluate(f, v) per
+// lattice point.  Here the walk is a breadth-first frontier on the host -- cubes by integer offset from the start cube,
+// a hash set for "already sampled" -- and every frontier is ONE device batch: the mean on all (steps + 1)^3 lattice
+// points of all its cubes, compaction of |f| <= f_tol, the variance for the kept points only.  Lattice coordinates and
+// cube centres are computed in float exactly as the reference does (:1210-1212, :1271-1281); order of the output:
+// cubes in discovery order (faces -x +x -y +y -z +z), lattice points i, j, k -- see oracle/gp_oracle.c:orc_march_surface
+// for the points where the reference's own order is left to thread timing.
+namespace {
+inline float f_add(float a, float b)
+{
+    volatile float r = a + b;  // one rounding per operation, no contraction into an fma
+    return r;
+}
+inline float f_mul(float a, float b)
+{
+    volatile float r = a * b;
+    return r;
+}
+struct MarchCube {
+    int ox, oy, oz;
+    float cx, cy, cz;
+};
+inline uint64_t march_key(int a, int b, int c)
+{
+    return ((uint64_t)(a + 1048576) << 42) | ((uint64_t)(b + 1048576) << 21) | (uint64_t)(c + 1048576);
+}
+}  // namespace
+
+extern "C" int gpx_model_march_surface(const gpx_model *cm, const double *start_xyz, double leaf_d, double pass_d,
+                                       double f_tol, size_t max_cubes, size_t capacity, double *xyz, double *f,
+                                       double *v, size_t *n_out, size_t *n_cubes)
+{
+    if (!n_out || !xyz || !f)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    *n_out = 0;
+    if (n_cubes)
+        *n_cubes = 0;
+    if (!cm)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!cm->ready)
+        return fail(GPX_E_STATE, "model is not ready (shell not committed or create failed)");
+    const float leaf = (float)leaf_d, pass = (float)pass_d;
+    if (!(leaf > 0.0f) || !(pass > 0.0f) || !(f_tol >= 0.0) || !std::isfinite(leaf) || !std::isfinite(pass))
+        return fail(GPX_E_BAD_ARG, "leaf and pass must be positive, f_tol non-negative");
+    const long steps = std::lround(leaf / pass);  // :1201
+    if (steps < 1 || steps > 64)
+        return fail(GPX_E_BAD_ARG, "round(leaf / pass) must be between 1 and 64");
+    gpx_model *m = const_cast<gpx_model *>(cm);
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    int rc;
+    float sx = 0, sy = 0, sz = 0;
+    if (start_xyz) {
+        sx = (float)start_xyz[0], sy = (float)start_xyz[1], sz = (float)start_xyz[2];
+    } else {
+        // :1126-1152: the first point of the 0.1 lattice on [-1.1, 1.1]^3 (accumulated doubles, x outermost) with
+        // |f| <= f_tol, found with one batched mean instead of up to 12167 single-point calls
+        std::vector<double> ax;
+        for (double t = -1.1; t <= 1.1; t += 0.1)
+            ax.push_back(t);
+        const size_t g = ax.size(), nq = g * g * g;
+        std::vector<double> qx(nq), qy(nq), qz(nq), ff(nq);
+        for (size_t i = 0, q = 0; i < g; ++i)
+            for (size_t j = 0; j < g; ++j)
+                for (size_t k = 0; k < g; ++k, ++q)
+                    qx[q] = ax[i], qy[q] = ax[j], qz[q] = ax[k];
+        if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * 4 * nq)))
+            return rc;
+        double *d = m->ws_host_io;
+        HIPCHK(hipMemcpyAsync(d, qx.data(), sizeof(double) * nq, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(d + nq, qy.data(), sizeof(double) * nq, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(d + 2 * nq, qz.data(), sizeof(double) * nq, hipMemcpyHostToDevice, m->stream));
+        if ((rc = evaluate_locked(m, nq, d, d + nq, d + 2 * nq, d + 3 * nq, nullptr, nullptr, nullptr, nullptr, m->stream)))
+            return rc;
+        HIPCHK(hipMemcpyAsync(ff.data(), d + 3 * nq, sizeof(double) * nq, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        size_t hit = nq;
+        for (size_t q = 0; q < nq; ++q)
+            if (std::fabs(ff[q]) <= f_tol) {
+                hit = q;
+                break;
+            }
+        if (hit == nq)
+            return fail(GPX_E_EMPTY, "No starting point found. Relax grid pass.");  // :1155
+        sx = (float)qx[hit], sy = (float)qy[hit], sz = (float)qz[hit];
+    }
+    const size_t per_cube = (size_t)(steps + 1) * (steps + 1) * (steps + 1);
+    std::vector<MarchCube> frontier{{0, 0, 0, sx, sy, sz}}, next;
+    std::vector<uint64_t> seen_keys;  // open addressing, 0 = empty (march_key is never 0)
+    size_t seen_cap = 4096, seen_cnt = 0;
+    seen_keys.assign(seen_cap, 0);
+    auto seen_insert = [&](uint64_t key) -> bool {  // true if newly inserted
+        if ((seen_cnt + 1) * 2 > seen_cap) {
+            std::vector<uint64_t> old;
+            old.swap(seen_keys);
+            seen_cap *= 4;
+            seen_keys.assign(seen_cap, 0);
+            for (uint64_t k : old)
+                if (k) {
+                    size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) % seen_cap;
+                    while (seen_keys[h])
+                        h = (h + 1) % seen_cap;
+                    seen_keys[h] = k;
+                }
+        }
+        size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) % seen_cap;
+        while (seen_keys[h]) {
+            if (seen_keys[h] == key)
+                return false;
+            h = (h + 1) % seen_cap;
+        }
+        seen_keys[h] = key;
+        ++seen_cnt;
+        return true;
+    };
+    seen_insert(march_key(0, 0, 0));
+    size_t done_cubes = 0, kept = 0;
+    std::vector<double> qx, qy, qz, fs, vs;
+    std::vector<int64_t> idx;
+    bool truncated = false;
+    while (!frontier.empty() && done_cubes < max_cubes) {
+        if (frontier.size() > max_cubes - done_cubes)
+            frontier.resize(max_cubes - done_cubes);
+        const size_t nc = frontier.size(), nq = nc * per_cube;
+        qx.resize(nq), qy.resize(nq), qz.resize(nq);
+        for (size_t c = 0, q = 0; c < nc; ++c) {
+            const MarchCube &cb = frontier[c];
+            const float hx = f_add(cb.cx, -(leaf / 2)), hy = f_add(cb.cy, -(leaf / 2)), hz = f_add(cb.cz, -(leaf / 2));
+            for (long i = 0; i <= steps; ++i)
+                for (long j = 0; j <= steps; ++j)
+                    for (long k = 0; k <= steps; ++k, ++q) {
+                        qx[q] = (double)f_add(hx, f_mul((float)i, pass));  // :1210-1212
+                        qy[q] = (double)f_add(hy, f_mul((float)j, pass));
+                        qz[q] = (double)f_add(hz, f_mul((float)k, pass));
+                    }
+        }
+        idx.resize(nq), fs.resize(nq), vs.resize(nq);
+        size_t ns = 0;
+        rc = sample_surface_locked(m, nq, qx.data(), qy.data(), qz.data(), f_tol, nq, idx.data(), fs.data(),
+                                   v ? vs.data() : nullptr, &ns);
+        if (rc)
+            return rc;
+        next.clear();
+        std::vector<unsigned char> where(nc * 6, 0);
+        for (size_t t = 0; t < ns; ++t) {
+            const size_t q = (size_t)idx[t], c = q / per_cube, r = q % per_cube;
+            const long i = (long)(r / ((steps + 1) * (steps + 1))), j = (long)(r / (steps + 1)) % (steps + 1),
+                       k = (long)(r % (steps + 1));
+            if (kept < capacity) {
+                xyz[3 * kept] = qx[q], xyz[3 * kept + 1] = qy[q], xyz[3 * kept + 2] = qz[q];
+                f[kept] = fs[t];
+                if (v)
+                    v[kept] = vs[t];
+            } else {
+                truncated = true;
+            }
+            ++kept;
+            unsigned char *w = &where[c * 6];  // :1240-1251
+            w[0] |= i == 0, w[1] |= i == steps, w[2] |= j == 0, w[3] |= j == steps, w[4] |= k == 0, w[5] |= k == steps;
+        }
+        for (size_t c = 0; c < nc; ++c)
+            for (int w = 0; w < 6; ++w) {  // :1266-1288
+                if (!where[c * 6 + w])
+                    continue;
+                MarchCube nb = frontier[c];
+                switch (w) {
+                case 0: nb.ox -= 1, nb.cx = f_add(nb.cx, -leaf); break;
+                case 1: nb.ox += 1, nb.cx = f_add(nb.cx, leaf); break;
+                case 2: nb.oy -= 1, nb.cy = f_add(nb.cy, -leaf); break;
+                case 3: nb.oy += 1, nb.cy = f_add(nb.cy, leaf); break;
+                case 4: nb.oz -= 1, nb.cz = f_add(nb.cz, -leaf); break;
+                default: nb.oz += 1, nb.cz = f_add(nb.cz, leaf); break;
+                }
+                if (std::abs(nb.ox) > 1000000 || std::abs(nb.oy) > 1000000 || std::abs(nb.oz) > 1000000)
+                    continue;
+                if (seen_insert(march_key(nb.ox, nb.oy, nb.oz)))
+                    next.push_back(nb);
+            }
+        done_cubes += nc;
+        frontier.swap(next);
+    }
+    *n_out = kept;
+    if (n_cubes)
+        *n_cubes = done_cubes;
+    if (truncated)
         return fail(GPX_E_SIZE_MISMATCH, "more surface points than capacity");
     return GPX_OK;
 }

@@ -68,7 +68,7 @@ EXPORTS = [
     "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
-    "gpx_model_replicate", "gpx_trim",
+    "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
     "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
@@ -142,6 +142,9 @@ def lib():
     L.gpx_model_state_blob.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gpx_model_commit.restype = C.c_int
     L.gpx_model_commit.argtypes = [vp, C.c_int]
+    L.gpx_model_march_surface.restype = C.c_int
+    L.gpx_model_march_surface.argtypes = [vp, dp, C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_size_t, dp, dp, dp,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.gpx_trim.restype = None
     L.gpx_model_replicate.restype = C.c_int
     L.gpx_model_replicate.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
@@ -341,6 +344,28 @@ class Model:
             _check(rc)
         k = min(n, cap)
         out = {"idx": idx[:k], "f": f[:k], "n_total": n, "truncated": rc == E_SIZE_MISMATCH}
+        if v is not None:
+            out["v"] = v[:k]
+        return out
+
+    def march_surface(self, leaf, step, f_tol=0.01, start=None, max_cubes=1 << 20, capacity=1 << 20, want_v=True):
+        """marchingSampling / marchingCubes (src/gp_node.cpp:1102-1291) as a frontier of device batches:
+        dict(xyz, f, v, n_total, n_cubes, truncated)."""
+        xyz = np.empty((capacity, 3)); f = np.empty(capacity)
+        v = np.empty(capacity) if want_v else None
+        n_out, n_cubes = C.c_size_t(0), C.c_size_t(0)
+        sp = None
+        if start is not None:
+            st = np.ascontiguousarray(start, dtype=np.float64)
+            sp = _dptr(st)
+        rc = self._L.gpx_model_march_surface(self._h, sp, float(leaf), float(step), float(f_tol), int(max_cubes),
+                                             int(capacity), _dptr(xyz), _dptr(f), _dptr(v) if v is not None else None,
+                                             C.byref(n_out), C.byref(n_cubes))
+        if rc != OK and rc != E_SIZE_MISMATCH:
+            _check(rc)
+        k = min(int(n_out.value), capacity)
+        out = {"xyz": xyz[:k], "f": f[:k], "n_total": int(n_out.value), "n_cubes": int(n_cubes.value),
+               "truncated": rc == E_SIZE_MISMATCH}
         if v is not None:
             out["v"] = v[:k]
         return out

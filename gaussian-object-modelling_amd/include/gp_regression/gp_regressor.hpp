@@ -271,6 +271,36 @@ public:
         v.resize(n);
     }
 
+    // The node's surface-following sampler (src/gp_node.cpp:1102-1291, marchingSampling + marchingCubes) as a
+    // frontier of device batches: `out` receives the kept points (coord_x/y/z), f and v their mean and variance.
+    // start == nullptr: the start point is searched on the 0.1 lattice as the node does.  Returns the number of cubes
+    // sampled.  New entry (gpx_model_march_surface), not in the reference header.
+    size_t marchSurface(Model::ConstPtr gp, const double *start_xyz, float leaf_size, float leaf_pass, Data::Ptr out,
+                        std::vector<double> &f, std::vector<double> &v, double f_tol = 0.01, size_t max_points = 1u << 22)
+    {
+        if (!gp || !gp->handle_)
+            throw GPRegressionException("Empty Model pointer");
+        if (!out)
+            throw GPRegressionException("Empty data pointer");
+        std::vector<double> xyz(3 * max_points);
+        f.assign(max_points, 0.0);
+        v.assign(max_points, 0.0);
+        size_t n = 0, cubes = 0;
+        const int rc = gpx_model_march_surface(gp->handle_, start_xyz, leaf_size, leaf_pass, f_tol, (size_t)1 << 24,
+                                               max_points, xyz.data(), f.data(), v.data(), &n, &cubes);
+        if (rc != GPX_OK)
+            throw GPRegressionException(message(rc));
+        out->clear();
+        for (size_t i = 0; i < n; ++i) {
+            out->coord_x.push_back(xyz[3 * i]);
+            out->coord_y.push_back(xyz[3 * i + 1]);
+            out->coord_z.push_back(xyz[3 * i + 2]);
+        }
+        f.resize(n);
+        v.resize(n);
+        return cubes;
+    }
+
     // Batched form of AtlasBase::project (include/atlas/atlas.hpp:201-276): every start point of `start` descends
     // onto f = 0 along its gradient, with the reference's tolerances, step rule and stopping criteria; `normals`
     // holds the un-normalised start directions (3 per point, row-major).  `out` receives the projected points

@@ -187,6 +187,22 @@ int gpx_model_project(const gpx_model *m, size_t nq, const double *x, const doub
 int gpx_model_sample_surface(const gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
                              double f_tol, size_t capacity, int64_t *idx, double *f, double *v, size_t *n_out);
 
+/* The node's surface-following sampler, GaussianProcessNode::marchingSampling + marchingCubes
+ * (src/gp_node.cpp:1102-1291), as a breadth-first frontier of device batches: starting from the cube of side `leaf`
+ * around a point on the surface, every cube is sampled on (steps + 1)^3 lattice points, steps = round(leaf / pass)
+ * (:1201-1212, coordinates in float as there); points with |f| <= f_tol (the node's 0.01, :1218) are kept with
+ * their variance; a kept point on a face of the cube makes the neighbour across that face the next to sample
+ * (:1240-1288); each cube is sampled once.  One mean batch per frontier, the variance only for the kept points.
+ * start_xyz: 3 doubles, or NULL to look for the start as the node does -- the first point of the 0.1 lattice on
+ * [-1.1, 1.1]^3 with |f| <= f_tol (:1126-1152; GPX_E_EMPTY "No starting point found" if there is none).
+ * xyz (3 * capacity, row-major), f, v (capacity each; v may be NULL): the kept points in discovery order (cubes
+ * breadth first, faces -x +x -y +y -z +z, lattice points i, j, k); *n_out = their number (GPX_E_SIZE_MISMATCH and the
+ * first `capacity` points if more); *n_cubes = cubes sampled (expansion stops at max_cubes).  The voxel-grid
+ * de-duplication that follows in the node (:1163-1168) is the caller's. */
+int gpx_model_march_surface(const gpx_model *m, const double *start_xyz, double leaf, double pass, double f_tol,
+                            size_t max_cubes, size_t capacity, double *xyz, double *f, double *v, size_t *n_out,
+                            size_t *n_cubes);
+
 /* Ensure the inverse factor needed by variance queries exists (else built at first use). */
 int gpx_model_prepare_variance(gpx_model *m);
 

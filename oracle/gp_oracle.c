@@ -670,6 +670,158 @@ void orc_project(const orc_model *m, int n, const double *x, const double *y, co
     }
 }
 
+/* GaussianProcessNode::marchingSampling + marchingCubes, reference src/gp_node.cpp:1102-1291: the surface-following
+ * sampler (the node's second sampling mode).  (1) Start point: the first lattice point of x, y, z in [-1.1, 1.1], step
+ * 0.1 (accumulated doubles, x outermost, :1126-1152) with |f| <= f_tol, stored as float (pcl::PointXYZ).  (2) A cube of
+ * side `leaf` centred there is sampled on (steps + 1)^3 points, steps = round(leaf / pass), coordinates in FLOAT
+ * arithmetic as in :1210-1212 (start.x - leaf / 2 + i * pass with start.x, leaf, pass float); points with |f| <= f_tol
+ * are kept with their variance (:1219-1225); a kept point on a face of the cube (i == 0, i == steps, ...) makes the
+ * neighbour cube across that face a candidate (:1240-1251), centred at start -+ leaf in float (:1271-1281); every cube
+ * is sampled once (:1283-1287, the octree occupancy test).
+ * Differences from the reference, all about ORDER (its recursion runs one std::thread per neighbour, so its output
+ * order and, through float accumulation along different paths, the last bit of a cube centre depend on thread timing):
+ * cubes are processed breadth first in discovery order (faces -x +x -y +y -z +z), a cube is identified by its integer
+ * offset from the start cube, and its centre is the parent's centre -+ leaf along the discovering step.  The PCL
+ * VoxelGrid de-duplication that follows in the node (:1163-1168) is outside the GP path.
+ * start_xyz == NULL: scan for the start point; returns the number of kept points (the first `capacity` are written),
+ * -1 if no start point is found; *n_cubes = cubes sampled (stops expanding at max_cubes). */
+static float marchf_add(float a, float b) { volatile float r = a + b; return r; }
+static float marchf_mul(float a, float b) { volatile float r = a * b; return r; }
+long orc_march_surface(const orc_model *m, const double *start_xyz, double leaf_d, double pass_d, double f_tol, long max_cubes,
+                       long capacity, double *out_xyz, double *out_f, double *out_v, long *n_cubes)
+{
+    const float leaf = (float)leaf_d, pass = (float)pass_d;
+    float sx, sy, sz;
+    if (start_xyz) {
+        sx = (float)start_xyz[0], sy = (float)start_xyz[1], sz = (float)start_xyz[2];
+    } else {
+        int found = 0;
+        for (double x = -1.1; x <= 1.1 && !found; x += 0.1)
+            for (double y = -1.1; y <= 1.1 && !found; y += 0.1)
+                for (double z = -1.1; z <= 1.1; z += 0.1) {
+                    double ff;
+                    orc_evaluate(m, 1, &x, &y, &z, &ff, NULL, NULL, NULL, NULL); /* :1136 */
+                    if (fabs(ff) <= f_tol) { /* :1137 */
+                        sx = (float)x, sy = (float)y, sz = (float)z;
+                        found = 1;
+                        break;
+                    }
+                }
+        if (!found) {
+            if (n_cubes)
+                *n_cubes = 0;
+            return -1;
+        }
+    }
+    const long steps = lroundf(leaf / pass); /* :1201 */
+    /* breadth-first queue of cubes: integer offsets + float centres */
+    long cap_q = 1024, nq = 0, head = 0;
+    int *off = (int *)malloc(sizeof(int) * 3 * (size_t)cap_q);
+    float *cen = (float *)malloc(sizeof(float) * 3 * (size_t)cap_q);
+    /* visited set: open addressing on packed offsets */
+    size_t hcap = 4096, hcnt = 0;
+    long long *hkeys = (long long *)malloc(sizeof(long long) * hcap);
+    for (size_t i = 0; i < hcap; ++i)
+        hkeys[i] = -1;
+#define MARCH_KEY(a, b, c) ((((long long)(a) + 1048576) << 42) | (((long long)(b) + 1048576) << 21) | ((long long)(c) + 1048576))
+#define MARCH_HASH(k) ((size_t)(((unsigned long long)(k) * 0x9E3779B97F4A7C15ull) >> 20))
+    long long k0 = MARCH_KEY(0, 0, 0);
+    hkeys[MARCH_HASH(k0) % hcap] = k0;
+    hcnt = 1;
+    off[0] = off[1] = off[2] = 0;
+    cen[0] = sx, cen[1] = sy, cen[2] = sz;
+    nq = 1;
+    long kept = 0;
+    while (head < nq && head < max_cubes) {
+        const int ox = off[3 * head], oy = off[3 * head + 1], oz = off[3 * head + 2];
+        const float cx = cen[3 * head], cy = cen[3 * head + 1], cz = cen[3 * head + 2];
+        ++head;
+        int where[6] = {0, 0, 0, 0, 0, 0};
+        const float hx = marchf_add(cx, -(leaf / 2)), hy = marchf_add(cy, -(leaf / 2)), hz = marchf_add(cz, -(leaf / 2));
+        for (long i = 0; i <= steps; ++i)
+            for (long j = 0; j <= steps; ++j)
+                for (long k = 0; k <= steps; ++k) {
+                    double x = (double)marchf_add(hx, marchf_mul((float)i, pass)); /* :1210 */
+                    double y = (double)marchf_add(hy, marchf_mul((float)j, pass));
+                    double z = (double)marchf_add(hz, marchf_mul((float)k, pass));
+                    double ff, vv;
+                    orc_evaluate(m, 1, &x, &y, &z, &ff, NULL, NULL, NULL, NULL); /* :1217 (the variance only matters for kept points) */
+                    if (fabs(ff) <= f_tol) { /* :1218 */
+                        orc_evaluate(m, 1, &x, &y, &z, &ff, &vv, NULL, NULL, NULL);
+                        if (kept < capacity) {
+                            out_xyz[3 * kept] = x, out_xyz[3 * kept + 1] = y, out_xyz[3 * kept + 2] = z;
+                            out_f[kept] = ff;
+                            out_v[kept] = vv;
+                        }
+                        ++kept;
+                        if (i == 0) where[0] = 1; /* :1240-1251 */
+                        if (i == steps) where[1] = 1;
+                        if (j == 0) where[2] = 1;
+                        if (j == steps) where[3] = 1;
+                        if (k == 0) where[4] = 1;
+                        if (k == steps) where[5] = 1;
+                    }
+                }
+        for (int w = 0; w < 6; ++w) { /* :1266-1288 */
+            if (!where[w])
+                continue;
+            int nx = ox, ny = oy, nz = oz;
+            float px = cx, py = cy, pz = cz;
+            if (w == 0) { nx -= 1; px = marchf_add(px, -leaf); }
+            if (w == 1) { nx += 1; px = marchf_add(px, leaf); }
+            if (w == 2) { ny -= 1; py = marchf_add(py, -leaf); }
+            if (w == 3) { ny += 1; py = marchf_add(py, leaf); }
+            if (w == 4) { nz -= 1; pz = marchf_add(pz, -leaf); }
+            if (w == 5) { nz += 1; pz = marchf_add(pz, leaf); }
+            long long key = MARCH_KEY(nx, ny, nz);
+            size_t h = MARCH_HASH(key) % hcap;
+            int seen = 0;
+            while (hkeys[h] != -1) {
+                if (hkeys[h] == key) {
+                    seen = 1;
+                    break;
+                }
+                h = (h + 1) % hcap;
+            }
+            if (seen)
+                continue;
+            hkeys[h] = key;
+            if (++hcnt * 2 > hcap) { /* grow */
+                size_t ncap = hcap * 4;
+                long long *nk = (long long *)malloc(sizeof(long long) * ncap);
+                for (size_t t = 0; t < ncap; ++t)
+                    nk[t] = -1;
+                for (size_t t = 0; t < hcap; ++t)
+                    if (hkeys[t] != -1) {
+                        size_t hh = MARCH_HASH(hkeys[t]) % ncap;
+                        while (nk[hh] != -1)
+                            hh = (hh + 1) % ncap;
+                        nk[hh] = hkeys[t];
+                    }
+                free(hkeys);
+                hkeys = nk;
+                hcap = ncap;
+            }
+            if (nq == cap_q) {
+                cap_q *= 2;
+                off = (int *)realloc(off, sizeof(int) * 3 * (size_t)cap_q);
+                cen = (float *)realloc(cen, sizeof(float) * 3 * (size_t)cap_q);
+            }
+            off[3 * nq] = nx, off[3 * nq + 1] = ny, off[3 * nq + 2] = nz;
+            cen[3 * nq] = px, cen[3 * nq + 1] = py, cen[3 * nq + 2] = pz;
+            ++nq;
+        }
+    }
+#undef MARCH_KEY
+#undef MARCH_HASH
+    if (n_cubes)
+        *n_cubes = head;
+    free(off);
+    free(cen);
+    free(hkeys);
+    return kept;
+}
+
 int orc_n(const orc_model *m) { return m->n; }
 double orc_R(const orc_model *m) { return m->R; }
 int orc_ldlt_info(const orc_model *m) { return m->ldlt_info; }

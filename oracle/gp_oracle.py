@@ -67,6 +67,9 @@ def _lib(omp=False):
     L.orc_project.restype = None
     L.orc_project.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int, C.c_double, dp,
                               dp, ip, ip]
+    L.orc_march_surface.restype = C.c_long
+    L.orc_march_surface.argtypes = [C.c_void_p, dp, C.c_double, C.c_double, C.c_double, C.c_long, C.c_long, dp, dp, dp,
+                                    C.POINTER(C.c_long)]
     L.orc_evaluate_fullcov.restype = None
     L.orc_evaluate_fullcov.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
     L.orc_tangent_basis.restype = None
@@ -270,6 +273,20 @@ class Model:
                             step_mul, out.ctypes.data_as(dp), f.ctypes.data_as(dp), it.ctypes.data_as(ip),
                             st.ctypes.data_as(ip))
         return {"xyz": out, "f": f, "iter": it, "status": st}
+
+    def march_surface(self, leaf, step, f_tol=0.01, start=None, max_cubes=1 << 20, capacity=1 << 20):
+        """marchingSampling / marchingCubes (src/gp_node.cpp:1102-1291): dict(xyz, f, v, n_total, n_cubes)."""
+        dp = C.POINTER(C.c_double)
+        xyz = np.empty((capacity, 3)); f = np.empty(capacity); v = np.empty(capacity)
+        nc = C.c_long(0)
+        sp = None
+        if start is not None:
+            st = np.ascontiguousarray(start, dtype=np.float64)
+            sp = st.ctypes.data_as(dp)
+        n = self._L.orc_march_surface(self._h, sp, float(leaf), float(step), float(f_tol), int(max_cubes), int(capacity),
+                                      xyz.ctypes.data_as(dp), f.ctypes.data_as(dp), v.ctypes.data_as(dp), C.byref(nc))
+        k = max(0, min(int(n), capacity))
+        return {"xyz": xyz[:k], "f": f[:k], "v": v[:k], "n_total": int(n), "n_cubes": int(nc.value)}
 
     def evaluate_fullcov(self, qx, qy, qz):
         qx, px = _d(qx); qy, py = _d(qy); qz, pz = _d(qz)

@@ -688,6 +688,44 @@ def test_shell_broadcast_commit_roundtrip(gpu, orc, ds):
         dst.close()
 
 
+@pytest.mark.parametrize("prec", [1, 0])
+def test_march_surface_follows_the_reference_walk(gpu, orc, ds, prec):
+    """gpx_model_march_surface == marchingSampling + marchingCubes (src/gp_node.cpp:1102-1291) as restated in
+    oracle/gp_oracle.c:orc_march_surface: same start point (lattice search), same cubes, the same kept points in the
+    same order with float-computed coordinates bit-identical, f and v at the fp64 / fp32 tolerances; an explicit
+    start point, the max_cubes cut and the capacity overflow behave alike."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(300)
+    kn, par = "thinplate", (2.0,)
+    om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)
+    tol = 1e-10 if prec == 1 else 1e-5
+    for leaf, step, start in ((0.15, 0.05, None), (0.2, 0.05, None), (0.15, 0.05, (0.95, 0.15, 0.15))):
+        ref = om.march_surface(leaf, step, start=start)
+        out = gm.march_surface(leaf, step, start=start)
+        assert ref["n_total"] > 1000 and ref["n_cubes"] > 100
+        assert out["n_total"] == ref["n_total"] and out["n_cubes"] == ref["n_cubes"] and not out["truncated"]
+        np.testing.assert_array_equal(out["xyz"], ref["xyz"])
+        assert np.max(np.abs(out["f"] - ref["f"])) < tol * 1e-2 + 1e-12  # |f| <= 0.01 on every kept point
+        assert verr(out["v"], ref["v"], 8.0) < tol
+        assert np.max(np.abs(out["f"])) <= 0.01
+    # no kept lattice point sits on the threshold (the walk would then depend on the last bit of f)
+    ref = om.march_surface(0.15, 0.05, f_tol=0.0105)
+    assert ref["n_total"] != om.march_surface(0.15, 0.05)["n_total"]
+    # cut after 40 cubes, and a capacity smaller than the result
+    r40, o40 = om.march_surface(0.15, 0.05, max_cubes=40), gm.march_surface(0.15, 0.05, max_cubes=40)
+    assert o40["n_cubes"] == r40["n_cubes"] == 40 and o40["n_total"] == r40["n_total"]
+    np.testing.assert_array_equal(o40["xyz"], r40["xyz"])
+    few = gm.march_surface(0.15, 0.05, capacity=100)
+    assert few["truncated"] and few["n_total"] == om.march_surface(0.15, 0.05)["n_total"] and len(few["f"]) == 100
+    np.testing.assert_array_equal(few["xyz"], om.march_surface(0.15, 0.05)["xyz"][:100])
+    # a model whose surface misses the search lattice: the reference's error
+    far = gpu.Model(gpu.make_kernel("gaussian", 1, 3), [0.0, 0.1], [0.0, 0.0], [0.0, 0.0], [1.0, 1.0], [0.1, 0.1], precision=prec)
+    with pytest.raises(gpu.GpxError, match="No starting point found"):
+        far.march_surface(0.15, 0.05)
+    far.close()
+    gm.close()
+
+
 def test_sample_surface_matches_filtered_evaluate(gpu, orc, ds):
     """gpx_model_sample_surface == evaluate everywhere, keep |f| <= tol (src/gp_node.cpp:1066-1100),
     but the variance is only computed for the survivors."""
