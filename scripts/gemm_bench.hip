@@ -1,6 +1,10 @@
-// gemm_bench.hip -- development harness: times the GEMM core on the two hot shapes.
-//   build: hipcc --offload-arch=gfx950 -O2 -std=c++17 scripts/gemm_bench.hip -I gaussian-object-modelling_amd/csrc \
-//          -L gaussian-object-modelling_amd/lib -lgpx -Wl,-rpath,$PWD/gaussian-object-modelling_amd/lib -o /tmp/gemm_bench
+// gemm_bench.hip -- development harness: times the GEMM core on the two hot shapes (variance contraction with / without
+// the low-rank correction in its epilogue; trailing update of the LDL^T for K = 128 .. 2048).
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gaussian-object-modelling_amd/csrc scripts/gemm_bench.hip \
+//          gaussian-object-modelling_amd/csrc/gpx_gemm.hip -o scripts/gemm_bench.bin       [-DGEMM_WAVES_PER_EU=1|2]
+//   (compiled TOGETHER with the GEMM source, not linked to libgpx.so: struct GemmArgs is internal to the library and a
+//   harness built against another revision of it passes garbage pointers -- the round-1 faults)
+//   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -151,6 +151,32 @@ int main(int argc, char **argv)
                    "Input data vectors have different lengths", "project: normals length");
     }
 
+    // ---- src/gp_node.cpp:258 : marchingSampling(false, 0.06, 0.02) -- the surface-following sampler, batched ----
+    {
+        Data::Ptr surf = std::make_shared<Data>();
+        std::vector<double> mf, mv;
+        const size_t cubes = reg_->marchSurface(obj_gp, nullptr, 0.15f, 0.05f, surf, mf, mv);
+        bool ok = cubes > 10 && surf->coord_x.size() == mf.size() && mf.size() == mv.size() && mf.size() > 100;
+        for (size_t i = 0; ok && i < mf.size(); ++i)
+            ok = std::fabs(mf[i]) <= 0.01;
+        EXPECT(ok, "marchSurface: every kept point has |f| <= 0.01");
+        // a kept point, re-evaluated alone, gives the same mean and variance
+        Data::Ptr one = std::make_shared<Data>();
+        one->coord_x = {surf->coord_x[7]}, one->coord_y = {surf->coord_y[7]}, one->coord_z = {surf->coord_z[7]};
+        std::vector<double> of, ov;
+        reg_->evaluate(obj_gp, one, of, ov);
+        EXPECT(std::fabs(of[0] - mf[7]) < 1e-12 && std::fabs(ov[0] - mv[7]) < 1e-9 * (1 + std::fabs(mv[7])), "marchSurface values");
+    }
+
+    // ---- read-only replicas on other devices (here: the same one), the in-process form of the sharded query grid ----
+    {
+        std::vector<Model::Ptr> reps = reg_->replicate(obj_gp, std::vector<int>{0});
+        std::vector<double> rf, rv;
+        reg_->evaluate(reps[0], c, rf, rv);
+        EXPECT(reps.size() == 1 && rf == f && rv == v, "replica answers exactly like its source");
+        EXPECT(thrown([&] { reg_->replicate(obj_gp, std::vector<int>{99}); }) == "device ordinal out of range", "replicate: bad device");
+    }
+
     // ---- the four reference exceptions, verbatim (gp_regressor.hpp:198/:231/:374/:566/:570) ----
     Data::Ptr labelled = std::make_shared<Data>(*c);
     labelled->label = {0.0, 0.0};
