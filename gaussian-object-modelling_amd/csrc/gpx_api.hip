@@ -775,3 +775,25 @@ extern "C" int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n,
         return fail(GPX_E_HIP, hipGetErrorString(le));
     return GPX_OK;
 }
+
+// ---- stand-alone kqp (bench roofline leg) --------------------------------------------------------
+extern "C" int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_px,
+                           const void *d_py, const void *d_pz, size_t nq, const void *d_qx, const void *d_qy,
+                           const void *d_qz, const void *d_fab, void *d_Kqp, void *stream)
+{
+    if (!kernel || !d_px || !d_py || !d_pz || !d_qx || !d_qy || !d_qz || !d_Kqp)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (n == 0 || n_padded % PANEL != 0 || n_padded < n || nq == 0 || nq % TILE != 0)
+        return fail(GPX_E_BAD_ARG, "n_padded must be gpx_padded_n(n) and nq a multiple of 128");
+    if (precision != GPX_PREC_F32 && precision != GPX_PREC_F64)
+        return fail(GPX_E_BAD_ARG, "precision must be GPX_PREC_F32 or GPX_PREC_F64");
+    CovHost c = make_cov(*kernel);
+    const int np_rows = (int)std::min<size_t>(n_padded, (n + TILE - 1) / TILE * TILE);
+    launch_kqp(precision, c, (int)n, (int)n_padded, d_px, d_py, d_pz, (long)nq, (long)nq, (const double *)d_qx,
+               (const double *)d_qy, (const double *)d_qz, d_Kqp, (hipStream_t)stream, np_rows, d_fab, (long)nq);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, hipGetErrorString(le));
+    return GPX_OK;
+}
+

@@ -114,7 +114,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 const char *e = std::getenv("GPX_VAR_TILE");
                 return e ? std::atoi(e) : 0;
             }();
-            a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : 0;
+            a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : (var_tile == 3 ? 3 : 0);
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)

@@ -88,6 +88,12 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_CORR_STAGE
 #define GEMM_CORR_STAGE 0
 #endif
+// Padding (elements) of a [k][n] LDS row of the fp64 NN tiles (inverse-factor assembly).  A lane group fg reads k-rows
+// 2 fg and 2 fg + 1: with 2 elements of padding rows two apart start 8 banks apart and the 16-lane groups of one half
+// wave collide; see DESIGN.md for the measurement.
+#ifndef GEMM_NPAD64
+#define GEMM_NPAD64 2
+#endif
 
 template <typename T>
 struct GemmDev {
@@ -112,7 +118,7 @@ struct GemmDev {
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_EU : 1) void gemm_kernel(GemmDev<T> g)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 3 : GEMM_WAVES_PER_EU) : 1) void gemm_kernel(GemmDev<T> g)
 {
     using MF = MfmaT<T, M32>;
     using acc_t = typename MF::acc_t;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? GEMM_WAVES_PER_E
     constexpr int CPRW = KBYTES / 16;           // 16-byte chunks per staged [row][k] row
     constexpr int EPC = 16 / sizeof(T);         // elements per 16-byte chunk
     constexpr int BKP = BK + GEMM_KPAD * EPC;   // padded k extent of a [row][k] LDS tile
-    constexpr int BNP = BN + EPC;               // padded n extent of a [k][n] LDS tile (NN)
+    constexpr int BNP = BN + (sizeof(T) == 8 ? GEMM_NPAD64 : EPC);  // padded n extent of a [k][n] LDS tile (NN)
     constexpr int A_TILE = BM * BKP;
     constexpr int B_TILE = NN ? BK * BNP : BN * BKP;
     constexpr int A_CH = BM * CPRW / NT;        // 16-byte chunks per thread, A tile
@@ -536,7 +542,7 @@ static void gemm_launch_cfg(const GemmDev<T> &g, const GemmArgs &a, hipStream_t 
     constexpr int FR = M32 ? 32 : 16;
     constexpr int BM = WGM * FM * FR, BN = WGN * FN * FR;
     constexpr int EPC = 16 / sizeof(T), BK = KBYTES / sizeof(T);
-    constexpr int BKP = BK + GEMM_KPAD * EPC, BNP = BN + EPC;
+    constexpr int BKP = BK + GEMM_KPAD * EPC, BNP = BN + (sizeof(T) == 8 ? GEMM_NPAD64 : EPC);
     constexpr size_t shmem = sizeof(T) * (2 * (size_t)BM * BKP + 2 * (size_t)(NN ? BK * BNP : BN * BKP));
     static PerDeviceOnce attr_once;  // the LDS-size attribute is per device (one static per instantiation)
     auto kern = gemm_kernel<T, NN, EPI, FM, FN, WGM, WGN, KBYTES, M32>;
@@ -625,6 +631,10 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
             GPX_GEMM_CFG(false, EPI_STORE);
     } else if (a.epi == EPI_TRSM) {
         GPX_GEMM_CFG(false, EPI_TRSM);
+    } else if (sizeof(T) == 4 && a.cfg == 3) {
+        // experiment (GPX_VAR_TILE=3): 64-byte k rows, 40 KiB of LDS per workgroup, compiled for 3 workgroups per CU
+        if constexpr (sizeof(T) == 4)
+            gemm_launch_cfg<T, false, EPI_COLSQ, 4, 4, 2, 2, 64>(g, a, st);
     } else {
         // Measured on the variance shape (N = 16384, 8192 queries), all within 1.5 %: 128x128 tile 135-136 TF,
         // 256x256 tile 134-135 TF, 64-byte k rows at 3 workgroups/CU (KBYTES = 64) 136.6 TF, 32x32x2 MFMA

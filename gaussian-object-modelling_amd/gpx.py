@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpx.so")
+LIB_PATH = os.environ.get("GPX_LIB") or os.path.join(_HERE, "lib", "libgpx.so")  # GPX_LIB: A/B runs of library variants
 
 GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
 KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
@@ -69,7 +69,7 @@ EXPORTS = [
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
-    "gpx_dev_kbuild", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
+    "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
 _lib = None
@@ -150,6 +150,9 @@ def lib():
     L.gpx_model_replicate.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.gpx_dev_kbuild.restype = C.c_int
     L.gpx_dev_kbuild.argtypes = [C.POINTER(Kernel), C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
+    L.gpx_dev_kqp.restype = C.c_int
+    L.gpx_dev_kqp.argtypes = [C.POINTER(Kernel), C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_size_t, vp, vp, vp, vp,
+                              vp, vp]
     L.gpx_pcd_read.restype = C.c_long
     L.gpx_pcd_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
     L.gpx_node_training_set.restype = C.c_int

@@ -241,6 +241,13 @@ int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_mod
  * d_rmax: reserved, pass NULL (Model::R comes from gpx_model_get). */
 int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_x,
                    const void *d_y, const void *d_z, const void *d_s2, void *d_K, void *d_rmax, void *stream);
+/* kqp: Kqp[q][j] = k(|q - p_j|) - (a_q + b_q |q - p_j|^2) for nq queries (a multiple of 128) against the n training
+ * points, row-major nq x n_padded `precision` scalars -- the kernel operand of one variance batch (gp_regressor.hpp:
+ * 300-303).  d_px,d_py,d_pz: `precision` scalars; d_qx,d_qy,d_qz: doubles; d_fab: the per-query fit as 2 x nq
+ * `precision` scalars (a_q row, b_q row) or NULL for the plain kernel values. */
+int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_px, const void *d_py,
+                const void *d_pz, size_t nq, const void *d_qx, const void *d_qy, const void *d_qz, const void *d_fab,
+                void *d_Kqp, void *stream);
 size_t gpx_padded_n(size_t n); /* leading dimension / padded order used for n training points */
 
 /* ---- PCD input + node-equivalent data preparation (host) ----------------------------------
