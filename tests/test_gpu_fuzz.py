@@ -77,8 +77,12 @@ def test_fuzz_fp32_family_against_oracle(gpu, orc, seed, prec):
     n = int(r.choice([5, 129, 256, 300, 511, 700, 1100, 1500, 2305]))  # 2305: above the fp64-training threshold of F32
     kn, kpar = KERNELS[int(r.choice([0, 1, 2, 3, 4]))]
     par = tuple(float(p) for p in kpar(r))
-    if seed >= 12:  # two cases pinned above the fp64-training threshold: an fp32 LDL^T feeds the variance
-        n, (kn, kpar) = 2305, KERNELS[2 if seed == 12 else 3]
+    if seed >= 12:  # two cases pinned above the fp64-training threshold: an fp32 kernel matrix and LDL^T feed the variance.
+        # Not thin-plate: half of these queries lie outside the cloud, where the thin-plate predictor weights a = K^-1 k_q
+        # grow (|a|_1 ~ 20) and the fp32 rounding of K alone, 6e-8 k(0) |a|_1^2, exceeds 1e-5 k(0) (measured 4e-5 at
+        # N = 2305, R = 3) -- a property of fp32 storage, not of a kernel; thin-plate at these sizes is covered on
+        # interpolating queries by test_gpu_scale.py.
+        n, (kn, kpar) = 2305, KERNELS[4 if seed == 12 else 3]
         par = tuple(float(p) for p in kpar(r))
     if kn == "thinplate":
         par = (float(r.choice([3.0, 4.0])),)  # positive definite on this cloud (diameter 2.2); R = 2: test_gpu_parity.py
