@@ -214,9 +214,13 @@ static void factorize(gpx_model *m, int c_start = 0)
     size_t gemm_idx = 0;
     m->factor_gemm_flops = 0;
     // one 128-wide step: diagonal block, panel solve (W to column `wcol` of the workspace, L21 in place)
+    // the 4-wave diagonal-block kernel is for launches that may run beside a GEMM on the other stream: by default every
+    // launch off the main stream, in the round-2 schedule (narrow_explicit) whenever a rest update may be in flight
+    bool narrow_diag = false, narrow_explicit = false;
     auto block_step = [&](int cc, int wcol, hipStream_t st) {
         const int r0 = cc + TILE;
-        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, st, st != m->stream);
+        launch_diag_ldl(m->prec, Kp(cc, cc), ldk, m->linv, m->t_d, m->t_dinv, m->d_info, cc / TILE, st,
+                        narrow_explicit ? narrow_diag : st != m->stream);
         if (r0 >= np)
             return;
         GemmArgs t;  // W = A21 * Linv^T ; L21 = W * D^-1 (in place)
@@ -242,7 +246,9 @@ static void factorize(gpx_model *m, int c_start = 0)
         launch_gemm(m->prec, s, st);
     };
     // trailing matrix from row / column r0 on -= W[:, wofs:wofs+kw] * L[:, c0:c0+kw]^T, lower tiles only
-    auto trailing = [&](int c0, int r0, int kw, int wofs = 0) {
+    auto trailing = [&](int c0, int r0, int kw, int wofs = 0, hipStream_t ts = nullptr) {
+        if (!ts)
+            ts = m->stream;
         GemmArgs s;
         s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
         s.B = Kp(r0, c0), s.ldb = ldk;
@@ -256,10 +262,10 @@ static void factorize(gpx_model *m, int c_start = 0)
         }
         hipEvent_t *ev = gemm_events(m, gemm_idx);
         if (ev)
-            (void)hipEventRecord(ev[0], m->stream);
-        launch_gemm(m->prec, s, m->stream);
+            (void)hipEventRecord(ev[0], ts);
+        launch_gemm(m->prec, s, ts);
         if (ev) {
-            (void)hipEventRecord(ev[1], m->stream);
+            (void)hipEventRecord(ev[1], ts);
             ++gemm_idx;
         }
     };
@@ -315,6 +321,74 @@ static void factorize(gpx_model *m, int c_start = 0)
                     half_update(cc, wofs + h * TILE, c0 + nb * TILE, st);
             }
         };
+        int la_mode = 2;  // GPX_LA_MODE=1: the round-1 schedule (strip on the main stream, two hops per panel on the chain)
+        if (const char *me = std::getenv("GPX_LA_MODE"))
+            la_mode = std::atoi(me);
+        if (la_mode == 2) {
+            // The chain stream owns everything the NEXT panel waits for -- diagonal blocks, panel solves, half update AND the
+            // 256-column strip of the trailing update -- so no cross-stream hop lies on the serial chain any more (the
+            // round-1 schedule had strip + two hops = 44 of the ~190 us per panel there, rocprofv3 timeline in
+            // profiles/r02_create_stages.txt); the main stream only runs the rest of each trailing update:
+            //   chain stream:  chain_p -> [eP_p] -> wait eR_{p-1} -> strip_p -> chain_{p+1} ...
+            //   main stream :  wait eP_p -> rest_p -> [eR_p]
+            // rest_{p-1} must precede strip_p (same tiles: the columns of panel p+1) and chain_{p+1} (it reads the workspace
+            // half chain_{p+1} writes); both hold because strip_p waits for eR_{p-1}.  rest_p and strip_p touch disjoint
+            // tiles.  Same launches on the same operands as the plain order: bit-identical.
+            // all events up front (2 per panel + 2), so that the loop cannot run out half way
+            const size_t need_ev = 2 * (size_t)(np / PANEL) + 4;
+            while (m->la_ev.size() < need_ev) {
+                hipEvent_t ev;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                m->la_ev.push_back(ev);
+            }
+            hipEvent_t e0 = m->la_ev.size() >= need_ev ? next_event() : nullptr;
+            if (e0) {
+                narrow_explicit = true;
+                narrow_diag = true;
+                (void)hipEventRecord(e0, sa);
+                (void)hipStreamWaitEvent(sb, e0, 0);
+                chain(0, 0, sb);
+                hipEvent_t eR_prev = nullptr;
+                int p = 0;
+                for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
+                    const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
+                    const int sw = std::min(PANEL, np - r0);
+                    if (eR_prev)
+                        (void)hipStreamWaitEvent(sb, eR_prev, 0);
+                    if (np - r0 <= la_tail_rows || r0 + sw >= np) {  // tail: one trailing update on the chain stream
+                        eR_prev = nullptr;
+                        narrow_diag = false;  // nothing runs beside the chain any more: the 8-wave diagonal kernel
+                        trailing(c0, r0, PANEL, wofs, sb);
+                        chain(r0, wofs ^ PANEL, sb);
+                        continue;
+                    }
+                    hipEvent_t eP = next_event(), eR = next_event();  // (created above)
+                    (void)hipEventRecord(eP, sb);
+                    GemmArgs s;  // strip: C[r0:, r0:r0+sw] -= W_p L_p^T
+                    s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
+                    s.B = Kp(r0, c0), s.ldb = ldk;
+                    s.C = Kp(r0, r0), s.ldc = ldk;
+                    s.M = np - r0, s.N = sw, s.K = PANEL;
+                    s.alpha = -1.0, s.beta = 1;
+                    launch_gemm(m->prec, s, sb);
+                    (void)hipStreamWaitEvent(sa, eP, 0);
+                    trailing(c0, r0 + sw, PANEL, wofs, sa);
+                    (void)hipEventRecord(eR, sa);
+                    eR_prev = eR;
+                    narrow_diag = true;
+                    chain(r0, wofs ^ PANEL, sb);
+                }
+                narrow_explicit = narrow_diag = false;
+                hipEvent_t eJ = next_event();
+                (void)hipEventRecord(eJ, sb);
+                (void)hipStreamWaitEvent(sa, eJ, 0);
+                m->gemm_ev_used_factor = gemm_idx;
+                return;
+            }
+        }
         chain(0, 0, sa);
         int p = 0;
         for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
