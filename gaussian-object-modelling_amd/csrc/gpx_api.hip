@@ -195,6 +195,9 @@ extern "C" void gpx_model_destroy(gpx_model *m)
             (void)hipEventDestroy(e);
     for (auto &e : m->la_ev)
         (void)hipEventDestroy(e);
+    for (auto &e : m->pipe_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (m->stream2)
         (void)hipStreamDestroy(m->stream2);
     if (m->stream)

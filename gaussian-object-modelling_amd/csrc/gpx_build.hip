@@ -23,6 +23,10 @@ void free_dev(gpx_model *m)
     F(m->ws_kqp);
     F(m->ws_partial);
     F(m->ws_coef);
+    F(m->ws_kqp2);
+    F(m->ws_coef2);
+    m->ws_kqp2 = m->ws_coef2 = nullptr;
+    m->ws_kqp2_bytes = m->ws_coef2_bytes = 0;
     F(m->ws_grad);
     F(m->ws_host_io);
     F(m->ws_small);

@@ -54,10 +54,46 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     if (v) {
         const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
         const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
-        size_t gi = 0;
-        for (size_t q0 = 0; q0 < nq; q0 += qb) {
+        // Opt-in (GPX_VAR_PIPE=1) two-deep pipeline over the query batches: the kernel operand of batch i+1 (fit + kqp,
+        // ~0.13 ms of HBM-write / VALU work) is built on the second stream into a second buffer while the GEMM of batch i
+        // (15.6 ms of MFMA work at N = 16384) runs on the caller's stream.  Measured: the 3.4 ms per step it hides come
+        // back as a GEMM that runs 0.15 ms longer per launch beside the kqp (2098.2 vs 2099.3 ms per step) -- no gain, so
+        // the default stays one stream and one buffer.
+        static const bool pipe_on = [] {
+            const char *pe = std::getenv("GPX_VAR_PIPE");
+            return pe && std::atoi(pe) != 0;
+        }();
+        bool pipe = pipe_on && nq > qb;
+        if (pipe && !m->stream2 && hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            m->stream2 = nullptr;
+            pipe = false;
+        }
+        for (int i = 0; pipe && i < 5; ++i)
+            if (!m->pipe_ev[i] && hipEventCreateWithFlags(&m->pipe_ev[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                m->pipe_ev[i] = nullptr;
+                pipe = false;
+            }
+        if (pipe && (ensure(&m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * np) != GPX_OK ||
+                     (m->var_fit && ensure(&m->ws_coef2, &m->ws_coef2_bytes, e * qb * VAR_NCOEF) != GPX_OK))) {
+            (void)hipGetLastError();
+            pipe = false;  // no room for the second operand buffer: one stream, one buffer
+        }
+        hipStream_t sp = pipe ? m->stream2 : s;  // producer of the kernel operand
+        if (pipe) {
+            (void)hipEventRecord(m->pipe_ev[0], s);  // queries, model state and the workspaces are ready on s
+            (void)hipStreamWaitEvent(sp, m->pipe_ev[0], 0);
+        }
+        size_t gi = 0, bi = 0;
+        for (size_t q0 = 0; q0 < nq; q0 += qb, ++bi) {
             const size_t nv = std::min(qb, nq - q0);
             const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
+            const int buf = pipe ? (int)(bi & 1) : 0;
+            void *kqp_buf = buf ? m->ws_kqp2 : m->ws_kqp;
+            void *coef_buf = buf ? m->ws_coef2 : m->ws_coef;
+            if (pipe && bi >= 2)
+                (void)hipStreamWaitEvent(sp, m->pipe_ev[3 + buf], 0);  // the GEMM of batch bi - 2 has read this buffer
             // The kernel operand holds k - fit with a per-query fit that is rank 5 in (q, p); the GEMM epilogue adds
             // X * fit back from the model's five row-correction vectors (gpx_internal.hpp, "low-rank fit").
             hipEvent_t *kev = nullptr;  // brackets the Kqp launch of this batch (stats; only on the model's own stream)
@@ -74,36 +110,46 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             const char *fab = nullptr;  // rows a_q, b_q of the batch's coefficient array
             if (m->var_fit) {
                 launch_var_fit(m->prec, m->cov, m->n, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                               qz + q0, m->ws_coef, (long)qb, s);
-                fab = (const char *)m->ws_coef + e * qb * VAR_NCORR;
+                               qz + q0, coef_buf, (long)qb, sp);
+                fab = (const char *)coef_buf + e * qb * VAR_NCORR;
             }
             if (kev)
-                (void)hipEventRecord(kev[0], s);
+                (void)hipEventRecord(kev[0], sp);
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
-                                 qy + q0, qz + q0, m->ws_kqp, s, (const float *)fab, (long)qb);
+                                 qy + q0, qz + q0, kqp_buf, sp, (const float *)fab, (long)qb);
                 if (kev)
-                    (void)hipEventRecord(kev[1], s);
+                    (void)hipEventRecord(kev[1], sp);
+                if (pipe) {
+                    (void)hipEventRecord(m->pipe_ev[1 + buf], sp);
+                    (void)hipStreamWaitEvent(s, m->pipe_ev[1 + buf], 0);
+                }
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
-                launch_vsplit_gemm(m->X, m->ws_kqp, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
+                launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
                                    (long)qb, 2, s, np_rows, m->var_fit ? (const float *)m->t_corr : nullptr, np,
-                                   m->var_fit ? (const float *)m->ws_coef : nullptr, (long)qb);
+                                   m->var_fit ? (const float *)coef_buf : nullptr, (long)qb);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
                 }
+                if (pipe)
+                    (void)hipEventRecord(m->pipe_ev[3 + buf], s);
                 launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
             launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                       qz + q0, m->ws_kqp, s, np_rows, fab, (long)qb);
+                       qz + q0, kqp_buf, sp, np_rows, fab, (long)qb);
             if (kev)
-                (void)hipEventRecord(kev[1], s);
+                (void)hipEventRecord(kev[1], sp);
+            if (pipe) {
+                (void)hipEventRecord(m->pipe_ev[1 + buf], sp);
+                (void)hipStreamWaitEvent(s, m->pipe_ev[1 + buf], 0);
+            }
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
-            a.B = m->ws_kqp, a.ldb = np;
+            a.B = kqp_buf, a.ldb = np;
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
@@ -118,7 +164,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)
-                a.rowcorr = m->t_corr, a.ldrc = np, a.colcoef = m->ws_coef, a.ldcc = (long)qb;
+                a.rowcorr = m->t_corr, a.ldrc = np, a.colcoef = coef_buf, a.ldcc = (long)qb;
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (ev)
                 (void)hipEventRecord(ev[0], s);
@@ -127,6 +173,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 (void)hipEventRecord(ev[1], s);
                 ++gi;
             }
+            if (pipe)
+                (void)hipEventRecord(m->pipe_ev[3 + buf], s);
             const int bm = gemm_rows_per_partial(m->prec, a);
             launch_var_finish(m->prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
         }

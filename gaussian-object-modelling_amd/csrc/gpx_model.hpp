@@ -102,8 +102,12 @@ struct gpx_model {
     size_t ws_kqp_bytes = 0;
     void *ws_partial = nullptr;
     size_t ws_partial_bytes = 0;
-    void *ws_coef = nullptr;  // [VAR_NCORR][qbatch] query-side coefficients of the fit
+    void *ws_coef = nullptr;  // [VAR_NCOEF][qbatch] query-side coefficients of the fit, a_q, b_q
     size_t ws_coef_bytes = 0;
+    // second set for the two-deep pipeline of the variance batches (operand of batch i+1 built beside the GEMM of batch i)
+    void *ws_kqp2 = nullptr, *ws_coef2 = nullptr;
+    size_t ws_kqp2_bytes = 0, ws_coef2_bytes = 0;
+    hipEvent_t pipe_ev[5] = {};  // start | operand ready (2) | operand consumed (2); no timing
     double *ws_grad = nullptr;
     size_t ws_grad_doubles = 0;
     void *ws_small = nullptr;      // partial sums + counters of the one-launch path for a handful of queries
