@@ -59,10 +59,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         // (15.6 ms of MFMA work at N = 16384) runs on the caller's stream.  Measured: the 3.4 ms per step it hides come
         // back as a GEMM that runs 0.15 ms longer per launch beside the kqp (2098.2 vs 2099.3 ms per step) -- no gain, so
         // the default stays one stream and one buffer.
-        static const bool pipe_on = [] {
-            const char *pe = std::getenv("GPX_VAR_PIPE");
-            return pe && std::atoi(pe) != 0;
-        }();
+        const char *pipe_env = std::getenv("GPX_VAR_PIPE");  // read per call
+        const bool pipe_on = pipe_env && std::atoi(pipe_env) != 0;
         bool pipe = pipe_on && nq > qb;
         if (pipe && !m->stream2 && hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();

@@ -726,6 +726,24 @@ def test_march_surface_follows_the_reference_walk(gpu, orc, ds, prec):
     gm.close()
 
 
+@pytest.mark.parametrize("prec", [1, 0, 3])
+def test_pipelined_variance_batches_are_bit_identical(gpu, ds, prec, monkeypatch):
+    """GPX_VAR_PIPE=1 (opt-in): the kernel operand of batch i+1 is built on a second stream into a second buffer while
+    the GEMM of batch i runs.  Same kernels on the same operands: bit-identical variance, also over many small batches
+    and a ragged last one."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(700)
+    qx, qy, qz = ds.query_grid(11)  # 1331 queries
+    kern = gpu.make_kernel("matern52", 1.0, 1.0)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GPX_VAR_PIPE", mode)
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, query_batch=256)
+        res[mode] = [gm.evaluate(qx, qy, qz, want_v=True)["v"] for _ in range(2)]
+        gm.close()
+    for a in res["0"] + res["1"]:
+        np.testing.assert_array_equal(a, res["0"][0])
+
+
 def test_sample_surface_matches_filtered_evaluate(gpu, orc, ds):
     """gpx_model_sample_surface == evaluate everywhere, keep |f| <= tol (src/gp_node.cpp:1066-1100),
     but the variance is only computed for the survivors."""
