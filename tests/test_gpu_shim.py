@@ -56,3 +56,25 @@ def test_plain_c_caller_of_the_c_abi(gpu, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "projected to" in r.stdout and "(status 1)" in r.stdout and "after update (+16 points)" in r.stdout
+
+
+def test_eigen_typed_overloads_run(gpu, tmp_path):
+    """evaluate(gp, query, f, v, MatrixXd &N [, Tx, Ty]) and computeTangentBasis(Vector3d...) of the header
+    shim, compiled and RUN against their std::vector twins.  With the real Eigen where it is installed; this image has
+    none, so here the adapters are built against tests/cpp/eigen_iface -- an interface stand-in with the few
+    members they touch, which is not Eigen, is on no other include path and takes no part in any reference build."""
+    inc = None
+    for cand in ("/usr/include/eigen3", "/usr/local/include/eigen3"):
+        if os.path.exists(os.path.join(cand, "Eigen", "Core")):
+            inc = cand
+    which = "Eigen" if inc else "interface stand-in"
+    inc = inc or os.path.join(ROOT, "tests", "cpp", "eigen_iface")
+    exe = str(tmp_path / "eigen_adapters")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", inc, "-I", os.path.join(PKG, "include"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "eigen_adapters.cpp"), "-o", exe, "-L", os.path.join(PKG, "lib"), "-lgpx",
+           "-Wl,-rpath," + os.path.join(PKG, "lib"), "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, which + ": " + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "eigen_adapters: OK" in r.stdout, which + ": " + r.stdout + r.stderr
+
