@@ -360,17 +360,24 @@ static void factorize(gpx_model *m, int c_start = 0)
                 for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
                     const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
                     const int sw = std::min(PANEL, np - r0);
+                    const bool tail = np - r0 <= la_tail_rows || r0 + sw >= np;
+                    // the rest update is released as soon as chain_p is done -- BEFORE the chain stream waits for rest_{p-1}:
+                    // in the update-bound part the chain finishes long before that, and rest_p then follows rest_{p-1} on the
+                    // main stream without a hop (was: hop + start of the strip = ~37 us per panel between two rest updates)
+                    hipEvent_t eP = nullptr, eR = nullptr;
+                    if (!tail) {
+                        eP = next_event(), eR = next_event();  // (created above)
+                        (void)hipEventRecord(eP, sb);
+                    }
                     if (eR_prev)
                         (void)hipStreamWaitEvent(sb, eR_prev, 0);
-                    if (np - r0 <= la_tail_rows || r0 + sw >= np) {  // tail: one trailing update on the chain stream
+                    if (tail) {  // one trailing update on the chain stream
                         eR_prev = nullptr;
                         narrow_diag = false;  // nothing runs beside the chain any more: the 8-wave diagonal kernel
                         trailing(c0, r0, PANEL, wofs, sb);
                         chain(r0, wofs ^ PANEL, sb);
                         continue;
                     }
-                    hipEvent_t eP = next_event(), eR = next_event();  // (created above)
-                    (void)hipEventRecord(eP, sb);
                     GemmArgs s;  // strip: C[r0:, r0:r0+sw] -= W_p L_p^T
                     s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
                     s.B = Kp(r0, c0), s.ldb = ldk;

@@ -14,6 +14,8 @@ for rep in range(reps):
     gm = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=True)
     wall = time.perf_counter() - t
     st = gm.stats
+    import hashlib
+    digest = hashlib.sha1(gm.alpha.tobytes() + gm.D.tobytes()).hexdigest()[:12]
     gm.close()
-    print("create %.2f ms wall; kbuild %.2f LDL^T %.2f (GEMM %.2f) alpha %.2f inverse %.2f" % (
-        wall * 1e3, st["t_kbuild_ms"], st["t_factor_ms"], st["t_factor_gemm_ms"], st["t_solve_ms"], st["t_inverse_ms"]), flush=True)
+    print("create %.2f ms wall; kbuild %.2f LDL^T %.2f (GEMM %.2f) alpha %.2f inverse %.2f  sha1(alpha, D) %s" % (
+        wall * 1e3, st["t_kbuild_ms"], st["t_factor_ms"], st["t_factor_gemm_ms"], st["t_solve_ms"], st["t_inverse_ms"], digest), flush=True)
