@@ -554,11 +554,11 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
     T *Di = reinterpret_cast<T *>(smem_raw);       // [TILE]       1 / D
     T *Ls = Di + TILE;                             // [6][NB][PLD] L blocks (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2)
     T *Xd = Ls + 6 * BLK;                          // [4][NB][PLD] inverses of the diagonal sub-blocks
-    T *Dn = Xd + 4 * BLK;                          // [NB][PLD]    next diagonal sub-block, handed over by the trailing update;
-    T *Lt = Dn;                                    //              once it is in registers: L11 for its row-wise write-out
-    T *P = Dn + BLK;                               // [96][PLD]    panel rows 32 .. 127: A entries, then W = L D
+    T *Dn = Xd + 4 * BLK;                          // [NB][PLD]    next diagonal sub-block, handed over by the trailing update
+    T *Lx = Dn + BLK;                              // [NB][PLD]    L11 of the current sub-block, for its row-wise write-out
+    T *P = Lx + BLK;                               // [96][PLD]    panel rows 32 .. 127: A entries, then W = L D
     T *Pv = P - NB * PLD;                          //              (row r at Pv + r * PLD)
-    // 59.6 KB in all -- no more than a workgroup of the GEMM, so that the kernel finds room on a CU wherever one of those
+    // 63.8 KB in all -- no more than a workgroup of the GEMM, so that the kernel finds room on a CU wherever one of those
     // does (LDS is allocated contiguously).  The assembly of the inverse therefore lives in blocks that are dead by then:
     //   panel rows 32-63 : T0 (A2: L10 Xd0; B2: L20 Xd0 + L21 X10) -> X20 in place (C2)
     //   panel rows 64-95 : X10 (A2)                panel rows 96-127: S31 (A3; W of panel 2 until then)
@@ -578,6 +578,31 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
     // a product chain inside one wave goes through LDS: the LDS queue of a wave is in order, the fence only keeps the
     // compiler from moving the reads of the next product above the stores of this one
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+    T dvec = 1.0f;                                 // wave 0: D of the current sub-block (lane = row), kept for the write-out
+    unsigned long long mneg = 0, mbad = 0;
+    // L11 (strictly lower, from Lx) and D of sub-block jb to global: wave 0, off the critical path (steps B and C).
+    // (Tried: the inverse's recurrence on wave 1, fed column by column through Lx with self-validating entries -- the LDS
+    // polls make it the slower of the two waves: step A 5.0 us instead of 4.4.)
+    auto write_out = [&](int jb, int lane) {
+        const int c0 = NB * jb, half = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int c = 0; c < NB / 2; ++c) {
+            const int cc = half * (NB / 2) + c;
+            if (cc < col)
+                A[(size_t)(c0 + col) * lda + c0 + cc] = Lx[col * PLD + cc];
+        }
+        if (lane < NB) {
+            A[(size_t)(c0 + lane) * lda + c0 + lane] = dvec;
+            d[blk * TILE + c0 + lane] = dvec;
+            dinv[blk * TILE + c0 + lane] = Di[c0 + lane];
+            if (lane == 0) {
+                if (mbad)
+                    atomicCAS(&info[0], 0, blk * TILE + c0 + 1);
+                if (mneg)
+                    atomicAdd(&info[1], __builtin_popcountll(mneg));
+            }
+        }
+    };
 
     GPX_STAMP(0);
     if (wave >= 2) {
@@ -621,7 +646,6 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
                     X[r] = row == col ? 1.0f : 0.0f;
                 }
             }
-            T dvec = 1.0f;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;  // row j: register rj of wave half hj
@@ -635,35 +659,16 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
                 M = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rowj, M, 0, 0, 0);
                 X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, X[rj], X, 0, 0, 0);
                 if (act)
-                    Lt[col * PLD + j] = lj;  // L11[col][j]
+                    Lx[col * PLD + j] = lj;  // L11[col][j]
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Xd[(jb * NB + 8 * (r >> 2) + 4 * half + (r & 3)) * PLD + col] = X[r];  // exact zeros above, ones on the diagonal
             const bool neg = lane < NB && dvec < 0.0f;
             const bool bad = lane < NB && (!(fabsf(dvec) > 0.0f) || !(fabsf(dvec) < pivot_huge(0.0f)));
-            const unsigned long long mneg = __ballot(neg), mbad = __ballot(bad);
+            mneg = __ballot(neg), mbad = __ballot(bad);
             if (lane < NB)
                 Di[c0 + lane] = 1.0f / dvec;
-            wave_sync();
-            // L11 and D out: lane = (row col, half of the columns)
-#pragma unroll
-            for (int c = 0; c < NB / 2; ++c) {
-                const int cc = half * (NB / 2) + c;
-                if (cc < col)
-                    A[(size_t)(c0 + col) * lda + c0 + cc] = Lt[col * PLD + cc];
-            }
-            if (lane < NB) {
-                A[(size_t)(c0 + lane) * lda + c0 + lane] = dvec;
-                d[blk * TILE + c0 + lane] = dvec;
-                dinv[blk * TILE + c0 + lane] = Di[c0 + lane];
-                if (lane == 0) {
-                    if (mbad)
-                        atomicCAS(&info[0], 0, blk * TILE + c0 + 1);
-                    if (mneg)
-                        atomicAdd(&info[1], __builtin_popcountll(mneg));
-                }
-            }
         } else if (jb == 0) {
             // the rows below the first sub-block -> panel buffer (the later panels are left there by the trailing update)
             for (int idx = tid - 64; idx < (TILE - NB) * NB; idx += DT - 64) {
@@ -722,6 +727,8 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
         }
         lds_barrier();
         GPX_STAMP(2 + 4 * jb);
+        if (wave == 0 && jb < 3)
+            write_out(jb, lane);         // (wave 0 has nothing else to do in B and C; Lx is not touched again before the next A)
         const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
         if (nb_rows > 0) {
             T *Lsp = Ls + (jb == 0 ? 0 : (jb == 1 ? 3 : 5)) * BLK;  // L blocks (jb+1 .., jb)
@@ -809,6 +816,8 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
         acc.mac(Xd3, wave == 1 ? S30 : (wave == 2 ? S31 : S32), lane);
         acc.store(T(-1), (T *)nullptr, Xg + (size_t)3 * NB * TILE + (wave - 1) * NB, TILE, lane);
     } else {
+        if (wave == 0)
+            write_out(3, lane);
         const int ft = wave == 0 ? lane : 64 + (tid - 256);
         constexpr int NF = 64 + (DT > 256 ? DT - 256 : 0);
         for (int idx = ft; idx < NB * NB; idx += NF)
@@ -825,7 +834,7 @@ static size_t diag_shmem_bytes(size_t esz)
 
 static size_t diag32_shmem_bytes()
 {
-    return sizeof(float) * (size_t)(TILE + 11 * NB * PLD + 96 * PLD);  // Di + Ls[6] Xd[4] Dn + panel rows 32 .. 127
+    return sizeof(float) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);  // Di + Ls[6] Xd[4] Dn Lx + panel rows 32 .. 127
 }
 template <int DT>
 static void diag32_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
