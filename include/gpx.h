@@ -70,9 +70,10 @@ typedef struct gpx_kernel {
  *          residuals; the inverse factor is assembled in fp64 from the fp32 factor and rounded once; the variance
  *          GEMM contracts a centred kernel operand (k minus a per-query fit that is added back exactly in the
  *          epilogue), which keeps every kernel within 1e-5 of the fp64 result at N = 16384.  Models of up to 2048
- *          padded rows (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED -- free at that size, and the fp32
- *          LDL^T's backward error would otherwise show in the variance of ill-conditioned (thin-plate) systems;
- *          such models hold no factor afterwards, so gpx_model_update rebuilds them instead of appending
+ *          padded rows -- 8192 for the thin plate -- (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED: (nearly)
+ *          free at that size, and the fp32 LDL^T's backward error would otherwise show in the variance of
+ *          ill-conditioned (thin-plate) systems; such models hold no factor afterwards, so gpx_model_update
+ *          rebuilds them instead of appending
  *   F64    everything in fp64 (fp64 MFMA): the reference's arithmetic
  *   MIXED  train (kernel matrix, LDL^T, alpha, inverse factor) in fp64, then the inverse factor is
  *          rounded once to fp32 and the variance GEMM runs in fp32; the fp64 factor is released
