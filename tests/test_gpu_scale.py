@@ -32,6 +32,32 @@ def test_c2_n4096_fp64_gaussian_against_oracle(gpu, orc, ds):
     g32.close()
 
 
+def test_n8192_fp32_in_the_default_lookahead_window(gpu, ds, monkeypatch):
+    """From 8192 padded rows on the fp32 factorisation runs the look-ahead schedule by default (second stream, 4-wave
+    diagonal-block kernel beside the trailing update): bit-identical to the plain order, and the F32 pipeline within
+    its tolerances of the F64 one."""
+    n = 8192
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel("matern32", 1.0, 0.8)
+    qx, qy, qz = ds.query_grid(12)
+    res = {}
+    for mode in (None, "0"):
+        if mode is not None:
+            monkeypatch.setenv("GPX_LOOKAHEAD", mode)
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32)
+        o = gm.evaluate(qx, qy, qz, want_v=True)
+        res[mode] = (gm.D.copy(), gm.alpha.copy(), o["f"].copy(), o["v"].copy())
+        gm.close()
+    monkeypatch.delenv("GPX_LOOKAHEAD")
+    for a, b in zip(res[None], res["0"]):
+        np.testing.assert_array_equal(a, b)
+    g64 = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F64)
+    o64 = g64.evaluate(qx, qy, qz, want_v=True)
+    assert nerr(res[None][1], g64.alpha) < 1e-5
+    assert nerr(res[None][2], o64["f"]) < 1e-6 and verr(res[None][3], o64["v"], 1.0) < 1e-5
+    g64.close()
+
+
 @pytest.mark.parametrize("kn,par", [("matern52", (1.0, 1.0)), ("thinplate", (4.0,))])
 def test_n16384_properties(gpu, ds, kn, par):
     """BASELINE configs 3/4 sizes (N = 16384 fp32; Matern-5/2 and thin-plate R = 4)."""
