@@ -543,12 +543,123 @@ __device__ __forceinline__ void own_block(int k, int e, int &bi, int &bj)
     }
 }
 
-template <int DT>
-__global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A, long lda, float *__restrict__ linv,
-                                                        float *__restrict__ d, float *__restrict__ dinv,
-                                                        int *__restrict__ info, int blk)
+// Sub-block step of diag_ldlm_kernel, fp32: the 32 x 32 block Dn (lower triangle valid) is factorised in the accumulator of
+// v_mfma_f32_32x32x2_f32 by one wave; L11 (strictly lower) -> Lx, L11^-1 -> Xdb, D -> dvec (lane = row).
+__device__ __forceinline__ void subblock_ldl(const float *Dn, float *Lx, float *Xdb, int lane, float &dvec)
 {
     typedef float T;
+    const int half = lane >> 5, col = lane & 31;
+    f32x16 M, X;
+    {
+        // symmetric from the lower triangle: element (row, col) and its mirror image, two base addresses and immediate offsets
+        const T *b1 = Dn + 4 * half * PLD + col, *b2 = Dn + col * PLD + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = 8 * (r >> 2) + (r & 3), row = o + 4 * half;
+            const T v1 = b1[o * PLD], v2 = b2[o];
+            M[r] = row > col ? v1 : v2;
+            X[r] = row == col ? 1.0f : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;  // row j: register rj of wave half hj
+        const T rowj = M[rj];
+        const T dj = bcast_lane(rowj, j + 32 * hj);
+        const T lj = rowj * fast_rcp(dj);
+        const bool act = half == hj && col > j;
+        const T a = act ? -lj : 0.0f;
+        if (lane == j)
+            dvec = dj;
+        M = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rowj, M, 0, 0, 0);
+        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, X[rj], X, 0, 0, 0);
+        if (act)
+            Lx[col * PLD + j] = lj;  // L11[col][j]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        Xdb[(8 * (r >> 2) + 4 * half + (r & 3)) * PLD + col] = X[r];  // exact zeros above, ones on the diagonal
+}
+
+// fp64: no 32 x 32 form; the block is three 16 x 16 tiles of v_mfma_f64_16x16x4_f64 -- T00, T01 (rows 0-15 of the right
+// half: the mirror image of the lower-left tile, which is never needed because the steps read ROWS) and T11 -- and its
+// inverse three more (X00, X10, X11).  Element (row 4 r + g, col c) of a tile is register r of lane 16 g + c, so row j is
+// register j / 4 of lane group j % 4: again the B operand as it stands (k = lane group) and, scaled, the A operand.
+// Steps 0-15: 3 + 2 MFMAs, steps 16-31: 1 + 2.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, double *Xdb, int lane, double &dvec)
+{
+    typedef double T;
+    const int g = lane >> 4, c = lane & 15;
+    f64x4 T00, T01, T11, X00, X10, X11;
+    {
+        const T *b1 = Dn + g * PLD + c, *b2 = Dn + c * PLD + g;  // (row 4 r + g, col c) and its mirror image
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            const T lo = b1[4 * r * PLD], up = b2[4 * r];
+            const T lo11 = b1[(16 + 4 * r) * PLD + 16], up11 = b2[16 * PLD + 16 + 4 * r];
+            T00[r] = row > c ? lo : up;
+            T01[r] = b2[16 * PLD + 4 * r];           // (row, 16 + c) = mirror of (16 + c, row)
+            T11[r] = row > c ? lo11 : up11;
+            X00[r] = row == c ? 1.0 : 0.0;
+            X10[r] = 0.0;
+            X11[r] = row == c ? 1.0 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = j >> 2, gj = j & 3;
+        const T row0 = T00[r], row1 = T01[r];
+        const T dj = bcast_lane(row0, 16 * gj + j);
+        const T rinv = fast_rcp(dj);
+        const T l0 = row0 * rinv, l1 = row1 * rinv;
+        const bool ing = g == gj, act = ing && c > j;
+        const T a0 = act ? -l0 : 0.0, a1 = ing ? -l1 : 0.0;
+        if (lane == j)
+            dvec = dj;
+        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row0, T00, 0, 0, 0);
+        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row1, T01, 0, 0, 0);
+        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
+        const T xr = X00[r];
+        X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xr, X00, 0, 0, 0);
+        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xr, X10, 0, 0, 0);
+        if (act)
+            Lx[c * PLD + j] = l0;
+        if (ing)
+            Lx[(16 + c) * PLD + j] = l1;
+    }
+#pragma unroll
+    for (int j = 16; j < NB; ++j) {
+        const int jj = j - 16, r = jj >> 2, gj = jj & 3;
+        const T row1 = T11[r];
+        const T dj = bcast_lane(row1, 16 * gj + jj);
+        const T l1 = row1 * fast_rcp(dj);
+        const bool act = g == gj && c > jj;
+        const T a1 = act ? -l1 : 0.0;
+        if (lane == j)
+            dvec = dj;
+        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
+        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X10[r], X10, 0, 0, 0);
+        X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X11[r], X11, 0, 0, 0);
+        if (act)
+            Lx[(16 + c) * PLD + j] = l1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + g;
+        Xdb[row * PLD + c] = X00[r];
+        Xdb[row * PLD + 16 + c] = 0.0;
+        Xdb[(16 + row) * PLD + c] = X10[r];
+        Xdb[(16 + row) * PLD + 16 + c] = X11[r];
+    }
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(DT, 2) void diag_ldlm_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
+                                                       T *__restrict__ d, T *__restrict__ dinv, int *__restrict__ info,
+                                                       int blk)
+{
     constexpr int BLK = NB * PLD;                  // one 32 x 32 LDS block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Di = reinterpret_cast<T *>(smem_raw);       // [TILE]       1 / D
@@ -558,8 +669,8 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
     T *Lx = Dn + BLK;                              // [NB][PLD]    L11 of the current sub-block, for its row-wise write-out
     T *P = Lx + BLK;                               // [96][PLD]    panel rows 32 .. 127: A entries, then W = L D
     T *Pv = P - NB * PLD;                          //              (row r at Pv + r * PLD)
-    // 63.8 KB in all -- no more than a workgroup of the GEMM, so that the kernel finds room on a CU wherever one of those
-    // does (LDS is allocated contiguously).  The assembly of the inverse therefore lives in blocks that are dead by then:
+    // fp32: 63.8 KB in all -- no more than a workgroup of the GEMM, so that the kernel finds room on a CU wherever one of
+    // those does (LDS is allocated contiguously); fp64: 127.7 KB, a CU of its own (as the round-1 kernel: 132 KB).  The assembly of the inverse therefore lives in blocks that are dead by then:
     //   panel rows 32-63 : T0 (A2: L10 Xd0; B2: L20 Xd0 + L21 X10) -> X20 in place (C2)
     //   panel rows 64-95 : X10 (A2)                panel rows 96-127: S31 (A3; W of panel 2 until then)
     //   L10 block        : L21 Xd1 -> X21 in place (B2)
@@ -578,7 +689,7 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
     // a product chain inside one wave goes through LDS: the LDS queue of a wave is in order, the fence only keeps the
     // compiler from moving the reads of the next product above the stores of this one
     auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
-    T dvec = 1.0f;                                 // wave 0: D of the current sub-block (lane = row), kept for the write-out
+    T dvec = T(1);                                 // wave 0: D of the current sub-block (lane = row), kept for the write-out
     unsigned long long mneg = 0, mbad = 0;
     // L11 (strictly lower, from Lx) and D of sub-block jb to global: wave 0, off the critical path (steps B and C).
     // (Tried: the inverse's recurrence on wave 1, fed column by column through Lx with self-validating entries -- the LDS
@@ -624,8 +735,6 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
         GPX_STAMP(1 + 4 * jb);
         // ---- A: wave 0 factorises sub-block jb and inverts its L on the matrix core ----
         if (wave == 0) {
-            const int half = lane >> 5, col = lane & 31;
-            f32x16 M, X;
             if (jb == 0) {  // the first sub-block comes from global; the later ones were left in Dn by the trailing update
 #pragma unroll
                 for (int k = 0; k < NB * NB / 64; ++k) {
@@ -634,46 +743,27 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl32_kernel(float *__restrict__ A
                 }
                 wave_sync();
             }
-            {
-                // symmetric from the lower triangle (the valid one): element (row, col) and its mirror image, two base
-                // addresses and immediate offsets
-                const T *b1 = Dn + 4 * half * PLD + col, *b2 = Dn + col * PLD + 4 * half;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = 8 * (r >> 2) + (r & 3), row = o + 4 * half;
-                    const T v1 = b1[o * PLD], v2 = b2[o];
-                    M[r] = row > col ? v1 : v2;
-                    X[r] = row == col ? 1.0f : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;  // row j: register rj of wave half hj
-                const T rowj = M[rj];
-                const T dj = bcast_lane(rowj, j + 32 * hj);
-                const T lj = rowj * fast_rcp(dj);
-                const bool act = half == hj && col > j;
-                const T a = act ? -lj : 0.0f;
-                if (lane == j)
-                    dvec = dj;
-                M = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rowj, M, 0, 0, 0);
-                X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, X[rj], X, 0, 0, 0);
-                if (act)
-                    Lx[col * PLD + j] = lj;  // L11[col][j]
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Xd[(jb * NB + 8 * (r >> 2) + 4 * half + (r & 3)) * PLD + col] = X[r];  // exact zeros above, ones on the diagonal
-            const bool neg = lane < NB && dvec < 0.0f;
-            const bool bad = lane < NB && (!(fabsf(dvec) > 0.0f) || !(fabsf(dvec) < pivot_huge(0.0f)));
+            subblock_ldl(Dn, Lx, Xd + jb * BLK, lane, dvec);
+            const bool neg = lane < NB && dvec < T(0);
+            const bool bad = lane < NB && (!(fabs(dvec) > T(0)) || !(fabs(dvec) < pivot_huge(T(0))));
             mneg = __ballot(neg), mbad = __ballot(bad);
             if (lane < NB)
-                Di[c0 + lane] = 1.0f / dvec;
+                Di[c0 + lane] = T(1) / dvec;
         } else if (jb == 0) {
-            // the rows below the first sub-block -> panel buffer (the later panels are left there by the trailing update)
-            for (int idx = tid - 64; idx < (TILE - NB) * NB; idx += DT - 64) {
-                const int r_ = NB + (idx >> 5), c_ = idx & 31;
-                Pv[r_ * PLD + c_] = A[(size_t)r_ * lda + c_];
+            // the rows below the first sub-block -> panel buffer (the later panels are left there by the trailing update);
+            // all loads first: as one load-store loop the 7 trips were 7 serial round trips to L2 (fp64: 7 us)
+            constexpr int NST = ((TILE - NB) * NB + DT - 64 - 1) / (DT - 64);
+            T stage[NST];
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int idx = tid - 64 + k * (DT - 64);
+                stage[k] = idx < (TILE - NB) * NB ? A[(size_t)(NB + (idx >> 5)) * lda + (idx & 31)] : T(0);
+            }
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int idx = tid - 64 + k * (DT - 64);
+                if (idx < (TILE - NB) * NB)
+                    Pv[(NB + (idx >> 5)) * PLD + (idx & 31)] = stage[k];
             }
         }
         if (wave >= 2) {
@@ -832,17 +922,17 @@ static size_t diag_shmem_bytes(size_t esz)
     return esz * (size_t)(TILE * PLD + 2 * NB * NB + TILE + 6 * NB * PLD + 4 * NB * PLD);  // Pa + Lt + Di + Ls + Xd
 }
 
-static size_t diag32_shmem_bytes()
+static size_t diagm_shmem_bytes(size_t esz)
 {
-    return sizeof(float) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);  // Di + Ls[6] Xd[4] Dn Lx + panel rows 32 .. 127
+    return esz * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);  // Di + Ls[6] Xd[4] Dn Lx + panel rows 32 .. 127
 }
-template <int DT>
-static void diag32_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
+template <typename T, int DT>
+static void diagm_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
 {
-    hipLaunchKernelGGL((diag_ldl32_kernel<DT>), dim3(1), dim3(DT), diag32_shmem_bytes(), st, (float *)Ablk, lda, (float *)linv,
-                       (float *)d, (float *)dinv, info, blk);
+    hipLaunchKernelGGL((diag_ldlm_kernel<T, DT>), dim3(1), dim3(DT), diagm_shmem_bytes(sizeof(T)), st, (T *)Ablk, lda, (T *)linv,
+                       (T *)d, (T *)dinv, info, blk);
 }
-// GPX_DIAG_LEGACY=1: the round-1 fp32 kernel (sub-block by v_readlane + FMA), for A/B timing
+// GPX_DIAG_LEGACY=1: the round-1 kernels (sub-block by v_readlane + FMA, inverse on a second wave), for A/B timing
 static bool diag_legacy()
 {
     static const bool v = [] {
@@ -867,6 +957,8 @@ void factor_init(int prec)
         once64.run([] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double, DIAG_THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<double, DIAG_THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diagm_shmem_bytes(sizeof(double)));
         });
     } else {
         once32.run([] {
@@ -874,10 +966,10 @@ void factor_init(int prec)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS_NARROW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl32_kernel<DIAG_THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag32_shmem_bytes());
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl32_kernel<DIAG_THREADS_NARROW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag32_shmem_bytes());
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<float, DIAG_THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diagm_shmem_bytes(sizeof(float)));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<float, DIAG_THREADS_NARROW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diagm_shmem_bytes(sizeof(float)));
         });
     }
 }
@@ -886,16 +978,18 @@ void factor_init(int prec)
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
                      hipStream_t st, bool narrow)
 {
-    if (prec == GPX_PREC_F64)
+    if (prec == GPX_PREC_F64 && diag_legacy())
         diag_t<double, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
+    else if (prec == GPX_PREC_F64)
+        diagm_t<double, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
     else if (diag_legacy() && narrow)
         diag_t<float, DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
     else if (diag_legacy())
         diag_t<float, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
     else if (narrow)
-        diag32_t<DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
+        diagm_t<float, DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
     else
-        diag32_t<DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
+        diagm_t<float, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
 }
 
 // Diagonal blocks that lie entirely in the padding (the kernel matrix is the identity there): L = I, D = 1, inverse = I

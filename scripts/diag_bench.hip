@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/diag_bench.hip -I gaussian-object-modelling_amd/csrc -I include -o scripts/diag_bench.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 __device__ long long gpx_dbg_stamps[32];
@@ -12,6 +13,18 @@ __device__ long long gpx_dbg_stamps[32];
     } while (0)
 #include "../gaussian-object-modelling_amd/csrc/gpx_factor.hip"
 using namespace gpx;
+
+// reads the block once, so that the timed launch finds it in L2 (as it does inside the factorisation, where the
+// preceding update has just written it); GPX_BENCH_COLD=1 skips this
+template <typename T>
+__global__ void touch_kernel(const T *a, int n, T *sink)
+{
+    T s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        s += a[i];
+    if (s == T(12345.678))
+        *sink = s;
+}
 
 template <typename T>
 static void run(const char *name, int prec, bool narrow = false)
@@ -35,6 +48,8 @@ static void run(const char *name, int prec, bool narrow = false)
                     P[(size_t)i * n + j] = (T)NAN;
             hipMemcpy(dA, P.data(), sizeof(T) * n * n, hipMemcpyHostToDevice);
         }
+        if (!getenv("GPX_BENCH_COLD"))
+            hipLaunchKernelGGL(touch_kernel<T>, dim3(1), dim3(256), 0, 0, dA, n * n, dd);
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
         hipEventRecord(e0, 0);

@@ -1,5 +1,5 @@
 // mfma_lat_probe.hip -- development probe: issue / dependent latency of the f32-input MFMAs and of the elimination step
-// of diag_ldl32_kernel (one wave, one workgroup), in shader clocks (s_memtime) and ns (s_memrealtime, 100 MHz).
+// of diag_ldlm_kernel<float> (one wave, one workgroup), in shader clocks (s_memtime) and ns (s_memrealtime, 100 MHz).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/mfma_lat_probe.hip -o scripts/mfma_lat_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
