@@ -274,18 +274,18 @@ static void factorize(gpx_model *m, int c_start = 0)
         }
     };
     // ---- look-ahead: panel p+1 is factorised on a second stream while the trailing update of panel p runs ----
-    // Per 256-panel the serial chain (2 diagonal blocks, 2 panel solves, 1 half update: ~130 us at N = 16384) is as
-    // long as the trailing update itself.  The update is split into the 256-column strip the next panel lives in
-    // (main stream, first) and the rest; the chain of panel p+1 starts on the second stream as soon as the strip is
-    // done and the main stream waits for it after the rest.  Two event hops per panel (~15 us each); the two halves
-    // of the 512-wide workspace alternate; bit-identical to the plain order with 256-wide panels.  What it buys is modest -- LDL^T at
-    // N = 16384: fp32 22.8 -> 21.9 ms, fp64 40.0 -> 37.1 ms -- because the chain runs 2.6x slower beside the GEMM
-    // (diagonal block 45 -> 95-145 us, panel solve 18 -> 46 us: they share SIMDs and slots with it), and the
-    // 8-wave diagonal kernel does not even fit on a CU next to a GEMM workgroup (it then waits for the GEMM to
-    // drain: measured 315 us), hence the 4-wave variant for these launches.  Setting CUs aside for the chain with
-    // hipExtStreamCreateWithCUMask was measured twice (this design and an earlier one): 47 ms, i.e. twice as slow
-    // as no look-ahead -- kernels on CU-masked streams pay far more than the 15 us hop; stream priority and
-    // s_setprio in the chain kernels changed nothing.  GPX_LOOKAHEAD=0 selects the plain order.
+    // Per 256-panel the serial chain (2 diagonal blocks, 2 panel solves, 1 half update, the 256-column strip of the update
+    // the next panel lives in: ~150 us on an idle GPU) does not shrink with the remaining rows, the update does
+    // (600 us at panel 2, 125 us at 56 tile rows): the second half of the panels is chain-bound.  The update is split
+    // into that strip and the rest; the two halves of the 512-wide workspace alternate; bit-identical to the plain order
+    // with 256-wide panels.  What overlap can buy is bounded by one effect (scripts/diag_beside.hip):
+    // a kernel that shares a CU with a workgroup of the update runs 2.3x slower (diagonal block 28 -> 60-70 us, whatever
+    // its priority), and one that does not fit beside it waits for the update to drain -- hence the 4-wave variant of the
+    // diagonal-block kernel for launches that run beside an update.  Setting CUs aside for the chain was tried three ways:
+    // hipExtStreamCreateWithCUMask (round 1, twice: 47 ms -- kernels on masked streams pay far more than the hop),
+    // stream priority / s_setprio (nothing), and a persistent update that leaves one CU per shader engine empty
+    // (round 2: the chain then runs at its stand-alone speed, the update 25-30 % slower, the LDL^T the same:
+    // profiles/r02_ldlt_reserved_cus.txt).  GPX_LOOKAHEAD=0 selects the plain order.
     const char *pw_e = std::getenv("GPX_PANEL");
     const int wide_env = pw_e ? std::atoi(pw_e) : 0;
     const char *la_e = std::getenv("GPX_LOOKAHEAD");
