@@ -842,16 +842,11 @@ __global__ __launch_bounds__(DT, 2) void diag_ldlm_kernel(T *__restrict__ A, lon
                             A[(size_t)(c0 + NB + NB * t + row) * lda + c0 + cl] = l;
                         }
             }
-            if (jb == 2 && wave == NW - 1) {     // block row 2, column 1: X21 = -Xd2 (L21 Xd1), in the dead L10 block
+            if (jb == 2 && wave == NW - 1) {     // block row 2, column 1, first half: L21 Xd1 into the dead L10 block
                 BlkAcc<T> acc;
                 acc.zero();
                 acc.mac(L21, Xd1, lane);
                 acc.store(T(1), X21, (T *)nullptr, 0, lane);
-                wave_sync();
-                acc.zero();
-                acc.mac(Xd2, X21, lane);
-                wave_sync();
-                acc.store(T(-1), X21, Xg + (size_t)2 * NB * TILE + NB, TILE, lane);
             }
             if (jb == 2 && wave == NW - 2) {     // column 0, first half: T0 = L20 Xd0 + L21 X10
                 BlkAcc<T> acc;
@@ -883,6 +878,13 @@ __global__ __launch_bounds__(DT, 2) void diag_ldlm_kernel(T *__restrict__ A, lon
                     acc.mac(Xd2, T0, lane);
                     wave_sync();
                     acc.store(T(-1), X20, Xg + (size_t)2 * NB * TILE, TILE, lane);
+                }
+                if (wave == 0) {                 // second half: X21 = -Xd2 (L21 Xd1), in place
+                    BlkAcc<T> acc;
+                    acc.zero();
+                    acc.mac(Xd2, X21, lane);
+                    wave_sync();
+                    acc.store(T(-1), X21, Xg + (size_t)2 * NB * TILE + NB, TILE, lane);
                 }
                 if (wave == 1) {                 // S32 = L32 Xd2, in the dead L20 block
                     BlkAcc<T> acc;
