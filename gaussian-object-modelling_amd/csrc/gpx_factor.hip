@@ -2,13 +2,15 @@
 // triangular solves (gfx950).  Replaces Eigen::LDLT<MatrixXd>::compute / ::solve as used by the
 // reference (gp_regressor.hpp:161-163); the O(N^3) work is in gpx_gemm.hip.
 //
-//   diag_ldl   : one 128 x 128 diagonal block by one workgroup of 8 waves: right-looking LDL^T blocked by 32 (the
-//                32 x 32 sub-block is factorised by one wave in registers, the rows below by substitution, the
-//                trailing update on MFMA), no pivoting inside the block (the Eigen rule picks pivots from the
-//                ORIGINAL diagonal, so the permutation is applied to the points before kbuild), then the unit-lower
-//                inverse of L assembled from the four 32 x 32 inverses on MFMA.  The inverse blocks turn every
-//                panel solve and every block substitution into matrix products.  identity_blocks: the same result
-//                for blocks that lie in the padding.
+//   diag_ldl   : one 128 x 128 diagonal block by one workgroup of 8 (4) waves: right-looking LDL^T blocked by 32, no
+//                pivoting inside the block (the Eigen rule picks pivots from the ORIGINAL diagonal, so the permutation
+//                is applied to the points before kbuild), and the unit-lower inverse of its L.  The inverse blocks turn
+//                every panel solve and every block substitution into matrix products.  Round 2 (diag_ldlm_kernel):
+//                the 32 x 32 sub-block is factorised AND inverted by rank-1 MFMA updates of accumulators that hold it,
+//                the rows below by one product with that inverse, the trailing blocks stay in registers, the 128 x 128
+//                inverse is assembled left-looking in the shadow of the panel steps.  Round 1 (diag_ldl_kernel, kept
+//                for A/B runs): sub-block in the registers of one wave by v_readlane + FMA, substitution, recursive
+//                doubling at the end.  identity_blocks: the same result for blocks that lie in the padding.
 //   tri_solve  : L y = b and L^T x = D^-1 y in one launch each (a workgroup per block row, results handed on
 //                through self-validating entries); fwd / bwd step kernels: the same, one launch per block step.
 #include "gpx_internal.hpp"
@@ -498,8 +500,10 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long
     GPX_STAMP(24);
 }
 
-// ---- fp32 diagonal block on the matrix cores (round 2) -------------------------------------------------------------
-// Same contract as diag_ldl_kernel (LDL^T of a 128 x 128 block without pivoting + the unit-lower inverse of its L), but
+// ---- diagonal block on the matrix cores (round 2): diag_ldlm_kernel<float | double> ---------------------------------
+// Same contract as diag_ldl_kernel (LDL^T of a 128 x 128 block without pivoting + the unit-lower inverse of its L), which
+// it replaces in both precisions (GPX_DIAG_LEGACY=1 brings the old one back for A/B runs).  In fp32 -- fp64: subblock_ldl
+// below --
 // the 32 x 32 sub-block is no longer factorised by 1000 v_readlane + FMA pairs in one wave (5.1 us): it sits in the
 // accumulator of v_mfma_f32_32x32x2_f32 (column on the lane, rows in the 16 registers) and every elimination step is
 // ONE rank-1 MFMA:  M <- M - (u_j / d_j) u_j^T  with u_j = row j of M, which is one accumulator register of one wave
