@@ -36,7 +36,7 @@ PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 matrix peak (the opt-in split contraction runs three fp16 products per fp32 one)
 # VALU instructions per (query, training point) pair in the inner loop of predict_kernel<double, KID, false> (mean only),
 # counted in the gfx950 ISA of the shipped library (scripts/predict_isa.py -> profiles/r02_predict_isa.txt)
-MEAN_VALU_PER_PAIR = {"gaussian": 30.125, "laplace": 30.125, "thinplate": 16.125, "matern32": 32.125, "matern52": 34.125}
+MEAN_VALU_PER_PAIR = {"gaussian": 26.125, "laplace": 26.125, "thinplate": 16.125, "matern32": 28.125, "matern52": 29.125}
 
 
 def parse():

@@ -84,6 +84,83 @@ struct MathFast {
     }
 };
 
+// The exponential kernels a e^(-s d) [x polynomial in s d] for the fp64 mean / gradient kernel (gpx_predict.hip), VALU-issue
+// bound at ~30 instructions per (query, point) pair, 13 of them the exponential:
+//   e^x from a 512-entry table of 2^(j/512) in LDS (4 KB): x = -s d = (512 m + j) ln2/512 + r, |r| <= 0.00068, so that a
+//   degree-4 polynomial is exact to 1e-18 (was: Taylor degree 12);
+//   everything that depends on s alone is prepared once per thread: the polynomial runs in u = d + n ln2/(512 s) with the
+//   coefficients (-s)^k / k!, the Matern factors in d, so t = s d is never formed;
+// The kernel that uses it calls ExpTab::init() with all its threads and passes a barrier before the first value.
+struct ExpTab {
+    static constexpr int NTAB = 512;
+    static __device__ __forceinline__ double *tab()
+    {
+        __shared__ double t[NTAB];
+        return t;
+    }
+    static __device__ __forceinline__ void init(int tid, int nthreads)
+    {
+        for (int j = tid; j < NTAB; j += nthreads)
+            tab()[j] = exp2((double)j * (1.0 / NTAB));
+    }
+};
+template <int KID>
+struct ExpMean {
+    double k1, lq, a1, a2, a3, a4, dmax, s, s2_3;
+    __device__ __forceinline__ void prep(const Cov<double> &c)
+    {
+        s = c.s;
+        k1 = -s * (ExpTab::NTAB * 1.4426950408889634);          // nb = MAGIC + rint(x 512 / ln 2)
+        lq = 0.6931471805599453 / ExpTab::NTAB / s;             // u = d + n ln2 / (512 s),  r = -s u
+        a1 = -s, a2 = 0.5 * s * s, a3 = -s * s * s * (1.0 / 6.0), a4 = s * s * s * s * (1.0 / 24.0);
+        dmax = 700.0 / s;                                       // e^x is ~1e-304 there
+        s2_3 = s * s * (1.0 / 3.0);
+    }
+    // e^(-s d), d >= 0
+    __device__ __forceinline__ double e(double d) const
+    {
+        constexpr double MAGIC = 6755399441055744.0;            // 1.5 * 2^52: n sits in the low word of the sum
+        d = fmin(d, dmax);
+        const double nb = fma(d, k1, MAGIC);
+        const int n = __double2loint(nb);
+        const double u = fma(nb - MAGIC, lq, d);
+        double p = fma(a4, u, a3);
+        p = fma(p, u, a2);
+        p = fma(p, u, a1);
+        p = fma(p, u, 1.0);
+        p *= ExpTab::tab()[n & (ExpTab::NTAB - 1)];
+        // p in [0.999, 2.002): scale by 2^m, m = n >> 9 >= -1010, with one integer add on the exponent field
+        return __hiloint2double(__double2hiint(p) + ((n >> 9) << 20), __double2loint(p));
+    }
+    // k(d) without the amplitude (the caller has folded it into the weights)
+    __device__ __forceinline__ double k(double d) const
+    {
+        const double ev = e(d);
+        if constexpr (KID == GPX_KERNEL_MATERN32)
+            return ev * fma(d, s, 1.0);
+        else if constexpr (KID == GPX_KERNEL_MATERN52)
+            return ev * fma(d, fma(d, s2_3, s), 1.0);
+        else
+            return ev;
+    }
+    // k(d) and the reference's "computediff" (cov_k_diff below), both without the amplitude
+    __device__ __forceinline__ void k_diff(double d, double &kv, double &kd) const
+    {
+        const double ev = e(d);
+        if constexpr (KID == GPX_KERNEL_MATERN32) {
+            kv = ev * fma(d, s, 1.0);
+            kd = -(s * s) * ev;
+        } else if constexpr (KID == GPX_KERNEL_MATERN52) {
+            const double t1 = fma(d, s, 1.0);
+            kv = ev * fma(d * d, s2_3, t1);
+            kd = -s2_3 * t1 * ev;
+        } else {
+            kv = ev;
+            kd = -s * ev;
+        }
+    }
+};
+
 // k(d) given the squared distance d2.  UNIT_A: without the amplitude c.a of the exponential kernels (the caller has
 // folded it into the weights the values are multiplied with); thin-plate has none.
 template <typename T, int KID, typename M = MathAcc, bool UNIT_A = false>

@@ -64,6 +64,13 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
     // the amplitude of the exponential kernels rides on alpha (one multiply per point and tile instead of one per pair)
     const T amp = KID == GPX_KERNEL_THINPLATE ? T(1) : cov.a;
     constexpr T TINY = sizeof(T) == 8 ? T(1e-300) : T(0);  // keeps the rsq seed of MathFast::sqrt_ finite at d = 0
+    // fp64 exponential kernels: the table-based evaluator of gpx_cov.hpp
+    constexpr bool TAB = sizeof(T) == 8 && KID != GPX_KERNEL_THINPLATE;
+    ExpMean<KID> em;
+    if constexpr (TAB) {
+        ExpTab::init(tid, 256);  // (the barrier at the top of the tile loop follows)
+        em.prep(cov);
+    }
     for (int jt = j0; jt < j1; jt += PT) {
         __syncthreads();
         tile[tid] = P4<T>{px[jt + tid], py[jt + tid], pz[jt + tid], alpha[jt + tid] * amp};
@@ -78,8 +85,13 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
             T d2b = fma(dzb, dzb, fma(dyb, dyb, fma(dxb, dxb, TINY)));
             if constexpr (GRAD) {
                 T ka, kda, kb, kdb;
-                cov_k_diff<T, KID, MathFast, true>(cov, d2a, ka, kda);
-                cov_k_diff<T, KID, MathFast, true>(cov, d2b, kb, kdb);
+                if constexpr (TAB) {
+                    em.k_diff(MathFast::sqrt_(d2a), ka, kda);
+                    em.k_diff(MathFast::sqrt_(d2b), kb, kdb);
+                } else {
+                    cov_k_diff<T, KID, MathFast, true>(cov, d2a, ka, kda);
+                    cov_k_diff<T, KID, MathFast, true>(cov, d2b, kb, kdb);
+                }
                 sa += ka * p.a;
                 sb += kb * p.a;
                 T wa = kda * p.a, wb = kdb * p.a;
@@ -89,6 +101,9 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
                 tbx += wb * dxb;
                 tby += wb * dyb;
                 tbz += wb * dzb;
+            } else if constexpr (TAB) {
+                sa += em.k(MathFast::sqrt_(d2a)) * p.a;
+                sb += em.k(MathFast::sqrt_(d2b)) * p.a;
             } else {
                 sa += cov_k<T, KID, MathFast, true>(cov, d2a) * p.a;
                 sb += cov_k<T, KID, MathFast, true>(cov, d2b) * p.a;
