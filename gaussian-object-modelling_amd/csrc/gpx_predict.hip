@@ -43,7 +43,10 @@ size_t predict_ws_doubles(long nq, int npts, bool grad)
     return chunks > 1 ? (size_t)chunks * (size_t)nq * (grad ? 4 : 1) : 0;
 }
 
-template <typename T, int KID, bool GRAD>
+// FASTEXP: the table-based evaluator of the exponential kernels (gpx_cov.hpp, ExpMean); the host selects it when the decay
+// parameter is a positive finite number -- anything else (infinite or negative length scales: whatever the reference's
+// formula gives for them) takes the general path
+template <typename T, int KID, bool GRAD, bool FASTEXP>
 __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int chunk_len,
                                                       const T *__restrict__ px, const T *__restrict__ py,
                                                       const T *__restrict__ pz, const T *__restrict__ alpha,
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
     const T amp = KID == GPX_KERNEL_THINPLATE ? T(1) : cov.a;
     constexpr T TINY = sizeof(T) == 8 ? T(1e-300) : T(0);  // keeps the rsq seed of MathFast::sqrt_ finite at d = 0
     // fp64 exponential kernels: the table-based evaluator of gpx_cov.hpp
-    constexpr bool TAB = sizeof(T) == 8 && KID != GPX_KERNEL_THINPLATE;
+    constexpr bool TAB = FASTEXP && sizeof(T) == 8 && KID != GPX_KERNEL_THINPLATE;
     ExpMean<KID> em;
     if constexpr (TAB) {
         ExpTab::init(tid, 256);  // (the barrier at the top of the tile loop follows)
@@ -191,9 +194,15 @@ static void predict_t(const CovHost &h, int npts, const void *px, const void *py
     double *pf = chunks > 1 ? ws : f;
     double *pg = chunks > 1 ? ws + (size_t)chunks * nq : grad;
     int direct = chunks > 1 ? 0 : 1;
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((predict_kernel<T, KID, GRAD>), grid, dim3(256), 0, st, c, npts,
-                                              chunk_len, (const T *)px, (const T *)py, (const T *)pz,
-                                              (const T *)alpha, nq, qx, qy, qz, pf, pg, direct));
+    if (h.s > 0 && h.s < 1e100) {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((predict_kernel<T, KID, GRAD, true>), grid, dim3(256), 0, st, c, npts,
+                                                  chunk_len, (const T *)px, (const T *)py, (const T *)pz,
+                                                  (const T *)alpha, nq, qx, qy, qz, pf, pg, direct));
+    } else {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((predict_kernel<T, KID, GRAD, false>), grid, dim3(256), 0, st, c, npts,
+                                                  chunk_len, (const T *)px, (const T *)py, (const T *)pz,
+                                                  (const T *)alpha, nq, qx, qy, qz, pf, pg, direct));
+    }
     if (chunks > 1)
         hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, chunks, nq,
                            pf, GRAD ? pg : nullptr, f, GRAD ? grad : nullptr);

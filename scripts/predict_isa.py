@@ -16,7 +16,7 @@ print("# %-22s %5s %10s %12s   %s" % ("kernel", "grad", "VALU/iter", "VALU/pair"
 table = {}
 for kid in (0, 2, 3, 4):
     for grad in (0, 1):
-        m = re.search(r"^_ZN3gpx14predict_kernelIdLi%dELb%dEEE\S*:.*?s_endpgm" % (kid, grad), asm, re.S | re.M)
+        m = re.search(r"^_ZN3gpx14predict_kernelIdLi%dELb%dELb1EEE\S*:.*?s_endpgm" % (kid, grad), asm, re.S | re.M)
         body = m.group(0)
         # the innermost loop: from the Depth=2 header to its back edge
         i = body.index("Depth=2")

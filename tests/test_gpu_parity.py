@@ -831,3 +831,22 @@ def test_round1_and_round2_diagonal_block_kernels_agree(gpu, ds, tmp_path, monke
         a, b = res["0"][key], res["1"][key]
         scale = max(np.max(np.abs(b)), 64.0 if key.endswith("/v") and "thinplate" in key else 0.0)
         assert np.max(np.abs(a - b)) / scale < tol, key
+
+
+@pytest.mark.parametrize("kn,par", [("gaussian", (1.3, float("inf"))), ("laplace", (0.7, 1e200)), ("matern52", (1.0, float("inf")))])
+def test_degenerate_length_scales(gpu, orc, ds, kn, par):
+    """kernels/gaussian.hpp:15-20 etc. put no condition on the length scale.  An infinite one makes the decay parameter 0
+    (k = const): the mean / gradient kernel's table-based exponential is selected on the host only for a positive finite
+    decay, anything else takes the general path; a huge finite one (decay 1e-200) stays on the table path."""
+    n = 200
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    om = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2)
+    gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=gpu.F64)
+    qx, qy, qz = ds.query_grid(5)
+    ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    out = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+    assert np.all(np.isfinite(out["f"])) and np.all(np.isfinite(out["grad"]))
+    assert nerr(gm.alpha, om.alpha) < 1e-9
+    assert nerr(out["f"], ref["f"]) < 1e-9
+    assert np.max(np.abs(out["grad"] - ref["grad"])) <= 1e-9 * max(np.max(np.abs(ref["grad"])), 1e-300) + 1e-300
+    gm.close()
