@@ -4,7 +4,7 @@
 //          gaussian-object-modelling_amd/csrc/gpx_gemm.hip -o scripts/gemm_bench.bin       [-DGEMM_WAVES_PER_EU=1|2]
 //   (compiled TOGETHER with the GEMM source, not linked to libgpx.so: struct GemmArgs is internal to the library and a
 //   harness built against another revision of it passes garbage pointers -- the round-1 faults)
-//   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1]
+//   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1] [inverse-assembly shapes = 0]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -85,6 +85,29 @@ int main(int argc, char **argv)
         double flop = (double)M * M * KK;  // lower triangle only: M^2/2 * K * 2
         const double tiles = (M / 128) * (M / 128 + 1) / 2.0;
         printf("SYRK cfg%d prec%d M=%d K=%d : %.3f ms  %.1f TFLOP/s   %.2f us per tile-slot (512 slots)\n", cfg, prec, M, KK, ms, flop / ms / 1e9, ms * 1e3 / (tiles / 512.0));
+    }
+    // the two products of the top level of the inverse-factor assembly (h = N / 2), as launched (NN) and as NT products
+    // of the same size, for the "what would a transposed copy buy" question
+    if (argc > 5 && atoi(argv[5]) != 0) {
+        const int h = N / 2;
+        struct { const char *what; int nn, a_lower, b_lower; } cases[] = {
+            {"T = L21 X11   (NN, B lower)        ", 1, 0, 1}, {"X21 = -X22 T  (NN, A lower)        ", 1, 1, 0},
+            {"same size     (NT, A lower)        ", 0, 1, 0}, {"same size     (NT, B lower [n][k]) ", 0, 0, 1},
+            {"same size     (NT, full)           ", 0, 0, 0}, {"same size     (NN, full)           ", 1, 0, 0}};
+        for (auto &c : cases) {
+            GemmArgs g;
+            g.A = X, g.lda = N; g.B = Kqp, g.ldb = N; g.C = C, g.ldc = N; g.M = h, g.N = h, g.K = h;
+            g.nn = c.nn, g.a_lower = c.a_lower, g.b_lower = c.b_lower;
+            launch_gemm(prec, g, st);
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < 3; ++r) launch_gemm(prec, g, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+            const double flop = 2.0 * h * (double)h * h * ((c.a_lower || c.b_lower) ? 0.5 : 1.0);
+            printf("INV  prec%d h=%d %s: %.3f ms  %.1f TFLOP/s\n", prec, h, c.what, ms, flop / ms / 1e9);
+        }
     }
     return 0;
 }
