@@ -292,10 +292,11 @@ static void factorize(gpx_model *m, int c_start = 0)
     // Default window, from measurements (LDL^T ms, look-ahead on / off): fp32, with the round-2 diagonal-block kernel and
     // schedule, N = 8192 5.35 / 5.50, 12288 10.0 / 11.3, 16384 18.3 / 20.6, 32768 111 / 119 -> from 8192 rows on (round 1:
     // 6.9 / 6.5, -, 21.3 / 22.8, 117 / 125 -> from 16384); fp64 N = 4096 4.15 / 3.95, 8192 9.7 / 10.5, 16384 36.9 / 40.0,
-    // 32768 239 / 232 (there the 512-wide panels of the plain order win) -> 8192 <= rows < 32768.
+    // 32768 239 / 232 (there the 512-wide panels of the plain order win) -> 8192 <= rows < 32768; with the round-2 kernel
+    // N = 4096 3.62 / 3.44, 6144 5.7 / 5.95, 8192 8.4 / 9.5, 16384 35.2 / 37.9 -> 6144 <= rows < 32768.
     // GPX_LOOKAHEAD=1 forces it from 512 rows on, 0 switches it off; it works on 256-wide panels.
     const bool la_forced = la_e && std::atoi(la_e) != 0;
-    const bool la_window = m->prec == GPX_PREC_F64 ? (np >= 32 * PANEL && np < 128 * PANEL) : np >= 32 * PANEL;
+    const bool la_window = m->prec == GPX_PREC_F64 ? (np >= 24 * PANEL && np < 128 * PANEL) : np >= 32 * PANEL;
     const bool la_env = (!la_e || la_forced) && wide_env != WIDE_PANEL && (la_forced ? np >= 2 * PANEL : la_window);
     if (la_env && c_start == 0 && !m->stream2 &&
         hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
