@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--query-batch", type=int, default=0, help="queries per variance batch (0 = library default)")
     ap.add_argument("--mean-only", action="store_true", help="diagnostic: skip the variance")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra F32_SPLIT line (not part of value)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra F32_SPLIT / F64 / host-API legs (not part of value)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the record of the other BASELINE configs (C1, C2, C4 slab, C5)")
     return ap.parse_args()
 
 
@@ -102,22 +103,155 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
     return out
 
 
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first
+
+
 def pmc_traffic(args, n_train, q_per_launch):
-    """HBM bytes per launch of the variance GEMM from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-    passes of this bench, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes for wide streaming
-    reads, + WRITE_SIZE); only valid for the shape and the tile those passes were taken on."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not (os.path.exists(path) and args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192
+    """(bytes, source): HBM bytes per launch of the variance GEMM from the newest COMMITTED PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this bench, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes
+    for wide streaming reads, + WRITE_SIZE) -- counters cannot be collected inside an un-profiled run, so this figure
+    is NOT measured by the run that prints it; only valid for the shape and the tile those passes were taken on."""
+    if not (args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192
             and os.environ.get("GPX_VAR_TILE", "0") == "0"):
-        return None
+        return None, None
     prefix = "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2"  # <f32, NT, EPI_COLSQ, 128 x 128 tile>
-    try:
-        for name, k in json.load(open(path))["kernels"].items():
-            if name.startswith(prefix):
-                return k["hbm_bytes_per_dispatch"]
-        return None
-    except Exception:
-        return None
+    for fn in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", fn)
+        try:
+            for name, k in json.load(open(path))["kernels"].items():
+                if name.startswith(prefix):
+                    return k["hbm_bytes_per_dispatch"], "profiles/%s (committed rocprofv3 --pmc pass of this command, not this run)" % fn
+        except Exception:
+            continue
+    return None, None
+
+
+def accuracy_record(torch, f_a, v_a, f_ref, v_ref, k0):
+    """Error of one precision mode against the fp64 pipeline over ALL timed queries, in both normalisations of the
+    variance error: SURVEY 8d's max|dv| / max|v_ref| and the k(0)-scaled one (v = k(0) - quadratic form)."""
+    dv = (v_a - v_ref).abs()
+    df = (f_a - f_ref).abs()
+    vmax = float(v_ref.abs().max().item())
+    fmax = float(f_ref.abs().max().item())
+    return {"n_queries": int(v_ref.numel()), "reference": "GPX_PREC_F64 pipeline on the same queries",
+            "v_err_over_max_v": float(dv.max().item()) / vmax, "v_err_over_max_v_k0": float(dv.max().item()) / max(vmax, k0),
+            "v_err_mean_over_max_v": float(dv.mean().item()) / vmax, "max_abs_v_ref": vmax, "min_v_ref": float(v_ref.min().item()),
+            "k0": k0, "f_err_over_max_f": float(df.max().item()) / fmax,
+            "tolerance": "1e-5 (north star, SURVEY 8d: max|dv| / max|v_ref|)"}
+
+
+def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
+    """The other BASELINE.json configurations on this one GPU, after the timed region and never part of `value`:
+    ms per train+predict(mean+variance) step and query-points/s each (one warm-up, then timed once or twice)."""
+    import numpy as np
+    out = {}
+
+    def lattice(g, lo=0, hi=None, scale=1.01):
+        hi = g ** 3 if hi is None else hi
+        t = torch.linspace(-scale, scale, g, dtype=torch.float64, device=dev)
+        idx = torch.arange(lo, hi, device=dev, dtype=torch.int64)
+        return t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()
+
+    def run(name, what, kern, data, prec, q, reps):
+        qx, qy, qz = q
+        nq = int(qx.numel())
+        f = torch.empty(nq, dtype=torch.float64, device=dev)
+        v = torch.empty(nq, dtype=torch.float64, device=dev)
+
+        def step():
+            m = gpx.Model(kern, *data, precision=prec, prepare_variance=True, device=local_rank)
+            m.evaluate_device(nq, qx.data_ptr(), qy.data_ptr(), qz.data_ptr(), f.data_ptr(), v.data_ptr())
+            m.sync()
+            st = m.stats
+            m.close()
+            return st
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st = step()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"workload": what, "ms_per_step": dt * 1e3, "value": nq / dt, "unit": "query-points/s",
+                     "n_train": int(st["n"]), "n_query": nq,
+                     "stages_ms": {k: st[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_solve_ms", "t_inverse_ms", "t_mean_ms", "t_var_ms")}}
+
+    pcd_dir = os.path.join(ROOT, "tests", "golden", "pcd")
+    try:  # C1: the reference's own CPU-runnable case (tests/test_gp.cpp shape): mugD, Gaussian, 32^3 grid, fp64
+        pts = gpx.pcd_read(os.path.join(pcd_dir, "mugD.pcd"))
+        run("C1", "resources/mugD.pcd -> node training set (262 + 15 points), Gaussian(1,1), fp64, 32^3 grid",
+            gpx.make_kernel("gaussian", 1.0, 1.0), gpx.node_training_set(pts), gpx.F64, lattice(32), 3)
+    except Exception as e:
+        out["C1"] = {"error": str(e)}
+    try:  # C2
+        run("C2", "synthetic sphere N=4096, Gaussian(1,1), fp64, 64^3 grid", gpx.make_kernel("gaussian", 1.0, 1.0),
+            ds.fibonacci_training_set(4096), gpx.F64, lattice(64), 2)
+    except Exception as e:
+        out["C2"] = {"error": str(e)}
+    try:  # C5: the eight objects of scripts/perform.sh one after the other, 128^3 grid each, the node's own kernel
+        names = ["bowlA", "bowlB", "containerA", "containerB", "jug", "kettle", "pot", "mugD"]
+        sets = [gpx.node_training_set(gpx.pcd_read(os.path.join(pcd_dir, nm + ".pcd"))) for nm in names]
+        kern = gpx.make_kernel("thinplate", 2.0)  # src/gp_node.cpp:919
+        q = lattice(128)
+        nq = int(q[0].numel())
+        f = torch.empty(nq, dtype=torch.float64, device=dev)
+        v = torch.empty(nq, dtype=torch.float64, device=dev)
+
+        def all_objects():
+            for d_ in sets:
+                m = gpx.Model(kern, *d_, precision=gpx.F32, prepare_variance=True, device=local_rank)
+                m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+                m.sync()
+                m.close()
+        all_objects()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        all_objects()
+        dt = time.perf_counter() - t0
+        out["C5"] = {"workload": "8 objects (%s; N = %s), ThinPlate(2.0) as the node, fp32 mode, 128^3 grid each, one after "
+                                 "the other on ONE GPU (the 8-GPU form is one object per rank: bench.py --gpus 8)"
+                                 % (", ".join(names), ", ".join(str(len(d_[0])) for d_ in sets)),
+                     "ms_per_step": dt * 1e3, "ms_per_object": dt * 1e3 / len(sets), "value": nq * len(sets) / dt,
+                     "unit": "query-points/s", "n_query": nq * len(sets)}
+    except Exception as e:
+        out["C5"] = {"error": str(e)}
+    try:  # C4: one rank's share of the 256^3 grid sharded over 8 GPUs, on a shell committed from the state blobs
+        n = N_TRAIN
+        kern = gpx.make_kernel("thinplate", 4.0)
+        data = ds.fibonacci_training_set(n)
+        world4, rank4 = 8, 3
+        lo, hi = sharding.slab_range(256 ** 3, rank4, world4)
+        q = lattice(256, lo, hi)
+        nq = hi - lo
+        f = torch.empty(nq, dtype=torch.float64, device=dev)
+        v = torch.empty(nq, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        src = gpx.Model(kern, *data, precision=gpx.F32, prepare_variance=True, device=local_rank)
+        src.sync()
+        t1 = time.perf_counter()
+        sh = gpx.Model.shell(kern, n, precision=gpx.F32, device=local_rank)
+        for part in (0, 1):
+            a = sharding.device_blob_as_tensor(torch, *src.state_blob(part), dev)
+            b = sharding.device_blob_as_tensor(torch, *sh.state_blob(part), dev)
+            b.copy_(a)  # stands in for the RCCL broadcast of the same bytes
+        torch.cuda.synchronize()
+        sh.commit(with_variance=True)
+        t2 = time.perf_counter()
+        sh.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+        sh.sync()
+        t3 = time.perf_counter()
+        st = src.stats
+        src.close()
+        sh.close()
+        out["C4_slab"] = {"workload": "N=16384 thin-plate R=4 fp32 mode; slab %d of %d of the 256^3 grid (%d queries) evaluated on a shell "
+                                      "committed from the two state blobs (device-to-device copy in place of the RCCL broadcast)" % (rank4, world4, nq),
+                          "t_train_ms": (t1 - t0) * 1e3, "t_state_copy_commit_ms": (t2 - t1) * 1e3, "t_predict_ms": (t3 - t2) * 1e3,
+                          "ms_per_step": (t3 - t0) * 1e3, "value": nq / (t3 - t0), "unit": "query-points/s (one rank's slab)",
+                          "n_query": nq, "v_min": float(v.min().item()), "v_max": float(v.max().item()),
+                          "train_stages_ms": {k: st[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_solve_ms", "t_inverse_ms")}}
+    except Exception as e:
+        out["C4_slab"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -242,7 +376,8 @@ def main():
                 vkernel, vpeak, achieved = "vsplit_gemm_kernel (3 fp16 MFMA products per fp32 product)", PEAK_F16_MFMA_TFLOPS, 3 * achieved
             roof = {"bound": "mfma", "kernel": vkernel,
                     "achieved": achieved, "peak": vpeak, "unit": "TFLOP/s", "frac": achieved / vpeak,
-                    "traffic": pmc_traffic(args, n_train, q_per_launch),
+                    "traffic": pmc_traffic(args, n_train, q_per_launch)[0],
+                    "traffic_source": pmc_traffic(args, n_train, q_per_launch)[1],
                     "avg_launch_ms": avg_ms, "launches_per_step": launches,
                     "algorithmic_flops_per_launch": flops_per_launch}
         out = {
@@ -277,6 +412,8 @@ def main():
                                    "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
         esz = 8 if prec == gpx.F64 else 4
         npad = int(st["n_padded"])
+        k0 = 64.0 if args.kernel == "thinplate" else (2.0 if args.kernel == "laplace" else 1.0)
+        f_timed, v_timed = f.clone(), v.clone()  # results of the last timed step (the legs below overwrite f, v)
         HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
         if world == 1 and not shard:
             # The two HBM-write-bound stages last ~0.1 ms per launch: a HIP event pair around ONE such launch mostly
@@ -320,16 +457,18 @@ def main():
                                           "in_create_ms": st["t_kbuild_ms"]}
                 del Kbuf
                 qb = 8192
-                fab = torch.zeros(2 * qb, dtype=tdt, device=dev)
+                fab = torch.zeros(3 * qb, dtype=torch.float64, device=dev)
                 fab[:qb] = 0.3
-                fab[qb:] = -0.1  # a representative per-query fit (values do not change the work)
+                fab[qb:2 * qb] = -0.1  # a representative per-query fit (values do not change the work)
+                fab[2 * qb:] = 0.01
                 np_rows = min(npad, (n_train + 127) // 128 * 128)
                 Kq = torch.empty(qb * npad, dtype=tdt, device=dev)
+                pts = [t_.double() for t_ in pts]  # the operand kernel reads the fp64 points (k - fit is formed in fp64)
                 kq = lambda: gpx._check(L.gpx_dev_kqp(C.byref(kern), stage_prec, n_train, npad, vp(pts[0]), vp(pts[1]), vp(pts[2]),
                                                       qb, vp(qx), vp(qy), vp(qz), vp(fab) if prec != gpx.F64 else None, vp(Kq),
                                                       C.c_void_p(strm.cuda_stream)))
                 ms = timed(kq)
-                kq_bytes = qb * np_rows * esz + 4 * npad * esz + qb * 24  # Kqp written + points + queries read
+                kq_bytes = qb * np_rows * esz + 3 * npad * 8 + qb * 48  # Kqp written + points + queries and fit read
                 out["roofline_kqp"] = {"bound": "hbm", "kernel": "kqp_kernel<%s> (kernel operand of one variance batch of %d queries)" % (gemm_t, qb),
                                        "bytes_per_launch": kq_bytes, "avg_launch_ms": ms, "launches_timed": reps,
                                        "achieved": kq_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -366,6 +505,7 @@ def main():
                 dt = time.perf_counter() - t1
                 sst = ms.stats
                 ms.close()
+                f_split, v_split = f.clone(), v.clone()
                 out["fast_mode"] = {
                     "precision": "f32split (3 fp16 MFMA products on hi/lo halves, fp32 accumulation; opt-in)",
                     "ms_per_step": dt * 1e3, "value": nq / dt, "unit": "query-points/s",
@@ -401,7 +541,14 @@ def main():
                                                 "frac": a64 / PEAK_F64_MFMA_TFLOPS, "avg_launch_ms": s64["t_var_gemm_ms"] / l64},
                               "stages_ms": {k: s64[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_solve_ms", "t_inverse_ms",
                                                                 "t_mean_ms", "t_var_ms")},
-                              "alpha_residual": s64["alpha_residual"]}
+                              "alpha_residual": s64["alpha_residual"],
+                              "whole_ldlt": {"what": "N^3/3 flop / t_factor_ms, fp64", "ms": s64["t_factor_ms"],
+                                             "achieved": (n_train ** 3 / 3.0) / (s64["t_factor_ms"] * 1e-3) / 1e12,
+                                             "frac": (n_train ** 3 / 3.0) / (s64["t_factor_ms"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+                # accuracy of the TIMED workload: f, v now hold the fp64 pipeline's results for the same 2^20 queries
+                out["accuracy"] = accuracy_record(torch, f_timed, v_timed, f, v, k0)
+                if "fast_mode" in out and "error" not in out["fast_mode"]:
+                    out["fast_mode"]["accuracy"] = accuracy_record(torch, f_split, v_split, f, v, k0)
             except Exception as e:
                 out["f64"] = {"error": str(e)}
         if world == 1 and want_v and not shard and not args.no_fast_mode and model[0] is not None:
@@ -417,6 +564,15 @@ def main():
                                    "ms": dt * 1e3, "value": nq_local / dt, "unit": "query-points/s"}
             except Exception as e:
                 out["host_api"] = {"error": str(e)}
+        if world == 1 and not shard and not args.no_fast_mode and not args.no_configs:
+            try:
+                if model[0] is not None:
+                    model[0].close()
+                    model[0] = None
+                gpx.trim()
+                out["configs"] = extra_configs(torch, gpx, ds, sharding, dev, local_rank)
+            except Exception as e:
+                out["configs"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_train, nq, args.kernel, kpar)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

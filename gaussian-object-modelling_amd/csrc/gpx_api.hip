@@ -26,107 +26,75 @@ int fail(int code, const std::string &msg)
 }
 }  // namespace gpxh
 
-// ---- pool of large device buffers -------------------------------------------------------------------------
+// ---- pool of large device buffers: gpxh::BigPool (gpx_host.cpp) over the HIP backend ------------------------------
 namespace gpxh {
 namespace {
-struct BigBuf {
-    void *p;
-    size_t bytes;
-    int dev;
-};
-std::mutex g_pool_mtx;
-std::vector<BigBuf> g_pool_free;  // parked
-std::vector<BigBuf> g_pool_live;  // handed out through big_alloc (so that big_free knows size and device)
-size_t g_pool_parked = 0;
-size_t pool_cap()
+int hip_get_device()
 {
-    static const size_t cap = [] {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
+}
+void hip_set_device(int d) { (void)hipSetDevice(d); }
+int hip_dev_malloc(void **p, size_t bytes)
+{
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess)
+        return 0;
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? 1 : 2;
+}
+void hip_dev_free(void *p) { (void)hipFree(p); }
+const DeviceBackend g_hip_backend{hip_get_device, hip_set_device, hip_dev_malloc, hip_dev_free};
+const bool g_backend_installed = (set_device_backend(&g_hip_backend), true);
+
+BigPool &pool()
+{
+    static BigPool p([] {
         const char *e = std::getenv("GPX_POOL_MB");
         return (size_t)(e ? std::atol(e) : 16384) << 20;
-    }();
-    return cap;
+    }());
+    return p;
 }
 }  // namespace
+struct KbuildScratch {  // gpx_dev_kbuild's per-device arg-max scratch
+    float *tm = nullptr;
+    int *tj = nullptr;
+    int cap = 0;
+};
+std::mutex g_kb_mtx;
+KbuildScratch g_kb_scratch[MAX_DEVICES];
 
 hipError_t big_alloc(void **p, size_t bytes)
 {
-    *p = nullptr;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (bytes >= BIG_POOL_MIN) {
-        std::lock_guard<std::mutex> lk(g_pool_mtx);
-        int best = -1;
-        for (int i = 0; i < (int)g_pool_free.size(); ++i) {
-            const BigBuf &b = g_pool_free[i];
-            if (b.dev == dev && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 &&
-                (best < 0 || b.bytes < g_pool_free[best].bytes))
-                best = i;
-        }
-        if (best >= 0) {
-            BigBuf b = g_pool_free[best];
-            g_pool_free.erase(g_pool_free.begin() + best);
-            g_pool_parked -= b.bytes;
-            g_pool_live.push_back(b);
-            *p = b.p;
-            return hipSuccess;
-        }
-    }
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess && bytes >= BIG_POOL_MIN) {  // out of memory with buffers parked: release them and retry
-        (void)hipGetLastError();
-        gpx_trim();
-        e = hipMalloc(p, bytes);
-    }
-    if (e == hipSuccess && bytes >= BIG_POOL_MIN) {
-        std::lock_guard<std::mutex> lk(g_pool_mtx);
-        g_pool_live.push_back(BigBuf{*p, bytes, dev});
-    }
-    return e;
+    (void)g_backend_installed;
+    const int rc = pool().alloc(p, bytes);
+    return rc == 0 ? hipSuccess : (rc == 1 ? hipErrorOutOfMemory : hipErrorUnknown);
 }
 
-void big_free(void *p)
-{
-    if (!p)
-        return;
-    BigBuf b{nullptr, 0, 0};
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mtx);
-        for (size_t i = 0; i < g_pool_live.size(); ++i)
-            if (g_pool_live[i].p == p) {
-                b = g_pool_live[i];
-                g_pool_live.erase(g_pool_live.begin() + i);
-                break;
-            }
-    }
-    if (!b.p || g_pool_parked + b.bytes > pool_cap()) {
-        (void)hipFree(p);
-        return;
-    }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(b.dev);
-    (void)hipDeviceSynchronize();  // what hipFree would have done: nothing in flight may still use the buffer
-    if (prev >= 0)
-        (void)hipSetDevice(prev);
-    std::lock_guard<std::mutex> lk(g_pool_mtx);
-    g_pool_free.push_back(b);
-    g_pool_parked += b.bytes;
-}
+void big_free(void *p) { pool().release(p); }
 }  // namespace gpxh
 
 extern "C" void gpx_trim(void)
 {
-    std::vector<gpxh::BigBuf> drop;
-    {
-        std::lock_guard<std::mutex> lk(gpxh::g_pool_mtx);
-        drop.swap(gpxh::g_pool_free);
-        gpxh::g_pool_parked = 0;
-    }
+    gpxh::pool().trim();
     int prev = -1;
     (void)hipGetDevice(&prev);
-    for (const auto &b : drop) {
-        (void)hipSetDevice(b.dev);
-        (void)hipFree(b.p);
+    {
+        std::lock_guard<std::mutex> lk(gpxh::g_kb_mtx);
+        for (int d = 0; d < MAX_DEVICES; ++d) {
+            gpxh::KbuildScratch &ks = gpxh::g_kb_scratch[d];
+            if (!ks.tm && !ks.tj)
+                continue;
+            (void)hipSetDevice(d);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ks.tm);
+            (void)hipFree(ks.tj);
+            ks = gpxh::KbuildScratch{};
+        }
     }
     if (prev >= 0)
         (void)hipSetDevice(prev);
@@ -250,6 +218,13 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     m->var_fit = o.precision != GPX_PREC_F64;
     if (const char *vf = std::getenv("GPX_VAR_FIT"))
         m->var_fit = m->var_fit && std::atoi(vf) != 0;
+    // ... and form that operand, k - fit, in fp64 from the fp64 points, rounding once -- for the thin plate, whose
+    // values are all of the size of k(0) = R^3 while the variance is ~k(0)/60 at N = 16384: forming k and the fit
+    // separately in fp32 costs 8e-6 of max|v| there, against 4e-7 for Matern-5/2 (profiles/r03_fit_variants_*.txt), and the
+    // exponential kernels would pay ~40 % more operand time for the fp64 exp.  GPX_VAR_OP64=0 / 1 forces either.
+    m->op64 = kernel->id == GPX_KERNEL_THINPLATE;
+    if (const char *vo = std::getenv("GPX_VAR_OP64"))
+        m->op64 = std::atoi(vo) != 0;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");
@@ -518,22 +493,23 @@ extern "C" int gpx_model_get(const gpx_model *cm, int field, void *dst, size_t b
         const int np = m->npad;
         const size_t e = m->esz;
         std::vector<double> st((size_t)np * 4, 0.0);
-        for (size_t i = 0; i < n; ++i) {
-            st[i] = m->hx[i];
-            st[np + i] = m->hy[i];
-            st[2 * (size_t)np + i] = m->hz[i];
+        for (size_t i = 0; i < n; ++i) {  // relative to the centre, like the model's own working-precision points
+            st[i] = m->hx[i] - m->cen[0];
+            st[np + i] = m->hy[i] - m->cen[1];
+            st[2 * (size_t)np + i] = m->hz[i] - m->cen[2];
             st[3 * (size_t)np + i] = m->hs2[i];
         }
-        double *dd = nullptr;
-        void *tt = nullptr, *Kt = nullptr;
-        float *tm = nullptr;
-        int *tj = nullptr;
         const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
-        HIPCHK(hipMalloc((void **)&dd, sizeof(double) * 4 * np));
-        HIPCHK(hipMalloc(&tt, e * 4 * np));
-        HIPCHK(hipMalloc(&Kt, e * (size_t)np * np));
-        HIPCHK(hipMalloc((void **)&tm, sizeof(float) * ntiles));
-        HIPCHK(hipMalloc((void **)&tj, sizeof(int) * 2 * ntiles));
+        DevGuard gdd, gtt, gKt, gtm, gtj;  // freed on every exit (HIPCHK returns early)
+        HIPCHK(hipMalloc(&gdd.p, sizeof(double) * 4 * np));
+        HIPCHK(hipMalloc(&gtt.p, e * 4 * np));
+        HIPCHK(hipMalloc(&gKt.p, e * (size_t)np * np));
+        HIPCHK(hipMalloc(&gtm.p, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc(&gtj.p, sizeof(int) * 2 * ntiles));
+        double *dd = (double *)gdd.p;
+        void *tt = gtt.p, *Kt = gKt.p;
+        float *tm = (float *)gtm.p;
+        int *tj = (int *)gtj.p;
         HIPCHK(hipMemcpy(dd, st.data(), sizeof(double) * 4 * np, hipMemcpyHostToDevice));
         char *tb = (char *)tt;
         for (int c = 0; c < 4; ++c)
@@ -552,11 +528,6 @@ extern "C" int gpx_model_get(const gpx_model *cm, int field, void *dst, size_t b
                 o[i * n + j] = val;
                 o[j * n + i] = val;
             }
-        (void)hipFree(dd);
-        (void)hipFree(tt);
-        (void)hipFree(Kt);
-        (void)hipFree(tm);
-        (void)hipFree(tj);
         return GPX_OK;
     }
     return fail(GPX_E_BAD_ARG, "unknown field");
@@ -633,6 +604,16 @@ extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
         return fail(GPX_E_NULL, "Empty Model pointer");
     if (!m->blob0)
         return fail(GPX_E_STATE, "model has no device state");
+    {  // the centre of the cloud travels in the meta block of state part 0
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        HIPCHK(hipSetDevice(m->device));
+        const hipError_t e = hipMemcpy(m->cen, m->d_meta, sizeof(double) * 3, hipMemcpyDeviceToHost);
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+        if (e != hipSuccess)
+            return fail(GPX_E_HIP, std::string("commit: ") + hipGetErrorString(e));
+    }
     m->ready = true;
     if (with_variance) {
         if (!m->X)
@@ -655,6 +636,18 @@ extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
 // hipMemcpyPeerAsync, i.e. xGMI when peer access is available, staged through the host otherwise -- into shells and
 // committed.  No RCCL communicator is needed inside one process; the one-process-per-GPU path (bench.py --mode
 // shard) moves the same two blobs with a torch.distributed broadcast.
+namespace {
+struct DeviceRestore {  // the caller's current device survives every exit path
+    int prev = -1;
+    DeviceRestore() { (void)hipGetDevice(&prev); }
+    ~DeviceRestore()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
 extern "C" int gpx_model_replicate(const gpx_model *csrc, int ndev, const int *devs, gpx_model **out)
 {
     if (!csrc)
@@ -672,80 +665,105 @@ extern "C" int gpx_model_replicate(const gpx_model *csrc, int ndev, const int *d
         if (devs[i] < 0 || devs[i] >= have)
             return fail(GPX_E_BAD_ARG, "device ordinal out of range");
     }
-    std::lock_guard<std::mutex> lk(src->mtx);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    HIPCHK(hipSetDevice(src->device));
-    int rc = build_inverse(src);  // replicas carry the inverse factor: they hold no LDL^T to build it from
-    if (rc)
-        return rc;
-    HIPCHK(hipStreamSynchronize(src->stream));
-    const size_t xbytes = src->esz * (size_t)src->npad * src->npad;
-    for (int i = 0; i < ndev && rc == GPX_OK; ++i) {
-        gpx_options o = src->opt;
-        o.device = devs[i];
-        gpx_model *r = nullptr;
-        if ((rc = gpx_model_create_shell(&src->kern, (size_t)src->n, &o, &r)))
-            break;
-        out[i] = r;
-        if (devs[i] != src->device) {  // best effort: direct xGMI copies instead of staging through the host
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devs[i], src->device) == hipSuccess && can) {
-                (void)hipSetDevice(devs[i]);
-                (void)hipDeviceEnablePeerAccess(src->device, 0);
-                (void)hipGetLastError();  // "already enabled" is fine
-            }
-        }
-        hipError_t e = hipSetDevice(src->device);
-        if (e == hipSuccess)
-            e = hipMemcpyPeerAsync(r->blob0, devs[i], src->blob0, src->device, src->blob0_bytes, src->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyPeerAsync(r->X, devs[i], src->X, src->device, xbytes, src->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(src->stream);
-        if (e != hipSuccess) {
-            rc = fail(e == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
-            break;
-        }
-        // host-side fields (accessors, a later update() by rebuild)
-        r->hx = src->hx, r->hy = src->hy, r->hz = src->hz, r->hlabel = src->hlabel, r->hs2 = src->hs2;
-        r->has_s2 = src->has_s2;
-        r->perm = src->perm;
-        r->R = src->R;
-        r->hD = src->hD;
-        if (r->hD.empty() && src->t_d) {  // replicas hold no factor: keep D readable (GPX_FIELD_D)
-            r->hD.resize((size_t)src->n);
-            if (src->prec == GPX_PREC_F64) {
-                e = hipMemcpy(r->hD.data(), src->t_d, sizeof(double) * (size_t)src->n, hipMemcpyDeviceToHost);
-            } else {
-                std::vector<float> t((size_t)src->n);
-                e = hipMemcpy(t.data(), src->t_d, sizeof(float) * (size_t)src->n, hipMemcpyDeviceToHost);
-                r->hD.assign(t.begin(), t.end());
-            }
-            if (e != hipSuccess) {
-                rc = fail(GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
-                break;
-            }
-        }
-        r->stats = src->stats;
-        r->sk = src->sk;
-        r->var_fit = src->var_fit;
-        if ((rc = gpx_model_commit(r, 1)))
-            break;
-        r->x_packed = src->x_packed;
-    }
-    if (rc) {
+    DeviceRestore restore;
+    std::vector<hipEvent_t> done((size_t)ndev, nullptr);
+    int rc = GPX_OK;
+    auto cleanup = [&](int code) {
         const std::string keep = g_err;
         for (int i = 0; i < ndev; ++i) {
+            if (done[i]) {
+                (void)hipEventSynchronize(done[i]);  // no copy may still be writing into a shell that is about to go
+                (void)hipEventDestroy(done[i]);
+            }
             if (out[i])
                 gpx_model_destroy(out[i]);
             out[i] = nullptr;
         }
         g_err = keep;
+        return code;
+    };
+    {
+        // Under the source's lock: make sure its inverse factor exists, create all shells and ISSUE all copies -- one
+        // pair of peer copies per replica on that replica's own stream, so that the transfers to different devices run
+        // side by side on their own xGMI links (round 2 copied one replica after the other on the source's stream and
+        // waited for each).  The source's stream is made to wait for every copy, so that anything that later
+        // synchronises it (update, destroy) also waits for them; the lock is released while the copies fly.
+        std::lock_guard<std::mutex> lk(src->mtx);
+        HIPCHK(hipSetDevice(src->device));
+        if ((rc = build_inverse(src)))  // replicas carry the inverse factor: they hold no LDL^T to build it from
+            return rc;
+        HIPCHK(hipStreamSynchronize(src->stream));
+        const size_t xbytes = src->esz * (size_t)src->npad * src->npad;
+        std::vector<double> hD = src->hD;
+        if (hD.empty() && src->t_d) {  // replicas hold no factor: keep D readable (GPX_FIELD_D)
+            hD.resize((size_t)src->n);
+            hipError_t e;
+            if (src->prec == GPX_PREC_F64) {
+                e = hipMemcpy(hD.data(), src->t_d, sizeof(double) * (size_t)src->n, hipMemcpyDeviceToHost);
+            } else {
+                std::vector<float> t((size_t)src->n);
+                e = hipMemcpy(t.data(), src->t_d, sizeof(float) * (size_t)src->n, hipMemcpyDeviceToHost);
+                hD.assign(t.begin(), t.end());
+            }
+            if (e != hipSuccess)
+                return fail(GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
+        }
+        for (int i = 0; i < ndev && rc == GPX_OK; ++i) {
+            gpx_options o = src->opt;
+            o.device = devs[i];
+            gpx_model *r = nullptr;
+            if ((rc = gpx_model_create_shell(&src->kern, (size_t)src->n, &o, &r)))
+                break;
+            out[i] = r;
+            hipError_t e = hipSetDevice(devs[i]);
+            if (e == hipSuccess && devs[i] != src->device) {  // best effort: direct xGMI copies instead of staging through the host
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[i], src->device) == hipSuccess && can) {
+                    (void)hipDeviceEnablePeerAccess(src->device, 0);
+                    (void)hipGetLastError();  // "already enabled" is fine
+                }
+            }
+            if (e == hipSuccess)
+                e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipMemcpyPeerAsync(r->blob0, devs[i], src->blob0, src->device, src->blob0_bytes, r->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyPeerAsync(r->X, devs[i], src->X, src->device, xbytes, r->stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(done[i], r->stream);
+            if (e == hipSuccess)
+                e = hipStreamWaitEvent(src->stream, done[i], 0);
+            if (e != hipSuccess) {
+                rc = fail(e == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e));
+                break;
+            }
+            // host-side fields (accessors, a later update() by rebuild)
+            r->hx = src->hx, r->hy = src->hy, r->hz = src->hz, r->hlabel = src->hlabel, r->hs2 = src->hs2;
+            r->has_s2 = src->has_s2;
+            r->perm = src->perm;
+            r->R = src->R;
+            r->hD = hD;
+            r->stats = src->stats;
+            r->sk = src->sk;
+            r->var_fit = src->var_fit;
+            r->op64 = src->op64;
+        }
+        if (rc)
+            return cleanup(rc);
     }
-    if (prev >= 0)
-        (void)hipSetDevice(prev);
-    return rc;
+    // one wait per replica, outside the lock; then commit (reads the centre back from the received blob)
+    const bool packed = src->x_packed;  // (fixed once the inverse factor exists)
+    for (int i = 0; i < ndev; ++i) {
+        const hipError_t e = hipEventSynchronize(done[i]);
+        (void)hipEventDestroy(done[i]);
+        done[i] = nullptr;
+        if (e != hipSuccess)
+            return cleanup(fail(GPX_E_HIP, std::string("replicate: ") + hipGetErrorString(e)));
+        if ((rc = gpx_model_commit(out[i], 1)))
+            return cleanup(rc);
+        out[i]->x_packed = packed;
+    }
+    return GPX_OK;
 }
 
 // ---- stand-alone kbuild (tests / roofline leg) ---------------------------------------------------
@@ -758,20 +776,28 @@ extern "C" int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n,
     if (n == 0 || n_padded % PANEL != 0 || n_padded < n)
         return fail(GPX_E_BAD_ARG, "n_padded must be gpx_padded_n(n)");
     const int nt = (int)(n_padded / TILE), ntiles = nt * (nt + 1) / 2;
-    static thread_local float *tm = nullptr;
-    static thread_local int *tj = nullptr;
-    static thread_local int cap = 0;
-    if (cap < ntiles) {
-        if (tm)
-            (void)hipFree(tm);
-        if (tj)
-            (void)hipFree(tj);
-        HIPCHK(hipMalloc((void **)&tm, sizeof(float) * ntiles));
-        HIPCHK(hipMalloc((void **)&tj, sizeof(int) * (2 * ntiles + 2)));
-        cap = ntiles;
+    // per-tile arg-max scratch of the kernel: one buffer per DEVICE (round 2 kept a thread-local one that stayed on
+    // whichever device had been current first), grown on demand, released by gpx_trim().  The stage entry is a bench /
+    // test hook: calls on one device are serialised by the lock for as long as they are being enqueued.
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES)
+        return fail(GPX_E_BAD_ARG, "device ordinal out of range");
+    std::lock_guard<std::mutex> lk(gpxh::g_kb_mtx);
+    gpxh::KbuildScratch &ks = gpxh::g_kb_scratch[dev];
+    if (ks.cap < ntiles) {
+        (void)hipDeviceSynchronize();  // an earlier launch on another stream may still write the old scratch
+        if (ks.tm)
+            (void)hipFree(ks.tm);
+        if (ks.tj)
+            (void)hipFree(ks.tj);
+        ks.tm = nullptr, ks.tj = nullptr, ks.cap = 0;
+        HIPCHK(hipMalloc((void **)&ks.tm, sizeof(float) * ntiles));
+        HIPCHK(hipMalloc((void **)&ks.tj, sizeof(int) * (2 * ntiles + 2)));
+        ks.cap = ntiles;
     }
     CovHost c = make_cov(*kernel);
-    launch_kbuild(precision, c, (int)n, (int)n_padded, d_x, d_y, d_z, d_s2, d_K, tm, tj, (hipStream_t)stream);
+    launch_kbuild(precision, c, (int)n, (int)n_padded, d_x, d_y, d_z, d_s2, d_K, ks.tm, ks.tj, (hipStream_t)stream);
     (void)d_rmax;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess)
@@ -792,8 +818,11 @@ extern "C" int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, si
         return fail(GPX_E_BAD_ARG, "precision must be GPX_PREC_F32 or GPX_PREC_F64");
     CovHost c = make_cov(*kernel);
     const int np_rows = (int)std::min<size_t>(n_padded, (n + TILE - 1) / TILE * TILE);
-    launch_kqp(precision, c, (int)n, (int)n_padded, d_px, d_py, d_pz, (long)nq, (long)nq, (const double *)d_qx,
-               (const double *)d_qy, (const double *)d_qz, d_Kqp, (hipStream_t)stream, np_rows, d_fab, (long)nq);
+    // the points are fp64; distances, kernel and fit are formed in fp64 and rounded once to `precision` (what
+    // evaluate does for every model that takes the fit out of its operand); no centre is needed for fp64 differences
+    launch_kqp(true, precision, precision == GPX_PREC_F64, c, (int)n, (int)n_padded, d_px, d_py, d_pz, nullptr, (long)nq,
+               (long)nq, (const double *)d_qx, (const double *)d_qy, (const double *)d_qz, d_Kqp, (hipStream_t)stream,
+               np_rows, (const double *)d_fab, (long)nq);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess)
         return fail(GPX_E_HIP, hipGetErrorString(le));

@@ -8,6 +8,7 @@ namespace gpxh {
 
 void free_dev(gpx_model *m)
 {
+    quiesce(m);
     auto F = [](void *p) { big_free(p); };  // parks buffers of 64 MiB and more, hipFree otherwise
     F(m->dvecs);
     F(m->blob0);
@@ -70,10 +71,26 @@ void free_dev(gpx_model *m)
 }
 
 
-int ensure(void **p, size_t *have, size_t need)
+// Waits for everything this model has enqueued -- its own two streams and, through the workspace event, the last
+// evaluation a caller put on a stream of its own -- so that its buffers can be released or parked.  This replaces
+// the device-wide synchronisation the pool did in round 2: other models and threads on the device keep running.
+void quiesce(gpx_model *m)
+{
+    if (m->stream)
+        (void)hipStreamSynchronize(m->stream);
+    if (m->stream2)
+        (void)hipStreamSynchronize(m->stream2);
+    if (m->ws_in_flight && m->ev[EV_WS])
+        (void)hipEventSynchronize(m->ev[EV_WS]);
+    m->ws_in_flight = false;
+}
+
+int ensure(gpx_model *m, void **p, size_t *have, size_t need)
 {
     if (*have >= need && *p)
         return GPX_OK;
+    if (*p)
+        quiesce(m);  // an earlier evaluation may still be using the buffer that is about to be replaced
     big_free(*p);
     *p = nullptr;
     *have = 0;
@@ -82,40 +99,10 @@ int ensure(void **p, size_t *have, size_t need)
     return GPX_OK;
 }
 
-// Eigen 3.2 LDLT pivot rule restated: at step k pick the FIRST largest |diagonal| among the
-// not-yet-eliminated rows and swap it to k.  The left-looking algorithm never updates the
-// trailing diagonal before it is chosen, so the sequence depends on diag(K) only.
-void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
-{
-    const int n = (int)diag.size();
-    perm.resize(n);
-    for (int i = 0; i < n; ++i)
-        perm[i] = i;
-    bool uniform = true;
-    for (int i = 1; i < n && uniform; ++i)
-        uniform = std::fabs(diag[i]) == std::fabs(diag[0]);
-    if (uniform)
-        return;
-    std::vector<double> d(diag);
-    for (int k = 0; k < n; ++k) {
-        int big = k;
-        double bv = std::fabs(d[k]);
-        for (int i = k + 1; i < n; ++i)
-            if (std::fabs(d[i]) > bv) {
-                bv = std::fabs(d[i]);
-                big = i;
-            }
-        if (big != k) {
-            std::swap(d[k], d[big]);
-            std::swap(perm[k], perm[big]);
-        }
-    }
-}
-
 int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
 {
     const size_t np = (size_t)m->npad;
-    *bytes = sizeof(double) * np * 4 + esz * np * (4 + VAR_NCORR);
+    *bytes = sizeof(double) * np * (5 + VAR_NCORR) + esz * np * 4 + sizeof(double) * BLOB_META;
     HIPCHK(hipMalloc(blob, *bytes));
     return GPX_OK;
 }
@@ -127,12 +114,14 @@ void carve_blob0(gpx_model *m)
     m->d_y = m->d_x + np;
     m->d_z = m->d_y + np;
     m->d_alpha = m->d_z + np;
-    char *b = (char *)(m->d_alpha + np);
+    m->d_dinv64 = m->d_alpha + np;
+    m->d_corr = m->d_dinv64 + np;
+    char *b = (char *)(m->d_corr + (size_t)VAR_NCORR * np);
     m->t_x = b;
     m->t_y = b + e * np;
     m->t_z = b + 2 * e * np;
     m->t_dinv = b + 3 * e * np;
-    m->t_corr = b + 4 * e * np;
+    m->d_meta = (double *)(b + 4 * e * np);
 }
 
 int alloc_model(gpx_model *m)
@@ -553,41 +542,49 @@ static int pack_split(gpx_model *m)
     (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
     m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
     launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream,
-                         m->var_fit ? (float *)m->t_corr : nullptr);
+                         m->d_meta + 3);
     HIPCHK(hipStreamSynchronize(m->stream));
     m->x_packed = true;
     return GPX_OK;
+}
+
+// 1/D in fp64 for the fp64 epilogue of the variance contraction (state part 0; the T copy serves the solves)
+static void store_dinv64(gpx_model *m, hipStream_t s)
+{
+    if (m->prec == GPX_PREC_F64)
+        (void)hipMemcpyAsync(m->d_dinv64, m->t_dinv, sizeof(double) * (size_t)m->npad, hipMemcpyDeviceToDevice, s);
+    else
+        launch_cast_f2d((size_t)m->npad, (const float *)m->t_dinv, m->d_dinv64, s);
 }
 
 int build_inverse(gpx_model *m)
 {
     if (m->has_inverse)
         return GPX_OK;
+    // a shell committed without its inverse factor (gpx_model_commit(m, 0)) or a replica holds no LDL^T to build one from
+    if (!m->Kmat || !m->linv)
+        return fail(GPX_E_STATE, "model holds no factor to build the inverse factor from (mean-only shell)");
     const int np = m->npad;
     const size_t e = m->esz;
     if (!m->X)
         HIPCHK(big_alloc(&m->X, e * (size_t)np * np));
     (void)hipEventRecord(m->ev[EV_INV0], m->stream);
-    void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
+    // temporaries behind guards: every early return below (HIPCHK) releases them
+    DevGuard gTws(nullptr, true), gL64(nullptr, true), gX64(nullptr, true), glinv64(nullptr, false);
     bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
     if (assemble64) {
         // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
         const size_t nn = (size_t)np * np;
-        if (big_alloc(&L64, sizeof(double) * nn) != hipSuccess || big_alloc(&X64, sizeof(double) * nn) != hipSuccess ||
-            big_alloc(&Tws, sizeof(double) * nn) != hipSuccess ||
-            hipMalloc(&linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
+        if (big_alloc(&gL64.p, sizeof(double) * nn) != hipSuccess || big_alloc(&gX64.p, sizeof(double) * nn) != hipSuccess ||
+            big_alloc(&gTws.p, sizeof(double) * nn) != hipSuccess ||
+            hipMalloc(&glinv64.p, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
             (void)hipGetLastError();
-            for (void **q : {&L64, &X64, &Tws}) {
-                big_free(*q);
-                *q = nullptr;
-            }
-            if (linv64)
-                (void)hipFree(linv64);
-            linv64 = nullptr;
+            gL64.reset(), gX64.reset(), gTws.reset(), glinv64.reset();
             assemble64 = false;
         }
     }
     if (assemble64) {
+        void *L64 = gL64.p, *X64 = gX64.p, *Tws = gTws.p, *linv64 = glinv64.p;
         // The fp32 factor is kept (that is what runs on the fp32 MFMA), but its inverse is assembled in fp64 and
         // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
         // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
@@ -601,29 +598,35 @@ int build_inverse(gpx_model *m)
         trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
         launch_cast_lower_d2f(np, (const double *)X64, (float *)m->X, true, m->stream);
         if (m->var_fit)  // from the un-rounded rows: the rounding of X then only meets the small fit residual
-            launch_var_rowcorr(true, m->prec, m->n, np, X64, np, m->t_x, m->t_y, m->t_z, m->t_corr, m->stream);
+            launch_var_rowcorr(true, m->op64, m->n, np, X64, np, m->d_x, m->d_y, m->d_z, m->d_meta, m->d_corr, m->stream);
     } else {
-        HIPCHK(big_alloc(&Tws, e * (size_t)np * np));
+        HIPCHK(big_alloc(&gTws.p, e * (size_t)np * np));
         // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
         // 128-block of every 256-diagonal block
         HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
         launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
-        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)Tws, np, m->stream);
+        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)gTws.p, np, m->stream);
         if (m->var_fit)
-            launch_var_rowcorr(false, m->prec, m->n, np, m->X, np, m->t_x, m->t_y, m->t_z, m->t_corr, m->stream);
+            launch_var_rowcorr(m->prec == GPX_PREC_F64, m->op64, m->n, np, m->X, np, m->d_x, m->d_y, m->d_z, m->d_meta,
+                               m->d_corr, m->stream);
     }
+    store_dinv64(m, m->stream);
     {
         hipError_t le = hipGetLastError();  // launches are not checked one by one
-        if (le != hipSuccess)
+        if (le != hipSuccess) {
+            (void)hipStreamSynchronize(m->stream);  // the guards release the temporaries: nothing may still use them
             return fail(GPX_E_HIP, std::string("inverse factor: kernel launch: ") + hipGetErrorString(le));
+        }
     }
     (void)hipEventRecord(m->ev[EV_INV1], m->stream);
-    HIPCHK(hipStreamSynchronize(m->stream));
-    big_free(Tws);
-    big_free(L64);
-    big_free(X64);
-    if (linv64)
-        HIPCHK(hipFree(linv64));
+    {
+        const hipError_t se = hipStreamSynchronize(m->stream);
+        if (se != hipSuccess) {
+            (void)hipDeviceSynchronize();  // before the guards hand the temporaries back
+            return fail(GPX_E_HIP, std::string("inverse factor: ") + hipGetErrorString(se));
+        }
+    }
+    gTws.reset(), gL64.reset(), gX64.reset(), glinv64.reset();
     float ms = 0;
     if (hipEventElapsedTime(&ms, m->ev[EV_INV0], m->ev[EV_INV1]) == hipSuccess)
         m->stats.t_inverse_ms = ms;
@@ -676,8 +679,10 @@ static void append_inverse(gpx_model *m, kept_factor *keep)
         g2.nn = 1, g2.a_lower = 1;
         g2.alpha = -1.0;
         launch_gemm(m->prec, g2, s);
-        if (m->var_fit)  // the cloud (hence its moments) and the rows of X changed: all rows again (N^2/2 reads)
-            launch_var_rowcorr(false, m->prec, m->n, np, m->X, np, m->t_x, m->t_y, m->t_z, m->t_corr, s);
+        if (m->var_fit)  // the cloud (hence its centre) and the rows of X changed: all rows again (N^2/2 reads)
+            launch_var_rowcorr(m->prec == GPX_PREC_F64, m->op64, m->n, np, m->X, np, m->d_x, m->d_y, m->d_z, m->d_meta,
+                               m->d_corr, s);
+        store_dinv64(m, s);
     }
     (void)hipEventRecord(m->ev[EV_INV1], s);
     ok = ok && hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
@@ -706,16 +711,23 @@ static int demote_to_f32(gpx_model *m)
     int rc = alloc_blob0(m, 4, &nb, &nbytes);
     if (rc)
         return rc;
-    HIPCHK(big_alloc(&nX, sizeof(float) * np * np));
-    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * 4, hipMemcpyDeviceToDevice, s));
-    float *tf = (float *)((char *)nb + sizeof(double) * np * 4);
-    launch_cast_d2f(np, (const double *)m->t_x, tf, s);
-    launch_cast_d2f(np, (const double *)m->t_y, tf + np, s);
-    launch_cast_d2f(np, (const double *)m->t_z, tf + 2 * np, s);
-    launch_cast_d2f(np, (const double *)m->t_dinv, tf + 3 * np, s);
-    launch_cast_d2f(np * VAR_NCORR, (const double *)m->t_corr, tf + 4 * np, s);
+    DevGuard gnb(nb, false), gnX(nullptr, true);  // released if a call below fails
+    HIPCHK(big_alloc(&gnX.p, sizeof(float) * np * np));
+    nX = gnX.p;
+    // the fp64 part (points, alpha, 1/D, row-correction vectors) and the meta block as they are; the T part rounded
+    HIPCHK(hipMemcpyAsync(nb, m->blob0, sizeof(double) * np * (5 + VAR_NCORR), hipMemcpyDeviceToDevice, s));
+    float *tf = (float *)((char *)nb + sizeof(double) * np * (5 + VAR_NCORR));
+    launch_cast_d2f(np * 4, (const double *)m->t_x, tf, s);  // x' y' z' 1/D are contiguous
+    HIPCHK(hipMemcpyAsync(tf + 4 * np, m->d_meta, sizeof(double) * BLOB_META, hipMemcpyDeviceToDevice, s));
     launch_cast_lower_d2f((int)np, (const double *)m->X, (float *)nX, true, s);
-    HIPCHK(hipStreamSynchronize(s));
+    {
+        const hipError_t se = hipStreamSynchronize(s);
+        if (se != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            return fail(GPX_E_HIP, std::string("demotion to fp32: ") + hipGetErrorString(se));
+        }
+    }
+    (void)gnb.release(), (void)gnX.release();  // the model owns them from here on
     HIPCHK(hipFree(m->blob0));
     big_free(m->X);
     big_free(m->Kmat);
@@ -769,7 +781,7 @@ int build_model(gpx_model *m, kept_factor *keep)
     {  // workspace of the matrix-free residual / normals passes (n queries against npad points)
         size_t need = predict_ws_doubles(n, np, m->opt.with_normals != 0) * sizeof(double);
         if (need) {
-            int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+            int rc = ensure(m, (void **)&m->ws_pred, &m->ws_pred_doubles, need);
             if (rc)
                 return rc;
         }
@@ -781,9 +793,23 @@ int build_model(gpx_model *m, kept_factor *keep)
     HIPCHK(hipMemsetAsync(m->d_alpha, 0, sizeof(double) * (size_t)np, s));
     HIPCHK(hipMemsetAsync(m->d_r, 0, sizeof(double) * (size_t)np * 2 + 64, s));
     HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
-    launch_cast_vec(m->prec, np, np, m->d_x, m->t_x, s);
-    launch_cast_vec(m->prec, np, np, m->d_y, m->t_y, s);
-    launch_cast_vec(m->prec, np, np, m->d_z, m->t_z, s);
+    // The working-precision copies of the points are relative to the centroid: every kernel depends on differences
+    // only, so the shift is free, and fp32 arithmetic (kernel matrix, fp32 operand kernels) then rounds coordinates of
+    // the size of the cloud, not of its distance from the origin (a cloud of radius 0.5 at offset 100 would lose 8
+    // bits).  The fp64 points stay as given: the mean / gradient and the fp64 operand kernels use them.
+    {
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < n; ++k)
+            c[0] += st[k], c[1] += st[np + k], c[2] += st[2 * (size_t)np + k];
+        for (int d = 0; d < 3; ++d)
+            m->cen[d] = c[d] / n;
+        double meta[BLOB_META] = {m->cen[0], m->cen[1], m->cen[2], 1.0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(m->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));  // meta lives on this stack frame
+    }
+    launch_cast_vec(m->prec, n, np, m->d_x, m->t_x, s, m->cen[0]);
+    launch_cast_vec(m->prec, n, np, m->d_y, m->t_y, s, m->cen[1]);
+    launch_cast_vec(m->prec, n, np, m->d_z, m->t_z, s, m->cen[2]);
     launch_cast_vec(m->prec, np, np, m->d_s2, m->t_s2, s);
     // ---- kernel matrix ----
     (void)hipEventRecord(m->ev[EV_T0], s);
@@ -920,6 +946,12 @@ int build_model(gpx_model *m, kept_factor *keep)
             m->R = std::sqrt(dx * dx + dy * dy + dz * dz);
         }
     }
+    {  // weight offset of the variance fit (gpx_internal.hpp), from the extent of the cloud; travels in the meta block
+        double wd = m->R * m->R / VAR_FIT_WDELTA_DIV;
+        if (const char *we = std::getenv("GPX_VAR_FIT_WDELTA"))
+            wd = std::atof(we);
+        HIPCHK(hipMemcpy(m->d_meta + 4, &wd, sizeof(double), hipMemcpyHostToDevice));
+    }
     m->ready = true;
     if (keep && keep->t0 > 0 && keep->X)
         append_inverse(m, keep);
@@ -938,20 +970,30 @@ int build_model(gpx_model *m, kept_factor *keep)
 // Arithmetic of the training stage.  MIXED trains in fp64 by definition.  F32 / F32_SPLIT models of up to
 // GPX_TRAIN_F64_MAX padded rows (default 2048; 0 = never) do too: there the whole fp64 create costs under two
 // milliseconds, while an fp32 LDL^T accumulates its Schur complements with errors of ~1e-5 k(0) against pivots that
-// sink to the noise level sigma^2 -- for the thin-plate matrices that alone is 5e-6 .. 1e-5 of max|v| in the variance
-// (measured, scripts/tp_err_survey.py; with the fp64 factor 1e-7 .. 1e-6).  Larger models keep the fp32 MFMA
-// factorisation (N = 4096: 9e-7, N = 16384: 1.1e-6 with the centred contraction).
+// sink to the noise level sigma^2.  Larger models keep the fp32 MFMA factorisation (N = 4096: 9e-7, N = 16384: 1.1e-6
+// with the centred contraction) -- except the thin plate:
+// its matrices have cond > 1e6 and predictor weights |K^-1 k_q|_1 of 10-70, so that the backward error of an fp32
+// LDL^T shows in the variance (4e-5 k(0) at N = 2305 on a random cloud with extrapolating queries, and k(0) / max|v| is
+// ~60 at N = 16384).  Thin-plate models therefore ALWAYS train in fp64 while the fp64 temporaries fit the device
+// (kernel matrix, inverse factor and the assembly workspace: 24 N^2 bytes + the fp32 state): the fp64 LDL^T costs 42.7
+// instead of 18.6 ms at N = 16384 -- 1 % of a step whose inverse factor is assembled in fp64 anyway -- and the
+// variance contraction stays on the fp32 matrix cores.  GPX_TRAIN_F64_MAX overrides both thresholds.
 void set_training_precision(gpx_model *m)
 {
     const int p = m->opt.precision;
-    // fp64 training for F32 / F32_SPLIT models while it is (nearly) free: up to 2048 padded rows for every kernel, up to
-    // 8192 for the thin plate -- its matrices have cond > 1e6 and predictor weights |K^-1 k_q|_1 of 10-70, so that the
-    // backward error of an fp32 LDL^T shows in the variance (4e-5 k(0) at N = 2305 on a random cloud); fp64 LDL^T there
-    // costs 3.8 instead of 2.1 ms (N = 4096) / 9.7 instead of 5.4 ms (N = 8192).  GPX_TRAIN_F64_MAX overrides both.
-    long thr = m->kern.id == GPX_KERNEL_THINPLATE ? 8192 : 2048;
+    long thr = m->kern.id == GPX_KERNEL_THINPLATE ? (1L << 20) : 2048;
     if (const char *e = std::getenv("GPX_TRAIN_F64_MAX"))
         thr = std::atol(e);
-    m->train64 = p == GPX_PREC_MIXED || ((p == GPX_PREC_F32 || p == GPX_PREC_F32_SPLIT) && m->npad <= thr);
+    bool f64_fits = true;
+    if (m->kern.id == GPX_KERNEL_THINPLATE && m->npad > 8192 && (p == GPX_PREC_F32 || p == GPX_PREC_F32_SPLIT)) {
+        size_t free_b = 0, total_b = 0;
+        const double need = 30.0 * (double)m->npad * (double)m->npad;  // 3 fp64 N x N buffers + the fp32 state + slack
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            f64_fits = need < 0.9 * (double)total_b;  // parked pool buffers are handed back on demand (gpx_trim in big_alloc)
+        else
+            (void)hipGetLastError();
+    }
+    m->train64 = p == GPX_PREC_MIXED || ((p == GPX_PREC_F32 || p == GPX_PREC_F32_SPLIT) && m->npad <= thr && f64_fits);
     m->prec = (p == GPX_PREC_F64 || m->train64) ? GPX_PREC_F64 : GPX_PREC_F32;
     m->esz = m->prec == GPX_PREC_F64 ? 8 : 4;
 }

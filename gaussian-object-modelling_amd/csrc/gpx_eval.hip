@@ -15,14 +15,14 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     const bool want_basis = tx || ty;
     double *g = grad;
     if (want_basis && !g) {
-        int rc = ensure((void **)&m->ws_grad, &m->ws_grad_doubles, sizeof(double) * 3 * nq);
+        int rc = ensure(m, (void **)&m->ws_grad, &m->ws_grad_doubles, sizeof(double) * 3 * nq);
         if (rc)
             return rc;
         g = m->ws_grad;
     }
     size_t need = predict_ws_doubles((long)nq, np, g != nullptr) * sizeof(double);
     if (need) {
-        int rc = ensure((void **)&m->ws_pred, &m->ws_pred_doubles, need);
+        int rc = ensure(m, (void **)&m->ws_pred, &m->ws_pred_doubles, need);
         if (rc)
             return rc;
     }
@@ -31,11 +31,12 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         if (rc)
             return rc;
         const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
-        if ((rc = ensure(&m->ws_kqp, &m->ws_kqp_bytes, e * qb * np)))
+        if ((rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * np)))
             return rc;
-        if ((rc = ensure(&m->ws_partial, &m->ws_partial_bytes, e * qb * m->nblk)))
+        // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
+        if ((rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
             return rc;
-        if (m->var_fit && (rc = ensure(&m->ws_coef, &m->ws_coef_bytes, e * qb * VAR_NCOEF)))
+        if (m->var_fit && (rc = ensure(m, &m->ws_coef, &m->ws_coef_bytes, sizeof(double) * qb * VAR_NCOEF)))
             return rc;
     }
     // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
@@ -73,8 +74,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 m->pipe_ev[i] = nullptr;
                 pipe = false;
             }
-        if (pipe && (ensure(&m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * np) != GPX_OK ||
-                     (m->var_fit && ensure(&m->ws_coef2, &m->ws_coef2_bytes, e * qb * VAR_NCOEF) != GPX_OK))) {
+        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * np) != GPX_OK ||
+                     (m->var_fit && ensure(m, &m->ws_coef2, &m->ws_coef2_bytes, sizeof(double) * qb * VAR_NCOEF) != GPX_OK))) {
             (void)hipGetLastError();
             pipe = false;  // no room for the second operand buffer: one stream, one buffer
         }
@@ -92,8 +93,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             void *coef_buf = buf ? m->ws_coef2 : m->ws_coef;
             if (pipe && bi >= 2)
                 (void)hipStreamWaitEvent(sp, m->pipe_ev[3 + buf], 0);  // the GEMM of batch bi - 2 has read this buffer
-            // The kernel operand holds k - fit with a per-query fit that is rank 5 in (q, p); the GEMM epilogue adds
-            // X * fit back from the model's five row-correction vectors (gpx_internal.hpp, "low-rank fit").
+            // The kernel operand holds k - fit with a per-query fit that is rank 14 in (q, p); the GEMM epilogue adds
+            // X * fit back, in fp64, from the model's 14 row-correction vectors (gpx_internal.hpp, "low-rank fit").
             hipEvent_t *kev = nullptr;  // brackets the Kqp launch of this batch (stats; only on the model's own stream)
             if (s == m->stream) {
                 while (m->kqp_ev.size() < 2 * (gi + 1)) {
@@ -105,17 +106,19 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 if (m->kqp_ev.size() >= 2 * (gi + 1))
                     kev = &m->kqp_ev[2 * gi];
             }
-            const char *fab = nullptr;  // rows a_q, b_q of the batch's coefficient array
+            const double *fab = nullptr;  // rows a_q, b_q, c_q of the batch's coefficient array
             if (m->var_fit) {
-                launch_var_fit(m->prec, m->cov, m->n, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                               qz + q0, coef_buf, (long)qb, sp);
-                fab = (const char *)coef_buf + e * qb * VAR_NCORR;
+                launch_var_fit(m->op64, m->cov, m->n, m->d_x, m->d_y, m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0,
+                               qy + q0, qz + q0, (double *)coef_buf, (long)qb, sp);
+                fab = (const double *)coef_buf + qb * VAR_NCORR;
             }
+            const int part_prec = m->var_fit ? GPX_PREC_F64 : m->prec;  // type of the partial sums
             if (kev)
                 (void)hipEventRecord(kev[0], sp);
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
-                launch_kqp_split(m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0,
-                                 qy + q0, qz + q0, kqp_buf, sp, (const float *)fab, (long)qb);
+                launch_kqp_split(m->var_fit && m->op64, m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, m->d_x, m->d_y,
+                                 m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, fab,
+                                 (long)qb);
                 if (kev)
                     (void)hipEventRecord(kev[1], sp);
                 if (pipe) {
@@ -125,20 +128,26 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
-                launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, (float *)m->ws_partial,
-                                   (long)qb, 2, s, np_rows, m->var_fit ? (const float *)m->t_corr : nullptr, np,
-                                   m->var_fit ? (const float *)coef_buf : nullptr, (long)qb);
+                launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, 2, s,
+                                   np_rows, m->var_fit ? m->d_corr : nullptr, np,
+                                   m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
                 }
                 if (pipe)
                     (void)hipEventRecord(m->pipe_ev[3 + buf], s);
-                launch_var_finish(m->prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+                launch_var_finish(part_prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
-            launch_kqp(m->prec, m->cov, m->n, np, m->t_x, m->t_y, m->t_z, (long)nv, (long)ntile, qx + q0, qy + q0,
-                       qz + q0, kqp_buf, sp, np_rows, fab, (long)qb);
+            {
+                // fp64 models and the fp64-formed fp32 operand read the model's fp64 points (differences do not depend
+                // on where the cloud sits); the fp32-formed operand reads the centred fp32 points
+                const bool c64 = m->prec == GPX_PREC_F64 || (m->var_fit && m->op64);
+                launch_kqp(c64, m->prec, m->prec == GPX_PREC_F64, m->cov, m->n, np, c64 ? (const void *)m->d_x : m->t_x,
+                           c64 ? (const void *)m->d_y : m->t_y, c64 ? (const void *)m->d_z : m->t_z, m->d_meta, (long)nv,
+                           (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, np_rows, fab, (long)qb);
+            }
             if (kev)
                 (void)hipEventRecord(kev[1], sp);
             if (pipe) {
@@ -162,7 +171,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)
-                a.rowcorr = m->t_corr, a.ldrc = np, a.colcoef = coef_buf, a.ldcc = (long)qb;
+                a.rowcorr = m->d_corr, a.ldrc = np, a.colcoef = (const double *)coef_buf, a.ldcc = (long)qb,
+                a.rowweight64 = m->d_dinv64;
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (ev)
                 (void)hipEventRecord(ev[0], s);
@@ -174,7 +184,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             if (pipe)
                 (void)hipEventRecord(m->pipe_ev[3 + buf], s);
             const int bm = gemm_rows_per_partial(m->prec, a);
-            launch_var_finish(m->prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
+            launch_var_finish(part_prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
         }
         m->gemm_ev_used_var = gi;
         m->kqp_ev_used = (s == m->stream) ? gi : 0;
@@ -239,7 +249,7 @@ static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
     // layout (host pinned and device alike): qx qy qz | f | v | grad | tx | ty
     const size_t doubles = total * (3 + 1 + 1 + 3 + 3 + 3);
     int rc;
-    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+    if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
         return rc;
     if (m->pin_doubles < doubles) {
         if (m->pin)
@@ -338,7 +348,7 @@ static int run_large(gpx_model *m, const gpx_pending &r)
     HIPCHK(hipSetDevice(m->device));
     const size_t S = std::min(SLICE, r.nq);
     int rc;
-    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * S * per_q)))
+    if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * S * per_q)))
         return rc;
     if (m->pin2_doubles < S * per_q) {
         for (int b = 0; b < 2; ++b) {
@@ -418,33 +428,16 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
     gpx_pending req{nq, qx, qy, qz, f, v, grad, tx, ty};
     if (nq > COMBINE_MAX_NQ)
         return run_large(m, req);
-    // flat combining: the calling thread either becomes the leader of a batch or waits for one
-    std::unique_lock<std::mutex> lk(m->qmtx);
-    m->pending.push_back(&req);
-    while (!req.done) {
-        if (!m->leader_active) {
-            m->leader_active = true;
-            std::vector<gpx_pending *> batch;
-            batch.swap(m->pending);
-            lk.unlock();
-            const int brc = run_requests(m, batch);
-            const std::string berr = brc ? g_err : std::string();
-            lk.lock();
-            for (gpx_pending *p : batch) {
-                p->rc = brc;
-                p->err = berr;
-                p->done = true;
-            }
-            m->leader_active = false;
-            m->qcv.notify_all();
-        } else {
-            m->qcv.wait(lk);
-        }
-    }
-    lk.unlock();
-    if (req.rc)
+    // flat combining (gpx_host.hpp): the calling thread either becomes the leader of a batch or waits for one
+    const int rc2 = m->combiner.submit(req, [m](std::vector<gpx_pending *> &batch, std::string &err) {
+        const int brc = run_requests(m, batch);
+        if (brc)
+            err = g_err;  // the leader's thread-local message travels to every caller of the batch
+        return brc;
+    });
+    if (rc2)
         g_err = req.err;
-    return req.rc;
+    return rc2;
 }
 
 // mean on all queries -> deterministic compaction of |f| <= f_tol -> variance of the survivors only; the caller holds
@@ -458,7 +451,7 @@ static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, cons
     const size_t nb = (nq + 255) / 256;
     // device staging: qx qy qz f_all | compacted sx sy sz fs vs (cap each) | idx (cap int64) | block counters | total
     const size_t doubles = nq * 4 + cap * 5 + cap + nb / 2 + 4;
-    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+    if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
         return rc;
     double *d = m->ws_host_io;
     double *dqx = d, *dqy = d + nq, *dqz = d + 2 * nq, *dfa = d + 3 * nq;
@@ -577,7 +570,7 @@ extern "C" int gpx_model_march_surface(const gpx_model *cm, const double *start_
             for (size_t j = 0; j < g; ++j)
                 for (size_t k = 0; k < g; ++k, ++q)
                     qx[q] = ax[i], qy[q] = ax[j], qz[q] = ax[k];
-        if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * 4 * nq)))
+        if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * 4 * nq)))
             return rc;
         double *d = m->ws_host_io;
         HIPCHK(hipMemcpyAsync(d, qx.data(), sizeof(double) * nq, hipMemcpyHostToDevice, m->stream));
@@ -721,7 +714,7 @@ extern "C" int gpx_model_project(const gpx_model *cm, size_t nq, const double *x
     hipStream_t s = m->stream;
     // device state: cx cy cz f_cur f_new (nq each) | g grad_new (3 nq each) | iter status (nq ints each) | active
     const size_t doubles = nq * 5 + nq * 6 + nq + 2;
-    if ((rc = ensure((void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
+    if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
         return rc;
     double *d = m->ws_host_io;
     double *cx = d, *cy = d + nq, *cz = d + 2 * nq, *fcur = d + 3 * nq, *fnew = d + 4 * nq;

@@ -80,14 +80,6 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_WAVES_PER_EU
 #define GEMM_WAVES_PER_EU 2
 #endif
-// How the COLSQ epilogue gets this tile's slices of the low-rank correction (5 row vectors, 5 column vectors):
-// 0: scattered global loads in the epilogue; 1: requested before the k-loop (registers), parked in LDS after it;
-// 2: cooperative coalesced loads after the k-loop, through LDS.  Measured (scripts/gemm_bench.hip, N = 16384, 8192
-// queries, 128 x 128 tiles): 15.69 / 16.44 / 16.16 ms -- with two workgroups per CU the other workgroup's MFMAs cover
-// the scattered loads, while the parked registers and the extra barrier of the LDS variants cost more than they save.
-#ifndef GEMM_CORR_STAGE
-#define GEMM_CORR_STAGE 0
-#endif
 // Padding (elements) of a [k][n] LDS row of the fp64 NN tiles (inverse-factor assembly).  A lane group fg reads k-rows
 // 2 fg and 2 fg + 1: with 2 elements of padding rows two apart start 8 banks apart and the 16-lane groups of one half
 // wave collide; see DESIGN.md for the measurement.
@@ -111,7 +103,10 @@ struct GemmDev {
     const T *rowweight;
     T *partial;
     long ldp;
-    const T *rowcorr, *colcoef;  // EPI_COLSQ: acc[m][n] += sum_c colcoef[c][n] * rowcorr[c][m], c < VAR_NCORR (null: none)
+    // EPI_COLSQ of an fp32 product with the low-rank fit added back (colcoef != null): the epilogue runs in fp64,
+    // w = acc[m][n] + sum_c colcoef[c][n] * rowcorr[c][m] (c < VAR_NCORR), partial64[mt][n] = sum_rows w^2 rowweight64[m]
+    const double *rowcorr, *colcoef, *rowweight64;
+    double *partial64;
     long ldrc, ldcc;
 };
 
@@ -286,29 +281,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 
                                         (wn * FN + j) * FR + fr];
     }
 
-    // ---- EPI_COLSQ with the low-rank correction: this tile's slices of the five row vectors and five column
-    // coefficient vectors go through LDS, so that the epilogue does not wait for ~200 scattered global loads per lane
     // (fp32 only: the fp64 contraction needs no correction, and its hinted main loop is sensitive to every extra
     // register -- with the correction code compiled in, the fp64 variance product dropped from 72.5 to 64 TFLOP/s)
     constexpr bool CORR_OK = (EPI == EPI_COLSQ) && sizeof(T) == 4;
-    constexpr int NPC = (CORR_OK && GEMM_CORR_STAGE != 0) ? ((BM + BN) * VAR_NCORR + NT - 1) / NT : 1;
-    T pc[NPC];
     const bool corr = CORR_OK && g.colcoef != nullptr;
-#define GPX_CORR_LOAD()                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < NPC; ++i_)                                                               \
-    {                                                                                                                \
-        const int e_ = tid + NT * i_;                                                                                \
-        T v_ = T(0);                                                                                                 \
-        if (e_ < VAR_NCORR * BM)                                                                                     \
-            v_ = g.rowcorr[(size_t)(e_ / BM) * g.ldrc + m0 + e_ % BM];                                               \
-        else if (e_ < VAR_NCORR * (BM + BN))                                                                         \
-            v_ = g.colcoef[(size_t)((e_ - VAR_NCORR * BM) / BN) * g.ldcc + n0 + (e_ - VAR_NCORR * BM) % BN];         \
-        pc[i_] = v_;                                                                                                 \
-    }
-    if constexpr (CORR_OK && GEMM_CORR_STAGE == 1) {
-        if (corr)
-            GPX_CORR_LOAD();
-    }
 
     // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
     // The last iteration re-loads its own tile (clamped index) so that nothing in the loop is conditional.
@@ -433,107 +409,104 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 
                 }
         }
     } else {  // EPI_COLSQ
-        T *red = smem;  // [WGM][BN], re-using the staging buffers (all waves are past the k-loop barrier)
-        // Low-rank correction of the contraction (gpx_eval.hip, "centred kernel operand"): the B operand holds
-        // k - fit with fit[n][k] = sum_c colcoef[c][n] b_c[k]; the product of A with the fit is added back here from
-        // rowcorr[c][m] = sum_k A[m][k] b_c[k], which was accumulated once per model in fp64.
+        // plain form: partial[mt][n] = sum over the tile's rows of acc^2 * rowweight[row], in T
+        // (the fp64 instantiation keeps exactly this form: its main loop's schedule -- 72.5 TFLOP/s -- changed with every
+        // other arrangement of the epilogue, down to 57 TFLOP/s)
+#define GPX_COLSQ_PLAIN()                                                                          \
+    {                                                                                              \
+        T *red = smem; /* [WGM][BN], re-using the staging buffers (all waves are past the k-loop barrier) */ \
+        T w[FM][NACC];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int r = 0; r < NACC; ++r)      \
+            w[i][r] = g.rowweight[m0 + (wm * FM + i) * FR + MF::crow(lane, r)];                    \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j)                                             \
+        {                                                                                          \
+            T s = T(0);                                                                            \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int r = 0; r < NACC; ++r)  \
+                s += acc[i][j][r] * acc[i][j][r] * w[i][r];                                        \
+            if constexpr (FR == 16)                                                                \
+                s += __shfl_xor(s, 16);                                                            \
+            s += __shfl_xor(s, 32);                                                                \
+            if (fg == 0)                                                                           \
+                red[wm * BN + (wn * FN + j) * FR + fr] = s;                                        \
+        }                                                                                          \
+        __syncthreads();                                                                           \
+        for (int c = tid; c < BN; c += NT) {                                                       \
+            T s = T(0);                                                                            \
+            _Pragma("unroll") for (int w2 = 0; w2 < WGM; ++w2) s += red[w2 * BN + c];              \
+            g.partial[(size_t)mt * g.ldp + n0 + c] = s;                                            \
+        }                                                                                          \
+    }
         if constexpr (!CORR_OK) {
-            // (the fp64 instantiation keeps exactly this form: its main loop's schedule -- 72.5 TFLOP/s -- changed
-            // with every other arrangement of the epilogue, down to 57 TFLOP/s)
-            T w[FM][NACC];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int r = 0; r < NACC; ++r)
-                    w[i][r] = g.rowweight[m0 + (wm * FM + i) * FR + MF::crow(lane, r)];
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                T s = T(0);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int r = 0; r < NACC; ++r)
-                        s += acc[i][j][r] * acc[i][j][r] * w[i][r];
-                if constexpr (FR == 16)
-                    s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                if (fg == 0)
-                    red[wm * BN + (wn * FN + j) * FR + fr] = s;
-            }
+            GPX_COLSQ_PLAIN();
         } else {
-        T colsum[FN];
-        T *cs = smem + WGM * BN;  // [VAR_NCORR][BM] row vectors | [VAR_NCORR][BN] column coefficients of this tile
-        if constexpr (CORR_OK && GEMM_CORR_STAGE != 0) {
-          if (corr) {
-            if constexpr (GEMM_CORR_STAGE == 2)
-                GPX_CORR_LOAD();
+            if (!corr) {
+                GPX_COLSQ_PLAIN();
+            } else {
+                // Low-rank correction of the contraction (gpx_eval.hip, "centred kernel operand"): the B operand holds
+                // k - fit with fit[n][k] = sum_c colcoef[c][n] b_c[k]; the product of A with the fit comes back here from
+                // rowcorr[c][m] = sum_k A[m][k] b_c[k] (fp64, once per model).  The 14 terms cancel among themselves and
+                // against the accumulator, so everything from here on is fp64: the sum, the square, 1/D, the column sums
+                // (fp32 row vectors and coefficients cost 9.5e-7 k(0) at N = 16384 thin-plate against 1.3e-7 in fp64,
+                // profiles/r03_tp_fit_probe.txt).  ~900 fp64 FMAs and LDS reads per lane: < 1 % of a tile's MFMA time.
+                // This tile's slices of the row vectors, the coefficient vectors and 1/D go through the (now idle) LDS.
+                double *ds = reinterpret_cast<double *>(gemm_smem_raw);
+                double *rowc = ds;                           // [VAR_NCORR][BM]
+                double *colc = rowc + VAR_NCORR * BM;        // [VAR_NCORR][BN]
+                double *roww = colc + VAR_NCORR * BN;        // [BM]
+                double *red64 = roww + BM;                   // [WGM][BN]
+                static_assert(sizeof(double) * (VAR_NCORR * (BM + BN) + BM + WGM * BN) <=
+                                  sizeof(T) * (2 * (size_t)A_TILE + 2 * (size_t)B_TILE),
+                              "the fp64 epilogue must fit the staging buffers");
+                for (int e = tid; e < VAR_NCORR * (BM + BN) + BM; e += NT) {
+                    double v;
+                    if (e < VAR_NCORR * BM) {
+                        v = g.rowcorr[(size_t)(e / BM) * g.ldrc + m0 + e % BM];
+                    } else if (e < VAR_NCORR * (BM + BN)) {
+                        const int e2 = e - VAR_NCORR * BM;
+                        v = g.colcoef[(size_t)(e2 / BN) * g.ldcc + n0 + e2 % BN];
+                    } else {
+                        v = g.rowweight64[m0 + e - VAR_NCORR * (BM + BN)];
+                    }
+                    ds[e] = v;
+                }
+                __syncthreads();
 #pragma unroll
-            for (int i = 0; i < NPC; ++i) {
-                const int e = tid + NT * i;
-                if (e < VAR_NCORR * (BM + BN))
-                    cs[e] = pc[i];
-            }
-            __syncthreads();
-          }
-        }
-        T ca[FN][VAR_NCORR];
-        if (corr) {
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int c = 0; c < VAR_NCORR; ++c)
-                    ca[j][c] = GEMM_CORR_STAGE != 0 ? cs[VAR_NCORR * BM + c * BN + (wn * FN + j) * FR + fr]
-                                                    : g.colcoef[(size_t)c * g.ldcc + n0 + (wn * FN + j) * FR + fr];
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-            colsum[j] = T(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            T w[NACC], sr[VAR_NCORR][NACC];
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                const int lrow = (wm * FM + i) * FR + MF::crow(lane, r);
-                w[r] = g.rowweight[m0 + lrow];
-                if (corr) {
+                for (int j = 0; j < FN; ++j) {
+                    const int lcol = (wn * FN + j) * FR + fr;
+                    double ca[VAR_NCORR];
 #pragma unroll
                     for (int c = 0; c < VAR_NCORR; ++c)
-                        sr[c][r] = GEMM_CORR_STAGE != 0 ? cs[c * BM + lrow] : g.rowcorr[(size_t)c * g.ldrc + m0 + lrow];
+                        ca[c] = colc[c * BN + lcol];
+                    double sj = 0.0;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int r = 0; r < NACC; ++r) {
+                            const int lrow = (wm * FM + i) * FR + MF::crow(lane, r);
+                            double w = (double)acc[i][j][r];
+#pragma unroll
+                            for (int c = 0; c < VAR_NCORR; ++c)
+                                w = fma(ca[c], rowc[c * BM + lrow], w);
+                            sj = fma(w * w, roww[lrow], sj);
+                        }
+                    if constexpr (FR == 16)
+                        sj += __shfl_xor(sj, 16);
+                    sj += __shfl_xor(sj, 32);
+                    if (fg == 0)
+                        red64[wm * BN + lcol] = sj;
+                }
+                __syncthreads();
+                for (int c = tid; c < BN; c += NT) {
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int w2 = 0; w2 < WGM; ++w2)
+                        s2 += red64[w2 * BN + c];
+                    g.partial64[(size_t)mt * g.ldp + n0 + c] = s2;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) {
-                    T a = acc[i][j][r];
-                    if (corr) {
-#pragma unroll
-                        for (int c = 0; c < VAR_NCORR; ++c)
-                            a += ca[j][c] * sr[c][r];
-                    }
-                    colsum[j] += a * a * w[r];
-                }
         }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            T s = colsum[j];
-            if constexpr (FR == 16)
-                s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (fg == 0)
-                red[wm * BN + (wn * FN + j) * FR + fr] = s;
-        }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            T s = T(0);
-#pragma unroll
-            for (int w2 = 0; w2 < WGM; ++w2)
-                s += red[w2 * BN + c];
-            g.partial[(size_t)mt * g.ldp + n0 + c] = s;
-        }
+#undef GPX_COLSQ_PLAIN
     }
-#undef GPX_CORR_LOAD
 }
 
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES = 128, bool M32 = false>
@@ -610,7 +583,8 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     g.colscale = (const T *)a.colscale;
     g.rowweight = (const T *)a.rowweight;
     g.partial = (T *)a.partial, g.ldp = a.ldp;
-    g.rowcorr = (const T *)a.rowcorr, g.colcoef = (const T *)a.colcoef;
+    g.rowcorr = a.rowcorr, g.colcoef = a.colcoef, g.rowweight64 = a.rowweight64;
+    g.partial64 = (double *)a.partial;
     g.ldrc = a.ldrc, g.ldcc = a.ldcc;
     const int cfg = pick_cfg(a, sizeof(T));
 #define GPX_GEMM_CFG(NN_, EPI_)                                                \

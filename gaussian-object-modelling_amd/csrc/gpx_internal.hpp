@@ -8,6 +8,7 @@
 #include <mutex>
 
 #include "../../include/gpx.h"
+#include "gpx_host.hpp"
 
 namespace gpx {
 
@@ -15,26 +16,21 @@ constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
 constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
 constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
-// terms of the low-rank fit taken out of the kernel operand of the variance contraction: {1, p_x, p_y, p_z, |p|^2}
-constexpr int VAR_NCORR = 5;
+// Terms of the low-rank fit taken out of the kernel operand of the variance contraction.  The fit is a polynomial of
+// degree two in s = |q - p|^2, which is rank 14 in (q, p): basis functions of the training point, relative to the
+// model's centre c (p' = p - c):  1 | p'_x p'_y p'_z | p'_x^2 p'_y^2 p'_z^2 p'_x p'_y p'_x p'_z p'_y p'_z |
+// |p'|^2 p'_x  |p'|^2 p'_y  |p'|^2 p'_z | |p'|^4
+constexpr int VAR_NCORR = 14;
+constexpr int VAR_NFIT = 3;                      // a_q, b_q, c_q of the fit a + b s + c s^2
+constexpr int VAR_NCOEF = VAR_NCORR + VAR_NFIT;  // rows of the per-batch coefficient array (doubles)
+constexpr int BLOB_META = 8;  // doubles at the end of state part 0: centre x y z, 1 / (sx sk) of the split operands, weight offset of the fit, reserved
 
 // Kernel attributes such as hipFuncAttributeMaxDynamicSharedMemorySize are PER DEVICE (and per kernel instantiation):
 // one flag per device ordinal, run under std::call_once so that concurrent builders on several host threads (or a
 // process that drives more than one GPU through gpx_options.device / gpx_model_replicate) each set them exactly once.
-constexpr int MAX_DEVICES = 64;
-struct PerDeviceOnce {
-    std::once_flag flag[MAX_DEVICES];
-    template <typename F>
-    void run(F &&f)
-    {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
-            f();  // unknown ordinal: set the attribute every time (idempotent)
-            return;
-        }
-        std::call_once(flag[dev], f);
-    }
-};
+// (gpx_host.hpp: the host-side machinery that is also built and run under sanitizers on the CPU)
+using gpxh::MAX_DEVICES;
+using gpxh::PerDeviceOnce;
 
 // Host-side description of a covariance function, lowered to Cov<T> for the device.
 struct CovHost {
@@ -78,32 +74,44 @@ void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x,
 void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile_max_ij, int *out_ij,
                            hipStream_t st);
 // ---- low-rank fit taken out of the kernel operand of the variance contraction (gpx_eval.hip) ----
-// Per query q the B operand holds k(d) - (a_q + b_q d^2): what a polynomial of degree one in
-// d^2 = |q|^2 - 2 q.p + |p|^2 cannot represent.  ANY (a_q, b_q) gives the same variance in exact arithmetic (the fit is
-// rank 5 in (q, p) and its product with the inverse factor is added back in the GEMM epilogue from five per-model
-// vectors); a good one shrinks the operand, and with it the fp32 rounding of the N-term contractions, by an order of
-// magnitude (thin-plate R = 4, N = 16384: variance error 2.0e-5 k(0) -> 1.1e-6).  (a_q, b_q) is the
-// least-squares line of k against d^2 over a strided sample of ~512 training points (all of them for small models),
-// so it follows the actual distances of the query, outliers such as the node's exterior sphere included.
+// Per query q the B operand holds k'(q, p) = k(d) - (a_q + b_q s + c_q s^2), s = d^2 = |q - p|^2: what a polynomial of
+// degree two in s cannot represent.  ANY (a_q, b_q, c_q) gives the same variance in exact arithmetic -- the fit is
+// rank 14 in (q, p) and its product with the inverse factor is added back in the GEMM epilogue, in fp64, from 14
+// per-model vectors X b_c accumulated in fp64; a good fit shrinks the operand and with it every fp32 error of the
+// N-term contraction (rounding of X, accumulation in the matrix core), which all scale with |k'|.  Round 3 measured
+// the pieces at N = 16384, thin-plate R = 4 (profiles/r03_tp_fit_probe.txt; variance error / max|v_ref|): degree-one
+// fit with the operand formed in fp32 and an fp32 add-back (round 2) 3.9e-5; degree two, operand formed in fp64 and
+// rounded once, fp64 add-back 7e-6.  The fit is a weighted least-squares parabola of k against s over a strided
+// sample of <= 512 training points, so it follows the distances the query actually sees.
 constexpr int VAR_FIT_SAMPLES = 512;
-constexpr int VAR_NCOEF = VAR_NCORR + 2;  // rows of the per-batch coefficient array: the 5 epilogue coefficients, a_q, b_q
-// coef (prec scalars, [VAR_NCOEF][ldcc]) for the queries [0, nq_tile) of a batch (zero from nq_valid on); px, py, pz:
-// the n training points as prec scalars
-void launch_var_fit(int prec, const CovHost &cov, int n, const void *px, const void *py, const void *pz, long nq_valid,
-                    long nq_tile, const double *qx, const double *qy, const double *qz, void *coef, long ldcc,
-                    hipStream_t st);
-// Kqp[q][j] = k(|q - p_j|) - (a_q + b_q |q - p_j|^2), q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
-// fab: rows a_q, b_q of launch_var_fit's array (prec scalars, stride ldcc), or null for the plain kernel values.
-void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
-                long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st,
+// weights 1 / (s + delta) of the least squares, delta = R_max^2 / VAR_FIT_WDELTA_DIV with R_max = Model::R, the largest
+// pairwise training distance (0.05 for the node's unit-ball clouds with their exterior sphere of radius 2);
+// GPX_VAR_FIT_WDELTA overrides delta itself, <= 0: uniform weights
+constexpr double VAR_FIT_WDELTA_DIV = 320.0;
+// coef (doubles, [VAR_NCOEF][ldcc]) for the queries [0, nq_tile) of a batch (zero from nq_valid on): rows 0..13 the
+// query-side coefficients of the 14 basis functions, rows 14..16 a_q, b_q, c_q.
+// px, py, pz: the model's fp64 points; cen (device): the model's meta block (centre in [0..2], weight offset in [4]).  op64: everything in fp64 (for the
+// operand kernel that forms k - fit in fp64); else centred points and query are rounded to fp32 and so are a, b, c --
+// the values the fp32 operand kernel uses, so that the identity fit = sum_c coef_c b_c holds exactly for what it subtracts.
+void launch_var_fit(bool op64, const CovHost &cov, int n, const double *px, const double *py, const double *pz,
+                    const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
+                    const double *qz, double *coef, long ldcc, hipStream_t st);
+// Kqp[q][j] = k(|q - p_j|) [- (a_q + b_q s + c_q s^2)], q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
+// compute64: distances, kernel and fit in fp64 from fp64 points px.. (differences are translation invariant: no
+// centring), rounded once to the output type; else fp32 arithmetic on the centred fp32 points, queries centred by
+// cen before rounding.  out_prec: GPX_PREC_F32 / _F64 = type of Kqp.  fab: rows a_q, b_q, c_q (doubles, stride ldcc) or
+// null for the plain kernel values.  accurate_math: the compiler library's sqrt / exp (fp64 models: pinned to the
+// reference classes) instead of the fast fp64 forms of gpx_cov.hpp.
+void launch_kqp(bool compute64, int out_prec, bool accurate_math, const CovHost &cov, int n, int npad, const void *px,
+                const void *py, const void *pz, const double *cen, long nq_valid, long nq_tile, const double *qx,
+                const double *qy, const double *qz, void *Kqp, hipStream_t st,
                 int ncols = 0,  // > 0: only the first ncols columns are written (columns in the padding are never read)
-                const void *fab = nullptr, long ldcc = 0);
+                const double *fab = nullptr, long ldcc = 0);
 
-// out (prec scalars, [VAR_NCORR][np]) = X b_c for b = {1, p_x, p_y, p_z, |p|^2} (fp64 accumulation); X: np x np
-// lower-triangular, fp64 if x_is_f64 (or prec is F64) else fp32; the points are `prec` scalars
-void launch_var_rowcorr(bool x_is_f64, int prec, int n, int np, const void *X, long ldx, const void *px, const void *py,
-                        const void *pz, void *out, hipStream_t st);
+// out (doubles, [VAR_NCORR][np]) = X b_c over the training points l < n, fp64 accumulation; X: np x np lower-triangular,
+// fp64 if x_is_f64 else fp32.  px..: the fp64 points, p' = p - cen (rounded to fp32 unless op64, as in launch_var_fit).
+void launch_var_rowcorr(bool x_is_f64, bool op64, int n, int np, const void *X, long ldx, const double *px,
+                        const double *py, const double *pz, const double *cen, double *out, hipStream_t st);
 
 // ---- prediction : gpx_predict.hip -----------------------------------------------------------
 // f[q] = sum_j k(|q-p_j|) alpha_j ; grad[q] = sum_j alpha_j k'(.)(q-p_j)  (double outputs).
@@ -140,7 +148,8 @@ void launch_residual(int n, const double *y, const double *f, const double *s2, 
                      double *rmax, hipStream_t st);
 void launch_axpy_cast(int prec, int n, int npad, double *alpha_d, const void *delta /*T*/, void *alpha_t,
                       hipStream_t st);  // alpha_d += delta ; alpha_t = (T)alpha_d (zero padded)
-void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st);
+void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st,
+                     double offset = 0.0);  // dst[i] = (T)(src[i] - offset), zero from n on
 void launch_normalize_rows3(long n, double *g, hipStream_t st);
 void launch_cast_d2f(size_t n, const double *src, float *dst, hipStream_t st);
 void launch_cast_f2d(size_t n, const float *src, double *dst, hipStream_t st);
@@ -173,9 +182,12 @@ struct GemmArgs {
     const void *rowweight = nullptr; // EPI_COLSQ: partial[mt][n] = sum_rows acc^2 * rowweight[m]
     void *partial = nullptr;
     long ldp = 0;
-    const void *rowcorr = nullptr;   // EPI_COLSQ: acc[m][n] += sum_c colcoef[c][n] * rowcorr[c][m] before squaring
-    const void *colcoef = nullptr;   //   (c < VAR_NCORR; leading dimensions ldrc / ldcc; null: no correction)
-    long ldrc = 0, ldcc = 0;
+    // EPI_COLSQ, fp32 product with the low-rank fit added back (colcoef != null): the epilogue runs in fp64 --
+    // w = (double)acc[m][n] + sum_c colcoef[c][n] * rowcorr[c][m], partial64[mt][n] = sum_rows w^2 * rowweight64[m]
+    const double *rowcorr = nullptr;     // [VAR_NCORR][ldrc]
+    const double *colcoef = nullptr;     // [VAR_NCORR][ldcc]
+    const double *rowweight64 = nullptr; // 1/D in fp64
+    long ldrc = 0, ldcc = 0;             // (partial then holds doubles)
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
@@ -184,16 +196,22 @@ int gemm_tile_n(int cfg);
 
 // ---- split-fp16 variance contraction : gpx_vsplit.hip ------------------------------------------
 // in place: X (fp32, np x np) -> packed hi/lo halves with a device-chosen power-of-two scale sx;
-// dinv -> w = dinv / (sx sk)^2
-//   rowcorr ([VAR_NCORR][np] or null): the row-correction vectors of the fit, scaled by sx sk in place
+// dinv -> w = dinv / (sx sk)^2 (the weights of the plain epilogue); *inv_scale = 1 / (sx sk) (the fp64 epilogue
+// brings the accumulators back to true units with it before the fit is added)
 void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st,
-                          float *rowcorr = nullptr);
-void launch_kqp_split(const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
-                      long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st, const float *fab = nullptr, long ldcc = 0);
-void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial, long ldp,
-                        int prefetch, hipStream_t st, int m_rows = 0, const float *rowcorr = nullptr, long ldrc = 0,
-                        const float *colcoef = nullptr, long ldcc = 0);
+                          double *inv_scale = nullptr);
+// fab: rows a_q, b_q, c_q (doubles) of the fit or null; compute64: the operand is formed in fp64 from the fp64 points
+// px64.., else in fp32 from the centred fp32 points px.. (queries centred by cen)
+void launch_kqp_split(bool compute64, const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
+                      const double *px64, const double *py64, const double *pz64, const double *cen, long nq_valid,
+                      long nq_tile, const double *qx, const double *qy, const double *qz, void *P, hipStream_t st,
+                      const double *fab = nullptr, long ldcc = 0);
+// colcoef != null: fp64 epilogue (rowcorr, colcoef, dinv64, inv_scale as above; partial holds doubles); else the plain
+// fp32 epilogue with the scaled weights w
+void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial, long ldp,
+                        int prefetch, hipStream_t st, int m_rows = 0, const double *rowcorr = nullptr, long ldrc = 0,
+                        const double *colcoef = nullptr, long ldcc = 0, const double *dinv64 = nullptr,
+                        const double *inv_scale = nullptr);
 
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower

@@ -74,13 +74,18 @@ struct gpx_model {
     double factor_gemm_flops = 0;     // algorithmic flops of the event-timed trailing-update launches
 
     // state blob part 0 = everything evaluate() reads besides X, internal order, npad each:
-    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | T x y z 1/D | T [VAR_NCORR][npad]:
-    //   X {1, p_x, p_y, p_z, |p|^2}, the row-correction vectors of the variance contraction
+    //   fp64 x y z alpha (the mean / gradient are always evaluated in fp64) | fp64 1/D | fp64 [VAR_NCORR][npad]: the
+    //   row-correction vectors X b_c of the variance contraction (gpx_internal.hpp) | T x' y' z' (points RELATIVE TO THE
+    //   CENTRE, so that fp32 arithmetic never sees where the cloud sits) | T 1/D | BLOB_META doubles: centre x y z,
+    //   1 / (sx sk) of the split operands, reserved
     void *blob0 = nullptr;
     size_t blob0_bytes = 0;
-    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;
-    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr, *t_corr = nullptr;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr, *d_dinv64 = nullptr, *d_corr = nullptr;
+    void *t_x = nullptr, *t_y = nullptr, *t_z = nullptr, *t_dinv = nullptr;
+    double *d_meta = nullptr;  // [0..2] centre (also the device-side `cen` argument), [3] 1 / (sx sk)
+    double cen[3] = {0, 0, 0};  // centroid of the training points (fp64), fixed at create / update
     bool var_fit = false;  // the low-rank fit is taken out of the kernel operand of the variance GEMM (fp32 modes)
+    bool op64 = true;      // ... and that operand, k - fit, is formed in fp64 and rounded once (GPX_VAR_OP64=0: in fp32)
     // other fp64 vectors (npad each): label s2 r f, then one double for max|r|
     double *dvecs = nullptr;
     double *d_lab = nullptr, *d_s2 = nullptr, *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;
@@ -102,7 +107,7 @@ struct gpx_model {
     size_t ws_kqp_bytes = 0;
     void *ws_partial = nullptr;
     size_t ws_partial_bytes = 0;
-    void *ws_coef = nullptr;  // [VAR_NCOEF][qbatch] query-side coefficients of the fit, a_q, b_q
+    void *ws_coef = nullptr;  // doubles [VAR_NCOEF][qbatch]: query-side coefficients of the fit, then a_q, b_q, c_q
     size_t ws_coef_bytes = 0;
     // second set for the two-deep pipeline of the variance batches (operand of batch i+1 built beside the GEMM of batch i)
     void *ws_kqp2 = nullptr, *ws_coef2 = nullptr;
@@ -117,10 +122,7 @@ struct gpx_model {
     // flat combining of concurrent small evaluate() calls (the node issues one call per grid point from
     // hundreds of threads, src/gp_node.cpp:1027-1038): whoever finds no leader takes every pending request
     // and runs them as ONE device batch
-    std::mutex qmtx;
-    std::condition_variable qcv;
-    std::vector<struct gpx_pending *> pending;
-    bool leader_active = false;
+    gpxh::FlatCombiner<gpx_pending> combiner;  // gpx_host.hpp
     double *pin = nullptr;  // pinned host staging of the combiner
     size_t pin_doubles = 0;
     double *pin2[2] = {nullptr, nullptr};  // pinned double buffer of the pipelined large-batch path
@@ -140,10 +142,36 @@ namespace gpxh {
 // scripts/la_check.py, create() wall 49 ms or 300-710 ms for 25 ms of device work).  Buffers of at least
 // BIG_POOL_MIN bytes released by one model are therefore parked in a per-process pool (per device, best fit within
 // 25 %) and handed to the next; GPX_POOL_MB caps the parked bytes (default 16384, 0 disables), gpx_trim() empties
-// the pool.  big_free() synchronises the device before parking, as hipFree would have.
-constexpr size_t BIG_POOL_MIN = (size_t)64 << 20;
-hipError_t big_alloc(void **p, size_t bytes);
+// the pool.  big_free() does NOT synchronise: the caller has waited for the work that used the buffer (quiesce(model):
+// the model's own streams and workspace event -- not the whole device, which would stall every other model and thread).
+hipError_t big_alloc(void **p, size_t bytes);  // BigPool of gpx_host.hpp over the HIP backend
 void big_free(void *p);
+// releases a device allocation when the scope is left on an error path (HIPCHK returns early); release() hands it on
+struct DevGuard {
+    void *p = nullptr;
+    bool big = false;  // from big_alloc (parked on release) or hipMalloc
+    DevGuard() = default;
+    DevGuard(void *q, bool b) : p(q), big(b) {}
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+    ~DevGuard() { reset(); }
+    void reset()
+    {
+        if (p) {
+            if (big)
+                big_free(p);
+            else
+                (void)hipFree(p);
+        }
+        p = nullptr;
+    }
+    void *release()
+    {
+        void *q = p;
+        p = nullptr;
+        return q;
+    }
+};
 
 // What a rank-n update carries over from the previous factorisation (device buffers of the OLD padded size)
 struct kept_factor {
@@ -168,8 +196,8 @@ constexpr size_t COMBINE_MAX_NQ = 4096;   // larger host calls fill the device o
 
 // ---- gpx_build.hip ----------------------------------------------------------------------------------
 void free_dev(gpx_model *m);
-int ensure(void **p, size_t *have, size_t need);
-void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm);
+void quiesce(gpx_model *m);
+int ensure(gpx_model *m, void **p, size_t *have, size_t need);
 int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes);
 void carve_blob0(gpx_model *m);
 int alloc_model(gpx_model *m);

@@ -3,13 +3,16 @@
 //   kbuild : K[i][j] = k(|p_i - p_j|) + sigma2_i * delta_ij   (lower block-triangle, 128x128 tiles)
 //            replaces buildEuclideanDistanceMatrix + the kernel loop of GPRegressor::create
 //            (reference gp_regressor.hpp:132-159, :548-557) and Kpp.maxCoeff() (:135).
-//   kqp    : Kqp[q][j] = k(|q - p_j|) for one batch of queries (gp_regressor.hpp:300-303), the
-//            B operand of the variance GEMM.
+//   kqp    : Kqp[q][j] = k(|q - p_j|) [- the per-query fit] for one batch of queries (gp_regressor.hpp:300-303),
+//            the B operand of the variance GEMM; var_fit / var_rowcorr: the fit and its per-model row vectors.
 //
 // Both are HBM-write-bound: every lane produces 4 consecutive columns and issues one 16-byte
 // (fp32) / two 16-byte (fp64) stores, a wave writes 2 x 512 contiguous bytes per instruction.
 // Distances are direct differences (dx^2+dy^2+dz^2): exact 0 on the diagonal, never negative
 // (documented deviation from the reference's norm expansion).
+#include <cstdlib>
+#include <type_traits>
+
 #include "gpx_cov.hpp"
 
 namespace gpx {
@@ -147,106 +150,181 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
     }
 }
 
-// Per-query fit of the variance contraction, once per query batch: (a_q, b_q) = least-squares line of k against
-// u = d^2 over every `stride`-th training point (sums in fp64: the normal equations cancel).  coef rows 0..4 = the
-// fit's query-side coefficients for b = {1, p_x, p_y, p_z, |p|^2}: {a_q + b_q |q|^2, -2 b_q q_xyz, b_q} (read by the GEMM
-// epilogue), rows 5, 6 = a_q, b_q (read by the kqp kernels).  Queries are rounded to T first: they are the coordinates
-// the kqp kernels use.
-template <typename T, int KID>
-__global__ __launch_bounds__(256) void var_fit_kernel(Cov<T> cov, int n, int stride, const T *__restrict__ px,
-                                                      const T *__restrict__ py, const T *__restrict__ pz, long nq_valid,
+// ---- the per-query fit of the variance contraction, once per query batch ------------------------------------------
+// (a, b, c) = weighted least-squares parabola of k against s = d^2 over every `stride`-th training point (<= 512 samples,
+// 16 lanes per query, the samples stay in registers), weights 1 / (s + wdelta) (wdelta <= 0: uniform): the rows of the
+// inverse factor weigh a query's NEAREST training points most, so that is where the residual should be smallest
+// (measured at N = 16384, variance error / max|v_ref|, thin-plate R = 4: uniform 7.1e-6, wdelta = 0.05 3.8e-6;
+// Matern-5/2 1.8e-6 -> 8.5e-7; profiles/r03_fit_variants_*.txt).  wdelta is a per-model number (R_max^2 / 320).  The normal
+// equations are solved by orthogonalising 1, s, s^2 against the weights; a degenerate direction (all sampled distances
+// equal, fewer than three samples) simply gets no coefficient -- any (a, b, c) yields the same variance.
+// coef rows 0..13: query-side coefficients of the 14 basis functions of gpx_internal.hpp for
+//   a + b s + c s^2,   s = |q'|^2 - 2 q'.p' + |p'|^2   (q', p' relative to the model's centre)
+// rows 14..16: a, b, c (read by the operand kernels).
+// px.. are the model's fp64 points.  R32 = false: p' = p - cen, q' = q - cen in fp64.  R32 = true (fp32 operand kernel):
+// p' = (float)(p - cen) -- the stored centred fp32 points --, q' = (float)(q - cen), and a, b, c are rounded to fp32:
+// exactly the numbers that kernel works with, so that fit = sum_c coef_c b_c holds for what it subtracts.
+constexpr int FIT_PER_LANE = VAR_FIT_SAMPLES / 16;
+
+template <bool R32, int KID>
+__global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, int stride, const double *__restrict__ px,
+                                                      const double *__restrict__ py, const double *__restrict__ pz,
+                                                      const double *__restrict__ cen, long nq_valid,
                                                       long nq_tile, const double *__restrict__ qx,
                                                       const double *__restrict__ qy, const double *__restrict__ qz,
-                                                      T *__restrict__ coef, long ldcc)
+                                                      double *__restrict__ coef, long ldcc)
 {
-    // 16 lanes share a query: lane `sub` takes the samples sub, sub + 16, ... of the strided list
+    constexpr bool P64 = !R32;
     const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
     if (q >= nq_tile)
         return;
-    T fa = T(0), fb = T(0), ax = T(0), ay = T(0), az = T(0);
+    double fa = 0, fb = 0, fc = 0, ax = 0, ay = 0, az = 0;
+    const double wdelta = cen[4];  // meta block of the model: centre x y z, 1 / (sx sk), weight offset of this fit
     if (q < nq_valid) {
-        ax = (T)qx[q], ay = (T)qy[q], az = (T)qz[q];
-        double s1 = 0, su = 0, suu = 0, sk = 0, suk = 0;
-        for (int l = sub * stride; l < n; l += 16 * stride) {
-            const T dx = ax - px[l], dy = ay - py[l], dz = az - pz[l];
-            const T d2 = dx * dx + dy * dy + dz * dz;
-            const double u = (double)d2, kv = (double)cov_k<T, KID>(cov, d2);
-            s1 += 1.0;
-            su += u;
-            suu = fma(u, u, suu);
-            sk += kv;
-            suk = fma(u, kv, suk);
+        ax = qx[q] - cen[0], ay = qy[q] - cen[1], az = qz[q] - cen[2];
+        if constexpr (!P64)
+            ax = (double)(float)ax, ay = (double)(float)ay, az = (double)(float)az;
+        double sv[FIT_PER_LANE], kv[FIT_PER_LANE], wv[FIT_PER_LANE];
+        double sw = 0, sws = 0, swk = 0;
+#pragma unroll
+        for (int i = 0; i < FIT_PER_LANE; ++i) {
+            const int l = (sub + 16 * i) * stride;
+            sv[i] = kv[i] = wv[i] = 0.0;
+            if (l < n) {
+                double bx = px[l] - cen[0], by = py[l] - cen[1], bz = pz[l] - cen[2];
+                if constexpr (!P64)
+                    bx = (double)(float)bx, by = (double)(float)by, bz = (double)(float)bz;
+                const double dx = ax - bx, dy = ay - by, dz = az - bz;
+                const double u = dx * dx + dy * dy + dz * dz;
+                sv[i] = u;
+                kv[i] = cov_k<double, KID, MathFast>(cov, u + 1e-300);
+                wv[i] = wdelta > 0.0 ? 1.0 / (u + wdelta) : 1.0;
+                sw += wv[i];
+                sws = fma(wv[i], u, sws);
+                swk = fma(wv[i], kv[i], swk);
+            }
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
-            s1 += __shfl_xor(s1, off);
-            su += __shfl_xor(su, off);
-            suu += __shfl_xor(suu, off);
-            sk += __shfl_xor(sk, off);
-            suk += __shfl_xor(suk, off);
+            sw += __shfl_xor(sw, off);
+            sws += __shfl_xor(sws, off);
+            swk += __shfl_xor(swk, off);
         }
-        const double det = s1 * suu - su * su;
-        double b = 0.0;
-        if (det > 1e-12 * s1 * suu)
-            b = (s1 * suk - su * sk) / det;
-        fb = (T)b;
-        fa = (T)((sk - (double)fb * su) / s1);
+        // orthogonal polynomials under the weights: p0 = 1, p1 = s - m1, p2 = s^2 - al p1 - be
+        const double m1 = sws / sw, a0 = swk / sw;
+        double s11 = 0, s1k = 0, s21 = 0, s20 = 0;
+#pragma unroll
+        for (int i = 0; i < FIT_PER_LANE; ++i) {
+            const double p1 = sv[i] - m1, w = wv[i];
+            s11 = fma(w * p1, p1, s11);
+            s1k = fma(w * p1, kv[i], s1k);
+            s21 = fma(w * p1, sv[i] * sv[i], s21);
+            s20 = fma(w, sv[i] * sv[i], s20);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            s11 += __shfl_xor(s11, off);
+            s1k += __shfl_xor(s1k, off);
+            s21 += __shfl_xor(s21, off);
+            s20 += __shfl_xor(s20, off);
+        }
+        const double scale2 = sws * sws / sw;  // ~ sum w s^2: what s11 is compared against
+        const bool ok1 = s11 > 1e-10 * scale2 && s11 > 0.0;
+        const double b1 = ok1 ? s1k / s11 : 0.0, al = ok1 ? s21 / s11 : 0.0, be = s20 / sw;
+        double s22 = 0, s2k = 0;
+#pragma unroll
+        for (int i = 0; i < FIT_PER_LANE; ++i) {
+            const double p2 = sv[i] * sv[i] - al * (sv[i] - m1) - be, w = wv[i];
+            s22 = fma(w * p2, p2, s22);
+            s2k = fma(w * p2, kv[i], s2k);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            s22 += __shfl_xor(s22, off);
+            s2k += __shfl_xor(s2k, off);
+        }
+        const bool ok2 = ok1 && s22 > 1e-10 * s20 * be && s22 > 0.0;
+        const double c2 = ok2 ? s2k / s22 : 0.0;
+        // a0 + b1 (s - m1) + c2 (s^2 - al (s - m1) - be) as a + b s + c s^2
+        fa = a0 - b1 * m1 + c2 * (al * m1 - be);
+        fb = b1 - c2 * al;
+        fc = c2;
+        if constexpr (!P64)
+            fa = (double)(float)fa, fb = (double)(float)fb, fc = (double)(float)fc;
     }
     if (sub != 0)
         return;
-    coef[q] = fa + fb * (ax * ax + ay * ay + az * az);
-    coef[ldcc + q] = T(-2) * fb * ax;
-    coef[2 * ldcc + q] = T(-2) * fb * ay;
-    coef[3 * ldcc + q] = T(-2) * fb * az;
-    coef[4 * ldcc + q] = fb;
-    coef[5 * ldcc + q] = fa;
-    coef[6 * ldcc + q] = fb;
+    const double q2 = ax * ax + ay * ay + az * az;
+    const double lin = -2.0 * fb - 4.0 * fc * q2, dg = fb + 2.0 * fc * q2;
+    coef[q] = fa + q2 * (fb + fc * q2);
+    coef[1 * ldcc + q] = lin * ax;
+    coef[2 * ldcc + q] = lin * ay;
+    coef[3 * ldcc + q] = lin * az;
+    coef[4 * ldcc + q] = dg + 4.0 * fc * ax * ax;
+    coef[5 * ldcc + q] = dg + 4.0 * fc * ay * ay;
+    coef[6 * ldcc + q] = dg + 4.0 * fc * az * az;
+    coef[7 * ldcc + q] = 8.0 * fc * ax * ay;
+    coef[8 * ldcc + q] = 8.0 * fc * ax * az;
+    coef[9 * ldcc + q] = 8.0 * fc * ay * az;
+    coef[10 * ldcc + q] = -4.0 * fc * ax;
+    coef[11 * ldcc + q] = -4.0 * fc * ay;
+    coef[12 * ldcc + q] = -4.0 * fc * az;
+    coef[13 * ldcc + q] = fc;
+    coef[14 * ldcc + q] = fa;
+    coef[15 * ldcc + q] = fb;
+    coef[16 * ldcc + q] = fc;
 }
 
-void launch_var_fit(int prec, const CovHost &h, int n, const void *px, const void *py, const void *pz, long nq_valid,
-                    long nq_tile, const double *qx, const double *qy, const double *qz, void *coef, long ldcc,
-                    hipStream_t st)
+void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const double *py, const double *pz,
+                    const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
+                    const double *qz, double *coef, long ldcc, hipStream_t st)
 {
     const dim3 grid((unsigned)((nq_tile + 15) / 16));
     const int stride = (n + VAR_FIT_SAMPLES - 1) / VAR_FIT_SAMPLES;
-    if (prec == GPX_PREC_F64) {
-        Cov<double> c = lower_cov<double>(h);
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<double, KID>), grid, dim3(256), 0, st, c, n, stride,
-                                                  (const double *)px, (const double *)py, (const double *)pz, nq_valid,
-                                                  nq_tile, qx, qy, qz, (double *)coef, ldcc));
+    Cov<double> c = lower_cov<double>(h);
+    if (op64) {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), grid, dim3(256), 0, st, c, n, stride, px,
+                                                  py, pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     } else {
-        Cov<float> c = lower_cov<float>(h);
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<float, KID>), grid, dim3(256), 0, st, c, n, stride,
-                                                  (const float *)px, (const float *)py, (const float *)pz, nq_valid,
-                                                  nq_tile, qx, qy, qz, (float *)coef, ldcc));
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID>), grid, dim3(256), 0, st, c, n, stride, px,
+                                                  py, pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     }
 }
 
-// fab != null: Kqp holds k(d) - (a_q + b_q d^2) with the per-query fit (a_q, b_q) = fab[q], fab[ldcc + q] of
-// var_fit_kernel; fab == null: the plain kernel values.
-template <typename T, int KID>
-__global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ px,
-                                                  const T *__restrict__ py, const T *__restrict__ pz,
-                                                  long nq_valid, const double *__restrict__ qx,
-                                                  const double *__restrict__ qy, const double *__restrict__ qz,
-                                                  T *__restrict__ Kqp, const T *__restrict__ fab, long ldcc)
+// ---- the kernel operand of one variance batch ---------------------------------------------------------------------
+// TC: arithmetic of distances, kernel and fit (double: from the fp64 points as they are -- differences do not see the
+// position of the cloud; float: from the centred fp32 points, the queries centred before rounding); TO: what is stored.
+// With TC = double, TO = float the residual k - fit is formed in fp64 and rounded ONCE: its error is 6e-8 of the
+// (small) residual, where forming k and the fit separately in fp32 costs 6e-8 of k(0) each (measured: 1.2e-7 k(0) of
+// variance error from the operand alone at N = 16384 thin-plate, against 2e-9 -- profiles/r03_tp_fit_probe.txt).
+template <typename TC, typename TO, int KID, typename M>
+__global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, const TC *__restrict__ px,
+                                                  const TC *__restrict__ py, const TC *__restrict__ pz,
+                                                  const double *__restrict__ cen, long nq_valid,
+                                                  const double *__restrict__ qx, const double *__restrict__ qy,
+                                                  const double *__restrict__ qz, TO *__restrict__ Kqp,
+                                                  const double *__restrict__ fab, long ldcc)
 {
-    __shared__ T rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
+    __shared__ TC rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE], rfc[TILE];
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.y * TILE;
     if (tid < TILE) {
         long q = q0 + tid;
         bool ok = q < nq_valid;
-        rx[tid] = ok ? (T)qx[q] : T(0);
-        ry[tid] = ok ? (T)qy[q] : T(0);
-        rz[tid] = ok ? (T)qz[q] : T(0);
-        rfa[tid] = fab ? fab[q] : T(0);
-        rfb[tid] = fab ? fab[ldcc + q] : T(0);
+        // fp32 arithmetic works in coordinates relative to the model's centre (the fp32 points are stored that way)
+        const double c0 = sizeof(TC) == 4 ? cen[0] : 0.0, c1 = sizeof(TC) == 4 ? cen[1] : 0.0,
+                     c2 = sizeof(TC) == 4 ? cen[2] : 0.0;
+        rx[tid] = ok ? (TC)(qx[q] - c0) : TC(0);
+        ry[tid] = ok ? (TC)(qy[q] - c1) : TC(0);
+        rz[tid] = ok ? (TC)(qz[q] - c2) : TC(0);
+        rfa[tid] = fab ? (TC)fab[q] : TC(0);
+        rfb[tid] = fab ? (TC)fab[ldcc + q] : TC(0);
+        rfc[tid] = fab ? (TC)fab[2 * ldcc + q] : TC(0);
     }
     const int tx = tid & 31, ty = tid >> 5;
     const int gj0 = blockIdx.x * TILE + tx * 4;
-    T cx[4], cy[4], cz[4];
+    TC cx[4], cy[4], cz[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         cx[c] = px[gj0 + c];
@@ -258,40 +336,64 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<T> cov, int n, int npad, c
     for (int r = 0; r < 16; ++r) {
         const int li = ty + 8 * r;
         const long q = q0 + li;
-        const T ax = rx[li], ay = ry[li], az = rz[li], fa = rfa[li], fb = rfb[li];
-        T out[4];
+        const TC ax = rx[li], ay = ry[li], az = rz[li], fa = rfa[li], fb = rfb[li], fc = rfc[li];
+        TO out[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
-            T d2 = dx * dx + dy * dy + dz * dz;
-            T kv = cov_k<T, KID>(cov, d2) - (fa + fb * d2);
-            out[c] = (q < nq_valid && gj0 + c < n) ? kv : T(0);
+            TC dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            TC d2 = dx * dx + dy * dy + dz * dz;
+            TC kv;
+            if constexpr (sizeof(TC) == 8 && std::is_same<M, MathFast>::value)
+                kv = cov_k<TC, KID, M>(cov, d2 + 1e-300);  // the fast fp64 sqrt wants a positive argument
+            else
+                kv = cov_k<TC, KID, M>(cov, d2);
+            kv -= fa + d2 * (fb + fc * d2);
+            out[c] = (q < nq_valid && gj0 + c < n) ? (TO)kv : TO(0);
         }
-        store4<T>(Kqp + (size_t)q * npad + gj0, out);
+        store4<TO>(Kqp + (size_t)q * npad + gj0, out);
     }
 }
 
-// Row-correction vectors of the variance contraction: out[c][j] = sum_l X[j][l] b_c[l], b = {1, p_x, p_y, p_z, |p|^2}
-// over the training points l < n, accumulated in fp64 whatever the types (TX: X, T: points and output).  X is
-// lower-triangular: row j is read up to its diagonal.  One workgroup per row; ~N^2/2 reads once per model.
-template <typename TX, typename T>
+// Row-correction vectors of the variance contraction: out[c][j] = sum_l X[j][l] b_c(p'_l) for the 14 basis functions of
+// gpx_internal.hpp over the training points l < n, accumulated in fp64 (TX: type of X; px..: the model's fp64 points,
+// p' = p - cen, rounded to fp32 when R32 -- the coordinates the fp32 operand kernel uses).  X is lower-triangular: row j
+// is read up to its diagonal.  One workgroup per row; ~N^2/2 reads once per model.
+template <typename TX, bool R32>
 __global__ __launch_bounds__(256) void var_rowcorr_kernel(int n, int np, const TX *__restrict__ X, long ldx,
-                                                          const T *__restrict__ px, const T *__restrict__ py,
-                                                          const T *__restrict__ pz, T *__restrict__ out)
+                                                          const double *__restrict__ px, const double *__restrict__ py,
+                                                          const double *__restrict__ pz, const double *__restrict__ cen,
+                                                          double *__restrict__ out)
 {
     __shared__ double red[4][VAR_NCORR];
     const int j = blockIdx.x, tid = threadIdx.x;
     const int lend = min(n, j + 1);
-    double s[VAR_NCORR] = {0, 0, 0, 0, 0};
+    const double c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    double s[VAR_NCORR];
+#pragma unroll
+    for (int c = 0; c < VAR_NCORR; ++c)
+        s[c] = 0.0;
     const TX *row = X + (size_t)j * ldx;
     for (int l = tid; l < lend; l += 256) {
         const double xv = (double)row[l];
-        const double x = (double)px[l], y = (double)py[l], z = (double)pz[l];
+        double x = px[l] - c0, y = py[l] - c1, z = pz[l] - c2;
+        if constexpr (R32)
+            x = (double)(float)x, y = (double)(float)y, z = (double)(float)z;
+        const double r2 = x * x + y * y + z * z;
+        const double xx = xv * x, xy = xv * y, xz = xv * z, xr = xv * r2;
         s[0] += xv;
-        s[1] = fma(xv, x, s[1]);
-        s[2] = fma(xv, y, s[2]);
-        s[3] = fma(xv, z, s[3]);
-        s[4] = fma(xv, x * x + y * y + z * z, s[4]);
+        s[1] += xx;
+        s[2] += xy;
+        s[3] += xz;
+        s[4] = fma(xx, x, s[4]);
+        s[5] = fma(xy, y, s[5]);
+        s[6] = fma(xz, z, s[6]);
+        s[7] = fma(xx, y, s[7]);
+        s[8] = fma(xx, z, s[8]);
+        s[9] = fma(xy, z, s[9]);
+        s[10] = fma(xr, x, s[10]);
+        s[11] = fma(xr, y, s[11]);
+        s[12] = fma(xr, z, s[12]);
+        s[13] = fma(xr, r2, s[13]);
     }
 #pragma unroll
     for (int c = 0; c < VAR_NCORR; ++c) {
@@ -303,21 +405,27 @@ __global__ __launch_bounds__(256) void var_rowcorr_kernel(int n, int np, const T
     }
     __syncthreads();
     if (tid < VAR_NCORR)
-        out[(size_t)tid * np + j] = (T)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        out[(size_t)tid * np + j] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-void launch_var_rowcorr(bool x_is_f64, int prec, int n, int np, const void *X, long ldx, const void *px, const void *py,
-                        const void *pz, void *out, hipStream_t st)
+void launch_var_rowcorr(bool x_is_f64, bool op64, int n, int np, const void *X, long ldx, const double *px,
+                        const double *py, const double *pz, const double *cen, double *out, hipStream_t st)
 {
-    if (prec == GPX_PREC_F64)  // fp64 model: X is fp64 too
-        hipLaunchKernelGGL((var_rowcorr_kernel<double, double>), dim3(np), dim3(256), 0, st, n, np, (const double *)X, ldx,
-                           (const double *)px, (const double *)py, (const double *)pz, (double *)out);
-    else if (x_is_f64)
-        hipLaunchKernelGGL((var_rowcorr_kernel<double, float>), dim3(np), dim3(256), 0, st, n, np, (const double *)X, ldx,
-                           (const float *)px, (const float *)py, (const float *)pz, (float *)out);
-    else
-        hipLaunchKernelGGL((var_rowcorr_kernel<float, float>), dim3(np), dim3(256), 0, st, n, np, (const float *)X, ldx,
-                           (const float *)px, (const float *)py, (const float *)pz, (float *)out);
+#define GPX_ROWCORR(TX, R32)                                                                                         \
+    hipLaunchKernelGGL((var_rowcorr_kernel<TX, R32>), dim3(np), dim3(256), 0, st, n, np, (const TX *)X, ldx, px, py, pz, \
+                       cen, out)
+    if (x_is_f64) {
+        if (op64)
+            GPX_ROWCORR(double, false);
+        else
+            GPX_ROWCORR(double, true);
+    } else {
+        if (op64)
+            GPX_ROWCORR(float, false);
+        else
+            GPX_ROWCORR(float, true);
+    }
+#undef GPX_ROWCORR
 }
 
 template <typename T>
@@ -349,26 +457,35 @@ void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *o
     hipLaunchKernelGGL(reduce_tilemax_kernel, dim3(1), dim3(256), 0, st, ntiles, tmax, tij, out_ij);
 }
 
-template <typename T>
-static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz,
+template <typename TC, typename TO, typename M>
+static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void *py, const void *pz, const double *cen,
                   long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                  hipStream_t st, int ncols, const void *fab, long ldcc)
+                  hipStream_t st, int ncols, const double *fab, long ldcc)
 {
-    Cov<T> c = lower_cov<T>(h);
+    Cov<TC> c = lower_cov<TC>(h);
     dim3 grid((ncols > 0 ? ncols : npad) / TILE, (unsigned)(nq_tile / TILE));
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<T, KID>), grid, dim3(256), 0, st, c, n, npad,
-                                              (const T *)px, (const T *)py, (const T *)pz, nq_valid, qx, qy, qz,
-                                              (T *)Kqp, (const T *)fab, ldcc));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<TC, TO, KID, M>), grid, dim3(256), 0, st, c, n, npad,
+                                              (const TC *)px, (const TC *)py, (const TC *)pz, cen, nq_valid, qx, qy, qz,
+                                              (TO *)Kqp, fab, ldcc));
 }
 
-void launch_kqp(int prec, const CovHost &cov, int n, int npad, const void *px, const void *py, const void *pz,
-                long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *Kqp,
-                hipStream_t st, int ncols, const void *fab, long ldcc)
+void launch_kqp(bool compute64, int out_prec, bool accurate_math, const CovHost &cov, int n, int npad, const void *px,
+                const void *py, const void *pz, const double *cen, long nq_valid, long nq_tile, const double *qx,
+                const double *qy, const double *qz, void *Kqp, hipStream_t st, int ncols, const double *fab, long ldcc)
 {
-    if (prec == GPX_PREC_F64)
-        kqp_t<double>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fab, ldcc);
-    else
-        kqp_t<float>(cov, n, npad, px, py, pz, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fab, ldcc);
+#define GPX_KQP(TC, TO, M) \
+    kqp_t<TC, TO, M>(cov, n, npad, px, py, pz, cen, nq_valid, nq_tile, qx, qy, qz, Kqp, st, ncols, fab, ldcc)
+    if (out_prec == GPX_PREC_F64) {  // fp64 models: fp64 throughout, the library's sqrt / exp
+        GPX_KQP(double, double, MathAcc);
+    } else if (compute64) {
+        if (accurate_math)
+            GPX_KQP(double, float, MathAcc);
+        else
+            GPX_KQP(double, float, MathFast);
+    } else {
+        GPX_KQP(float, float, MathAcc);
+    }
+#undef GPX_KQP
 }
 
 }  // namespace gpx

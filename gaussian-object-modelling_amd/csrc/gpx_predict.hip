@@ -820,20 +820,20 @@ void launch_axpy_cast(int prec, int n, int npad, double *alpha_d, const void *de
 
 template <typename T>
 __global__ __launch_bounds__(256) void cast_vec_kernel(int n, int npad, const double *__restrict__ src,
-                                                       T *__restrict__ dst)
+                                                       T *__restrict__ dst, double offset)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i < npad)
-        dst[i] = i < n ? (T)src[i] : T(0);
+        dst[i] = i < n ? (T)(src[i] - offset) : T(0);
 }
 
-void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st)
+void launch_cast_vec(int prec, int n, int npad, const double *src, void *dst, hipStream_t st, double offset)
 {
     dim3 grid((npad + 255) / 256);
     if (prec == GPX_PREC_F64)
-        hipLaunchKernelGGL(cast_vec_kernel<double>, grid, dim3(256), 0, st, n, npad, src, (double *)dst);
+        hipLaunchKernelGGL(cast_vec_kernel<double>, grid, dim3(256), 0, st, n, npad, src, (double *)dst, offset);
     else
-        hipLaunchKernelGGL(cast_vec_kernel<float>, grid, dim3(256), 0, st, n, npad, src, (float *)dst);
+        hipLaunchKernelGGL(cast_vec_kernel<float>, grid, dim3(256), 0, st, n, npad, src, (float *)dst, offset);
 }
 
 __global__ __launch_bounds__(256) void cast_d2f_kernel(size_t n, const double *__restrict__ src,

@@ -57,23 +57,19 @@ __device__ __forceinline__ float pow2_scale_below_one(float amax)
     return ldexpf(1.0f, -e);
 }
 
-// scale_inv2[0] = 1 / (sx * sk)^2 ; w[j] = dinv[j] * scale_inv2 ; the VAR_NCORR row-correction vectors of the
-// low-rank fit (rowcorr, n each, may be null) are brought to the accumulators' units: *= sx sk (a power of two)
+// w[j] = dinv[j] / (sx sk)^2: the weights of the plain epilogue (accumulators in scaled units);
+// *inv_scale = 1 / (sx sk): what the fp64 epilogue multiplies the accumulators with before the fit is added back
 __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *dinv,
                                                             const unsigned *__restrict__ amax_bits, float sk, float *w,
-                                                            float *rowcorr)
+                                                            double *inv_scale)
 {
     const float sx = pow2_scale_below_one(__uint_as_float(*amax_bits));
     const float inv = 1.0f / (sx * sk);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
+    if (i < n)
         w[i] = dinv[i] * inv * inv;
-        if (rowcorr) {
-#pragma unroll
-            for (int c = 0; c < VAR_NCORR; ++c)
-                rowcorr[(size_t)c * n + i] *= sx * sk;
-        }
-    }
+    if (i == 0 && inv_scale)
+        *inv_scale = (double)inv;
 }
 
 // One call = the 8 consecutive k that ONE lane feeds to v_mfma_f32_32x32x16_f16.  The matrix core adds the 8
@@ -134,30 +130,36 @@ __global__ __launch_bounds__(256) void split_pack_kernel(float *__restrict__ X, 
 }
 
 // ---- Kqp tile straight into P16 --------------------------------------------------------------------------
-template <int KID>
-__global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk, int n, int npad,
-                                                        const float *__restrict__ px, const float *__restrict__ py,
-                                                        const float *__restrict__ pz, long nq_valid,
-                                                        const double *__restrict__ qx,
+// TC = float: plain kernel values from the centred fp32 points (queries centred by cen before rounding).
+// TC = double (with a fit): k - (a_q + b_q s + c_q s^2) formed in fp64 from the fp64 points and rounded once, as in
+// kqp_kernel (gpx_pairwise.hip).
+template <typename TC, int KID>
+__global__ __launch_bounds__(256) void kqp_split_kernel(Cov<TC> cov, float sk, int n, int npad,
+                                                        const TC *__restrict__ px, const TC *__restrict__ py,
+                                                        const TC *__restrict__ pz, const double *__restrict__ cen,
+                                                        long nq_valid, const double *__restrict__ qx,
                                                         const double *__restrict__ qy,
                                                         const double *__restrict__ qz, half_t *__restrict__ P,
-                                                        const float *__restrict__ fab, long ldcc)
+                                                        const double *__restrict__ fab, long ldcc)
 {
-    __shared__ float rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE];
+    __shared__ TC rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE], rfc[TILE];
     const int tid = threadIdx.x;
     const long q0 = (long)blockIdx.y * TILE;
     if (tid < TILE) {
         const long q = q0 + tid;
         const bool ok = q < nq_valid;
-        rx[tid] = ok ? (float)qx[q] : 0.0f;
-        ry[tid] = ok ? (float)qy[q] : 0.0f;
-        rz[tid] = ok ? (float)qz[q] : 0.0f;
-        rfa[tid] = fab ? fab[q] : 0.0f;  // per-query fit taken out of the kernel values (var_fit_kernel, gpx_pairwise.hip)
-        rfb[tid] = fab ? fab[ldcc + q] : 0.0f;
+        const double c0 = sizeof(TC) == 4 ? cen[0] : 0.0, c1 = sizeof(TC) == 4 ? cen[1] : 0.0,
+                     c2 = sizeof(TC) == 4 ? cen[2] : 0.0;
+        rx[tid] = ok ? (TC)(qx[q] - c0) : TC(0);
+        ry[tid] = ok ? (TC)(qy[q] - c1) : TC(0);
+        rz[tid] = ok ? (TC)(qz[q] - c2) : TC(0);
+        rfa[tid] = fab ? (TC)fab[q] : TC(0);  // per-query fit taken out of the kernel values (var_fit_kernel, gpx_pairwise.hip)
+        rfb[tid] = fab ? (TC)fab[ldcc + q] : TC(0);
+        rfc[tid] = fab ? (TC)fab[2 * ldcc + q] : TC(0);
     }
     const int tx = tid & 15, ty = tid >> 4;  // 16 lanes x 8 columns = 128 training points per row
     const int gj0 = blockIdx.x * TILE + tx * 8;
-    float cx[8], cy[8], cz[8];
+    TC cx[8], cy[8], cz[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         cx[c] = px[gj0 + c];
@@ -169,14 +171,19 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<float> cov, float sk
     for (int r = 0; r < 8; ++r) {
         const int li = ty + 16 * r;
         const long q = q0 + li;
-        const float ax = rx[li], ay = ry[li], az = rz[li], fit_a = rfa[li], fit_b = rfb[li];
+        const TC ax = rx[li], ay = ry[li], az = rz[li], fit_a = rfa[li], fit_b = rfb[li], fit_c = rfc[li];
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            const float kv = cov_k<float, KID>(cov, d2) - (fit_a + fit_b * d2);
-            v[c] = (q < nq_valid && gj0 + c < n) ? kv : 0.0f;
+            const TC dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            const TC d2 = dx * dx + dy * dy + dz * dz;
+            TC kv;
+            if constexpr (sizeof(TC) == 8)
+                kv = cov_k<TC, KID, MathFast>(cov, d2 + 1e-300);
+            else
+                kv = cov_k<TC, KID>(cov, d2);
+            kv -= fit_a + d2 * (fit_b + fit_c * d2);
+            v[c] = (q < nq_valid && gj0 + c < n) ? (float)kv : 0.0f;
         }
         half8 hi, lo;
         split8(v, sk, hi, lo);
@@ -191,10 +198,13 @@ struct VsplitDev {
     const unsigned char *A;  // P16 X,   row stride 4 K bytes
     const unsigned char *B;  // P16 Kqp, row stride 4 K bytes
     int M, N, K;             // rows of X, queries (multiples of 128), K (multiple of 32)
-    const float *w;          // per-row weight (1/D, scales folded in)
+    const float *w;          // per-row weight (1/D, scales folded in): plain epilogue
     float *partial;
     long ldp;
-    const float *rowcorr, *colcoef;  // low-rank fit added back before squaring (rowcorr pre-scaled by sx sk); null: none
+    // low-rank fit added back before squaring, in fp64 (colcoef != null): accumulators * inv_scale + sum_c colcoef rowcorr,
+    // squared, times dinv64, summed into partial64
+    const double *rowcorr, *colcoef, *dinv64, *inv_scale;
+    double *partial64;
     long ldrc, ldcc;
 };
 
@@ -334,59 +344,87 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
 
     // ---- epilogue: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
-    // low-rank correction, as in the COLSQ epilogue of gemm_kernel (gpx_gemm.hip): the B operand holds k - fit, the
-    // product of X with the fit comes back from the model's five row vectors (pre-scaled by sx sk) and the batch's
-    // five column coefficient vectors.  Plain global loads: staging them through LDS was measured slower (971 vs 929 ms
-    // per fast-mode bench step).
-    const bool corr = g.colcoef != nullptr;
-    float ca[2][VAR_NCORR];
-    if (corr) {
+    if (g.colcoef == nullptr) {
+        float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
+        float colsum[2] = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int c = 0; c < VAR_NCORR; ++c)
-                ca[j][c] = g.colcoef[(size_t)c * g.ldcc + n0 + wn * 64 + j * 32 + (lane & 31)];
-    }
-    float colsum[2] = {0.0f, 0.0f};
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float wr = g.w[row];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float wr = g.w[row];
-            float sr[VAR_NCORR];
-            if (corr) {
-#pragma unroll
-                for (int c = 0; c < VAR_NCORR; ++c)
-                    sr[c] = g.rowcorr[(size_t)c * g.ldrc + row];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
-                if (corr) {
-#pragma unroll
-                    for (int c = 0; c < VAR_NCORR; ++c)
-                        wv += ca[j][c] * sr[c];
+                for (int j = 0; j < 2; ++j) {
+                    const float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
+                    colsum[j] += wv * wv * wr;
                 }
-                colsum[j] += wv * wv * wr;
             }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s = colsum[j];
+            s += __shfl_xor(s, 32);
+            if (lane < 32)
+                red[wm * TILE + wn * 64 + j * 32 + lane] = s;
         }
+        __syncthreads();
+        if (tid < TILE)
+            g.partial[(size_t)mt * g.ldp + n0 + tid] = red[tid] + red[TILE + tid];
+        return;
+    }
+    // low-rank correction, as in the COLSQ epilogue of gemm_kernel (gpx_gemm.hip): the B operand holds k - fit, the
+    // product of X with the fit comes back in fp64 from the model's 14 row vectors and the batch's 14 coefficient
+    // vectors; the accumulators return to true units first (inv_scale = 1 / (sx sk), a power of two)
+    double *ds = reinterpret_cast<double *>(vs_smem);
+    double *rowc = ds;                       // [VAR_NCORR][TILE]
+    double *colc = rowc + VAR_NCORR * TILE;  // [VAR_NCORR][TILE]
+    double *roww = colc + VAR_NCORR * TILE;  // [TILE]
+    double *red64 = roww + TILE;             // [2][TILE]
+    static_assert(sizeof(double) * (2 * VAR_NCORR * TILE + 3 * TILE) <= 4 * (size_t)TILE_B, "fp64 epilogue must fit the staging buffers");
+    const double inv = *g.inv_scale;
+    for (int e = tid; e < 2 * VAR_NCORR * TILE + TILE; e += 256) {
+        double v;
+        if (e < VAR_NCORR * TILE) {
+            v = g.rowcorr[(size_t)(e / TILE) * g.ldrc + m0 + e % TILE];
+        } else if (e < 2 * VAR_NCORR * TILE) {
+            const int e2 = e - VAR_NCORR * TILE;
+            v = g.colcoef[(size_t)(e2 / TILE) * g.ldcc + n0 + e2 % TILE];
+        } else {
+            v = g.dinv64[m0 + e - 2 * VAR_NCORR * TILE];
+        }
+        ds[e] = v;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float s = colsum[j];
-        s += __shfl_xor(s, 32);
+        const int lcol = wn * 64 + j * 32 + (lane & 31);
+        double ca[VAR_NCORR];
+#pragma unroll
+        for (int c = 0; c < VAR_NCORR; ++c)
+            ca[c] = colc[c * TILE + lcol];
+        double sj = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                double w = ((double)acc[i][j][r] + (double)cor[i][j][r] * (1.0 / 2048.0)) * inv;
+#pragma unroll
+                for (int c = 0; c < VAR_NCORR; ++c)
+                    w = fma(ca[c], rowc[c * TILE + lrow], w);
+                sj = fma(w * w, roww[lrow], sj);
+            }
+        sj += __shfl_xor(sj, 32);
         if (lane < 32)
-            red[wm * TILE + wn * 64 + j * 32 + lane] = s;
+            red64[wm * TILE + lcol] = sj;
     }
     __syncthreads();
     if (tid < TILE)
-        g.partial[(size_t)mt * g.ldp + n0 + tid] = red[tid] + red[TILE + tid];
+        g.partial64[(size_t)mt * g.ldp + n0 + tid] = red64[tid] + red64[TILE + tid];
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------
 void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned *amax_bits, hipStream_t st,
-                          float *rowcorr)
+                          double *inv_scale)
 {
     // X (fp32) -> P16 in place; dinv -> w = dinv / (sx sk)^2 in place
     (void)hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
@@ -394,32 +432,41 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
     hipLaunchKernelGGL(split_absmax_kernel, dim3(2048), dim3(256), 0, st, X, n, amax_bits);
     hipLaunchKernelGGL(split_pack_kernel, dim3(4096), dim3(256), 0, st, X, n / 32, amax_bits);
     hipLaunchKernelGGL(split_weights_kernel, dim3((np + 255) / 256), dim3(256), 0, st, np, dinv_to_w, amax_bits, sk,
-                       dinv_to_w, rowcorr);
+                       dinv_to_w, inv_scale);
 }
 
-void launch_kqp_split(const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
-                      long nq_valid, long nq_tile, const double *qx, const double *qy, const double *qz, void *P,
-                      hipStream_t st, const float *fab, long ldcc)
+void launch_kqp_split(bool compute64, const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
+                      const double *px64, const double *py64, const double *pz64, const double *cen, long nq_valid,
+                      long nq_tile, const double *qx, const double *qy, const double *qz, void *P, hipStream_t st,
+                      const double *fab, long ldcc)
 {
-    Cov<float> c = lower_cov<float>(h);
     dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<KID>), grid, dim3(256), 0, st, c, sk, n, npad,
-                                              (const float *)px, (const float *)py, (const float *)pz, nq_valid, qx,
-                                              qy, qz, (half_t *)P, fab, ldcc));
+    if (compute64) {
+        Cov<double> c = lower_cov<double>(h);
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<double, KID>), grid, dim3(256), 0, st, c, sk, n, npad,
+                                                  px64, py64, pz64, cen, nq_valid, qx, qy, qz, (half_t *)P, fab, ldcc));
+    } else {
+        Cov<float> c = lower_cov<float>(h);
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<float, KID>), grid, dim3(256), 0, st, c, sk, n, npad,
+                                                  (const float *)px, (const float *)py, (const float *)pz, cen, nq_valid,
+                                                  qx, qy, qz, (half_t *)P, fab, ldcc));
+    }
 }
 
-void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, float *partial,
-                        long ldp, int prefetch, hipStream_t st, int m_rows, const float *rowcorr, long ldrc,
-                        const float *colcoef, long ldcc)
+void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial,
+                        long ldp, int prefetch, hipStream_t st, int m_rows, const double *rowcorr, long ldrc,
+                        const double *colcoef, long ldcc, const double *dinv64, const double *inv_scale)
 {
     VsplitDev g;
-    g.rowcorr = colcoef ? rowcorr : nullptr, g.colcoef = rowcorr ? colcoef : nullptr;
+    const bool corr = rowcorr && colcoef && dinv64 && inv_scale;
+    g.rowcorr = corr ? rowcorr : nullptr, g.colcoef = corr ? colcoef : nullptr;
+    g.dinv64 = dinv64, g.inv_scale = inv_scale;
     g.ldrc = ldrc, g.ldcc = ldcc;
     g.A = (const unsigned char *)Xp;
     g.B = (const unsigned char *)Kp;
     g.M = np, g.N = nq_tile, g.K = np;
     g.w = w;
-    g.partial = partial, g.ldp = ldp;
+    g.partial = (float *)partial, g.partial64 = (double *)partial, g.ldp = ldp;
     constexpr size_t shmem = 4 * (size_t)TILE * (128 + 16);
     static PerDeviceOnce attr_once;  // per device, see gpx_internal.hpp
     attr_once.run([&] {

@@ -276,21 +276,31 @@ public:
     // start == nullptr: the start point is searched on the 0.1 lattice as the node does.  Returns the number of cubes
     // sampled.  New entry (gpx_model_march_surface), not in the reference header.
     size_t marchSurface(Model::ConstPtr gp, const double *start_xyz, float leaf_size, float leaf_pass, Data::Ptr out,
-                        std::vector<double> &f, std::vector<double> &v, double f_tol = 0.01, size_t max_points = 1u << 22)
+                        std::vector<double> &f, std::vector<double> &v, double f_tol = 0.01, size_t max_points = 1u << 18,
+                        bool *truncated = nullptr)
     {
         if (!gp || !gp->handle_)
             throw GPRegressionException("Empty Model pointer");
         if (!out)
             throw GPRegressionException("Empty data pointer");
+        if (truncated)
+            *truncated = false;
         std::vector<double> xyz(3 * max_points);
         f.assign(max_points, 0.0);
         v.assign(max_points, 0.0);
         size_t n = 0, cubes = 0;
         const int rc = gpx_model_march_surface(gp->handle_, start_xyz, leaf_size, leaf_pass, f_tol, (size_t)1 << 24,
                                                max_points, xyz.data(), f.data(), v.data(), &n, &cubes);
-        if (rc != GPX_OK)
+        // more surface points than max_points: the first max_points (discovery order) are valid and are returned
+        if (rc == GPX_E_SIZE_MISMATCH && n > max_points) {
+            if (truncated)
+                *truncated = true;
+            n = max_points;
+        } else if (rc != GPX_OK) {
             throw GPRegressionException(message(rc));
+        }
         out->clear();
+        out->coord_x.reserve(n), out->coord_y.reserve(n), out->coord_z.reserve(n);
         for (size_t i = 0; i < n; ++i) {
             out->coord_x.push_back(xyz[3 * i]);
             out->coord_y.push_back(xyz[3 * i + 1]);

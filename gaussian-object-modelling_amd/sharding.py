@@ -50,19 +50,27 @@ def gather_slabs(dist, torch, local, nq, rank, world, dst=0):
     return torch.cat([bufs[r][: sizes[r]] for r in range(world)])
 
 
+VAR_NCORR = 14  # row-correction vectors of the variance contraction (csrc/gpx_internal.hpp)
+BLOB_META = 8   # doubles at the end of part 0: centre x y z, 1 / (sx sk) of the split operands, reserved
+
+
 def state_blob_layout(npad, esz):
     """Byte layout of state blob part 0 of a model (gpx_model_state_blob(m, 0), csrc/gpx_model.hpp): name -> (offset,
-    count, bytes per element).  fp64 x y z alpha (internal = pivot order, zero padded to npad), then in the working
-    type (esz = 4 or 8): x y z 1/D and the five row-correction vectors X {1, p_x, p_y, p_z, |p|^2} of the variance
-    contraction.  Part 1 is the npad x npad inverse factor X = L^-1 (row-major, working type)."""
+    count, bytes per element).  fp64 x y z alpha (internal = pivot order, zero padded to npad), fp64 1/D ("dinv64"),
+    the 14 fp64 row-correction vectors X b_c of the variance contraction ("corr"), then in the working type
+    (esz = 4 or 8) the points relative to the model's centre ("tx", "ty", "tz") and 1/D ("dinv"), then the meta block
+    (8 doubles: centre x y z, 1 / (sx sk), reserved).  Part 1 is the npad x npad inverse factor X = L^-1 (row-major,
+    working type)."""
     out, off = {}, 0
-    for name in ("x", "y", "z", "alpha"):
+    for name in ("x", "y", "z", "alpha", "dinv64"):
         out[name] = (off, npad, 8)
         off += 8 * npad
+    out["corr"] = (off, VAR_NCORR * npad, 8)
+    off += 8 * VAR_NCORR * npad
     for name in ("tx", "ty", "tz", "dinv"):
         out[name] = (off, npad, esz)
         off += esz * npad
-    out["corr"] = (off, 5 * npad, esz)
-    off += esz * 5 * npad
+    out["meta"] = (off, BLOB_META, 8)
+    off += 8 * BLOB_META
     out["bytes"] = off
     return out

@@ -68,8 +68,8 @@ typedef struct gpx_kernel {
  * mean / gradient are always evaluated in fp64):
  *   F32    kernel matrix, LDL^T and variance GEMM in fp32 (fp32 MFMA); alpha is refined with fp64 matrix-free
  *          residuals; the inverse factor is assembled in fp64 from the fp32 factor and rounded once; the variance
- *          GEMM contracts a centred kernel operand (k minus a per-query fit that is added back exactly in the
- *          epilogue), which keeps every kernel within 1e-5 of the fp64 result at N = 16384.  Models of up to 2048
+ *          GEMM contracts a centred kernel operand -- k minus a per-query parabola in the squared distance, formed in
+ *          fp64 and rounded once -- and its epilogue adds the fit back, squares, weights and sums in fp64.  Models of up to 2048
  *          padded rows -- 8192 for the thin plate -- (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED: (nearly)
  *          free at that size, and the fp32 LDL^T's backward error would otherwise show in the variance of
  *          ill-conditioned (thin-plate) systems; such models hold no factor afterwards, so gpx_model_update
@@ -247,10 +247,11 @@ int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_mod
  * d_rmax: reserved, pass NULL (Model::R comes from gpx_model_get). */
 int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_x,
                    const void *d_y, const void *d_z, const void *d_s2, void *d_K, void *d_rmax, void *stream);
-/* kqp: Kqp[q][j] = k(|q - p_j|) - (a_q + b_q |q - p_j|^2) for nq queries (a multiple of 128) against the n training
- * points, row-major nq x n_padded `precision` scalars -- the kernel operand of one variance batch (gp_regressor.hpp:
- * 300-303).  d_px,d_py,d_pz: `precision` scalars; d_qx,d_qy,d_qz: doubles; d_fab: the per-query fit as 2 x nq
- * `precision` scalars (a_q row, b_q row) or NULL for the plain kernel values. */
+/* kqp: Kqp[q][j] = k(|q - p_j|) - (a_q + b_q s + c_q s^2), s = |q - p_j|^2, for nq queries (a multiple of 128) against
+ * the n training points, row-major nq x n_padded `precision` scalars -- the kernel operand of one variance batch
+ * (gp_regressor.hpp:300-303).  d_px,d_py,d_pz (n_padded) and d_qx,d_qy,d_qz (nq): doubles; distances, kernel and fit are
+ * formed in fp64 and rounded once to `precision`.  d_fab: the per-query fit as 3 x nq doubles (rows a_q, b_q, c_q) or NULL
+ * for the plain kernel values. */
 int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_px, const void *d_py,
                 const void *d_pz, size_t nq, const void *d_qx, const void *d_qy, const void *d_qz, const void *d_fab,
                 void *d_Kqp, void *stream);

@@ -10,9 +10,9 @@ L = gpx.lib()
 n, npad, qb = 16384, 16384, 8192
 dev = torch.device("cuda:0")
 x, y, z, lab, s2 = ds.fibonacci_training_set(n)
-pts = [torch.from_numpy(a).to(dev).float().contiguous() for a in (x, y, z)]
+pts = [torch.from_numpy(a).to(dev).contiguous() for a in (x, y, z)]  # fp64 points (round 3: the operand is formed in fp64)
 q = [torch.linspace(-1, 1, qb, dtype=torch.float64, device=dev) for _ in range(3)]
-fab = torch.full((2 * qb,), 0.1, dtype=torch.float32, device=dev)
+fab = torch.full((3 * qb,), 0.1, dtype=torch.float64, device=dev)
 Kq = torch.empty(qb * npad, dtype=torch.float32, device=dev)
 kern = gpx.make_kernel("matern52", 1.0, 1.0)
 strm = torch.cuda.current_stream()

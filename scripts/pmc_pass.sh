@@ -13,6 +13,10 @@ n=$(echo $ctrs | wc -w)
 if [ "$n" -gt 4 ]; then echo "pmc_pass: $n counters in one pass (max 4): split the list" >&2; exit 2; fi
 limit=${PMC_TIMEOUT:-300}
 mkdir -p "$out"
+out=$(realpath "$out")   # rocprofv3 runs from /tmp below: a relative OUTDIR would land there ...
+args=()                   # ... and so would a relative program / script path: make every argument that names a file absolute
+for a in "$@"; do if [ -e "$a" ]; then args+=("$(realpath "$a")"); else args+=("$a"); fi; done
+set -- "${args[@]}"
 log="$out/pass.log"
 ( cd /tmp && TMPDIR=/tmp timeout -k 10 "$limit" rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out" -- "$@" ) > "$log" 2>&1
 rc=$?

@@ -71,3 +71,10 @@ def verr(v, vref, k0):
     v = k(0) - (quadratic form), so its rounding error scales with k(0) even where v itself is small."""
     v, vref = np.asarray(v, dtype=np.float64), np.asarray(vref, dtype=np.float64)
     return float(np.max(np.abs(v - vref)) / max(float(np.max(np.abs(vref))), float(k0)))
+
+
+def verr_v(v, vref):
+    """Variance error in SURVEY 8d's own metric: max|v - v_ref| / max|v_ref| (no k(0) in the denominator).  The stricter
+    of the two wherever max|v_ref| < k(0) -- thin plate R = 4 at N = 16384: max|v| = 1.1 against k(0) = 64."""
+    v, vref = np.asarray(v, dtype=np.float64), np.asarray(vref, dtype=np.float64)
+    return float(np.max(np.abs(v - vref)) / max(float(np.max(np.abs(vref))), 1e-300))

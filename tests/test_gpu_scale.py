@@ -5,7 +5,7 @@ alpha in the labels, 0 <= v <= k(0), and agreement of the fp32 pipeline with the
 import numpy as np
 import pytest
 
-from conftest import nerr, verr
+from conftest import nerr, verr, verr_v
 
 pytestmark = pytest.mark.gpu
 
@@ -82,21 +82,21 @@ def test_n16384_properties(gpu, ds, kn, par):
     o64 = g64.evaluate(qx, qy, qz, want_v=True, want_grad=True)
     for key in ("f", "grad"):
         assert nerr(o32[key], o64[key]) < 1e-6, key
-    # variance: every fp32 mode within the north-star 1e-5 of the fp64 pipeline, thin-plate (cond > 1e6, all kernel
-    # values in [R^3/2, R^3]) included: the contraction runs on k - (a_q + b_q d^2), a per-query fit whose product
-    # with the inverse factor is added back exactly in the GEMM epilogue (measured at N = 16384: thin-plate 2.0e-5 ->
-    # 1.1e-6, Matern-5/2 4.0e-6 -> 1.4e-6)
-    assert verr(o32["v"], o64["v"], k0) < 1e-5
+    # variance: every fp32 mode within the north-star 1e-5 of the fp64 pipeline IN BOTH NORMALISATIONS -- SURVEY 8d's
+    # max|dv| / max|v_ref| and the k(0)-scaled one -- thin-plate (cond > 1e6, k(0) = 64 against max|v| = 1.1 on this
+    # lattice) included: the contraction runs on k - (a_q + b_q s + c_q s^2), formed in fp64 and rounded once, and the
+    # GEMM epilogue adds the product of the inverse factor with the fit back in fp64
+    assert verr(o32["v"], o64["v"], k0) < 1e-5 and verr_v(o32["v"], o64["v"]) < 1e-5
     gmx = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.MIXED)
     omx = gmx.evaluate(qx, qy, qz, want_v=True)
-    assert verr(omx["v"], o64["v"], k0) < 1e-5
+    assert verr(omx["v"], o64["v"], k0) < 1e-5 and verr_v(omx["v"], o64["v"]) < 1e-5
     assert nerr(omx["f"], o64["f"]) < 1e-9
     gmx.close()
     # split-fp16 contraction (3 fp16 MFMA products on hi/lo halves whose hi parts share one quantum per MFMA
     # k-group, so that the matrix core's fixed-point product sum is exact), same centred operand
     gsp = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32_SPLIT)
     osp = gsp.evaluate(qx, qy, qz, want_v=True)
-    assert verr(osp["v"], o64["v"], k0) < 1e-5
+    assert verr(osp["v"], o64["v"], k0) < 1e-5 and verr_v(osp["v"], o64["v"]) < 1e-5
     assert nerr(osp["f"], o64["f"]) < 1e-6
     gsp.close()
     # (3) variance bounds for an SPD prior + noise: 0 <= v <= k(0)
@@ -136,7 +136,7 @@ def test_n16384_against_independent_golden(gpu, ds, kkey, kn, par):
         mtol = tol if prec in (gpu.F64,) else (1e-9 if prec == gpu.MIXED else 1e-6)  # mean / gradient are fp64 work
         assert nerr(out["f"], g[pre + "f"]) < mtol, prec
         assert nerr(out["grad"], g[pre + "grad"]) < mtol, prec
-        assert verr(out["v"], g[pre + "v"], k0) < tol, prec
+        assert verr(out["v"], g[pre + "v"], k0) < tol and verr_v(out["v"], g[pre + "v"]) < tol, prec
         gm.close()
 
 
@@ -162,7 +162,8 @@ def test_c4_slab_of_the_256_cubed_grid_on_a_committed_shell(gpu, ds):
         b.copy_(a)
         moved += a.numel()
     torch.cuda.synchronize()
-    assert moved == 4 * 8 * n + 9 * 4 * n + 4 * n * n  # fp64 x y z alpha | fp32 x y z 1/D + 5 correction vectors | X
+    # fp64 x y z alpha 1/D + 14 correction vectors | fp32 x' y' z' 1/D | meta block | X
+    assert moved == (5 + 14) * 8 * n + 4 * 4 * n + 8 * 8 + 4 * n * n
     dst.commit(with_variance=True)
     qx, qy, qz, first = ds.query_grid_slab(G, rank, world)
     lo, hi = sh.slab_range(G ** 3, rank, world)

@@ -88,10 +88,12 @@ def _state_worker(rank, world, port, q):
                 b0[off:off + cnt * w] = a.astype(np.float64).view(np.uint8)
 
             put("x", x[perm]), put("y", y[perm]), put("z", z[perm]), put("alpha", model.alpha[perm])
-            put("tx", x[perm]), put("ty", y[perm]), put("tz", z[perm])
+            cen = np.array([x.mean(), y.mean(), z.mean()])
+            put("tx", x[perm] - cen[0]), put("ty", y[perm] - cen[1]), put("tz", z[perm] - cen[2])
             dinv = np.ones(npad)
             dinv[:n] = 1.0 / D
-            put("dinv", dinv)
+            put("dinv", dinv), put("dinv64", dinv)
+            put("meta", np.array([cen[0], cen[1], cen[2], 1.0]))
             blob1.numpy()[:] = X.astype(np.float64).view(np.uint8).ravel()
         sh.broadcast_state(dist, [blob0, blob1], src=0)
         # ---- every rank: decode ("commit") and evaluate its slab from the blobs alone ----
@@ -137,7 +139,7 @@ def test_factor_blobs_travel_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ef < 1e-10 and ev < 1e-10  # the slab of rank 1 was computed from the broadcast blobs alone
-    assert nbytes == 8 * 512 * (4 + 4 + 5) + 8 * 512 * 512
+    assert nbytes == 8 * 512 * (5 + 14 + 4) + 8 * 8 + 8 * 512 * 512
 
 
 def test_sharded_grid_world2_gloo():
