@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", choices=["independent", "shard"], default="independent")
+    ap.add_argument("--state", choices=["broadcast", "recompute"], default="broadcast",
+                    help="--mode shard: how the ranks get the model -- rank 0 factorises and broadcasts the two state blobs "
+                         "over RCCL, or every rank builds the model itself (no communication at all); SURVEY 8e: measure both")
     ap.add_argument("--n-train", type=int, default=N_TRAIN)
     ap.add_argument("--nq", type=int, default=NQ)
     ap.add_argument("--precision", choices=["f32", "f64", "mixed", "f32split"], default="f32")
@@ -313,29 +316,37 @@ def main():
 
     model = [None]
     stats_acc = []
+    phases = []  # per step: (t_model, t_exchange, t_commit, t_predict) of this rank, seconds
 
     def step():
         if model[0] is not None:
             model[0].close()
-        if shard:
+        t0 = time.perf_counter()
+        t2 = t3 = None
+        if shard and args.state == "broadcast":
             if rank == 0:
                 m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank,
                               query_batch=args.query_batch)
             else:
                 m = gpx.Model.shell(kern, n_train, precision=prec, device=local_rank)
+            t1 = time.perf_counter()
             bufs = [sharding.device_blob_as_tensor(torch, *m.state_blob(part), dev)
                     for part in ((0, 1) if want_v else (0,))]
             sharding.broadcast_state(dist, bufs, src=0)
             torch.cuda.synchronize()
+            t2 = time.perf_counter()
             if rank != 0:
                 m.commit(with_variance=want_v)
-        else:
+            t3 = time.perf_counter()
+        else:  # independent models, or the sharded grid with every rank building the (same) model itself
             m = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=want_v, device=local_rank,
                           query_batch=args.query_batch)
+            t1 = t2 = t3 = time.perf_counter()
         model[0] = m
         m.evaluate_device(nq_local, qx.data_ptr(), qy.data_ptr(), qz.data_ptr(), f.data_ptr(),
                           v.data_ptr() if want_v else None)
         m.sync()
+        phases.append((t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3))
 
     def fence():
         torch.cuda.synchronize()
@@ -345,6 +356,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    phases.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -357,6 +369,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
+    shard_rec = None
+    if shard:  # phase times of every rank (means over the timed steps) -> the `shard` record on rank 0
+        mine = torch.tensor([sum(p[i] for p in phases) / len(phases) for i in range(4)], dtype=torch.float64, device=dev)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        shard_rec = sharding.shard_record(args.state, [tuple(p.tolist()) for p in allp])
+        shard_rec["state_bytes"] = int(sum(model[0].state_blob(part)[1] for part in ((0, 1) if want_v else (0,))))
     total_q = nq if shard else nq * world
     value = total_q / (elapsed / args.steps)
 
@@ -390,11 +409,14 @@ def main():
                                    "factor) + predict mean%s over N_query=%d lattice points of the 128^3 grid per %s"
                                    % (n_train, args.precision, args.kernel, ",".join(str(p) for p in kpar),
                                       "+variance" if want_v else "", nq, "job" if shard else "GPU"),
-                       "mode": args.mode, "n_train": n_train, "n_query": nq, "parallelism": "%s x%d" % (args.mode, world)},
+                       "mode": args.mode, "n_train": n_train, "n_query": nq,
+                       "parallelism": "%s x%d" % (args.mode + ("/" + args.state if shard else ""), world)},
             "stages_ms": {k: st[k] for k in ("t_kbuild_ms", "t_factor_ms", "t_factor_gemm_ms", "t_solve_ms",
                                              "t_inverse_ms", "t_mean_ms", "t_var_ms", "t_var_gemm_ms")},
             "alpha_residual": st["alpha_residual"],
         }
+        if shard_rec:
+            out["shard"] = shard_rec
         if roof:
             out["roofline"] = roof
             fg = st["factor_gemm_launches"]

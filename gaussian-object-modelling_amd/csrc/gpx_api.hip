@@ -225,6 +225,7 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     m->op64 = kernel->id == GPX_KERNEL_THINPLATE;
     if (const char *vo = std::getenv("GPX_VAR_OP64"))
         m->op64 = std::atoi(vo) != 0;
+    m->var_fit_opt = m->var_fit;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");
@@ -583,6 +584,9 @@ extern "C" int gpx_model_state_blob(gpx_model *m, int part, void **d_ptr, size_t
 {
     if (!m || !d_ptr || !bytes)
         return fail(GPX_E_NULL, "Empty Model pointer");
+    if (m->promoted)
+        return fail(GPX_E_STATE, "the kernel matrix is indefinite and the model kept its fp64 state: its blobs have the "
+                                 "GPX_PREC_F64 layout -- create the source (and the shells) with GPX_PREC_F64");
     if (part == 0) {
         *d_ptr = m->blob0;
         *bytes = m->blob0_bytes;
@@ -711,6 +715,8 @@ extern "C" int gpx_model_replicate(const gpx_model *csrc, int ndev, const int *d
         for (int i = 0; i < ndev && rc == GPX_OK; ++i) {
             gpx_options o = src->opt;
             o.device = devs[i];
+            if (src->promoted)  // the source kept its fp64 state (indefinite kernel matrix): so do its replicas
+                o.precision = GPX_PREC_F64;
             gpx_model *r = nullptr;
             if ((rc = gpx_model_create_shell(&src->kern, (size_t)src->n, &o, &r)))
                 break;
@@ -829,3 +835,23 @@ extern "C" int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, si
     return GPX_OK;
 }
 
+// the fp32-formed operand (exponential kernels): fp32 arithmetic on fp32 points given relative to the centre d_cen
+// (3 doubles on the device), queries centred before rounding; d_fab as in gpx_dev_kqp
+extern "C" int gpx_dev_kqp_f32(const gpx_kernel *kernel, size_t n, size_t n_padded, const void *d_px, const void *d_py,
+                               const void *d_pz, const void *d_cen, size_t nq, const void *d_qx, const void *d_qy,
+                               const void *d_qz, const void *d_fab, void *d_Kqp, void *stream)
+{
+    if (!kernel || !d_px || !d_py || !d_pz || !d_cen || !d_qx || !d_qy || !d_qz || !d_Kqp)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (n == 0 || n_padded % PANEL != 0 || n_padded < n || nq == 0 || nq % TILE != 0)
+        return fail(GPX_E_BAD_ARG, "n_padded must be gpx_padded_n(n) and nq a multiple of 128");
+    CovHost c = make_cov(*kernel);
+    const int np_rows = (int)std::min<size_t>(n_padded, (n + TILE - 1) / TILE * TILE);
+    launch_kqp(false, GPX_PREC_F32, false, c, (int)n, (int)n_padded, d_px, d_py, d_pz, (const double *)d_cen, (long)nq,
+               (long)nq, (const double *)d_qx, (const double *)d_qy, (const double *)d_qz, d_Kqp, (hipStream_t)stream,
+               np_rows, (const double *)d_fab, (long)nq);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, hipGetErrorString(le));
+    return GPX_OK;
+}

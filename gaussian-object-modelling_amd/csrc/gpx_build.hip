@@ -953,6 +953,18 @@ int build_model(gpx_model *m, kept_factor *keep)
         HIPCHK(hipMemcpy(m->d_meta + 4, &wd, sizeof(double), hipMemcpyHostToDevice));
     }
     m->ready = true;
+    // An INDEFINITE kernel matrix (negative pivots: the thin plate with R below the diameter of the cloud, as the node's
+    // own R = 2, src/gp_node.cpp:919) keeps its fp64 state: v = k(0) - sum_j w_j^2 / D_j then has terms of both signs that
+    // cancel by a factor fp32 cannot carry (sum |w_j^2 / D_j| = 65 k(0) on the node's clouds; the fp32 contraction of such
+    // a model measured 1e-3 k(0) off on a random cloud).  The model then predicts like a GPX_PREC_F64 one, whatever
+    // precision was asked for (twice the variance time of fp32, on models that are small in practice).
+    m->var_fit = m->var_fit_opt;
+    m->promoted = false;
+    if (m->train64 && m->stats.n_negative_pivots > 0 && !std::getenv("GPX_NO_PROMOTE")) {
+        m->train64 = false;  // no demotion below; the fp64 factor stays (update() can append to it)
+        m->var_fit = false;  // the fp64 contraction carries no fit
+        m->promoted = true;
+    }
     if (keep && keep->t0 > 0 && keep->X)
         append_inverse(m, keep);
     if (m->opt.prepare_variance || m->train64) {

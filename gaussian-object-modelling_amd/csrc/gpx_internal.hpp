@@ -16,6 +16,7 @@ constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
 constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
 constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
+constexpr int PAIR_WIDE_DEFAULT = 0, PAIR_NT_DEFAULT = 0;  // store pattern of the operand kernel (gpx_pairwise.hip: kqp_t)
 // Terms of the low-rank fit taken out of the kernel operand of the variance contraction.  The fit is a polynomial of
 // degree two in s = |q - p|^2, which is rank 14 in (q, p): basis functions of the training point, relative to the
 // model's centre c (p' = p - c):  1 | p'_x p'_y p'_z | p'_x^2 p'_y^2 p'_z^2 p'_x p'_y p'_x p'_z p'_y p'_z |

@@ -22,14 +22,29 @@ struct Vec4 {
     T v[4];
 };
 
-template <typename T>
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using f64x2_t = __attribute__((ext_vector_type(2))) double;
+
+// NT: non-temporal stores (the matrix is re-read only after all of it exists; GPX_PAIR_NT=1 selects them -- measured, see
+// launch_kqp)
+template <typename T, bool NT = false>
 __device__ __forceinline__ void store4(T *dst, const T (&o)[4])
 {
     if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        const f32x4_t v = {o[0], o[1], o[2], o[3]};
+        if constexpr (NT)
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(dst));
+        else
+            *reinterpret_cast<f32x4_t *>(dst) = v;
     } else {
-        *reinterpret_cast<double2 *>(dst) = make_double2(o[0], o[1]);
-        *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[2], o[3]);
+        const f64x2_t v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
+        if constexpr (NT) {
+            __builtin_nontemporal_store(v0, reinterpret_cast<f64x2_t *>(dst));
+            __builtin_nontemporal_store(v1, reinterpret_cast<f64x2_t *>(dst + 2));
+        } else {
+            *reinterpret_cast<f64x2_t *>(dst) = v0;
+            *reinterpret_cast<f64x2_t *>(dst + 2) = v1;
+        }
     }
 }
 
@@ -298,7 +313,9 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
 // With TC = double, TO = float the residual k - fit is formed in fp64 and rounded ONCE: its error is 6e-8 of the
 // (small) residual, where forming k and the fit separately in fp32 costs 6e-8 of k(0) each (measured: 1.2e-7 k(0) of
 // variance error from the operand alone at N = 16384 thin-plate, against 2e-9 -- profiles/r03_tp_fit_probe.txt).
-template <typename TC, typename TO, int KID, typename M>
+// WIDE: a wave writes ONE row segment of 256 columns (64 lanes x 16 B = 1 KiB contiguous per store instruction; the
+// block covers 128 queries x 256 columns) instead of two 512-byte pieces in two rows (128 x 128 block).
+template <typename TC, typename TO, int KID, typename M, bool WIDE, bool NT>
 __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, const TC *__restrict__ px,
                                                   const TC *__restrict__ py, const TC *__restrict__ pz,
                                                   const double *__restrict__ cen, long nq_valid,
@@ -322,8 +339,9 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, 
         rfb[tid] = fab ? (TC)fab[ldcc + q] : TC(0);
         rfc[tid] = fab ? (TC)fab[2 * ldcc + q] : TC(0);
     }
-    const int tx = tid & 31, ty = tid >> 5;
-    const int gj0 = blockIdx.x * TILE + tx * 4;
+    constexpr int LANES_X = WIDE ? 64 : 32, ROWS_PER_PASS = 256 / LANES_X, PASSES = TILE / ROWS_PER_PASS;
+    const int tx = tid & (LANES_X - 1), ty = tid / LANES_X;
+    const int gj0 = blockIdx.x * (4 * LANES_X) + tx * 4;
     TC cx[4], cy[4], cz[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -333,8 +351,8 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, 
     }
     __syncthreads();
 #pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int li = ty + 8 * r;
+    for (int r = 0; r < PASSES; ++r) {
+        const int li = ty + ROWS_PER_PASS * r;
         const long q = q0 + li;
         const TC ax = rx[li], ay = ry[li], az = rz[li], fa = rfa[li], fb = rfb[li], fc = rfc[li];
         TO out[4];
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, 
             kv -= fa + d2 * (fb + fc * d2);
             out[c] = (q < nq_valid && gj0 + c < n) ? (TO)kv : TO(0);
         }
-        store4<TO>(Kqp + (size_t)q * npad + gj0, out);
+        store4<TO, NT>(Kqp + (size_t)q * npad + gj0, out);
     }
 }
 
@@ -463,10 +481,26 @@ static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void 
                   hipStream_t st, int ncols, const double *fab, long ldcc)
 {
     Cov<TC> c = lower_cov<TC>(h);
-    dim3 grid((ncols > 0 ? ncols : npad) / TILE, (unsigned)(nq_tile / TILE));
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<TC, TO, KID, M>), grid, dim3(256), 0, st, c, n, npad,
-                                              (const TC *)px, (const TC *)py, (const TC *)pz, cen, nq_valid, qx, qy, qz,
-                                              (TO *)Kqp, fab, ldcc));
+    // experiment switches (read once): GPX_PAIR_WIDE=1: 1-KiB row segments per wave store; GPX_PAIR_NT=1: non-temporal stores
+    static const int wide = [] { const char *e = std::getenv("GPX_PAIR_WIDE"); return e ? std::atoi(e) : PAIR_WIDE_DEFAULT; }();
+    static const int nt = [] { const char *e = std::getenv("GPX_PAIR_NT"); return e ? std::atoi(e) : PAIR_NT_DEFAULT; }();
+    const int cols = ncols > 0 ? ncols : npad;
+#define GPX_KQP_LAUNCH(WIDE_, NT_)                                                                                    \
+    {                                                                                                                 \
+        dim3 grid((cols + (WIDE_ ? 255 : 127)) / (WIDE_ ? 256 : 128), (unsigned)(nq_tile / TILE));                    \
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<TC, TO, KID, M, WIDE_, NT_>), grid, dim3(256), 0, st, c, n, \
+                                                  npad, (const TC *)px, (const TC *)py, (const TC *)pz, cen, nq_valid, \
+                                                  qx, qy, qz, (TO *)Kqp, fab, ldcc));                                 \
+    }
+    if (wide && nt)
+        GPX_KQP_LAUNCH(true, true)
+    else if (wide)
+        GPX_KQP_LAUNCH(true, false)
+    else if (nt)
+        GPX_KQP_LAUNCH(false, true)
+    else
+        GPX_KQP_LAUNCH(false, false)
+#undef GPX_KQP_LAUNCH
 }
 
 void launch_kqp(bool compute64, int out_prec, bool accurate_math, const CovHost &cov, int n, int npad, const void *px,

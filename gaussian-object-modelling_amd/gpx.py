@@ -69,7 +69,7 @@ EXPORTS = [
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
-    "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
+    "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
 _lib = None
@@ -153,6 +153,9 @@ def lib():
     L.gpx_dev_kqp.restype = C.c_int
     L.gpx_dev_kqp.argtypes = [C.POINTER(Kernel), C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, C.c_size_t, vp, vp, vp, vp,
                               vp, vp]
+    L.gpx_dev_kqp_f32.restype = C.c_int
+    L.gpx_dev_kqp_f32.argtypes = [C.POINTER(Kernel), C.c_size_t, C.c_size_t, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp,
+                                  vp]
     L.gpx_pcd_read.restype = C.c_long
     L.gpx_pcd_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
     L.gpx_node_training_set.restype = C.c_int

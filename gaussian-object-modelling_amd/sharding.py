@@ -74,3 +74,26 @@ def state_blob_layout(npad, esz):
     off += 8 * BLOB_META
     out["bytes"] = off
     return out
+
+
+def shard_record(state, per_rank):
+    """The `shard` record of bench.py --mode shard from the per-rank phase times of one step.
+    per_rank: list over ranks of (t_model, t_exchange, t_commit, t_predict) in seconds, where t_model is the time to have a
+    local model object (rank 0: train; other ranks: train when state == "recompute", else allocate a shell), t_exchange
+    the time inside the broadcast of the two state blobs (0 for "recompute": no communication at all), t_commit the
+    commit of the received state, t_predict the evaluation of the rank's slab.
+    Returns ms figures: the training rank's train time, the broadcast as the SOURCE sees it (the other ranks are already
+    waiting in it, so this is the transfer), the slowest commit, and the longest time a rank spent waiting for the
+    factorising rank (its time in the exchange minus the transfer itself)."""
+    if state not in ("broadcast", "recompute"):
+        raise ValueError("state must be 'broadcast' or 'recompute'")
+    ms = lambda t: 1e3 * float(t)
+    t_train = per_rank[0][0]
+    t_bcast = per_rank[0][1] if state == "broadcast" else 0.0
+    others = per_rank[1:]
+    idle = max([max(0.0, r[1] - t_bcast) for r in others], default=0.0) if state == "broadcast" else 0.0
+    return {"state": state, "t_train_ms": ms(t_train), "t_bcast_ms": ms(t_bcast),
+            "t_commit_ms": ms(max([r[2] for r in others], default=0.0)),
+            "t_train_other_ranks_ms": ms(max([r[0] for r in others], default=0.0)) if state == "recompute" else 0.0,
+            "idle_max_ms": ms(idle), "t_predict_max_ms": ms(max(r[3] for r in per_rank)),
+            "t_step_max_ms": ms(max(sum(r) for r in per_rank))}

@@ -255,6 +255,12 @@ int gpx_dev_kbuild(const gpx_kernel *kernel, int precision, size_t n, size_t n_p
 int gpx_dev_kqp(const gpx_kernel *kernel, int precision, size_t n, size_t n_padded, const void *d_px, const void *d_py,
                 const void *d_pz, size_t nq, const void *d_qx, const void *d_qy, const void *d_qz, const void *d_fab,
                 void *d_Kqp, void *stream);
+/* The same operand formed in fp32 arithmetic (what the exponential kernels use): d_px,d_py,d_pz are n_padded FLOATS, the
+ * training points relative to the centre d_cen (3 doubles on the device); queries are centred before rounding; Kqp:
+ * floats. */
+int gpx_dev_kqp_f32(const gpx_kernel *kernel, size_t n, size_t n_padded, const void *d_px, const void *d_py,
+                    const void *d_pz, const void *d_cen, size_t nq, const void *d_qx, const void *d_qy, const void *d_qz,
+                    const void *d_fab, void *d_Kqp, void *stream);
 size_t gpx_padded_n(size_t n); /* leading dimension / padded order used for n training points */
 
 /* ---- PCD input + node-equivalent data preparation (host) ----------------------------------

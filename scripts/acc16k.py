@@ -15,4 +15,7 @@ for kn, par, k0 in (("matern52", (1.0, 1.0), 1.0), ("gaussian", (1.0, 1.0), 1.0)
         g = gpx.Model(kern, x, y, z, lab, s2, precision=prec)
         o = g.evaluate(qx, qy, qz, want_v=True); g.close()
         e = np.abs(o["v"] - o64["v"])
-        print("%-9s N=%d %-6s verr=%.2e  (rms %.2e)  ferr=%.1e" % (kn, n, name, e.max() / max(k0, np.abs(o64["v"]).max()), np.sqrt((e**2).mean()) / k0, np.abs(o["f"] - o64["f"]).max() / np.abs(o64["f"]).max()), flush=True)
+        vmax = np.abs(o64["v"]).max()
+        print("%-9s N=%d %-6s e_k0=%.2e  e_v=%.2e (max|dv| / max|v_ref|, max|v_ref| = %.3g)  rms/k0 %.2e  ferr=%.1e" % (
+            kn, n, name, e.max() / max(k0, vmax), e.max() / vmax, vmax, np.sqrt((e**2).mean()) / k0,
+            np.abs(o["f"] - o64["f"]).max() / np.abs(o64["f"]).max()), flush=True)

@@ -157,3 +157,68 @@ def test_sharded_grid_world2_gloo():
     ef, ev, tmax = res
     assert ef == 0.0 and ev == 0.0  # same arithmetic, disjoint slabs: bit-identical
     assert tmax == 2.0
+
+
+def _recompute_worker(rank, world, port, q):
+    """--state recompute of bench.py --mode shard: every rank builds the (same) model itself from inputs it generates
+    itself -- ZERO communication before the gather of the output slabs -- and the phase times go through
+    sharding.shard_record exactly as bench.py feeds them."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import time
+    import torch
+    import torch.distributed as dist
+    import gp_oracle as orc
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n, g = 90, 6
+        nq = g ** 3
+        t0 = time.perf_counter()
+        model = orc.Model(orc.make_kernel("thinplate", 4.0), *ds.fibonacci_training_set(n))  # same seed on every rank
+        t1 = time.perf_counter()
+        qx, qy, qz = ds.query_grid(g)
+        lo, hi = sh.slab_range(nq, rank, world)
+        out = model.evaluate(qx[lo:hi], qy[lo:hi], qz[lo:hi], want_v=True)
+        t2 = time.perf_counter()
+        phases = torch.tensor([t1 - t0, 0.0, 0.0, t2 - t1], dtype=torch.float64)
+        allp = [torch.zeros_like(phases) for _ in range(world)]
+        dist.all_gather(allp, phases)
+        f = sh.gather_slabs(dist, torch, torch.from_numpy(out["f"]), nq, rank, world)
+        v = sh.gather_slabs(dist, torch, torch.from_numpy(out["v"]), nq, rank, world)
+        if rank == 0:
+            ref = model.evaluate(qx, qy, qz, want_v=True)
+            rec = sh.shard_record("recompute", [tuple(p.tolist()) for p in allp])
+            q.put((float(np.max(np.abs(f.numpy() - ref["f"]))), float(np.max(np.abs(v.numpy() - ref["v"]))), rec))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_grid_recompute_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_recompute_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ef, ev, rec = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ef == 0.0 and ev == 0.0  # every rank factorised the same matrix the same way: bit-identical slabs
+    assert rec["state"] == "recompute" and rec["t_bcast_ms"] == 0.0 and rec["idle_max_ms"] == 0.0
+    assert rec["t_train_ms"] > 0 and rec["t_train_other_ranks_ms"] > 0 and rec["t_step_max_ms"] >= rec["t_train_ms"]
+
+
+def test_shard_record_arithmetic():
+    import importlib
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    # rank 0 trains 45 ms and sees a 9 ms transfer; rank 1 made its shell in 2 ms and then sat 52 ms in the broadcast
+    rec = sh.shard_record("broadcast", [(0.045, 0.009, 0.0, 0.5), (0.002, 0.052, 0.001, 0.51)])
+    assert abs(rec["t_train_ms"] - 45) < 1e-9 and abs(rec["t_bcast_ms"] - 9) < 1e-9 and abs(rec["t_commit_ms"] - 1) < 1e-9
+    assert abs(rec["idle_max_ms"] - 43) < 1e-9 and abs(rec["t_predict_max_ms"] - 510) < 1e-9
+    with pytest.raises(ValueError):
+        sh.shard_record("gossip", [])
