@@ -485,13 +485,21 @@ def main():
                 fab[2 * qb:] = 0.01
                 np_rows = min(npad, (n_train + 127) // 128 * 128)
                 Kq = torch.empty(qb * npad, dtype=tdt, device=dev)
-                pts = [t_.double() for t_ in pts]  # the operand kernel reads the fp64 points (k - fit is formed in fp64)
-                kq = lambda: gpx._check(L.gpx_dev_kqp(C.byref(kern), stage_prec, n_train, npad, vp(pts[0]), vp(pts[1]), vp(pts[2]),
-                                                      qb, vp(qx), vp(qy), vp(qz), vp(fab) if prec != gpx.F64 else None, vp(Kq),
-                                                      C.c_void_p(strm.cuda_stream)))
+                # the library forms k - fit in fp64 from the fp64 points for the thin plate (and for fp64 models), in fp32 from
+                # the centred fp32 points for the exponential kernels: time the kernel the timed step actually ran
+                op64 = args.kernel == "thinplate" or prec == gpx.F64
+                if op64:
+                    p64 = [t_.double() for t_ in pts]
+                    kq = lambda: gpx._check(L.gpx_dev_kqp(C.byref(kern), stage_prec, n_train, npad, vp(p64[0]), vp(p64[1]), vp(p64[2]),
+                                                          qb, vp(qx), vp(qy), vp(qz), vp(fab) if prec != gpx.F64 else None, vp(Kq),
+                                                          C.c_void_p(strm.cuda_stream)))
+                else:
+                    cen = torch.zeros(8, dtype=torch.float64, device=dev)
+                    kq = lambda: gpx._check(L.gpx_dev_kqp_f32(C.byref(kern), n_train, npad, vp(pts[0]), vp(pts[1]), vp(pts[2]), vp(cen),
+                                                              qb, vp(qx), vp(qy), vp(qz), vp(fab), vp(Kq), C.c_void_p(strm.cuda_stream)))
                 ms = timed(kq)
                 kq_bytes = qb * np_rows * esz + 3 * npad * 8 + qb * 48  # Kqp written + points + queries and fit read
-                out["roofline_kqp"] = {"bound": "hbm", "kernel": "kqp_kernel<%s> (kernel operand of one variance batch of %d queries)" % (gemm_t, qb),
+                out["roofline_kqp"] = {"bound": "hbm", "kernel": "kqp_kernel<%s, formed in %s> (kernel operand of one variance batch of %d queries)" % (gemm_t, "fp64" if op64 else "fp32", qb),
                                        "bytes_per_launch": kq_bytes, "avg_launch_ms": ms, "launches_timed": reps,
                                        "achieved": kq_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                        "frac": kq_bytes / (ms * 1e-3) / HBM_PEAK,

@@ -202,6 +202,24 @@ def fibonacci_training_set(n, seed=20151106, jitter=1e-3, sigma2=SIGMA2, rad=OUT
     return P[:, 0].copy(), P[:, 1].copy(), P[:, 2].copy(), label, s2
 
 
+def random_shell_training_set(n, seed=7, r_lo=0.9, r_hi=1.1, sigma2=SIGMA2):
+    """An IRREGULAR cloud: n points uniform in the shell r_lo <= |p| <= r_hi (rejection from the cube, std::mt19937_64
+    stream `seed`, so the cloud is reproducible without NumPy's generators), label 1 for every tenth point else 0, plus
+    0.01 * a uniform(-1, 1) draw.  The thin-plate counterpart of the regular Fibonacci cloud for the N = 16384 anchor:
+    on random clouds the predictor weights K^-1 k_q are large."""
+    rng = MT19937_64(seed)
+    P = np.empty((n, 3))
+    k = 0
+    while k < n:
+        p = (rng.uniform(-r_hi, r_hi), rng.uniform(-r_hi, r_hi), rng.uniform(-r_hi, r_hi))
+        r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2]
+        if r_lo * r_lo <= r2 <= r_hi * r_hi:
+            P[k] = p
+            k += 1
+    label = np.array([(1.0 if i % 10 == 0 else 0.0) + 0.01 * rng.uniform(-1.0, 1.0) for i in range(n)])
+    return P[:, 0].copy(), P[:, 1].copy(), P[:, 2].copy(), label, np.full(n, float(sigma2))
+
+
 def query_grid(g, scale=1.01):
     """g^3 lattice on [-scale, scale]^3, x slowest / z fastest (src/gp_node.cpp:1025-1036)."""
     t = np.linspace(-scale, scale, g)

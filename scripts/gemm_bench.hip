@@ -4,7 +4,7 @@
 //          gaussian-object-modelling_amd/csrc/gpx_gemm.hip -o scripts/gemm_bench.bin       [-DGEMM_WAVES_PER_EU=1|2]
 //   (compiled TOGETHER with the GEMM source, not linked to libgpx.so: struct GemmArgs is internal to the library and a
 //   harness built against another revision of it passes garbage pointers -- the round-1 faults)
-//   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1] [inverse-assembly shapes = 0]
+//   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1] [inverse-assembly shapes = 0] [variance only = 0]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -41,13 +41,17 @@ int main(int argc, char **argv)
     CK(hipMalloc(&X, e * (size_t)N * N));
     CK(hipMalloc(&Kqp, e * (size_t)NQ * N));
     CK(hipMalloc(&dinv, e * N));
-    CK(hipMalloc(&partial, e * (size_t)NQ * (N / 128)));
+    CK(hipMalloc(&partial, 8 * (size_t)NQ * (N / 128)));  // doubles with the fp64 epilogue (low-rank correction)
     CK(hipMalloc(&C, e * (size_t)N * N));
     CK(hipMalloc(&W, e * (size_t)N * 2048));
-    CK(hipMalloc(&rowcorr, e * (size_t)N * VAR_NCORR));
-    CK(hipMalloc(&colcoef, e * (size_t)NQ * VAR_NCORR));
-    if (prec) { fill((double *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2); fill((double *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0); }
-    else { fill((float *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2); fill((float *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0); }
+    // the low-rank correction is fp64 data whatever the product's type (round 3: fp64 epilogue)
+    void *dinv64;
+    CK(hipMalloc(&rowcorr, 8 * (size_t)N * VAR_NCORR));
+    CK(hipMalloc(&colcoef, 8 * (size_t)NQ * VAR_NCORR));
+    CK(hipMalloc(&dinv64, 8 * (size_t)N));
+    fill((double *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2);
+    fill((double *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0);
+    fill((double *)dinv64, N, 7, 1.0);
     if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
     else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
     CK(hipMemset(C, 0, e * (size_t)N * N));
@@ -57,7 +61,7 @@ int main(int argc, char **argv)
         GemmArgs a;
         a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
         a.rowweight = dinv; a.partial = partial, a.ldp = NQ; a.cfg = cfg;
-        if (with_corr) { a.rowcorr = rowcorr, a.ldrc = N; a.colcoef = colcoef, a.ldcc = NQ; }
+        if (with_corr && !prec) { a.rowcorr = (const double *)rowcorr, a.ldrc = N; a.colcoef = (const double *)colcoef, a.ldcc = NQ; a.rowweight64 = (const double *)dinv64; }
         launch_gemm(prec, a, st);
         CK(hipStreamSynchronize(st));
         const int reps = 3;
@@ -69,6 +73,8 @@ int main(int argc, char **argv)
         double flop = (double)N * N * NQ;
         printf("VAR  cfg%d prec%d N=%d NQ=%d : %.3f ms  %.1f TFLOP/s (algorithmic N^2 per query)\n", cfg, prec, N, NQ, ms, flop / ms / 1e9);
     }
+    if (argc > 6 && atoi(argv[6]) != 0)
+        return 0;  // variance shapes only
     for (int KK : {128, 256, 512, 1024, 2048})
     for (int cfg = 0; cfg < 1; cfg += 2) {
         const int M = N - 256;

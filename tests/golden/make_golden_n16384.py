@@ -6,6 +6,12 @@ Matern closed form matlab_src/test_gp_regression_3Dsurf.m:121-123).  Stores alph
 f / v / grad at 64 queries (13 KB).  Run in the build container (~4 min on 8 cores, ~7 GiB):
 
     python tests/golden/make_golden_n16384.py
+    python tests/golden/make_golden_n16384.py random     # -> gp_golden_n16384_random.npz (round 3)
+
+`random`: thin-plate R = 4 on an IRREGULAR cloud (datasets.random_shell_training_set: 16384 points uniform in the shell
+0.9 <= |p| <= 1.1) with 64 EXTRAPOLATING queries uniform in [-1.3, 1.3]^3 (three of them on training points) -- the
+regime where thin-plate predictor weights K^-1 k_q are large and an fp32 factorisation showed 4.4e-5 k(0) in the variance
+at N = 2305; the Fibonacci cases above only have lattice queries on a regular cloud.
 """
 import importlib
 import os
@@ -87,5 +93,45 @@ def main():
     print("wrote gp_golden_n16384.npz (%d arrays)" % len(out))
 
 
+def main_random():
+    x, y, z, lab, s2 = ds.random_shell_training_set(N)
+    P = np.stack([x, y, z], 1)
+    rng = ds.MT19937_64(16384)
+    Q = np.array([rng.uniform(-1.3, 1.3) for _ in range(3 * 64)]).reshape(64, 3)
+    Q[:3] = P[[0, 8191, 16383]]
+    sel = np.arange(0, N, 64)
+    out = {"n": np.array(N), "Q": Q, "alpha_idx": sel, "P_check": P[[0, 1, 8191, 16383]], "label_check": lab[[0, 1, 8191, 16383]]}
+    kf, kd, k0 = KERNELS["thinplate4"]
+    t0 = time.time()
+    D = pdist(P, P)
+    Dq = pdist(Q, P)
+    K = kf(D)
+    K[np.diag_indices(N)] += s2
+    c = sl.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+    alpha = sl.cho_solve(c, lab, check_finite=False)
+    Kq = kf(Dq)
+    f = Kq @ alpha
+    S = sl.cho_solve(c, Kq.T, check_finite=False)
+    v = k0 - np.einsum("ij,ji->i", Kq, S)
+    W = kd(Dq) * alpha[None, :]
+    grad = (W[:, :, None] * (Q[:, None, :] - P[None, :, :])).sum(1)
+    del K, c
+    res = 0.0
+    for i in range(0, N, 2048):
+        r = lab[i:i + 2048] - kf(D[i:i + 2048]) @ alpha - s2[i:i + 2048] * alpha[i:i + 2048]
+        res = max(res, float(np.abs(r).max()))
+    pre = "thinplate4/"
+    out[pre + "alpha"], out[pre + "f"], out[pre + "v"], out[pre + "grad"] = alpha[sel], f, v, grad
+    out[pre + "alpha_max"] = np.array(np.abs(alpha).max())
+    out[pre + "residual"] = np.array(res)
+    print("random cloud thinplate4: %.1fs  max|alpha| %.4g  residual %.2e  v in [%.3g, %.3g]  |a_q|_1 up to %.3g" % (
+        time.time() - t0, np.abs(alpha).max(), res, v.min(), v.max(), np.abs(S).sum(0).max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "gp_golden_n16384_random.npz"), **out)
+    print("wrote gp_golden_n16384_random.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "random":
+        main_random()
+    else:
+        main()

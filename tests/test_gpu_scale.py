@@ -140,6 +140,34 @@ def test_n16384_against_independent_golden(gpu, ds, kkey, kn, par):
         gm.close()
 
 
+def test_n16384_thin_plate_on_a_random_cloud_with_extrapolating_queries(gpu, ds):
+    """C4's kernel at C4's size on an IRREGULAR cloud (16384 points uniform in the shell 0.9 <= |p| <= 1.1)
+    with queries uniform in [-1.3, 1.3]^3 -- the regime in which thin-plate predictor weights are large and an
+    fp32-trained factor showed 4.4e-5 k(0) in the variance at N = 2305.  Anchor: tests/golden/gp_golden_n16384_random.npz
+    (NumPy distances + LAPACK Cholesky in fp64, tests/golden/make_golden_n16384.py random).  F32 / F32_SPLIT thin-plate
+    models train in fp64 at every size the device holds (set_training_precision), so every fp32 mode is held to 1e-5 in
+    both normalisations of the variance error."""
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "gp_golden_n16384_random.npz"))
+    n = int(g["n"])
+    x, y, z, lab, s2 = ds.random_shell_training_set(n)
+    P = np.stack([x, y, z], 1)
+    np.testing.assert_array_equal(P[[0, 1, 8191, 16383]], g["P_check"])  # the generator reproduces the fixture's cloud
+    np.testing.assert_array_equal(lab[[0, 1, 8191, 16383]], g["label_check"])
+    kern = gpu.make_kernel("thinplate", 4.0)
+    Q, sel, pre, k0 = g["Q"], g["alpha_idx"], "thinplate4/", 64.0
+    for prec, tol, atol in ((gpu.F64, 1e-8, 1e-8), (gpu.F32, 1e-5, 1e-8), (gpu.MIXED, 1e-5, 1e-8), (gpu.F32_SPLIT, 1e-5, 1e-8)):
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+        assert gm.stats["n_negative_pivots"] == 0
+        out = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True)
+        assert np.max(np.abs(gm.alpha[sel] - g[pre + "alpha"])) / float(g[pre + "alpha_max"]) < atol, prec
+        mtol = 1e-8  # mean / gradient are fp64 work on an fp64-trained alpha in every mode
+        assert nerr(out["f"], g[pre + "f"]) < mtol and nerr(out["grad"], g[pre + "grad"]) < mtol, prec
+        assert verr(out["v"], g[pre + "v"], k0) < tol and verr_v(out["v"], g[pre + "v"]) < tol, prec
+        gm.close()
+
+
 def test_c4_slab_of_the_256_cubed_grid_on_a_committed_shell(gpu, ds):
     """BASELINE config 4: N = 16384 fp32 thin-plate R = 4, 256^3 query grid sharded over 8 ranks.  Rank 3's x-slab
     (32 planes = 2^21 queries) is evaluated on a SHELL that received the two state blobs of the factorised model (the
