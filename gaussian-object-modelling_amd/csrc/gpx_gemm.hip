@@ -73,32 +73,12 @@ struct MfmaT<double, false> {  // v_mfma_f64_16x16x4_f64
 #ifndef GEMM_F32_HINT
 #define GEMM_F32_HINT 0
 #endif
-// 1: the fp32 variance product (128-byte k rows) prefetches two k-tiles ahead (see the main loop).  Built and measured in
-// round 3: 16.31 ms per launch against 16.47 for the plain loop of the same build -- the exposed load latency is not what
-// separates the good schedules from the bad ones -- at 232 instead of 170 VGPRs; off.
-#ifndef GEMM_COLSQ_PF2
-#define GEMM_COLSQ_PF2 0
-#endif
-#ifndef GEMM_F32_LOADS_FIRST
-#define GEMM_F32_LOADS_FIRST 0
-#endif
 // Waves per SIMD the 4-wave (128 x 128) tiles are compiled for.  Without a bound hipcc budgets 512 registers per lane
 // (252 VGPRs + 80 AGPRs for the read-modify-write tile), which leaves ONE workgroup per CU although two fit its LDS;
 // 2 caps the tile at 256 registers (234 used, nothing spilled) so that two workgroups share a CU and one hides the
 // other's prologue / epilogue -- what the short k-loops of the LDL^T trailing update need.
 #ifndef GEMM_WAVES_PER_EU
 #define GEMM_WAVES_PER_EU 2
-#endif
-// 1: compile the 128 x 128 fp32 variance tile for THREE waves per SIMD (<= 168 VGPRs) although its LDS only lets two
-// workgroups share a CU (experiment of round 3, when the fp64 epilogue had raised the register count from 144 to 170 and
-// the main loop ran 16.3 instead of 15.6 ms per launch: the tighter budget was not the cure -- 16.6 ms)
-#ifndef GEMM_COLSQ_WAVES3
-#define GEMM_COLSQ_WAVES3 0
-#endif
-// 1: the fp64 COLSQ epilogue issues all its global loads (row vectors, coefficients, 1/D of the tile) before parking them
-// in LDS; 0: a plain load / store loop (kept for A/B runs)
-#ifndef GEMM_EPI64_LOADS
-#define GEMM_EPI64_LOADS 1
 #endif
 // Padding (elements) of a [k][n] LDS row of the fp64 NN tiles (inverse-factor assembly).  A lane group fg reads k-rows
 // 2 fg and 2 fg + 1: with 2 elements of padding rows two apart start 8 banks apart and the 16-lane groups of one half
@@ -133,7 +113,7 @@ struct GemmDev {
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? ((KBYTES == 64 || (EPI == EPI_COLSQ && sizeof(T) == 4 && GEMM_COLSQ_WAVES3)) ? 3 : GEMM_WAVES_PER_EU) : 1) void gemm_kernel(GemmDev<T> g)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 3 : GEMM_WAVES_PER_EU) : 1) void gemm_kernel(GemmDev<T> g)
 {
     using MF = MfmaT<T, M32>;
     using acc_t = typename MF::acc_t;
@@ -303,10 +283,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? ((KBYTES == 64 |
 
     // (fp32 only: the fp64 contraction needs no correction, and its hinted main loop is sensitive to every extra
     // register -- with the correction code compiled in, the fp64 variance product dropped from 72.5 to 64 TFLOP/s)
-#ifndef GEMM_NO_CORR
-#define GEMM_NO_CORR 0
-#endif
-    constexpr bool CORR_OK = (EPI == EPI_COLSQ) && sizeof(T) == 4 && !GEMM_NO_CORR;
+    constexpr bool CORR_OK = (EPI == EPI_COLSQ) && sizeof(T) == 4;
     const bool corr = CORR_OK && g.colcoef != nullptr;
 
     // one k-tile of MFMAs on LDS buffer BUF
@@ -357,61 +334,6 @@ _Pragma("unroll") \
                 } \
             }
 
-    // ---- the fp32 variance contraction: loads TWO k-tiles ahead, in two named register slots -------------------------
-    // In the plain loop below the scheduler sinks the next tile's global loads to the END of the current tile's MFMAs
-    // (shorter live ranges) and the wave waits for them a few instructions later, so every k-tile exposes a memory round
-    // trip that only the second workgroup on the CU covers -- and how well depends on accidents of the schedule (the same
-    // main-loop source measured 15.6 or 16.6 ms per launch depending on what the EPILOGUE looked like, round 3).  Here the
-    // loads issued during tile kt are parked in LDS during tile kt + 1 and used in tile kt + 2: wherever the scheduler
-    // puts them, they have a whole k-tile of MFMAs to arrive.  (Named scalars: hipcc keeps staging ARRAYS that live across
-    // the two halves of an unrolled loop in scratch memory, see gpx_vsplit.hip.)
-    constexpr bool PF2 = (EPI == EPI_COLSQ) && sizeof(T) == 4 && !NN && GEMM_COLSQ_PF2 && A_CH <= 4 && B_CH <= 4 &&
-                         WGM * WGN == 4 && KBYTES == 128;  // (the 8-wave and the 3-waves-per-SIMD tiles have no registers to spare)
-    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
-#define GPX_GLOAD_N(P, KT)                                                                                  \
-    {                                                                                                       \
-        const size_t k0_ = (size_t)(KT) * BK;                                                               \
-        P##a0 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(0));                                             \
-        P##b0 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(0));                                             \
-        if constexpr (A_CH > 1) P##a1 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(1));                     \
-        if constexpr (B_CH > 1) P##b1 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(1));                     \
-        if constexpr (A_CH > 2) P##a2 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(2));                     \
-        if constexpr (B_CH > 2) P##b2 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(2));                     \
-        if constexpr (A_CH > 3) P##a3 = *reinterpret_cast<const uint4 *>(GPX_A_PTR(3));                     \
-        if constexpr (B_CH > 3) P##b3 = *reinterpret_cast<const uint4 *>(GPX_B_PTR(3));                     \
-    }
-#define GPX_SSTORE_N(P, BUF)                                                                                \
-    {                                                                                                       \
-        *reinterpret_cast<uint4 *>(GPX_A_LDS(0, BUF)) = P##a0;                                              \
-        *reinterpret_cast<uint4 *>(GPX_B_LDS(0, BUF)) = P##b0;                                              \
-        if constexpr (A_CH > 1) *reinterpret_cast<uint4 *>(GPX_A_LDS(1, BUF)) = P##a1;                      \
-        if constexpr (B_CH > 1) *reinterpret_cast<uint4 *>(GPX_B_LDS(1, BUF)) = P##b1;                      \
-        if constexpr (A_CH > 2) *reinterpret_cast<uint4 *>(GPX_A_LDS(2, BUF)) = P##a2;                      \
-        if constexpr (B_CH > 2) *reinterpret_cast<uint4 *>(GPX_B_LDS(2, BUF)) = P##b2;                      \
-        if constexpr (A_CH > 3) *reinterpret_cast<uint4 *>(GPX_A_LDS(3, BUF)) = P##a3;                      \
-        if constexpr (B_CH > 3) *reinterpret_cast<uint4 *>(GPX_B_LDS(3, BUF)) = P##b3;                      \
-    }
-    // (the number of k-tiles of this product is a multiple of 4: K and the tile edge are multiples of 128 elements)
-    if (PF2 && kt0 < kt1 && ((kt1 - kt0) & 1) == 0) {
-        if constexpr (PF2) {
-            GPX_GLOAD_N(r, kt0);
-            GPX_GLOAD_N(s, min(kt0 + 1, kt1 - 1));
-            GPX_SSTORE_N(r, 0);
-            __syncthreads();
-            for (int kt = kt0; kt < kt1; kt += 2) {
-                // even tile kt in LDS buffer 0; slot r is free -> tile kt + 2; slot s holds tile kt + 1
-                GPX_GLOAD_N(r, min(kt + 2, kt1 - 1));
-                GPX_COMPUTE(0);
-                GPX_SSTORE_N(s, 1);
-                __syncthreads();
-                // odd tile kt + 1 in LDS buffer 1; slot s is free -> tile kt + 3; slot r holds tile kt + 2
-                GPX_GLOAD_N(s, min(kt + 3, kt1 - 1));
-                GPX_COMPUTE(1);
-                GPX_SSTORE_N(r, 0);
-                __syncthreads();
-            }
-        }
-    } else
     // ---- main loop: one barrier per k-tile; the next tile's global loads are in flight over the MFMAs.
     // The last iteration re-loads its own tile (clamped index) so that nothing in the loop is conditional.
     if (kt0 < kt1) {
@@ -430,10 +352,6 @@ _Pragma("unroll") \
             if constexpr (sizeof(T) == 8) {
                 __builtin_amdgcn_sched_group_barrier(0x020, A_CH + B_CH, 0);  // the VMEM reads first ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);            // ... then (at least) the first MFMAs
-            } else if (GEMM_F32_LOADS_FIRST) {
-                // fp32: only pin the prefetch above everything else of the k-tile (a full scheduling fence right after
-                // the loads); LDS reads and MFMAs below it are left to the scheduler
-                __builtin_amdgcn_sched_barrier(0);
             } else if (GEMM_F32_HINT) {
                 __builtin_amdgcn_sched_group_barrier(0x020, A_CH + B_CH, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
@@ -448,8 +366,6 @@ _Pragma("unroll") \
         }
     }
 #undef GPX_GLOAD
-#undef GPX_GLOAD_N
-#undef GPX_SSTORE_N
 #undef GPX_COMPUTE
 #undef GPX_SSTORE
 #undef GPX_A_PTR
@@ -543,10 +459,8 @@ _Pragma("unroll") \
                 static_assert(sizeof(double) * (VAR_NCORR * (BM + BN) + BM + WGM * BN) <=
                                   sizeof(T) * (2 * (size_t)A_TILE + 2 * (size_t)B_TILE),
                               "the fp64 epilogue must fit the staging buffers");
-                // all of a thread's loads are issued before the first LDS store (a load / store / load chain would expose
-                // one memory latency per element: GEMM_EPI64_LOADS=0, measured 16.6 instead of 15.6 ms per launch)
+                // (all of a thread's loads are issued before its first LDS store)
                 constexpr int NEL = VAR_NCORR * (BM + BN) + BM, NLD = (NEL + NT - 1) / NT;
-#if GEMM_EPI64_LOADS
                 double pv[NLD];
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
@@ -568,20 +482,6 @@ _Pragma("unroll") \
                     if (e < NEL)
                         ds[e] = pv[i];
                 }
-#else
-                for (int e = tid; e < NEL; e += NT) {
-                    double v;
-                    if (e < VAR_NCORR * BM) {
-                        v = g.rowcorr[(size_t)(e / BM) * g.ldrc + m0 + e % BM];
-                    } else if (e < VAR_NCORR * (BM + BN)) {
-                        const int e2 = e - VAR_NCORR * BM;
-                        v = g.colcoef[(size_t)(e2 / BN) * g.ldcc + n0 + e2 % BN];
-                    } else {
-                        v = g.rowweight64[m0 + e - VAR_NCORR * (BM + BN)];
-                    }
-                    ds[e] = v;
-                }
-#endif
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {

@@ -69,11 +69,15 @@ typedef struct gpx_kernel {
  *   F32    kernel matrix, LDL^T and variance GEMM in fp32 (fp32 MFMA); alpha is refined with fp64 matrix-free
  *          residuals; the inverse factor is assembled in fp64 from the fp32 factor and rounded once; the variance
  *          GEMM contracts a centred kernel operand -- k minus a per-query parabola in the squared distance, formed in
- *          fp64 and rounded once -- and its epilogue adds the fit back, squares, weights and sums in fp64.  Models of up to 2048
- *          padded rows -- 8192 for the thin plate -- (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED: (nearly)
- *          free at that size, and the fp32 LDL^T's backward error would otherwise show in the variance of
- *          ill-conditioned (thin-plate) systems; such models hold no factor afterwards, so gpx_model_update
- *          rebuilds them instead of appending
+ *          fp64 and rounded once -- and its epilogue adds the fit back, squares, weights and sums in fp64: every kernel
+ *          within 1e-5 of the fp64 result at N = 16384 in max|dv| / max|v_ref| (thin plate R = 4: 5e-6, where k(0) is
+ *          60 x max|v|).  Models of up to 2048 padded rows (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED: (nearly)
+ *          free at that size.  THIN-PLATE models are trained in fp64 at every size whose fp64 temporaries fit the device
+ *          (cond > 1e6, predictor weights of 10-100: an fp32 LDL^T shows in the variance); such models hold no factor
+ *          afterwards, so gpx_model_update rebuilds them instead of appending.  A model whose kernel matrix turns out
+ *          INDEFINITE (negative pivots: thin plate with R below the diameter of the cloud, as the node's R = 2) keeps
+ *          its fp64 state and predicts like an F64 model, whatever precision was asked: its quadratic form has terms of
+ *          both signs that cancel beyond what fp32 carries.
  *   F64    everything in fp64 (fp64 MFMA): the reference's arithmetic
  *   MIXED  train (kernel matrix, LDL^T, alpha, inverse factor) in fp64, then the inverse factor is
  *          rounded once to fp32 and the variance GEMM runs in fp32; the fp64 factor is released
@@ -221,10 +225,13 @@ void gpx_model_destroy(gpx_model *m);
 void gpx_trim(void);
 
 /* ---- one model, query grid sharded over ranks (one process per GPU) -----------------------
- * The rank that factorised exports its read-only state as ONE contiguous device blob
- * (points, alpha, D, inverse factor); the host moves it with RCCL (torch.distributed
- * broadcast over xGMI) into the blob of a shell created with the same kernel/n/options on the
- * other ranks, then commits it.  No reference equivalent (the reference is single-process). */
+ * The rank that factorised exports its read-only state as two contiguous device blobs (part 0: points, alpha, 1/D, the
+ * 14 row vectors of the variance fit, the centre of the cloud; part 1: the inverse factor); the host moves them with
+ * RCCL (torch.distributed broadcast over xGMI) into the blobs of a shell created with the same kernel / n / options on
+ * the other ranks, then commits it.  The byte layout depends on (n, options) only -- except that a model whose kernel
+ * matrix is indefinite keeps its fp64 state (see gpx_precision): gpx_model_state_blob then fails with GPX_E_STATE and
+ * source and shells must be created with GPX_PREC_F64.  The zero-communication alternative is every rank calling
+ * gpx_model_create itself (bench.py --mode shard --state recompute).  No reference equivalent (single-process). */
 int gpx_model_create_shell(const gpx_kernel *kernel, size_t n, const gpx_options *opt, gpx_model **out);
 int gpx_model_state_blob(gpx_model *m, int part /*0: points, alpha, 1/D; 1: inverse factor*/, void **d_ptr,
                          size_t *bytes);
@@ -233,10 +240,17 @@ int gpx_model_commit(gpx_model *m, int with_variance);
 /* In-process multi-device placement for a C++ caller of the reference's shape (one process, host threads sharing a
  * model: src/gp_node.cpp:1025-1038; no reference equivalent, the reference is single-device CPU code): out[i]
  * receives a read-only replica of `src` on HIP device devs[i] (state copied device to device, over xGMI where peer
- * access exists), ready for gpx_model_evaluate* / _sample_surface / _project; evaluate on a replica returns
- * bit-identical results to `src`.  The inverse factor is built on `src` first if it was not yet.  Replicas are
- * destroyed with gpx_model_destroy; gpx_model_update on a replica rebuilds it from its host copy of the data.
- * On failure no replica is left behind. */
+ * access exists; all replicas' copies are issued together, one pair per destination on its own stream, and waited for
+ * once), ready for gpx_model_evaluate* / _sample_surface / _project; evaluate on a replica returns bit-identical results
+ * to `src`.  The inverse factor is built on `src` first if it was not yet.  Replicas are destroyed with
+ * gpx_model_destroy; gpx_model_update on a replica rebuilds it from its host copy of the data.  On failure no replica is
+ * left behind and the caller's current device is unchanged.
+ * STATUS: the code specific to a SECOND device (peer enable, copies between ordinals, per-device kernel attributes) has
+ * only run on hardware where the test box offers more than one GPU (tests/test_gpu_parity.py::
+ * test_replicas_on_a_second_device skips otherwise); the one-GPU boxes of this project exercise devs = {0, 0} only.
+ * There is no RCCL inside the library: within one process replicas travel by peer copies (this call); across
+ * processes (one per GPU) the host moves the two state blobs with its own collective -- bench.py uses
+ * torch.distributed broadcast (backend "nccl" = RCCL over xGMI). */
 int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_model **out);
 
 /* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------

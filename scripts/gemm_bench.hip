@@ -71,7 +71,16 @@ int main(int argc, char **argv)
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
         double flop = (double)N * N * NQ;
-        printf("VAR  cfg%d prec%d N=%d NQ=%d : %.3f ms  %.1f TFLOP/s (algorithmic N^2 per query)\n", cfg, prec, N, NQ, ms, flop / ms / 1e9);
+        // checksum of the partial sums of the first row tile (epilogue variants of one product must agree)
+        double chk = 0;
+        {
+            const bool p64 = (with_corr && !prec) || prec;
+            std::vector<char> h((size_t)NQ * 8);
+            CK(hipMemcpy(h.data(), partial, (size_t)NQ * (p64 ? 8 : 4), hipMemcpyDeviceToHost));
+            for (int q = 0; q < NQ; ++q)
+                chk += p64 ? ((double *)h.data())[q] : (double)((float *)h.data())[q];
+        }
+        printf("VAR  cfg%d prec%d N=%d NQ=%d : %.3f ms  %.1f TFLOP/s (algorithmic N^2 per query)  checksum %.10e\n", cfg, prec, N, NQ, ms, flop / ms / 1e9, chk);
     }
     if (argc > 6 && atoi(argv[6]) != 0)
         return 0;  // variance shapes only
