@@ -106,26 +106,26 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
     return out
 
 
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first
+# committed PMC passes per variance tile (GPX_VAR_TILE): file, kernel-name prefix of that tile's instantiation
+PMC_TRAFFIC = {"3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64"),   # 64-byte k rows (round-3 default)
+               "0": ("r02_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 128")}  # 128-byte k rows
 
 
 def pmc_traffic(args, n_train, q_per_launch):
-    """(bytes, source): HBM bytes per launch of the variance GEMM from the newest COMMITTED PMC passes (separate --pmc
-    FETCH_SIZE / WRITE_SIZE passes of this bench, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes
-    for wide streaming reads, + WRITE_SIZE) -- counters cannot be collected inside an un-profiled run, so this figure
-    is NOT measured by the run that prints it; only valid for the shape and the tile those passes were taken on."""
-    if not (args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192
-            and os.environ.get("GPX_VAR_TILE", "0") == "0"):
+    """(bytes, source): HBM bytes per launch of the variance GEMM from the COMMITTED PMC passes of this bench (separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes for wide
+    streaming reads, + WRITE_SIZE) -- counters cannot be collected inside an un-profiled run, so this figure is NOT
+    measured by the run that prints it; only valid for the shape and the tile those passes were taken on."""
+    tile = os.environ.get("GPX_VAR_TILE", "3")
+    if not (args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192 and tile in PMC_TRAFFIC):
         return None, None
-    prefix = "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2"  # <f32, NT, EPI_COLSQ, 128 x 128 tile>
-    for fn in PMC_TRAFFIC_FILES:
-        path = os.path.join(ROOT, "profiles", fn)
-        try:
-            for name, k in json.load(open(path))["kernels"].items():
-                if name.startswith(prefix):
-                    return k["hbm_bytes_per_dispatch"], "profiles/%s (committed rocprofv3 --pmc pass of this command, not this run)" % fn
-        except Exception:
-            continue
+    fn, prefix = PMC_TRAFFIC[tile]
+    try:
+        for name, k in json.load(open(os.path.join(ROOT, "profiles", fn)))["kernels"].items():
+            if name.startswith(prefix):
+                return k["hbm_bytes_per_dispatch"], "profiles/%s (committed rocprofv3 --pmc pass of this command, not this run)" % fn
+    except Exception:
+        pass
     return None, None
 
 
