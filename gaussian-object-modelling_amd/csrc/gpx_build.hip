@@ -6,9 +6,25 @@
 
 namespace gpxh {
 
+static void release_inv_ahead(gpx_model *m)
+{
+    inv_ahead &ia = m->ia;
+    big_free(ia.Tws);
+    big_free(ia.L64);
+    big_free(ia.X64);
+    if (ia.linv64)
+        (void)hipFree(ia.linv64);
+    if (ia.start)
+        (void)hipEventDestroy(ia.start);
+    if (ia.done)
+        (void)hipEventDestroy(ia.done);
+    ia = inv_ahead{};
+}
+
 void free_dev(gpx_model *m)
 {
     quiesce(m);
+    release_inv_ahead(m);
     auto F = [](void *p) { big_free(p); };  // parks buffers of 64 MiB and more, hipFree otherwise
     F(m->dvecs);
     F(m->blob0);
@@ -80,6 +96,8 @@ void quiesce(gpx_model *m)
         (void)hipStreamSynchronize(m->stream);
     if (m->stream2)
         (void)hipStreamSynchronize(m->stream2);
+    if (m->stream3)
+        (void)hipStreamSynchronize(m->stream3);
     if (m->ws_in_flight && m->ev[EV_WS])
         (void)hipEventSynchronize(m->ev[EV_WS]);
     m->ws_in_flight = false;
@@ -179,6 +197,136 @@ static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x, b
     launch_scale_vec(m->prec, m->npad, ytmp, m->t_dinv, m->stream);
     for (int kb = m->nblk - 1; kb >= 0; --kb)
         launch_bwd_step(m->prec, kb, m->Kmat, m->npad, m->linv, ytmp, x, m->stream);
+}
+
+// ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
+// L, X, Tw point at the top-left corner of an np x np diagonal part of matrices with leading dimension ld.
+static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st, long ld = 0)
+{
+    if (ld == 0)
+        ld = np;
+    auto off = [&](size_t r, size_t c) { return (r * ld + c) * e; };
+    for (long b = TILE; b < np; b *= 2) {
+        // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
+        int P = 0;
+        for (long base = 0; base + b < np; base += 2 * b)
+            ++P;
+        if (P == 0)
+            break;
+        const long last_base = (long)(P - 1) * 2 * b;
+        const int m_last = (int)std::min<long>(b, np - (last_base + b));
+        const long stride = 2 * b * ld + 2 * b;
+        GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
+        g1.A = L + off(b, 0), g1.lda = ld;
+        g1.B = X + off(0, 0), g1.ldb = ld;
+        g1.C = Tw + off(b, 0), g1.ldc = ld;
+        g1.M = (int)b, g1.N = (int)b, g1.K = (int)b;
+        g1.sA = g1.sB = g1.sC = stride;
+        g1.batch = P, g1.M_last = m_last;
+        g1.nn = 1, g1.b_lower = 1;
+        launch_gemm(prec, g1, st);
+        GemmArgs g2;  // X21 = -X22 * T  (A lower)
+        g2.A = X + off(b, b), g2.lda = ld;
+        g2.B = Tw + off(b, 0), g2.ldb = ld;
+        g2.C = X + off(b, 0), g2.ldc = ld;
+        g2.M = (int)b, g2.N = (int)b, g2.K = (int)b;
+        g2.sA = g2.sB = g2.sC = stride;
+        g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
+        g2.nn = 1, g2.a_lower = 1;
+        g2.alpha = -1.0;
+        launch_gemm(prec, g2, st);
+    }
+}
+
+// one combine step with an arbitrary split: X = inverse of the np x np unit-lower L whose leading h x h and trailing
+// (np - h) x (np - h) inverses are already in X:  X21 = -X22 * (L21 * X11)
+static void trtri_combine(int prec, size_t e, char *L, char *X, char *Tw, int np, int h, hipStream_t st, long ld)
+{
+    auto off = [&](size_t r, size_t c) { return (r * ld + c) * e; };
+    const int m2 = np - h;
+    if (m2 <= 0 || h <= 0)
+        return;
+    GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
+    g1.A = L + off(h, 0), g1.lda = ld;
+    g1.B = X + off(0, 0), g1.ldb = ld;
+    g1.C = Tw + off(h, 0), g1.ldc = ld;
+    g1.M = m2, g1.N = h, g1.K = h;
+    g1.nn = 1, g1.b_lower = 1;
+    launch_gemm(prec, g1, st);
+    GemmArgs g2;  // X21 = -X22 * T  (A lower)
+    g2.A = X + off(h, h), g2.lda = ld;
+    g2.B = Tw + off(h, 0), g2.ldb = ld;
+    g2.C = X + off(h, 0), g2.ldc = ld;
+    g2.M = m2, g2.N = h, g2.K = m2;
+    g2.nn = 1, g2.a_lower = 1;
+    g2.alpha = -1.0;
+    launch_gemm(prec, g2, st);
+}
+
+// The part of the inverse-factor assembly that only needs the first h columns of the factor, enqueued on the model's
+// third stream behind an event of the stream `after` (the factorisation has just passed column h there).
+static void launch_inverse_left(gpx_model *m, hipStream_t after)
+{
+    inv_ahead &ia = m->ia;
+    if (!ia.active || ia.launched)
+        return;
+    ia.launched = true;
+    const int np = m->npad, h = ia.h;
+    hipStream_t s3 = m->stream3;
+    (void)hipEventRecord(ia.start, after);
+    (void)hipStreamWaitEvent(s3, ia.start, 0);
+    if (ia.f64) {
+        launch_cast_lower_f2d(np, (const float *)m->Kmat, (double *)ia.L64, false, s3, 0, h);
+        launch_cast_f2d((size_t)(h / TILE) * TILE * TILE, (const float *)m->linv, (double *)ia.linv64, s3);
+        launch_place_diag(GPX_PREC_F64, h / TILE, ia.linv64, ia.X64, np, s3);
+        trtri_levels(GPX_PREC_F64, 8, (char *)ia.L64, (char *)ia.X64, (char *)ia.Tws, h, s3, np);
+    } else {
+        launch_place_diag(m->prec, h / TILE, m->linv, m->X, np, s3);
+        trtri_levels(m->prec, m->esz, (char *)m->Kmat, (char *)m->X, (char *)ia.Tws, h, s3, np);
+    }
+    (void)hipEventRecord(ia.done, s3);
+}
+
+// Decide and prepare (buffers, stream, events) the ahead-of-time part of the inverse factor; any failure just leaves it off.
+static void prepare_inverse_ahead(gpx_model *m)
+{
+    release_inv_ahead(m);
+    // Built and measured in round 3 (profiles/r03_create_timeline.txt, N = 16384): the assembly that remains is 3.1 ms
+    // shorter, the factorisation 3.3 ms (fp32) / 3.8 ms (fp64) longer -- its chain-bound tail shares CUs with the fp64 GEMM
+    // tiles of X11 and runs ~2x slower there, exactly the co-residency effect of DESIGN.md section 4 -- create wall 46.0-47.2
+    // vs 46.3-46.9 ms.  No gain: OFF unless GPX_INV_AHEAD=1 (results are bit-identical either way; tested).
+    const char *env = std::getenv("GPX_INV_AHEAD");  // read per call (tests switch it)
+    const int on = env ? std::atoi(env) : 0;
+    const int np = m->npad;
+    const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);
+    const int h = np_rows / 2 / PANEL * PANEL;
+    if (!on || h < 4 * PANEL || m->has_inverse)
+        return;
+    inv_ahead &ia = m->ia;
+    const size_t nn = (size_t)np * np, e = m->esz;
+    ia.f64 = m->prec == GPX_PREC_F32 && m->inv64;
+    bool ok = true;
+    if (!m->X)
+        ok = big_alloc(&m->X, e * nn) == hipSuccess;
+    if (!m->stream3)
+        ok = ok && hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ia.start, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ia.done, hipEventDisableTiming) == hipSuccess;
+    if (ok && ia.f64) {
+        ok = big_alloc(&ia.L64, sizeof(double) * nn) == hipSuccess && big_alloc(&ia.X64, sizeof(double) * nn) == hipSuccess &&
+             big_alloc(&ia.Tws, sizeof(double) * nn) == hipSuccess &&
+             hipMalloc(&ia.linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) == hipSuccess;
+    } else if (ok) {
+        ok = big_alloc(&ia.Tws, e * nn) == hipSuccess &&
+             hipMemsetAsync(m->X, 0, e * nn, m->stream) == hipSuccess;  // structural zeros above the block diagonal
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        release_inv_ahead(m);
+        return;
+    }
+    ia.h = h;
+    ia.active = true;
 }
 
 // ---- blocked right-looking LDL^T -----------------------------------------------------------------
@@ -352,6 +500,8 @@ static void factorize(gpx_model *m, int c_start = 0)
                     const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
                     const int sw = std::min(PANEL, np - r0);
                     const bool tail = np - r0 <= la_tail_rows || r0 + sw >= np;
+                    if (m->ia.active && !m->ia.launched && c0 >= m->ia.h)
+                        launch_inverse_left(m, sb);  // the chain of panel c0 is enqueued on sb: columns < c0 + 256 are final
                     // the rest update is released as soon as chain_p is done -- BEFORE the chain stream waits for rest_{p-1}:
                     // in the update-bound part the chain finishes long before that, and rest_p then follows rest_{p-1} on the
                     // main stream without a hop (was: hop + start of the strip = ~37 us per panel between two rest updates)
@@ -441,6 +591,8 @@ static void factorize(gpx_model *m, int c_start = 0)
     const int wide = wide_env == WIDE_PANEL ? WIDE_PANEL
                                             : (wide_env == PANEL ? PANEL : (m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL));
     while (c0 < np) {
+        if (m->ia.active && !m->ia.launched && c0 >= m->ia.h)
+            launch_inverse_left(m, m->stream);  // columns < c0 are final
         const int pw = std::min(wide, np - c0), nb = pw / TILE;
         for (int h = 0; h < nb; ++h) {
             const int cc = c0 + h * TILE, r0 = cc + TILE;
@@ -483,45 +635,6 @@ static void factor_append_rows(gpx_model *m, int t0)
         s.M = np - t0, s.N = np - (cc + TILE), s.K = TILE;
         s.alpha = -1.0, s.beta = 1;
         launch_gemm(m->prec, s, m->stream);
-    }
-}
-
-// ---- X = L^-1 by recursive doubling: X21 = -X22 * (L21 * X11) ------------------------------------
-// L, X, Tw point at the top-left corner of an np x np diagonal part of matrices with leading dimension ld.
-static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np, hipStream_t st, long ld = 0)
-{
-    if (ld == 0)
-        ld = np;
-    auto off = [&](size_t r, size_t c) { return (r * ld + c) * e; };
-    for (long b = TILE; b < np; b *= 2) {
-        // nodes p: left = [p*2b, p*2b+b), right = [p*2b+b, min(p*2b+2b, np))
-        int P = 0;
-        for (long base = 0; base + b < np; base += 2 * b)
-            ++P;
-        if (P == 0)
-            break;
-        const long last_base = (long)(P - 1) * 2 * b;
-        const int m_last = (int)std::min<long>(b, np - (last_base + b));
-        const long stride = 2 * b * ld + 2 * b;
-        GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
-        g1.A = L + off(b, 0), g1.lda = ld;
-        g1.B = X + off(0, 0), g1.ldb = ld;
-        g1.C = Tw + off(b, 0), g1.ldc = ld;
-        g1.M = (int)b, g1.N = (int)b, g1.K = (int)b;
-        g1.sA = g1.sB = g1.sC = stride;
-        g1.batch = P, g1.M_last = m_last;
-        g1.nn = 1, g1.b_lower = 1;
-        launch_gemm(prec, g1, st);
-        GemmArgs g2;  // X21 = -X22 * T  (A lower)
-        g2.A = X + off(b, b), g2.lda = ld;
-        g2.B = Tw + off(b, 0), g2.ldb = ld;
-        g2.C = X + off(b, 0), g2.ldc = ld;
-        g2.M = (int)b, g2.N = (int)b, g2.K = (int)b;
-        g2.sA = g2.sB = g2.sC = stride;
-        g2.batch = P, g2.M_last = m_last, g2.k_eq_m = 1;
-        g2.nn = 1, g2.a_lower = 1;
-        g2.alpha = -1.0;
-        launch_gemm(prec, g2, st);
     }
 }
 
@@ -572,7 +685,22 @@ int build_inverse(gpx_model *m)
     // temporaries behind guards: every early return below (HIPCHK) releases them
     DevGuard gTws(nullptr, true), gL64(nullptr, true), gX64(nullptr, true), glinv64(nullptr, false);
     bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
-    if (assemble64) {
+    // the part that was started inside the factorisation (its buffers pass to the guards here)
+    inv_ahead &ia = m->ia;
+    const bool ahead = ia.active && ia.launched && ia.f64 == assemble64;
+    const int h = ahead ? ia.h : 0;
+    if (ia.active) {
+        if (ia.launched)
+            (void)hipStreamWaitEvent(m->stream, ia.done, 0);  // X11 is ready (or: nothing below touches buffers in use)
+        if (ahead) {
+            gTws.p = ia.Tws, gL64.p = ia.L64, gX64.p = ia.X64, glinv64.p = ia.linv64;
+            ia.Tws = ia.L64 = ia.X64 = ia.linv64 = nullptr;
+        } else if (ia.launched) {
+            (void)hipStreamSynchronize(m->stream3);
+        }
+        release_inv_ahead(m);
+    }
+    if (assemble64 && !ahead) {
         // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
         const size_t nn = (size_t)np * np;
         if (big_alloc(&gL64.p, sizeof(double) * nn) != hipSuccess || big_alloc(&gX64.p, sizeof(double) * nn) != hipSuccess ||
@@ -583,29 +711,41 @@ int build_inverse(gpx_model *m)
             assemble64 = false;
         }
     }
+    // With the leading h x h inverse already there (h > 0): the trailing block's own inverse, then one combine step
+    // X21 = -X22 (L21 X11) -- the same products as the top level of the recursive doubling.
     if (assemble64) {
-        void *L64 = gL64.p, *X64 = gX64.p, *Tws = gTws.p, *linv64 = glinv64.p;
+        double *L64 = (double *)gL64.p, *X64 = (double *)gX64.p, *linv64 = (double *)glinv64.p;
+        char *Tws = (char *)gTws.p;
         // The fp32 factor is kept (that is what runs on the fp32 MFMA), but its inverse is assembled in fp64 and
         // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
         // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
         // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
-        launch_cast_lower_f2d(np, (const float *)m->Kmat, (double *)L64, false, m->stream);  // the upper tiles are never read
-        launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, (double *)linv64, m->stream);
+        launch_cast_lower_f2d(np, (const float *)m->Kmat, L64, false, m->stream, h, -1);  // the upper tiles are never read
+        const size_t lb = (size_t)(h / TILE) * TILE * TILE;
+        launch_cast_f2d((size_t)m->nblk * TILE * TILE - lb, (const float *)m->linv + lb, linv64 + lb, m->stream);
         // (no memset of X64: the assembly reads and writes only tiles on / below the block diagonal -- place_diag
         // supplies the diagonal tiles, zeros above the diagonal inside them -- and the final cast writes the zeros of
         // the upper tiles of X without reading them)
-        launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
-        trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, (char *)Tws, np, m->stream);
-        launch_cast_lower_d2f(np, (const double *)X64, (float *)m->X, true, m->stream);
+        launch_place_diag(GPX_PREC_F64, m->nblk - h / TILE, linv64 + lb, X64 + (size_t)h * np + h, np, m->stream);
+        trtri_levels(GPX_PREC_F64, 8, (char *)(L64 + (size_t)h * np + h), (char *)(X64 + (size_t)h * np + h),
+                     Tws + ((size_t)h * np + h) * 8, np - h, m->stream, np);
+        if (h > 0)
+            trtri_combine(GPX_PREC_F64, 8, (char *)L64, (char *)X64, Tws, np, h, m->stream, np);
+        launch_cast_lower_d2f(np, X64, (float *)m->X, true, m->stream);
         if (m->var_fit)  // from the un-rounded rows: the rounding of X then only meets the small fit residual
             launch_var_rowcorr(true, m->op64, m->n, np, X64, np, m->d_x, m->d_y, m->d_z, m->d_meta, m->d_corr, m->stream);
     } else {
-        HIPCHK(big_alloc(&gTws.p, e * (size_t)np * np));
+        if (!gTws.p)
+            HIPCHK(big_alloc(&gTws.p, e * (size_t)np * np));
         // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
-        // 128-block of every 256-diagonal block
-        HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
-        launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
-        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)gTws.p, np, m->stream);
+        // 128-block of every 256-diagonal block (with the ahead-of-time part the memset ran before the factorisation)
+        if (!ahead)
+            HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
+        const size_t lb = (size_t)(h / TILE) * TILE * TILE, dg = ((size_t)h * np + h) * e;
+        launch_place_diag(m->prec, m->nblk - h / TILE, (char *)m->linv + lb * e, (char *)m->X + dg, np, m->stream);
+        trtri_levels(m->prec, e, (char *)m->Kmat + dg, (char *)m->X + dg, (char *)gTws.p + dg, np - h, m->stream, np);
+        if (h > 0)
+            trtri_combine(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)gTws.p, np, h, m->stream, np);
         if (m->var_fit)
             launch_var_rowcorr(m->prec == GPX_PREC_F64, m->op64, m->n, np, m->X, np, m->d_x, m->d_y, m->d_z, m->d_meta,
                                m->d_corr, m->stream);
@@ -830,7 +970,9 @@ int build_model(gpx_model *m, kept_factor *keep)
         launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
         launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
         (void)hipEventRecord(m->ev[EV_KBUILD], s);
-        // ---- factorisation ----
+        // ---- factorisation (with the finished half of the inverse factor assembled beside its tail, if one is wanted) ----
+        if (m->opt.prepare_variance || m->train64)
+            prepare_inverse_ahead(m);
         factorize(m);
     }
     (void)hipEventRecord(m->ev[EV_FACTOR], s);

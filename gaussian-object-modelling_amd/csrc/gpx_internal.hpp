@@ -155,7 +155,8 @@ void launch_normalize_rows3(long n, double *g, hipStream_t st);
 void launch_cast_d2f(size_t n, const double *src, float *dst, hipStream_t st);
 void launch_cast_f2d(size_t n, const float *src, double *dst, hipStream_t st);
 // np x np lower block-triangular matrices: tiles above the block diagonal are skipped, or written as zeros (never read)
-void launch_cast_lower_f2d(int np, const float *src, double *dst, bool zero_upper, hipStream_t st);
+void launch_cast_lower_f2d(int np, const float *src, double *dst, bool zero_upper, hipStream_t st, int row0 = 0,
+                           int row1 = -1);  // rows [row0, row1) only (multiples of 128; -1: to the end)
 void launch_cast_lower_d2f(int np, const double *src, float *dst, bool zero_upper, hipStream_t st);
 
 // ---- MFMA GEMM core : gpx_gemm.hip ----------------------------------------------------------

@@ -48,6 +48,17 @@ struct gpx_pending {
     std::string err;
 };
 
+// Inverse-factor assembly started INSIDE the factorisation (round 3): once the LDL^T has passed column h,
+// the leading h x h part of L is final and X11 = L11^-1 (1/8 of the assembly's flops for h = N/2) is assembled on a
+// third stream while the chain-bound tail of the factorisation runs; build_inverse() does the rest.
+struct inv_ahead {
+    bool active = false, launched = false;
+    bool f64 = false;  // fp64 assembly of an fp32 factor: L64 / X64 / linv64 in use (else the model's own Kmat / X / linv)
+    int h = 0;
+    void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
+    hipEvent_t start = nullptr, done = nullptr;
+};
+
 struct gpx_model {
     int device = 0, prec = 0;
     size_t esz = 4;
@@ -65,6 +76,8 @@ struct gpx_model {
     double R = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;         // look-ahead of the factorisation: the next panel beside the trailing update
+    hipStream_t stream3 = nullptr;         // inverse-factor assembly of the finished part beside the factorisation's tail
+    inv_ahead ia;
     std::vector<hipEvent_t> la_ev;         // its cross-stream events (no timing), reused
     hipEvent_t ev[EV_COUNT] = {};
     std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)

@@ -855,9 +855,9 @@ __global__ __launch_bounds__(256) void cast_f2d_kernel(size_t n, const float *__
 // zeros without being read.  4 consecutive elements per lane (16-byte fp32 / 32-byte fp64 accesses).
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void cast_lower_kernel(int np, const TS *__restrict__ src, TD *__restrict__ dst,
-                                                         int zero_upper)
+                                                         int zero_upper, int row_tile0)
 {
-    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int ti = blockIdx.y + row_tile0, tj = blockIdx.x;
     if (tj > ti && !zero_upper)
         return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 lanes x 4 columns, 8 rows per pass
@@ -888,16 +888,21 @@ __global__ __launch_bounds__(256) void cast_lower_kernel(int np, const TS *__res
     }
 }
 
-void launch_cast_lower_f2d(int np, const float *src, double *dst, bool zero_upper, hipStream_t st)
+// rows [row0, row1) of the np x np matrix only (multiples of 128; row1 < 0: to the end); column tiles beyond the last
+// row tile of the range are not visited
+void launch_cast_lower_f2d(int np, const float *src, double *dst, bool zero_upper, hipStream_t st, int row0, int row1)
 {
-    hipLaunchKernelGGL((cast_lower_kernel<float, double>), dim3(np / TILE, np / TILE), dim3(256), 0, st, np, src, dst,
-                       zero_upper ? 1 : 0);
+    const int t0 = row0 / TILE, t1 = (row1 < 0 ? np : row1) / TILE;
+    if (t1 <= t0)
+        return;
+    hipLaunchKernelGGL((cast_lower_kernel<float, double>), dim3(zero_upper ? np / TILE : t1, t1 - t0), dim3(256), 0, st, np,
+                       src, dst, zero_upper ? 1 : 0, t0);
 }
 
 void launch_cast_lower_d2f(int np, const double *src, float *dst, bool zero_upper, hipStream_t st)
 {
     hipLaunchKernelGGL((cast_lower_kernel<double, float>), dim3(np / TILE, np / TILE), dim3(256), 0, st, np, src, dst,
-                       zero_upper ? 1 : 0);
+                       zero_upper ? 1 : 0, 0);
 }
 
 void launch_cast_f2d(size_t n, const float *src, double *dst, hipStream_t st)
