@@ -112,8 +112,14 @@ struct GemmDev {
 
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
+#ifndef GEMM_LOOP_P2ALIGN
+#define GEMM_LOOP_P2ALIGN 0
+#endif
+#ifndef GEMM_KERNEL_ALIGN
+#define GEMM_KERNEL_ALIGN 256
+#endif
 template <typename T, bool NN, int EPI, int FM, int FN, int WGM, int WGN, int KBYTES, bool M32>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 3 : GEMM_WAVES_PER_EU) : 1) void gemm_kernel(GemmDev<T> g)
+__global__ __attribute__((aligned(GEMM_KERNEL_ALIGN))) __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? (KBYTES == 64 ? 3 : GEMM_WAVES_PER_EU) : 1) void gemm_kernel(GemmDev<T> g)
 {
     using MF = MfmaT<T, M32>;
     using acc_t = typename MF::acc_t;
@@ -341,6 +347,9 @@ _Pragma("unroll") \
         GPX_SSTORE(0);
         __syncthreads();
         int buf = 0;
+#if GEMM_LOOP_P2ALIGN
+        asm volatile(".p2align %0" ::"n"(GEMM_LOOP_P2ALIGN));
+#endif
         for (int kt = kt0; kt < kt1; ++kt) {
             const int ktn = min(kt + 1, kt1 - 1);
             GPX_GLOAD(ktn);
@@ -619,9 +628,19 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
     } else if (a.epi == EPI_TRSM) {
         GPX_GEMM_CFG(false, EPI_TRSM);
     } else if (sizeof(T) == 4 && a.cfg == 3) {
-        // experiment (GPX_VAR_TILE=3): 64-byte k rows, 40 KiB of LDS per workgroup, compiled for 3 workgroups per CU
+        // GPX_VAR_TILE=3 (default since round 3): 64-byte k rows, 40 KiB of LDS per workgroup, compiled for 3 workgroups per CU
         if constexpr (sizeof(T) == 4)
             gemm_launch_cfg<T, false, EPI_COLSQ, 4, 4, 2, 2, 64>(g, a, st);
+#ifdef GEMM_BENCH_M32
+    } else if (sizeof(T) == 4 && (a.cfg == 4 || a.cfg == 5)) {
+        // harness only: the same 128 x 128 tile on v_mfma_f32_32x32x2_f32 (2 x 2 fragments of 32 x 32 per wave)
+        if constexpr (sizeof(T) == 4) {
+            if (a.cfg == 4)
+                gemm_launch_cfg<T, false, EPI_COLSQ, 2, 2, 2, 2, 128, true>(g, a, st);
+            else
+                gemm_launch_cfg<T, false, EPI_COLSQ, 2, 2, 2, 2, 64, true>(g, a, st);
+        }
+#endif
     } else {
         // Measured on the variance shape (N = 16384, 8192 queries), all within 1.5 %: 128x128 tile 135-136 TF,
         // 256x256 tile 134-135 TF, 64-byte k rows at 3 workgroups/CU (KBYTES = 64) 136.6 TF, 32x32x2 MFMA

@@ -57,7 +57,11 @@ int main(int argc, char **argv)
     CK(hipMemset(C, 0, e * (size_t)N * N));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef GEMM_BENCH_M32
+    for (int cfg : {0, 2, 3, 4, 5}) {
+#else
     for (int cfg : {0, 2, 3}) {
+#endif
         GemmArgs a;
         a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
         a.rowweight = dinv; a.partial = partial, a.ldp = NQ; a.cfg = cfg;
