@@ -294,7 +294,7 @@ static void prepare_inverse_ahead(gpx_model *m)
     // Built and measured in round 3 (profiles/r03_create_timeline.txt, N = 16384): the assembly that remains is 3.1 ms
     // shorter, the factorisation 3.3 ms (fp32) / 3.8 ms (fp64) longer -- its chain-bound tail shares CUs with the fp64 GEMM
     // tiles of X11 and runs ~2x slower there, exactly the co-residency effect of DESIGN.md section 4 -- create wall 46.0-47.2
-    // vs 46.3-46.9 ms.  No gain: OFF unless GPX_INV_AHEAD=1 (results are bit-identical either way; tested).
+    // vs 46.3-46.9 ms.  No gain: OFF unless GPX_INV_AHEAD=1 (same factor, the inverse to fp64 rounding; tested).
     const char *env = std::getenv("GPX_INV_AHEAD");  // read per call (tests switch it)
     const int on = env ? std::atoi(env) : 0;
     const int np = m->npad;
@@ -953,7 +953,6 @@ int build_model(gpx_model *m, kept_factor *keep)
     launch_cast_vec(m->prec, np, np, m->d_s2, m->t_s2, s);
     // ---- kernel matrix ----
     (void)hipEventRecord(m->ev[EV_T0], s);
-    const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
     if (keep && keep->t0 > 0) {
         // rank-n update: the old factor goes back into the (possibly larger) matrix, only the new rows are built
         const size_t t0 = (size_t)keep->t0;
@@ -967,8 +966,8 @@ int build_model(gpx_model *m, kept_factor *keep)
         factor_append_rows(m, keep->t0);
         factorize(m, keep->t0);
     } else {
-        launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
-        launch_reduce_tilemax(ntiles, m->d_tmax, m->d_tij, m->d_info + 2, s);
+        const int nmax = launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
+        launch_reduce_tilemax(nmax, m->d_tmax, m->d_tij, m->d_info + 2, s);
         (void)hipEventRecord(m->ev[EV_KBUILD], s);
         // ---- factorisation (with the finished half of the inverse factor assembled beside its tail, if one is wanted) ----
         if (m->opt.prepare_variance || m->train64)

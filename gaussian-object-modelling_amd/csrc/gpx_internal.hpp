@@ -16,7 +16,7 @@ constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
 constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
 constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
-constexpr int PAIR_WIDE_DEFAULT = 0, PAIR_NT_DEFAULT = 0;  // store pattern of the operand kernel (gpx_pairwise.hip: kqp_t)
+constexpr int PAIR_WIDE_DEFAULT = 0, PAIR_NT_DEFAULT = 0, KBUILD_WIDE_DEFAULT = 0;  // store pattern of the operand kernel (gpx_pairwise.hip: kqp_t)
 // Terms of the low-rank fit taken out of the kernel operand of the variance contraction.  The fit is a polynomial of
 // degree two in s = |q - p|^2, which is rank 14 in (q, p): basis functions of the training point, relative to the
 // model's centre c (p' = p - c):  1 | p'_x p'_y p'_z | p'_x^2 p'_y^2 p'_z^2 p'_x p'_y p'_x p'_z p'_y p'_z |
@@ -68,9 +68,10 @@ __device__ __forceinline__ void tri_decode(int t, int &ti, int &tj)
 
 // ---- pairwise (kernel-matrix) stages : gpx_pairwise.hip -----------------------------------
 // K (lower block-triangle, identity on padding), per-tile maxima of the squared distance.
-void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
-                   const void *s2, void *K, float *tile_max_d2, int *tile_max_ij, hipStream_t st,
-                   int first_tile_row = 0);  // > 0: only the tile rows from that row block on (rank-n update)
+// returns the number of (tile_max_d2, tile_max_ij) entries it writes (what launch_reduce_tilemax then scans)
+int launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
+                  const void *s2, void *K, float *tile_max_d2, int *tile_max_ij, hipStream_t st,
+                  int first_tile_row = 0);  // > 0: only the tile rows from that row block on (rank-n update)
 // picks the global maximum of the per-tile maxima -> out_ij[2]
 void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile_max_ij, int *out_ij,
                            hipStream_t st);

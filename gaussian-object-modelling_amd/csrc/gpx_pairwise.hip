@@ -137,6 +137,105 @@ __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad
     }
 }
 
+// The same matrix with 1-KiB row segments per wave store: a block covers 128 rows x 256 columns = the tiles (ti, 2 bx) and
+// (ti, 2 bx + 1) of the lower block triangle (grid: ceil(nt / 2) x nt; blocks right of the diagonal leave at once; on
+// the diagonal of an even row tile the right half lies above it and is written all the same -- nobody reads it).  A pure
+// fill of this shape reaches 5.99 instead of 5.71 TB/s (profiles/r03_fill_bench.txt).  tmax / tij: one entry per block,
+// -1 for the idle ones.
+template <typename T, int KID, bool NT>
+__global__ __launch_bounds__(256) void kbuild_wide_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ x,
+                                                          const T *__restrict__ y, const T *__restrict__ z,
+                                                          const T *__restrict__ s2, T *__restrict__ K,
+                                                          float *__restrict__ tmax, int *__restrict__ tij)
+{
+    __shared__ T rx[TILE], ry[TILE], rz[TILE], rs[TILE];
+    __shared__ float wbest[4];
+    __shared__ int wbi[4], wbj[4];
+    const int ti = blockIdx.y, bx = blockIdx.x;
+    const int blk = ti * (int)gridDim.x + bx;
+    const int tid = threadIdx.x;
+    if (2 * bx > ti) {
+        if (tid == 0) {
+            tmax[blk] = -1.0f;
+            tij[2 * blk] = tij[2 * blk + 1] = 0;
+        }
+        return;
+    }
+    if (tid < TILE) {
+        int gi = ti * TILE + tid;
+        rx[tid] = x[gi];
+        ry[tid] = y[gi];
+        rz[tid] = z[gi];
+        rs[tid] = s2[gi];
+    }
+    const int tx = tid & 63, ty = tid >> 6;
+    const int gj0 = bx * 2 * TILE + tx * 4;
+    T cx[4], cy[4], cz[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cx[c] = x[gj0 + c];
+        cy[c] = y[gj0 + c];
+        cz[c] = z[gj0 + c];
+    }
+    __syncthreads();
+    float best = -1.0f;
+    int bi = 0, bj = 0;
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+        const int li = ty + 4 * r;
+        const int gi = ti * TILE + li;
+        const T ax = rx[li], ay = ry[li], az = rz[li];
+        T out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = gj0 + c;
+            T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
+            T d2 = dx * dx + dy * dy + dz * dz;
+            T kv = cov_k<T, KID>(cov, d2);
+            if (gi == gj)
+                kv += rs[li];
+            if (gi < n && gj < n) {
+                if ((float)d2 > best) {
+                    best = (float)d2;
+                    bi = gi;
+                    bj = gj;
+                }
+            } else {
+                kv = (gi == gj) ? T(1) : T(0);  // identity on the padding
+            }
+            out[c] = kv;
+        }
+        store4<T, NT>(K + (size_t)gi * npad + gj0, out);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(best, off);
+        int oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+        if (ob > best) {
+            best = ob;
+            bi = oi;
+            bj = oj;
+        }
+    }
+    if ((tid & 63) == 0) {
+        wbest[tid >> 6] = best;
+        wbi[tid >> 6] = bi;
+        wbj[tid >> 6] = bj;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (wbest[w] > best) {
+                best = wbest[w];
+                bi = wbi[w];
+                bj = wbj[w];
+            }
+        tmax[blk] = best;
+        tij[2 * blk] = bi;
+        tij[2 * blk + 1] = bj;
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const float *__restrict__ tmax,
                                                              const int *__restrict__ tij, int *__restrict__ out)
 {
@@ -447,27 +546,41 @@ void launch_var_rowcorr(bool x_is_f64, bool op64, int n, int np, const void *X, 
 }
 
 template <typename T>
-static void kbuild_t(const CovHost &h, int n, int npad, const void *x, const void *y, const void *z,
-                     const void *s2, void *K, float *tmax, int *tij, int first_tile_row, hipStream_t st)
+static int kbuild_t(const CovHost &h, int n, int npad, const void *x, const void *y, const void *z,
+                    const void *s2, void *K, float *tmax, int *tij, int first_tile_row, hipStream_t st)
 {
     const int nt = npad / TILE;
     const int ntiles = nt * (nt + 1) / 2;
     const int tile0 = first_tile_row * (first_tile_row + 1) / 2;  // row-major enumeration of the lower tiles
     if (tile0 >= ntiles)
-        return;
+        return 0;
     Cov<T> c = lower_cov<T>(h);
+    // store pattern of a fresh build (read once): GPX_KBUILD_WIDE=1: 1-KiB row segments per wave store; GPX_PAIR_NT=1: non-temporal
+    static const int wide = [] { const char *e = std::getenv("GPX_KBUILD_WIDE"); return e ? std::atoi(e) : KBUILD_WIDE_DEFAULT; }();
+    static const int nt_st = [] { const char *e = std::getenv("GPX_PAIR_NT"); return e ? std::atoi(e) : PAIR_NT_DEFAULT; }();
+    if (wide && first_tile_row == 0) {
+        const dim3 grid((nt + 1) / 2, nt);
+        if (nt_st) {
+            GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_wide_kernel<T, KID, true>), grid, dim3(256), 0, st, c, n, npad,
+                                                      (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K, tmax, tij));
+        } else {
+            GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_wide_kernel<T, KID, false>), grid, dim3(256), 0, st, c, n, npad,
+                                                      (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K, tmax, tij));
+        }
+        return (int)(grid.x * grid.y);
+    }
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_kernel<T, KID>), dim3(ntiles - tile0), dim3(256), 0, st, c, n,
                                               npad, (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K,
                                               tmax, tij, tile0));
+    return ntiles;
 }
 
-void launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
-                   const void *s2, void *K, float *tmax, int *tij, hipStream_t st, int first_tile_row)
+int launch_kbuild(int prec, const CovHost &cov, int n, int npad, const void *x, const void *y, const void *z,
+                  const void *s2, void *K, float *tmax, int *tij, hipStream_t st, int first_tile_row)
 {
     if (prec == GPX_PREC_F64)
-        kbuild_t<double>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
-    else
-        kbuild_t<float>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
+        return kbuild_t<double>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
+    return kbuild_t<float>(cov, n, npad, x, y, z, s2, K, tmax, tij, first_tile_row, st);
 }
 
 void launch_reduce_tilemax(int ntiles, const float *tmax, const int *tij, int *out_ij, hipStream_t st)

@@ -944,12 +944,13 @@ def test_replicas_on_a_second_device(gpu, ds, prec):
 
 @pytest.mark.parametrize("prec", [1, 0, 2])
 @pytest.mark.parametrize("n", [2305, 4096, 5000])
-def test_inverse_factor_started_inside_the_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch):
+def test_inverse_factor_started_inside_the_factorisation(gpu, ds, prec, n, monkeypatch):
     """GPX_INV_AHEAD=1 assembles X11 = L11^-1 (the leading half) on a third stream while the factorisation
     works on the trailing columns, and build_inverse() adds the trailing block's inverse and one combine step
-    X21 = -X22 (L21 X11).  Same tiles, same k ranges, same operands as the recursive doubling: alpha, D and the variance
-    are bit-identical to the default order (measured: no time gain, so it is off by default -- the test keeps the path
-    alive).  F64, F32 (fp64 assembly of the fp32 factor), MIXED (fp64-trained)."""
+    X21 = -X22 (L21 X11).  The factorisation itself is untouched (alpha, D bit-identical); the inverse factor is the same
+    matrix assembled through a different tree of block products (split at N/2 rounded to 256 instead of at powers of
+    two), so the variance agrees to fp64 rounding (1e-12), bit for bit where the trees coincide.  Measured: no time
+    gain, so it is off by default -- the test keeps the path alive.  F64, F32 (fp64 assembly of the fp32 factor), MIXED."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     kern = gpu.make_kernel("matern52", 1.0, 1.0)
     qx, qy, qz = ds.query_grid(6)
@@ -960,5 +961,7 @@ def test_inverse_factor_started_inside_the_factorisation_is_bit_identical(gpu, d
         o = gm.evaluate(qx, qy, qz, want_v=True)
         res[mode] = (gm.alpha.copy(), gm.D.copy(), o["f"].copy(), o["v"].copy())
         gm.close()
-    for a, b in zip(res["1"], res["0"]):
+    for a, b in zip(res["1"][:3], res["0"][:3]):
         np.testing.assert_array_equal(a, b)
+    # fp32 state: X is rounded to fp32 after the fp64 assembly, a 1e-16 difference can flip a last bit here and there
+    assert verr_v(res["1"][3], res["0"][3]) < (1e-12 if prec == 1 else 1e-7)
