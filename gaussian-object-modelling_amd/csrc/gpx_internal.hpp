@@ -84,8 +84,14 @@ void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile
 // the pieces at N = 16384, thin-plate R = 4 (profiles/r03_tp_fit_probe.txt; variance error / max|v_ref|): degree-one
 // fit with the operand formed in fp32 and an fp32 add-back (round 2) 3.9e-5; degree two, operand formed in fp64 and
 // rounded once, fp64 add-back 7e-6.  The fit is a weighted least-squares parabola of k against s over a strided
-// sample of <= 512 training points, so it follows the distances the query actually sees.
-constexpr int VAR_FIT_SAMPLES = 512;
+// sample of the training points, so it follows the distances the query actually sees.
+// samples of the fit: every stride-th training point, at most VAR_FIT_SAMPLES (register-resident, 8 per lane), default 64.
+// Measured (scripts/fit_samples_check.py, variance error / max|v_ref| at N = 16384): 512 / 256 / 128 / 64 / 32 samples give
+// thin plate 5.0 / 3.3 / 3.9 / 3.7 / 3.6e-6 and Matern-5/2 1.2 / 1.1 / 1.4 / 1.2 / 1.5e-6 -- the fit is a 3-parameter
+// parabola of a smooth function, more samples buy nothing -- while the kernel's time is proportional to them: 29 % of the
+// variance time of a C5-shaped model (N = 724, 128^3 queries) at 512 samples, 4 % at 64.
+constexpr int VAR_FIT_SAMPLES = 128;
+constexpr int VAR_FIT_SAMPLES_DEFAULT = 64;  // GPX_VAR_FIT_SAMPLES (16 .. 128)
 // weights 1 / (s + delta) of the least squares, delta = R_max^2 / VAR_FIT_WDELTA_DIV with R_max = Model::R, the largest
 // pairwise training distance (0.05 for the node's unit-ball clouds with their exterior sphere of radius 2);
 // GPX_VAR_FIT_WDELTA overrides delta itself, <= 0: uniform weights

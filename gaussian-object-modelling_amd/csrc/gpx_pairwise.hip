@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
 }
 
 // ---- the per-query fit of the variance contraction, once per query batch ------------------------------------------
-// (a, b, c) = weighted least-squares parabola of k against s = d^2 over every `stride`-th training point (<= 512 samples,
+// (a, b, c) = weighted least-squares parabola of k against s = d^2 over every `stride`-th training point (<= 128 samples,
 // 16 lanes per query, the samples stay in registers), weights 1 / (s + wdelta) (wdelta <= 0: uniform): the rows of the
 // inverse factor weigh a query's NEAREST training points most, so that is where the residual should be smallest
 // (measured at N = 16384, variance error / max|v_ref|, thin-plate R = 4: uniform 7.1e-6, wdelta = 0.05 3.8e-6;
@@ -395,7 +395,12 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
                     const double *qz, double *coef, long ldcc, hipStream_t st)
 {
     const dim3 grid((unsigned)((nq_tile + 15) / 16));
-    const int stride = (n + VAR_FIT_SAMPLES - 1) / VAR_FIT_SAMPLES;
+    static const int nsamp = [] {
+        const char *e = std::getenv("GPX_VAR_FIT_SAMPLES");  // 16 .. 128 strided training points per query
+        const int v = e ? std::atoi(e) : VAR_FIT_SAMPLES_DEFAULT;
+        return v < 16 ? 16 : (v > VAR_FIT_SAMPLES ? VAR_FIT_SAMPLES : v);
+    }();
+    const int stride = (n + nsamp - 1) / nsamp;
     Cov<double> c = lower_cov<double>(h);
     if (op64) {
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), grid, dim3(256), 0, st, c, n, stride, px,
