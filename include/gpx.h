@@ -70,7 +70,7 @@ typedef struct gpx_kernel {
  *          residuals; the inverse factor is assembled in fp64 from the fp32 factor and rounded once; the variance
  *          GEMM contracts a centred kernel operand -- k minus a per-query parabola in the squared distance, formed in
  *          fp64 and rounded once -- and its epilogue adds the fit back, squares, weights and sums in fp64: every kernel
- *          within 1e-5 of the fp64 result at N = 16384 in max|dv| / max|v_ref| (thin plate R = 4: 5e-6, where k(0) is
+ *          within 1e-5 of the fp64 result at N = 16384 in max|dv| / max|v_ref| (thin plate R = 4: 4e-6, where k(0) is
  *          60 x max|v|).  Models of up to 2048 padded rows (GPX_TRAIN_F64_MAX) are trained in fp64 like MIXED: (nearly)
  *          free at that size.  THIN-PLATE models are trained in fp64 at every size whose fp64 temporaries fit the device
  *          (cond > 1e6, predictor weights of 10-100: an fp32 LDL^T shows in the variance); such models hold no factor
