@@ -112,8 +112,11 @@ struct GemmDev {
 
 // FM x FN MFMA fragments (16 x 16) per wave, WGM x WGN waves per workgroup:
 // block tile BM x BN = (WGM * FM * FR) x (WGN * FN * FR), 64 * WGM * WGN threads.
+// The k-loop starts on a 32-byte boundary: where it starts relative to the instruction-fetch window matters (round 3,
+// profiles/r03_var_gemm_variants.txt: the 128-byte-k variance tile runs 16.0 ms per launch with the loop at 0, 16, 24 bytes
+// past a 32-byte boundary and 16.45 at 8 bytes past it; what surrounds the kernel in the code object decided that before).
 #ifndef GEMM_LOOP_P2ALIGN
-#define GEMM_LOOP_P2ALIGN 0
+#define GEMM_LOOP_P2ALIGN 5
 #endif
 #ifndef GEMM_KERNEL_ALIGN
 #define GEMM_KERNEL_ALIGN 256
@@ -349,6 +352,9 @@ _Pragma("unroll") \
         int buf = 0;
 #if GEMM_LOOP_P2ALIGN
         asm volatile(".p2align %0" ::"n"(GEMM_LOOP_P2ALIGN));
+#endif
+#ifdef GEMM_LOOP_NOPS  /* placement experiment: N 4-byte instructions after the alignment point */
+        asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(GEMM_LOOP_NOPS));
 #endif
         for (int kt = kt0; kt < kt1; ++kt) {
             const int ktn = min(kt + 1, kt1 - 1);
