@@ -607,6 +607,23 @@ static void factorize(gpx_model *m, int c_start = 0)
     m->gemm_ev_used_factor = gemm_idx;
 }
 
+// the factorisation and the substitution on a matrix somebody else has put into m->Kmat (gpx_dgp.hip: the 4N x 4N matrix of
+// a GP with derivative observations); everything they touch is allocated by alloc_model + the three buffers below
+int alloc_factor_buffers(gpx_model *m)
+{
+    const size_t np = (size_t)m->npad, e = m->esz;
+    HIPCHK(big_alloc(&m->Kmat, e * np * np));
+    HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
+    HIPCHK(hipMalloc(&m->Wp, e * np * WIDE_PANEL));
+    return GPX_OK;
+}
+void factorize_matrix(gpx_model *m)
+{
+    factor_init(m->prec);
+    factorize(m);
+}
+void solve_factored(gpx_model *m, void *b, void *ytmp, void *x) { solve_ldl(m, b, ytmp, x, false); }
+
 // Rank-n update, rows [t0, npad): the kernel rows have just been built; the columns [0, t0) hold the old factor.
 // Column block by column block: W = A_rows,j Linv_j^T (to the workspace), L_rows,j = W D_j^-1 (in place), then
 // every later column of these rows -= W L_{later rows, j}^T.  2 launches per old column block.

@@ -1,0 +1,436 @@
+// gpx_dgp.hip -- first slice of the reference's SECOND GP library, gp::GaussianProcess (SURVEY 8f.4 / VERDICT r2 #8):
+// a GP whose training data are function values AND gradients (surface normals) at the same points,
+// include/gp/GaussianProcess.h of the reference: compute() :532-583 (the 4N x 4N covariance of values and
+// derivatives, layout [values (N) | d/dx, d/dy, d/dz of point 0 | ... of point N-1], Cholesky), update_alpha()
+// :505-528, f() :237-252 (value and gradient at a query = k_star (4 x 4N) alpha), var() :256-269,
+// logLikelihood() :376-385, SampleSet (src/gp/SampleSet.cpp:23-35: targets, then the normals point by point).
+//
+// The reference's own code for this library does not build and has no defined results:
+// CovSE::getDiff2 (include/gp/CovSE.h:84-89) lacks the delta_de / l^2 term of the second derivative and multiplies
+// the noise into the kernel, ThinPlate has no getDiff2 at all, update_k_star (:459-497) indexes points up to 4N,
+// var() conditions on the value block only, evaluate() (:227-235) returns zeros.  What is built here is the algorithm
+// those functions are written towards, with exact derivative blocks: for a radial kernel k(r), u = x - x', r = |u|,
+// g = k'(r) / r, h = g'(r) / r:
+//     cov(f(x),      f(x'))       = k(r)
+//     cov(d_d f(x),  f(x'))       = g u_d                    cov(f(x), d_e f(x')) = -g u_e
+//     cov(d_d f(x),  d_e f(x'))   = -g delta_de - h u_d u_e
+//   CovSE     (CovSE.h:70-74)     k = sf^2 exp(-r^2 / (2 l^2)),  g = -k / l^2,  h = k / l^4
+//   ThinPlate (CovThinPlate.h:80-89) k = 2 r^3 - 3 R r^2 + R^3,  g = 6 r - 6 R, h = 6 / r  (h u_d u_e -> 0 at r = 0)
+// noise^2 on the whole diagonal (BaseCovFunc: "dirac").  fp64 throughout.
+//
+// Everything dense goes through the machinery of the first library: the matrix is filled in 128 x 128 tiles of the
+// lower block triangle, factorised by the blocked LDL^T on the matrix cores (factorize_matrix; for a positive
+// definite matrix L D^1/2 is the reference's llt().matrixL()), solved by block substitution, and the variance is the
+// same fused contraction v = k(0) - sum_j (X k_star)_j^2 / D_j with X = L^-1.
+#include "gpx_model.hpp"
+
+namespace gpx {
+
+struct DCov {
+    int id;  // GPX_KERNEL_SE or GPX_KERNEL_THINPLATE
+    double sf2, inv_l2, R, R3;
+};
+
+// k, g = k'/r, h = g'/r at squared distance r2 (h_rr = h * r2 is what multiplies the unit-vector products: finite at 0)
+__device__ __forceinline__ void dcov_eval(const DCov &c, double r2, double &k, double &g, double &h)
+{
+    if (c.id == GPX_KERNEL_THINPLATE) {
+        const double r = sqrt(r2);
+        k = (r - c.R) * (r - c.R) * (2.0 * r + c.R);
+        g = 6.0 * (r - c.R);
+        h = r > 0.0 ? 6.0 / r : 0.0;  // only ever multiplied by u_d u_e = O(r^2)
+    } else {
+        k = c.sf2 * exp(-0.5 * r2 * c.inv_l2);
+        g = -k * c.inv_l2;
+        h = k * c.inv_l2 * c.inv_l2;
+    }
+}
+
+// entry (a, b) of the 4N x 4N covariance; index a: [0, n) values, n + 3 i + d derivative d of point i
+__device__ __forceinline__ double dgp_entry(const DCov &c, int n, int a, int b, const double *__restrict__ x,
+                                            const double *__restrict__ y, const double *__restrict__ z, double sn2)
+{
+    const int ia = a < n ? a : (a - n) / 3, da = a < n ? -1 : (a - n) % 3;
+    const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+    const double u[3] = {x[ia] - x[ib], y[ia] - y[ib], z[ia] - z[ib]};
+    double k, g, h;
+    dcov_eval(c, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], k, g, h);
+    double v;
+    if (da < 0 && db < 0)
+        v = k;
+    else if (da >= 0 && db < 0)
+        v = g * u[da];  // d/dx_{a,d} k(x_a, x_b)
+    else if (da < 0)
+        v = -g * u[db];  // d/dx_{b,e} k(x_a, x_b)
+    else
+        v = -(da == db ? g : 0.0) - h * u[da] * u[db];
+    return a == b ? v + sn2 : v;
+}
+
+__global__ __launch_bounds__(256) void dgp_kbuild_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
+                                                         const double *__restrict__ y, const double *__restrict__ z,
+                                                         double sn2, double *__restrict__ K)
+{
+    int ti, tj;
+    tri_decode((int)blockIdx.x, ti, tj);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll 2
+    for (int r = ty; r < TILE; r += 8) {
+        const int a = ti * TILE + r;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int b = tj * TILE + tx * 4 + cc;
+            double v;
+            if (a < n4 && b < n4)
+                v = dgp_entry(c, n, a, b, x, y, z, sn2);
+            else
+                v = a == b ? 1.0 : 0.0;  // identity on the padding
+            K[(size_t)a * npad + b] = v;
+        }
+    }
+}
+
+// value and gradient of the posterior mean at the queries: out[q][0..3] = k_star(q) (4 x 4N) alpha.
+// One query per thread, the training points and their four weights through LDS.
+__global__ __launch_bounds__(256) void dgp_predict_kernel(DCov c, int n, const double *__restrict__ x,
+                                                          const double *__restrict__ y, const double *__restrict__ z,
+                                                          const double *__restrict__ alpha, long nq,
+                                                          const double *__restrict__ qx, const double *__restrict__ qy,
+                                                          const double *__restrict__ qz, double *__restrict__ out)
+{
+    __shared__ double sx[256], sy[256], sz[256], sa[256][4];
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < nq;
+    const double ax = live ? qx[q] : 0.0, ay = live ? qy[q] : 0.0, az = live ? qz[q] : 0.0;
+    double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        __syncthreads();
+        if (j < n) {
+            sx[threadIdx.x] = x[j], sy[threadIdx.x] = y[j], sz[threadIdx.x] = z[j];
+            sa[threadIdx.x][0] = alpha[j];
+            sa[threadIdx.x][1] = alpha[n + 3 * j], sa[threadIdx.x][2] = alpha[n + 3 * j + 1], sa[threadIdx.x][3] = alpha[n + 3 * j + 2];
+        }
+        __syncthreads();
+        const int cnt = min(256, n - j0);
+        for (int t = 0; t < cnt; ++t) {
+            const double u0 = ax - sx[t], u1 = ay - sy[t], u2 = az - sz[t];
+            double k, g, h;
+            dcov_eval(c, u0 * u0 + u1 * u1 + u2 * u2, k, g, h);
+            const double a0 = sa[t][0], a1 = sa[t][1], a2 = sa[t][2], a3 = sa[t][3];
+            const double ua = u0 * a1 + u1 * a2 + u2 * a3;  // u . (derivative weights of point t)
+            f0 += k * a0 - g * ua;
+            // d/dx*_d: g u_d alpha_value + sum_e (-g delta_de - h u_d u_e) alpha_e
+            const double s = g * a0 - h * ua;
+            f1 += s * u0 - g * a1;
+            f2 += s * u1 - g * a2;
+            f3 += s * u2 - g * a3;
+        }
+    }
+    if (live) {
+        out[4 * q] = f0;
+        out[4 * q + 1] = f1;
+        out[4 * q + 2] = f2;
+        out[4 * q + 3] = f3;
+    }
+}
+
+// operand of the variance contraction: row 0 of k_star for every query, Kq[q][b] = cov(f(q), observation b)
+__global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
+                                                        const double *__restrict__ y, const double *__restrict__ z,
+                                                        long nq_valid, const double *__restrict__ qx,
+                                                        const double *__restrict__ qy, const double *__restrict__ qz,
+                                                        double *__restrict__ Kq)
+{
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long q0 = (long)blockIdx.y * TILE;
+    const int b0 = blockIdx.x * TILE + tx * 4;
+#pragma unroll 2
+    for (int r = ty; r < TILE; r += 8) {
+        const long q = q0 + r;
+        const bool live = q < nq_valid;
+        const double ax = live ? qx[q] : 0.0, ay = live ? qy[q] : 0.0, az = live ? qz[q] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int b = b0 + cc;
+            double v = 0.0;
+            if (live && b < n4) {
+                const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+                const double u[3] = {ax - x[ib], ay - y[ib], az - z[ib]};
+                double k, g, h;
+                dcov_eval(c, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], k, g, h);
+                v = db < 0 ? k : -g * u[db];
+            }
+            Kq[(size_t)q * npad + b] = v;
+        }
+    }
+}
+
+}  // namespace gpx
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+struct gpx_dgp {
+    gpx_model *m = nullptr;  // the generic engine: matrix, factor, streams, workspaces (n = 4 n_pts)
+    int n_pts = 0;
+    gpx::DCov cov{};
+    double sn2 = 0, k0 = 0;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;  // n_pts, n_pts, n_pts, 4 n_pts
+    std::vector<double> h_alpha, h_y;
+    double loglik = 0;
+    int n_negative = 0;
+};
+
+extern "C" void gpx_dgp_destroy(gpx_dgp *g)
+{
+    if (!g)
+        return;
+    if (g->m) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(g->m->device);
+        (void)hipStreamSynchronize(g->m->stream);
+        for (double *p : {g->d_x, g->d_y, g->d_z, g->d_alpha})
+            if (p)
+                (void)hipFree(p);
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+        gpx_model_destroy(g->m);
+    }
+    delete g;
+}
+
+extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y,
+                              const double *z, const double *target, const double *normals, const gpx_options *opt,
+                              gpx_dgp **out)
+{
+    if (!out)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!kernel)
+        return fail(GPX_E_NULL, "Empty kernel pointer");
+    if (n == 0)
+        return fail(GPX_E_EMPTY, "No training data available");  // GaussianProcess.h:239
+    if (!x || !y || !z || !target)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (kernel->id != GPX_KERNEL_SE && kernel->id != GPX_KERNEL_THINPLATE)
+        return fail(GPX_E_BAD_ARG, "gpx_dgp: kernel must be GPX_KERNEL_SE or GPX_KERNEL_THINPLATE");
+    if (!(noise >= 0.0) || !std::isfinite(noise))
+        return fail(GPX_E_BAD_ARG, "noise must be finite and non-negative");  // Desc::isValid, GaussianProcess.h:216-222
+    if (n > ((size_t)1 << 18))
+        return fail(GPX_E_BAD_ARG, "n too large");
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i]) || !std::isfinite(target[i]) ||
+            (normals && (!std::isfinite(normals[3 * i]) || !std::isfinite(normals[3 * i + 1]) || !std::isfinite(normals[3 * i + 2]))))
+            return fail(GPX_E_NAN_INPUT, "non-finite value in the training data");
+    // the engine: an fp64 shell of order 4n on the requested device (its kernel id is irrelevant: nothing of the first
+    // library's kernel-specific code runs on it)
+    gpx_options o{};
+    if (opt)
+        o = *opt;
+    else
+        o.device = -1, o.ir_steps = -1;
+    o.precision = GPX_PREC_F64;
+    gpx_kernel gk{};
+    gk.id = GPX_KERNEL_GAUSSIAN, gk.p[0] = 1.0, gk.p[1] = 1.0;
+    gpx_model *m = nullptr;
+    int rc = gpx_model_create_shell(&gk, 4 * n, &o, &m);
+    if (rc)
+        return rc;
+    gpx_dgp *g = new gpx_dgp();
+    g->m = m;
+    g->n_pts = (int)n;
+    g->cov.id = kernel->id;
+    if (kernel->id == GPX_KERNEL_SE) {
+        g->cov.sf2 = kernel->p[0] * kernel->p[0];
+        g->cov.inv_l2 = 1.0 / (kernel->p[1] * kernel->p[1]);
+        g->k0 = g->cov.sf2;
+    } else {
+        g->cov.R = kernel->p[0];
+        g->cov.R3 = kernel->p[0] * kernel->p[0] * kernel->p[0];
+        g->k0 = g->cov.R3;
+    }
+    g->sn2 = noise * noise;  // ThinPlate::create, CovThinPlate.h:112: sn2 = noise^2
+    auto bail = [&](int code) {
+        const std::string keep = g_err;
+        gpx_dgp_destroy(g);
+        g_err = keep;
+        return code;
+    };
+    const int n4 = 4 * (int)n, np = m->npad;
+    hipStream_t s = m->stream;
+#define DGP_CHK(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return bail(fail(e__ == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); \
+    } while (0)
+    DGP_CHK(hipSetDevice(m->device));
+    if ((rc = alloc_factor_buffers(m)))
+        return bail(rc);
+    DGP_CHK(hipMalloc((void **)&g->d_x, sizeof(double) * n));
+    DGP_CHK(hipMalloc((void **)&g->d_y, sizeof(double) * n));
+    DGP_CHK(hipMalloc((void **)&g->d_z, sizeof(double) * n));
+    DGP_CHK(hipMalloc((void **)&g->d_alpha, sizeof(double) * (size_t)np));
+    DGP_CHK(hipMemcpyAsync(g->d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    DGP_CHK(hipMemcpyAsync(g->d_y, y, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    DGP_CHK(hipMemcpyAsync(g->d_z, z, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    // targets as SampleSet lays them out (src/gp/SampleSet.cpp:27-35): values, then the normals point by point
+    g->h_y.assign((size_t)np, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        g->h_y[i] = target[i];
+        if (normals)
+            for (int d = 0; d < 3; ++d)
+                g->h_y[n + 3 * i + d] = normals[3 * i + d];
+    }
+    DGP_CHK(hipMemcpyAsync(m->t_b, g->h_y.data(), sizeof(double) * (size_t)np, hipMemcpyHostToDevice, s));
+    DGP_CHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
+    // compute(): the covariance matrix (GaussianProcess.h:545-567) and its factorisation (:578)
+    const int nt = np / TILE;
+    (void)hipEventRecord(m->ev[EV_T0], s);
+    hipLaunchKernelGGL(gpx::dgp_kbuild_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, g->cov, (int)n, n4, np, g->d_x,
+                       g->d_y, g->d_z, g->sn2, (double *)m->Kmat);
+    (void)hipEventRecord(m->ev[EV_KBUILD], s);
+    factorize_matrix(m);
+    (void)hipEventRecord(m->ev[EV_FACTOR], s);
+    // update_alpha(): alpha = K^-1 y (:505-528)
+    solve_factored(m, m->t_b, m->t_yv, m->t_xs);
+    DGP_CHK(hipMemcpyAsync(g->d_alpha, m->t_xs, sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, s));
+    (void)hipEventRecord(m->ev[EV_SOLVE], s);
+    int info[8];
+    std::vector<double> hd((size_t)n4);
+    g->h_alpha.assign((size_t)n4, 0.0);
+    DGP_CHK(hipMemcpyAsync(info, m->d_info, sizeof(info), hipMemcpyDeviceToHost, s));
+    DGP_CHK(hipMemcpyAsync(hd.data(), m->t_d, sizeof(double) * (size_t)n4, hipMemcpyDeviceToHost, s));
+    DGP_CHK(hipMemcpyAsync(g->h_alpha.data(), g->d_alpha, sizeof(double) * (size_t)n4, hipMemcpyDeviceToHost, s));
+    DGP_CHK(hipStreamSynchronize(s));
+    DGP_CHK(hipGetLastError());
+#undef DGP_CHK
+    float ms;
+    m->stats = gpx_stats{};
+    if (hipEventElapsedTime(&ms, m->ev[EV_T0], m->ev[EV_KBUILD]) == hipSuccess)
+        m->stats.t_kbuild_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_KBUILD], m->ev[EV_FACTOR]) == hipSuccess)
+        m->stats.t_factor_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_FACTOR], m->ev[EV_SOLVE]) == hipSuccess)
+        m->stats.t_solve_ms = ms;
+    m->stats.n = n4, m->stats.n_padded = np, m->stats.n_negative_pivots = info[1];
+    g->n_negative = info[1];
+    if (info[0] != 0)
+        return bail(fail(GPX_E_SINGULAR, "covariance of values and derivatives: zero or non-finite pivot at row " + std::to_string(info[0] - 1)));
+    if (info[1] != 0)  // the reference takes llt() of this matrix (:578): it must be positive definite
+        return bail(fail(GPX_E_SINGULAR, "covariance of values and derivatives is not positive definite (" + std::to_string(info[1]) + " negative pivots)"));
+    // logLikelihood() (:376-385) with the determinant of the WHOLE matrix: -y.alpha / 2 - log det / 2 - 4n log(2 pi) / 2
+    double quad = 0, logdet = 0;
+    for (int i = 0; i < n4; ++i) {
+        quad += g->h_y[i] * g->h_alpha[i];
+        logdet += std::log(hd[i]);
+    }
+    g->loglik = -0.5 * quad - 0.5 * logdet - 0.5 * n4 * std::log(2.0 * M_PI);
+    m->ready = true;
+    *out = g;
+    return GPX_OK;
+}
+
+extern "C" int gpx_dgp_evaluate(const gpx_dgp *cg, size_t nq, const double *qx, const double *qy, const double *qz,
+                                double *f4, double *var)
+{
+    if (!cg || !cg->m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (nq == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    if (!qx || !qy || !qz)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (!f4)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    gpx_dgp *g = const_cast<gpx_dgp *>(cg);
+    gpx_model *m = g->m;
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int n = g->n_pts, n4 = 4 * n, np = m->npad;
+    int rc;
+    // device staging: qx qy qz | out (4 nq) | var (nq)
+    if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * nq * 8)))
+        return rc;
+    double *d = m->ws_host_io, *dq[3] = {d, d + nq, d + 2 * nq}, *dout = d + 3 * nq, *dvar = d + 7 * nq;
+    HIPCHK(hipMemcpyAsync(dq[0], qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dq[1], qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dq[2], qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
+    (void)hipEventRecord(m->ev[EV_M0], s);
+    hipLaunchKernelGGL(gpx::dgp_predict_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, g->cov, n, g->d_x,
+                       g->d_y, g->d_z, g->d_alpha, (long)nq, dq[0], dq[1], dq[2], dout);
+    (void)hipEventRecord(m->ev[EV_M1], s);
+    if (var) {
+        if ((rc = build_inverse(m)))  // X = L^-1 by recursive doubling on the GEMM core, once per model
+            return rc;
+        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        const int np_rows = std::min(np, (n4 + TILE - 1) / TILE * TILE);
+        if ((rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, sizeof(double) * qb * np)) ||
+            (rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, sizeof(double) * qb * m->nblk)))
+            return rc;
+        for (size_t q0 = 0; q0 < nq; q0 += qb) {
+            const size_t nv = std::min(qb, nq - q0), ntile = ((nv + TILE - 1) / TILE) * TILE;
+            hipLaunchKernelGGL(gpx::dgp_kstar_kernel, dim3(np_rows / TILE, (unsigned)(ntile / TILE)), dim3(256), 0, s, g->cov, n,
+                               n4, np, g->d_x, g->d_y, g->d_z, (long)nv, dq[0] + q0, dq[1] + q0, dq[2] + q0,
+                               (double *)m->ws_kqp);
+            GemmArgs a;  // partial[mt][q] = sum_rows (X * k_star^T)^2 / D
+            a.A = m->X, a.lda = np;
+            a.B = m->ws_kqp, a.ldb = np;
+            a.M = np_rows, a.N = (int)ntile, a.K = np;
+            a.a_lower = 1;
+            a.epi = EPI_COLSQ;
+            a.rowweight = m->t_dinv;
+            a.partial = m->ws_partial, a.ldp = (long)qb;
+            launch_gemm(GPX_PREC_F64, a, s);
+            launch_var_finish(GPX_PREC_F64, g->k0, np_rows / gemm_rows_per_partial(GPX_PREC_F64, a), (long)qb, m->ws_partial,
+                              (long)nv, dvar + q0, s);
+        }
+    }
+    (void)hipEventRecord(m->ev[EV_V1], s);
+    HIPCHK(hipMemcpyAsync(f4, dout, sizeof(double) * 4 * nq, hipMemcpyDeviceToHost, s));
+    if (var)
+        HIPCHK(hipMemcpyAsync(var, dvar, sizeof(double) * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess)
+        return fail(GPX_E_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    float ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_M0], m->ev[EV_M1]) == hipSuccess)
+        m->stats.t_mean_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_M1], m->ev[EV_V1]) == hipSuccess)
+        m->stats.t_var_ms = var ? ms : 0.0;
+    return GPX_OK;
+}
+
+extern "C" int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes)
+{
+    if (!g || !g->m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!dst)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    auto need = [&](size_t b) { return bytes >= b ? GPX_OK : fail(GPX_E_SIZE_MISMATCH, "destination too small"); };
+    int rc;
+    switch (field) {
+    case GPX_DGP_FIELD_N:
+        if ((rc = need(sizeof(int64_t))))
+            return rc;
+        *(int64_t *)dst = g->n_pts;
+        return GPX_OK;
+    case GPX_DGP_FIELD_ALPHA:
+        if ((rc = need(sizeof(double) * g->h_alpha.size())))
+            return rc;
+        std::memcpy(dst, g->h_alpha.data(), sizeof(double) * g->h_alpha.size());
+        return GPX_OK;
+    case GPX_DGP_FIELD_LOGLIK:
+        if ((rc = need(sizeof(double))))
+            return rc;
+        *(double *)dst = g->loglik;
+        return GPX_OK;
+    case GPX_DGP_FIELD_STATS:
+        if ((rc = need(sizeof(gpx_stats))))
+            return rc;
+        std::memcpy(dst, &g->m->stats, sizeof(gpx_stats));
+        return GPX_OK;
+    default:
+        return fail(GPX_E_BAD_ARG, "unknown field");
+    }
+}

@@ -13,9 +13,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPX_LIB") or os.path.join(_HERE, "lib", "libgpx.so")  # GPX_LIB: A/B runs of library variants
 
-GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52 = range(5)
+GAUSSIAN, LAPLACE, THINPLATE, MATERN32, MATERN52, SE = range(6)
 KERNEL_IDS = {"gaussian": GAUSSIAN, "laplace": LAPLACE, "thinplate": THINPLATE,
-              "matern32": MATERN32, "matern52": MATERN52}
+              "matern32": MATERN32, "matern52": MATERN52, "se": SE}
 F32, F64, MIXED, F32_SPLIT = 0, 1, 2, 3
 
 OK = 0
@@ -69,7 +69,8 @@ EXPORTS = [
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
-    "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_pcd_read", "gpx_node_training_set",
+    "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_dgp_create", "gpx_dgp_evaluate", "gpx_dgp_get",
+    "gpx_dgp_destroy", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
 _lib = None
@@ -156,6 +157,14 @@ def lib():
     L.gpx_dev_kqp_f32.restype = C.c_int
     L.gpx_dev_kqp_f32.argtypes = [C.POINTER(Kernel), C.c_size_t, C.c_size_t, vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp,
                                   vp]
+    L.gpx_dgp_create.restype = C.c_int
+    L.gpx_dgp_create.argtypes = [C.POINTER(Kernel), C.c_double, C.c_size_t, dp, dp, dp, dp, dp, C.POINTER(Options), C.POINTER(vp)]
+    L.gpx_dgp_evaluate.restype = C.c_int
+    L.gpx_dgp_evaluate.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp]
+    L.gpx_dgp_get.restype = C.c_int
+    L.gpx_dgp_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.gpx_dgp_destroy.restype = None
+    L.gpx_dgp_destroy.argtypes = [vp]
     L.gpx_pcd_read.restype = C.c_long
     L.gpx_pcd_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
     L.gpx_node_training_set.restype = C.c_int
@@ -415,6 +424,70 @@ class Model:
             r._L, r._h, r.kernel, r.precision = self._L, C.c_void_p(h), self.kernel, self.precision
             reps.append(r)
         return reps
+
+
+class DerivativeGP:
+    """gpx_dgp_*: the first slice of the reference's second library, gp::GaussianProcess (values + gradients)."""
+
+    def __init__(self, kernel, noise, x, y, z, target, normals=None, device=-1):
+        self._L = lib()
+        self._h = C.c_void_p(None)
+        x, y, z, target = _as_d(x), _as_d(y), _as_d(z), _as_d(target)
+        if not (len(x) == len(y) == len(z) == len(target)):
+            raise GpxError(E_SIZE_MISMATCH, "coordinate / target length mismatch")
+        nr = None
+        if normals is not None:
+            nr = _as_d(np.asarray(normals, dtype=np.float64).reshape(-1))
+            if len(nr) != 3 * len(x):
+                raise GpxError(E_SIZE_MISMATCH, "normals must be n x 3")
+        opt = Options()
+        opt.precision = F64
+        opt.device = int(device)
+        opt.ir_steps = -1
+        self.n = len(x)
+        _check(self._L.gpx_dgp_create(C.byref(kernel), float(noise), len(x), _dptr(x), _dptr(y), _dptr(z), _dptr(target),
+                                      _dptr(nr) if nr is not None else None, C.byref(opt), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.gpx_dgp_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def alpha(self):
+        a = np.zeros(4 * self.n)
+        _check(self._L.gpx_dgp_get(self._h, 1, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    @property
+    def loglik(self):
+        a = np.zeros(1)
+        _check(self._L.gpx_dgp_get(self._h, 2, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return float(a[0])
+
+    @property
+    def stats(self):
+        s = Stats()
+        _check(self._L.gpx_dgp_get(self._h, 3, C.byref(s), C.sizeof(s)))
+        return s.as_dict()
+
+    def evaluate(self, qx, qy, qz, want_v=True):
+        qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)
+        nq = len(qx)
+        f4 = np.zeros((nq, 4))
+        v = np.zeros(nq) if want_v else None
+        _check(self._L.gpx_dgp_evaluate(self._h, nq, _dptr(qx), _dptr(qy), _dptr(qz), _dptr(f4.reshape(-1)),
+                                        _dptr(v) if want_v else None))
+        out = {"f": f4[:, 0].copy(), "grad": f4[:, 1:].copy()}
+        if want_v:
+            out["v"] = v
+        return out
 
 
 def pcd_read(path):

@@ -55,7 +55,8 @@ typedef enum {
     GPX_KERNEL_LAPLACE = 1,
     GPX_KERNEL_THINPLATE = 2,
     GPX_KERNEL_MATERN32 = 3,
-    GPX_KERNEL_MATERN52 = 4
+    GPX_KERNEL_MATERN52 = 4,
+    GPX_KERNEL_SE = 5 /* gpx_dgp_* only: sf^2 exp(-|x - x'|^2 / (2 l^2)), p = {sf, l}   reference include/gp/CovSE.h:70-74 */
 } gpx_kernel_id;
 
 typedef struct gpx_kernel {
@@ -252,6 +253,34 @@ int gpx_model_commit(gpx_model *m, int with_variance);
  * processes (one per GPU) the host moves the two state blobs with its own collective -- bench.py uses
  * torch.distributed broadcast (backend "nccl" = RCCL over xGMI). */
 int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_model **out);
+
+/* ---- GP with derivative observations: first slice of the reference's second library, gp::GaussianProcess -----------
+ * (include/gp/GaussianProcess.h)  Training data: a value AND a gradient (surface normal) at every point;
+ * the model is the 4n x 4n covariance of values and derivatives -- compute() :532-583, layout [values (n) | d/dx d/dy
+ * d/dz of point 0 | ... | of point n-1] as :553-567 and SampleSet (src/gp/SampleSet.cpp:23-35) --, its factorisation
+ * (:578) and alpha = K^-1 y (update_alpha, :505-528).  kernel: GPX_KERNEL_SE {sf, l} (CovSE.h:70-74) or
+ * GPX_KERNEL_THINPLATE {R} (CovThinPlate.h:80-83); noise: sn, sn^2 is added to the whole diagonal.  fp64 throughout.
+ * NOT a drop-in: that library of the reference does not build and its derivative blocks are inconsistent (CovSE.h:84-89
+ * lacks the delta/l^2 term, ThinPlate has no second derivative at all); this is the algorithm they are written towards,
+ * with exact derivative blocks (csrc/gpx_dgp.hip), on the same device machinery as gpx_model (tiled matrix build,
+ * blocked LDL^T on the matrix cores -- the matrix must be positive definite, as for the reference's llt() --, the fused
+ * variance contraction).
+ * normals: 3n row-major or NULL (zeros).  gpx_dgp_evaluate = f() :237-252 for nq queries: f4[4 q + 0] the mean value,
+ * f4[4 q + 1..3] its gradient; var (nq, or NULL) = var() :256-269, conditioned on values AND derivatives (the reference
+ * conditions on the value block only). */
+typedef struct gpx_dgp gpx_dgp;
+typedef enum {
+    GPX_DGP_FIELD_N = 0,      /* int64: training points */
+    GPX_DGP_FIELD_ALPHA = 1,  /* double[4n], layout as above */
+    GPX_DGP_FIELD_LOGLIK = 2, /* double: logLikelihood() :376-385 over all 4n observations */
+    GPX_DGP_FIELD_STATS = 3   /* gpx_stats: t_kbuild_ms, t_factor_ms, t_solve_ms, t_mean_ms, t_var_ms, n = 4n, n_padded */
+} gpx_dgp_field;
+int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y, const double *z,
+                   const double *target, const double *normals, const gpx_options *opt, gpx_dgp **out);
+int gpx_dgp_evaluate(const gpx_dgp *g, size_t nq, const double *qx, const double *qy, const double *qz, double *f4,
+                     double *var);
+int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes);
+void gpx_dgp_destroy(gpx_dgp *g);
 
 /* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------
  * kbuild: K[i][j] = k(|p_i-p_j|) + sigma2_i*delta_ij on the lower block-triangle of an

@@ -858,3 +858,191 @@ void orc_set_num_threads(int t)
     (void)t;
 #endif
 }
+
+/* =============================================================================================================
+ * Second library of the reference, gp::GaussianProcess (include/gp/GaussianProcess.h): a GP trained on values AND
+ * gradients.  PARITY UNPINNED, and more than that: this library of the reference does not build and its derivative
+ * blocks are inconsistent (CovSE.h:84-89 lacks the delta/l^2 term of the second derivative and multiplies the noise
+ * into the kernel; ThinPlate has no second derivative; update_k_star :459-497 indexes past the sample set; var()
+ * :256-269 conditions on the value block only; evaluate() :227-235 returns zeros).  This is a restatement of the
+ * algorithm those functions are written towards -- same matrix layout (compute() :545-567: rows [0, n) values, row
+ * n + 3 i + d derivative d of point i), same target layout (src/gp/SampleSet.cpp:27-35), llt() (:578), alpha by two
+ * triangular solves (:517-519), f() = k_star alpha (:246-250), var() = k(x,x) - |L^-1 k_star_0|^2 (:263-268),
+ * logLikelihood (:382-384) -- with the exact derivative blocks of a radial kernel k(r), u = x - x', g = k'/r, h = g'/r:
+ *   cov(d_d f(x), f(x')) = g u_d,   cov(f(x), d_e f(x')) = -g u_e,   cov(d_d f(x), d_e f(x')) = -g delta_de - h u_d u_e.
+ * The blocks are checked against central differences of k in tests/test_oracle.py.
+ * kid 5: CovSE (CovSE.h:70-74) k = p0^2 exp(-r^2 / (2 p1^2));  kid 2: ThinPlate (CovThinPlate.h:80-83), R = p0.
+ * ============================================================================================================= */
+typedef struct {
+    int kid, n, info;
+    double p0, p1, sn2;
+    double *x, *y, *z, *L /* 4n x 4n col-major, lower = Cholesky factor */, *alpha, *yv;
+    double loglik;
+} orc_dgp;
+
+static void dgp_cov(const orc_dgp *g, double r2, double *k, double *gg, double *h)
+{
+    if (g->kid == ORC_THINPLATE) {
+        const double r = sqrt(r2), R = g->p0;
+        *k = 2 * r * r * r - 3 * R * r * r + R * R * R;
+        *gg = 6 * r - 6 * R;
+        *h = r > 0 ? 6 / r : 0.0;
+    } else {
+        const double l2 = g->p1 * g->p1;
+        *k = g->p0 * g->p0 * exp(-0.5 * r2 / l2);
+        *gg = -*k / l2;
+        *h = *k / (l2 * l2);
+    }
+}
+
+/* covariance of observation a of the training set with observation b (a, b in [0, 4n)), without noise */
+static double dgp_entry(const orc_dgp *g, int a, int b)
+{
+    const int n = g->n;
+    const int ia = a < n ? a : (a - n) / 3, da = a < n ? -1 : (a - n) % 3;
+    const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+    const double u[3] = {g->x[ia] - g->x[ib], g->y[ia] - g->y[ib], g->z[ia] - g->z[ib]};
+    double k, gg, h;
+    dgp_cov(g, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], &k, &gg, &h);
+    if (da < 0 && db < 0)
+        return k;
+    if (da >= 0 && db < 0)
+        return gg * u[da];
+    if (da < 0)
+        return -gg * u[db];
+    return -(da == db ? gg : 0.0) - h * u[da] * u[db];
+}
+
+void orc_dgp_free(orc_dgp *g)
+{
+    if (!g)
+        return;
+    free(g->x), free(g->y), free(g->z), free(g->L), free(g->alpha), free(g->yv);
+    free(g);
+}
+
+orc_dgp *orc_dgp_create(int kid, double p0, double p1, double noise, int n, const double *x, const double *y,
+                        const double *z, const double *target, const double *normals)
+{
+    orc_dgp *g = (orc_dgp *)calloc(1, sizeof(orc_dgp));
+    const int m = 4 * n;
+    g->kid = kid, g->n = n, g->p0 = p0, g->p1 = p1, g->sn2 = noise * noise;
+    g->x = (double *)malloc(sizeof(double) * n), g->y = (double *)malloc(sizeof(double) * n);
+    g->z = (double *)malloc(sizeof(double) * n);
+    memcpy(g->x, x, sizeof(double) * n), memcpy(g->y, y, sizeof(double) * n), memcpy(g->z, z, sizeof(double) * n);
+    g->L = (double *)calloc((size_t)m * m, sizeof(double));
+    g->alpha = (double *)calloc(m, sizeof(double));
+    g->yv = (double *)calloc(m, sizeof(double));
+    for (int i = 0; i < n; ++i) { /* SampleSet.cpp:27-35 */
+        g->yv[i] = target[i];
+        if (normals)
+            for (int d = 0; d < 3; ++d)
+                g->yv[n + 3 * i + d] = normals[3 * i + d];
+    }
+    /* compute() :545-567: lower triangle of the 4n x 4n matrix, noise on the diagonal */
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b <= a; ++b)
+            g->L[(size_t)b * m + a] = dgp_entry(g, a, b) + (a == b ? g->sn2 : 0.0);
+    /* :578 llt(): unblocked Cholesky, column by column */
+    for (int j = 0; j < m && !g->info; ++j) {
+        double d = g->L[(size_t)j * m + j];
+        for (int k = 0; k < j; ++k)
+            d -= g->L[(size_t)k * m + j] * g->L[(size_t)k * m + j];
+        if (!(d > 0.0)) {
+            g->info = j + 1;
+            break;
+        }
+        d = sqrt(d);
+        g->L[(size_t)j * m + j] = d;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (int i = j + 1; i < m; ++i) {
+            double s = g->L[(size_t)j * m + i];
+            for (int k = 0; k < j; ++k)
+                s -= g->L[(size_t)k * m + i] * g->L[(size_t)k * m + j];
+            g->L[(size_t)j * m + i] = s / d;
+        }
+    }
+    if (g->info)
+        return g;
+    /* update_alpha() :517-519: alpha = L^-T L^-1 y */
+    memcpy(g->alpha, g->yv, sizeof(double) * m);
+    for (int i = 0; i < m; ++i) {
+        double s = g->alpha[i];
+        for (int k = 0; k < i; ++k)
+            s -= g->L[(size_t)k * m + i] * g->alpha[k];
+        g->alpha[i] = s / g->L[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double s = g->alpha[i];
+        for (int k = i + 1; k < m; ++k)
+            s -= g->L[(size_t)i * m + k] * g->alpha[k];
+        g->alpha[i] = s / g->L[(size_t)i * m + i];
+    }
+    /* logLikelihood() :382-384 over all 4n observations */
+    double quad = 0, logdet = 0;
+    for (int i = 0; i < m; ++i) {
+        quad += g->yv[i] * g->alpha[i];
+        logdet += 2 * log(g->L[(size_t)i * m + i]);
+    }
+    g->loglik = -0.5 * quad - 0.5 * logdet - 0.5 * m * log(2 * M_PI);
+    return g;
+}
+
+int orc_dgp_info(const orc_dgp *g) { return g->info; }
+double orc_dgp_loglik(const orc_dgp *g) { return g->loglik; }
+void orc_dgp_get_alpha(const orc_dgp *g, double *out) { memcpy(out, g->alpha, sizeof(double) * 4 * (size_t)g->n); }
+/* the covariance matrix itself (symmetric, row-major = col-major), for the finite-difference test of its blocks */
+void orc_dgp_get_K(const orc_dgp *g, double *out)
+{
+    const int m = 4 * g->n;
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b)
+            out[(size_t)a * m + b] = dgp_entry(g, a, b) + (a == b ? g->sn2 : 0.0);
+}
+
+/* f() :237-252 and var() :256-269 for nq queries: f4[4 q] the mean, f4[4 q + 1..3] its gradient */
+void orc_dgp_evaluate(const orc_dgp *g, int nq, const double *qx, const double *qy, const double *qz, double *f4,
+                      double *var)
+{
+    const int n = g->n, m = 4 * n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int q = 0; q < nq; ++q) {
+        double *ks = (double *)malloc(sizeof(double) * 4 * (size_t)m); /* k_star, 4 x 4n (:465-489) */
+        for (int j = 0; j < n; ++j) {
+            const double u[3] = {qx[q] - g->x[j], qy[q] - g->y[j], qz[q] - g->z[j]};
+            double k, gg, h;
+            dgp_cov(g, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], &k, &gg, &h);
+            ks[j] = k;
+            for (int e = 0; e < 3; ++e)
+                ks[n + 3 * j + e] = -gg * u[e];
+            for (int d = 0; d < 3; ++d) {
+                ks[(size_t)(1 + d) * m + j] = gg * u[d];
+                for (int e = 0; e < 3; ++e)
+                    ks[(size_t)(1 + d) * m + n + 3 * j + e] = -(d == e ? gg : 0.0) - h * u[d] * u[e];
+            }
+        }
+        for (int r = 0; r < 4; ++r) {
+            double s = 0;
+            for (int b = 0; b < m; ++b)
+                s += ks[(size_t)r * m + b] * g->alpha[b];
+            f4[4 * q + r] = s;
+        }
+        if (var) { /* v = L^-1 k_star_0 ; var = k(x,x) - v.v */
+            double k0, gg, h, vv = 0;
+            dgp_cov(g, 0.0, &k0, &gg, &h);
+            for (int i = 0; i < m; ++i) {
+                double s = ks[i];
+                for (int k = 0; k < i; ++k)
+                    s -= g->L[(size_t)k * m + i] * ks[k];
+                ks[i] = s / g->L[(size_t)i * m + i];
+                vv += ks[i] * ks[i];
+            }
+            var[q] = k0 - vv;
+        }
+        free(ks);
+    }
+}

@@ -87,6 +87,16 @@ def _lib(omp=False):
     L.orc_get_ldlt.argtypes = [C.c_void_p, dp, ip]
     L.orc_get_normals.restype = C.c_int
     L.orc_get_normals.argtypes = [C.c_void_p, dp]
+    L.orc_dgp_create.restype = C.c_void_p
+    L.orc_dgp_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp, dp]
+    L.orc_dgp_free.argtypes = [C.c_void_p]
+    L.orc_dgp_info.restype = C.c_int
+    L.orc_dgp_info.argtypes = [C.c_void_p]
+    L.orc_dgp_loglik.restype = C.c_double
+    L.orc_dgp_loglik.argtypes = [C.c_void_p]
+    L.orc_dgp_get_alpha.argtypes = [C.c_void_p, dp]
+    L.orc_dgp_get_K.argtypes = [C.c_void_p, dp]
+    L.orc_dgp_evaluate.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
     L.orc_num_threads.restype = C.c_int
     L.orc_set_num_threads.argtypes = [C.c_int]
     if omp:
@@ -304,3 +314,65 @@ def num_threads(omp=True):
 
 def set_num_threads(t):
     _lib(True).orc_set_num_threads(int(t))
+
+
+SE = 5  # gp::CovSE of the reference's second library (include/gp/CovSE.h)
+
+
+class DerivativeGP:
+    """gp::GaussianProcess restated (oracle/gp_oracle.c, second half): a GP trained on values and gradients.
+    kernel: ('se', sf, ell) or ('thinplate', R)."""
+
+    def __init__(self, kernel, noise, x, y, z, target, normals=None, omp=False):
+        self._L = _lib(omp)
+        kid = SE if kernel[0] == "se" else THINPLATE
+        p0 = float(kernel[1])
+        p1 = float(kernel[2]) if len(kernel) > 2 else 1.0
+        x, px = _d(x)
+        y, py = _d(y)
+        z, pz = _d(z)
+        t, pt = _d(target)
+        self.n = len(x)
+        pn = None
+        if normals is not None:
+            nr, pn = _d(np.asarray(normals, dtype=np.float64).reshape(-1))
+        self._h = C.c_void_p(self._L.orc_dgp_create(kid, p0, p1, float(noise), self.n, px, py, pz, pt, pn))
+        self.info = int(self._L.orc_dgp_info(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_dgp_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def alpha(self):
+        a = np.zeros(4 * self.n)
+        self._L.orc_dgp_get_alpha(self._h, a.ctypes.data_as(C.POINTER(C.c_double)))
+        return a
+
+    @property
+    def K(self):
+        k = np.zeros((4 * self.n, 4 * self.n))
+        self._L.orc_dgp_get_K(self._h, k.ctypes.data_as(C.POINTER(C.c_double)))
+        return k
+
+    @property
+    def loglik(self):
+        return float(self._L.orc_dgp_loglik(self._h))
+
+    def evaluate(self, qx, qy, qz, want_v=True):
+        qx, px = _d(qx)
+        qy, py = _d(qy)
+        qz, pz = _d(qz)
+        nq = len(qx)
+        f4 = np.zeros((nq, 4))
+        v = np.zeros(nq) if want_v else None
+        self._L.orc_dgp_evaluate(self._h, nq, px, py, pz, f4.ctypes.data_as(C.POINTER(C.c_double)),
+                                 v.ctypes.data_as(C.POINTER(C.c_double)) if want_v else None)
+        out = {"f": f4[:, 0].copy(), "grad": f4[:, 1:].copy()}
+        if want_v:
+            out["v"] = v
+        return out

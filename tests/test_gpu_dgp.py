@@ -1,0 +1,95 @@
+"""GPU parity of the first slice of the reference's second library, gp::GaussianProcess (include/gp/GaussianProcess.h:
+a GP trained on values and gradients), through the C ABI (gpx_dgp_*) against the oracle restatement.  fp64: 1e-10
+norm-wise for alpha, the mean, its gradient and the variance (the systems are 4n x 4n with cond up to ~1e7 for the thin
+plate: 1e-8 there)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import nerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(n, seed):
+    r = np.random.default_rng(seed)
+    d = r.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    P = d * r.uniform(0.95, 1.05, size=(n, 1))
+    return P, np.zeros(n) + 0.01 * r.normal(size=n), d  # points, targets (~0 on the surface), outward normals
+
+
+@pytest.mark.parametrize("n", [1, 7, 33, 200, 300, 700])
+@pytest.mark.parametrize("kern", [("se", 1.2, 0.8), ("thinplate", 4.0)])  # R above every query-to-point distance
+def test_derivative_gp_against_oracle(gpu, orc, kern, n):
+    P, t, nr = _cloud(n, 100 + n)
+    noise = 0.05
+    og = orc.DerivativeGP(kern, noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    assert og.info == 0
+    gk = gpu.make_kernel("se", kern[1], kern[2]) if kern[0] == "se" else gpu.make_kernel("thinplate", kern[1])
+    gg = gpu.DerivativeGP(gk, noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    tol = 1e-10 if kern[0] == "se" else 1e-8
+    assert nerr(gg.alpha, og.alpha) < tol
+    assert abs(gg.loglik - og.loglik) < 1e-7 * max(1.0, abs(og.loglik))
+    st = gg.stats
+    assert st["n"] == 4 * n and st["n_padded"] % 256 == 0 and st["n_negative_pivots"] == 0
+    r = np.random.default_rng(n)
+    for nq in (1, 130, 1000):
+        Q = r.uniform(-1.3, 1.3, size=(nq, 3))
+        m = min(nq, n, 3)
+        Q[:m] = P[:m]  # on training points
+        ref = og.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
+        out = gg.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
+        # norm-wise; a single query on the surface has f ~ 1e-4, so the scale is at least the size of the field (~0.1 .. 1)
+        assert np.max(np.abs(out["f"] - ref["f"])) / max(np.max(np.abs(ref["f"])), 0.1) < tol, nq
+        assert np.max(np.abs(out["grad"] - ref["grad"])) / max(np.max(np.abs(ref["grad"])), 1e-300) < tol, nq
+        k0 = kern[1] ** 2 if kern[0] == "se" else kern[1] ** 3
+        assert np.max(np.abs(out["v"] - ref["v"])) / k0 < tol, nq
+        assert out["v"].min() > -1e-9 * k0 and out["v"].max() <= k0 * (1 + 1e-12)
+        mean_only = gg.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=False)
+        np.testing.assert_array_equal(mean_only["f"], out["f"])
+    gg.close()
+
+
+def test_derivative_gp_without_normals_and_errors(gpu, orc):
+    P, t, nr = _cloud(40, 9)
+    t = np.where(np.arange(40) % 5 == 0, 1.0, 0.0)
+    gk = gpu.make_kernel("se", 1.0, 0.6)
+    og = orc.DerivativeGP(("se", 1.0, 0.6), 0.1, P[:, 0], P[:, 1], P[:, 2], t, None)
+    gg = gpu.DerivativeGP(gk, 0.1, P[:, 0], P[:, 1], P[:, 2], t, None)
+    assert nerr(gg.alpha, og.alpha) < 1e-10
+    gg.close()
+    # a matrix that is not positive definite (two identical points, no noise) is a status, as llt() has no answer for it
+    P2 = np.concatenate([P[:5], P[:1]])
+    with pytest.raises(gpu.GpxError) as ei:
+        gpu.DerivativeGP(gk, 0.0, P2[:, 0], P2[:, 1], P2[:, 2], np.zeros(6), None)
+    assert ei.value.code == gpu.E_SINGULAR
+    with pytest.raises(gpu.GpxError) as ei:  # the first library's kernels have no derivative blocks here
+        gpu.DerivativeGP(gpu.make_kernel("matern52", 1, 1), 0.1, P[:, 0], P[:, 1], P[:, 2], t, None)
+    assert ei.value.code == gpu.E_BAD_ARG
+    with pytest.raises(gpu.GpxError) as ei:
+        gpu.DerivativeGP(gk, float("nan"), P[:, 0], P[:, 1], P[:, 2], t, None)
+    assert ei.value.code == gpu.E_BAD_ARG
+    lib = gpu.lib()
+    assert lib.gpx_dgp_evaluate(None, 1, None, None, None, None, None) == gpu.E_NULL
+    assert lib.gpx_last_error() == b"Empty Model pointer"
+
+
+def test_derivative_gp_reconstructs_a_sphere_from_points_and_normals(gpu):
+    """What the library is for (the reference's tests/test_gp.cpp shape): surface points with label 0 and their normals;
+    the zero level of the mean is the surface, its gradient there the normal."""
+    P, _, nr = _cloud(400, 1)
+    P = nr.copy()  # exactly on the unit sphere
+    gg = gpu.DerivativeGP(gpu.make_kernel("se", 1.0, 0.7), 0.01, P[:, 0], P[:, 1], P[:, 2], np.zeros(400), nr)
+    r = np.random.default_rng(5)
+    d = r.normal(size=(200, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    on = gg.evaluate(d[:, 0], d[:, 1], d[:, 2])
+    assert np.abs(on["f"]).max() < 5e-3  # new points of the sphere lie on the zero level
+    g = on["grad"] / np.linalg.norm(on["grad"], axis=1)[:, None]
+    assert np.min(np.einsum("ij,ij->i", g, d)) > 0.999  # and the gradient there is the outward normal
+    out = gg.evaluate(1.2 * d[:, 0], 1.2 * d[:, 1], 1.2 * d[:, 2], want_v=False)
+    inn = gg.evaluate(0.8 * d[:, 0], 0.8 * d[:, 1], 0.8 * d[:, 2], want_v=False)
+    assert out["f"].min() > 0.1 and inn["f"].max() < -0.1  # signed: positive outside, negative inside
+    gg.close()

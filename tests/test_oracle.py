@@ -204,3 +204,70 @@ def test_project_restatement_properties(orc, ds):
     # a zero start direction is a "wrong step" (atlas.hpp:246-249): the point stays until a gradient is adopted
     r1 = om.project(P[:1, 0], P[:1, 1], P[:1, 2], np.zeros((1, 3)), step_mul=0.5, max_iter=60)
     assert r1["status"][0] == 1
+
+
+# ---- second library of the reference, gp::GaussianProcess (values + gradients): the oracle's own consistency ----------
+@pytest.mark.parametrize("kern", [("se", 1.3, 0.7), ("thinplate", 3.0)])
+def test_derivative_gp_oracle_blocks_and_identities(orc, kern):
+    """oracle/gp_oracle.c, second half (include/gp/GaussianProcess.h:532-583 with exact derivative blocks; the
+    reference's own blocks are inconsistent, see the header there).  Pins the restatement WITHOUT the reference: the
+    derivative blocks of the 4n x 4n covariance against central differences of k, alpha against numpy.linalg.solve,
+    the gradient of the mean against differences of the mean, interpolation of values and normals at small noise."""
+    rng = np.random.default_rng(3)
+    n = 14
+    P = rng.normal(size=(n, 3))
+    P /= np.linalg.norm(P, axis=1)[:, None]
+    t, nr = np.zeros(n), P.copy()
+    g = orc.DerivativeGP(kern, 0.02, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    assert g.info == 0
+    K = g.K
+    assert np.abs(K - K.T).max() < 1e-14 and np.linalg.eigvalsh(K).min() > 0
+
+    def k(a, b):
+        r = np.linalg.norm(a - b)
+        return kern[1] ** 2 * np.exp(-0.5 * r * r / kern[2] ** 2) if kern[0] == "se" else 2 * r ** 3 - 3 * kern[1] * r * r + kern[1] ** 3
+
+    eps, e1, e2 = 1e-5, 0.0, 0.0
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                continue
+            for d in range(3):
+                a = np.zeros(3)
+                a[d] = eps
+                e1 = max(e1, abs((k(P[i] + a, P[j]) - k(P[i] - a, P[j])) / (2 * eps) - K[n + 3 * i + d, j]))
+                for d2 in range(3):
+                    b = np.zeros(3)
+                    b[d2] = eps
+                    fd = (k(P[i] + a, P[j] + b) - k(P[i] + a, P[j] - b) - k(P[i] - a, P[j] + b) + k(P[i] - a, P[j] - b)) / (4 * eps * eps)
+                    e2 = max(e2, abs(fd - K[n + 3 * i + d, n + 3 * j + d2]))
+    assert e1 < 1e-8 and e2 < 2e-4  # (second differences at eps = 1e-5 carry ~1e-5 of rounding)
+    yv = np.concatenate([t, nr.reshape(-1)])
+    a_np = np.linalg.solve(K, yv)
+    assert nerr(g.alpha, a_np) < 1e-10
+    sign, logdet = np.linalg.slogdet(K)
+    assert abs(g.loglik - (-0.5 * yv @ a_np - 0.5 * logdet - 0.5 * 4 * n * np.log(2 * np.pi))) < 1e-8
+    Q = rng.uniform(-1.2, 1.2, size=(6, 3))
+    o = g.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
+    fd = np.zeros((6, 3))
+    for d in range(3):
+        e = np.zeros(3)
+        e[d] = 1e-6
+        fp = g.evaluate(Q[:, 0] + e[0], Q[:, 1] + e[1], Q[:, 2] + e[2], want_v=False)["f"]
+        fm = g.evaluate(Q[:, 0] - e[0], Q[:, 1] - e[1], Q[:, 2] - e[2], want_v=False)["f"]
+        fd[:, d] = (fp - fm) / 2e-6
+    assert np.abs(fd - o["grad"]).max() < 1e-7
+    # variance against the dense formula, 0 <= v <= k(0)
+    ks = np.zeros((6, 4 * n))
+    for q in range(6):
+        for j in range(n):
+            u = Q[q] - P[j]
+            r = np.linalg.norm(u)
+            gg = (-k(Q[q], P[j]) / kern[2] ** 2) if kern[0] == "se" else 6 * r - 6 * kern[1]
+            ks[q, j] = k(Q[q], P[j])
+            ks[q, n + 3 * j:n + 3 * j + 3] = -gg * u
+    v_np = k(P[0], P[0]) - np.einsum("qi,qi->q", ks, np.linalg.solve(K, ks.T).T)
+    assert nerr(o["v"], v_np) < 1e-9 and o["v"].min() > -1e-12
+    # at the training points: the mean reproduces the targets and the gradient the normals (to the noise level)
+    at = g.evaluate(P[:, 0], P[:, 1], P[:, 2], want_v=False)
+    assert np.abs(at["f"] - t).max() < 5e-3 and np.abs(at["grad"] - nr).max() < 5e-2
