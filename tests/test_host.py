@@ -122,6 +122,28 @@ def test_argument_validation_and_reference_messages(gpx):
     assert h.value is None
 
 
+def test_derivative_gp_argument_validation(gpx):
+    """gpx_dgp_* (first slice of the reference's gp::GaussianProcess): argument checks at the C boundary, no GPU needed.
+    "No training data available" is the reference's message (include/gp/GaussianProcess.h:239)."""
+    lib = gpx.lib()
+    h = C.c_void_p(None)
+    one = (C.c_double * 3)(0.5, 0.5, 0.5)
+    k = gpx.make_kernel("se", 1.0, 1.0)
+    assert lib.gpx_dgp_create(C.byref(k), 0.1, 0, one, one, one, one, None, None, C.byref(h)) == gpx.E_EMPTY
+    assert lib.gpx_last_error() == b"No training data available"
+    assert lib.gpx_dgp_create(C.byref(k), 0.1, 1, None, one, one, one, None, None, C.byref(h)) == gpx.E_NULL
+    assert lib.gpx_dgp_create(C.byref(k), 0.1, 1, one, one, one, one, None, None, None) == gpx.E_NULL
+    assert lib.gpx_dgp_create(None, 0.1, 1, one, one, one, one, None, None, C.byref(h)) == gpx.E_NULL
+    assert lib.gpx_dgp_create(C.byref(k), -1.0, 1, one, one, one, one, None, None, C.byref(h)) == gpx.E_BAD_ARG
+    km = gpx.make_kernel("matern52", 1.0, 1.0)
+    assert lib.gpx_dgp_create(C.byref(km), 0.1, 1, one, one, one, one, None, None, C.byref(h)) == gpx.E_BAD_ARG
+    nan = (C.c_double * 1)(float("nan"))
+    assert lib.gpx_dgp_create(C.byref(k), 0.1, 1, nan, one, one, one, None, None, C.byref(h)) == gpx.E_NAN_INPUT
+    assert lib.gpx_dgp_get(None, 0, one, 8) == gpx.E_NULL
+    lib.gpx_dgp_destroy(None)
+    assert h.value is None
+
+
 def test_no_cpu_fallback(gpx):
     """Without a HIP device every compute entry point fails loudly (E_NO_DEVICE)."""
     if gpx.device_count() > 0:
