@@ -107,7 +107,8 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
 
 
 # committed PMC passes per variance tile (GPX_VAR_TILE): file, kernel-name prefix of that tile's instantiation
-PMC_TRAFFIC = {"3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64"),   # 64-byte k rows (round-3 default)
+PMC_TRAFFIC = {"6": ("r03_pmc_traffic_w1.json", "gpx::var_w1_kernel<true>"),    # one-wave tile (default)
+               "3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64"),   # 64-byte k rows, LDS-staged
                "0": ("r02_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 128")}  # 128-byte k rows
 
 
@@ -116,7 +117,7 @@ def pmc_traffic(args, n_train, q_per_launch):
     --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes for wide
     streaming reads, + WRITE_SIZE) -- counters cannot be collected inside an un-profiled run, so this figure is NOT
     measured by the run that prints it; only valid for the shape and the tile those passes were taken on."""
-    tile = os.environ.get("GPX_VAR_TILE", "3")
+    tile = os.environ.get("GPX_VAR_TILE", "6")
     if not (args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192 and tile in PMC_TRAFFIC):
         return None, None
     fn, prefix = PMC_TRAFFIC[tile]
@@ -391,6 +392,8 @@ def main():
             flops_per_launch = float(n_train) ** 2 * q_per_launch  # N^2 flop per query
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             vkernel, vpeak = "gemm_kernel<%s,NT,COLSQ> (predict_var)" % gemm_t, peak
+            if prec != gpx.F64 and os.environ.get("GPX_VAR_TILE", "6") == "6":
+                vkernel = "var_w1_kernel<fit added back in fp64> (predict_var; one wave per workgroup, 128x128 tile, no LDS)"
             if prec == gpx.F32_SPLIT:  # three fp16 MFMA products per algorithmic multiply-add: price against the fp16 peak
                 vkernel, vpeak, achieved = "vsplit_gemm_kernel (3 fp16 MFMA products per fp32 product)", PEAK_F16_MFMA_TFLOPS, 3 * achieved
             roof = {"bound": "mfma", "kernel": vkernel,

@@ -160,17 +160,23 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
-            // Tile of the fp32 product (GPX_VAR_TILE): 3 = 128 x 128 with 64-byte k rows, 40 KiB of LDS, compiled for three
-            // workgroups per CU (default since round 3); 0 = the same tile with 128-byte k rows, two workgroups per CU; 2 =
-            // 256 x 256 at one workgroup per CU (half the L2-miss traffic).  The three are within 1-2 % of each other and
-            // their ORDER depends on accidents of hipcc's schedule of the (identical) main loop: round 2 measured 141.1 /
-            // 141.7 / 138.1 TFLOP/s for 0 / 3 / 2; with the fp64 epilogue of round 3 in the kernel the same source runs at
-            // 133.5 / 139.5 / 136.7 (scripts/gemm_bench.hip) -- tile 3 moved least.
+            // Tile of the fp32 product (GPX_VAR_TILE).  6 (default for VAR_W1_MIN_ROWS rows and more): one wave per
+            // workgroup, a 128 x 128 tile per wave, no LDS, no barrier (gpx_vargemm.hip) -- 152 TFLOP/s against 139-140 for
+            // the LDS tiles at N = 16384.  The LDS tiles: 3 = 128 x 128 with 64-byte k rows at three workgroups per CU
+            // (what 6 falls back to for small models), 0 = the same tile with 128-byte k rows at two per CU, 2 = 256 x 256
+            // at one per CU; those three are within 1-2 % of each other (profiles/r03_var_gemm_variants.txt).
             static const int var_tile = [] {
                 const char *e = std::getenv("GPX_VAR_TILE");
-                return e ? std::atoi(e) : 3;
+                return e ? std::atoi(e) : 6;
             }();
-            a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : (var_tile == 3 ? 3 : 0);
+            static const int w1_min_rows = [] {
+                const char *e = std::getenv("GPX_VAR_W1_MIN_ROWS");
+                return e ? std::atoi(e) : VAR_W1_MIN_ROWS;
+            }();
+            if (var_tile == 6)
+                a.cfg = np_rows >= w1_min_rows ? 6 : 3;
+            else
+                a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : (var_tile == 3 ? 3 : 0);
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)

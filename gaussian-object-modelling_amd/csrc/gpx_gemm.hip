@@ -658,6 +658,16 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
 
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st)
 {
+    if (g.cfg == 6) {
+        if (prec != GPX_PREC_F64 && var_w1_fits(g)) {
+            launch_var_w1(g, st);
+            return;
+        }
+        GemmArgs h = g;
+        h.cfg = 3;
+        launch_gemm(prec, h, st);
+        return;
+    }
     if (prec == GPX_PREC_F64)
         gemm_t<double>(g, st);
     else

@@ -184,7 +184,8 @@ struct GemmArgs {
     int a_lower = 0;                // A lower-triangular: k < m0 + TILE
     int b_lower = 0;                // B lower-triangular: nn: k >= n0 ; nt: k < n0 + TILE
     int epi = EPI_STORE;
-    int cfg = 0;                    // preferred tile: 0 = 128x128, 1 = 256x128, 2 = 256x256 (falls back if it does not divide)
+    int cfg = 0;                    // preferred tile: 0 = 128x128, 2 = 256x256 (falls back if it does not divide); EPI_COLSQ fp32
+                                    // also 3 = 128x128 with 64-byte k rows, 6 = one-wave tile (gpx_vargemm.hip)
     void *W = nullptr;              // EPI_TRSM: un-scaled product
     long ldw = 0;
     const void *colscale = nullptr; // EPI_TRSM: C = acc * colscale[n]
@@ -199,6 +200,11 @@ struct GemmArgs {
     long ldrc = 0, ldcc = 0;             // (partial then holds doubles)
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
+// cfg 6 (fp32 EPI_COLSQ with a lower-triangular A only): one wave per workgroup, 128 x 128 tile, operands from global memory
+// straight into the MFMA fragments -- gpx_vargemm.hip.  launch_gemm routes cfg 6 there when var_w1_fits(), else to cfg 3.
+bool var_w1_fits(const GemmArgs &g);
+void launch_var_w1(const GemmArgs &g, hipStream_t st);
+constexpr int VAR_W1_MIN_ROWS = 128;  // i.e. always: measured faster than the LDS tiles from 512 rows up (scripts/var_tile_sweep.py)
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
 int gemm_tile_m(int cfg);
 int gemm_tile_n(int cfg);

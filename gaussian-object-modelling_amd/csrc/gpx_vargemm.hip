@@ -1,0 +1,199 @@
+// gpx_vargemm.hip -- the fp32 variance contraction as ONE WAVE PER WORKGROUP (round 3, GPX_VAR_TILE = 6).
+//
+//   partial[mt][n] = sum_{m in row tile mt} w[m][n]^2 / D_m ,   w = X[m][:] . K'[n][:]  (+ the low-rank fit, fp64)
+//
+// replaces, for large models, the LDS-staged 4-wave tiles of gpx_gemm.hip on this one product (the reference's
+// `cholesker.solve(Kqp^T)` + `Kqp * V` + `diagonal()`, gp_regressor.hpp:316-319, restated as a column sum of squares of
+// L^-1 K'^T).  Why a different structure: the 4-wave tiles hold the MFMA pipe 88-91 % busy whatever their shape
+// (DESIGN.md section 4); what they lose is the per-k-tile barrier that couples four SIMDs each shared by three
+// workgroups.  Here a workgroup is a single wave that owns one SIMD and its whole 512-entry register file:
+//   * 128 x 128 tile per wave: 8 x 8 accumulator fragments of v_mfma_f32_16x16x4_f32 = 256 AGPRs;
+//   * NO LDS and NO barrier: a lane's MFMA operands are 16 contiguous bytes of one row of X or K' (k = 4 g .. 4 g + 3
+//     of a 16-deep chunk for lane group g -- the same k-to-lane assignment on both operands, so any assignment is
+//     valid), fetched straight from global memory into the fragment registers, one chunk ahead (2 x 64 VGPRs);
+//   * buffer loads (one descriptor per operand, the row-block step in the scalar offset, one shared per-lane offset):
+//     no per-load address arithmetic.  With flat loads the 64-bit VALU adds in front of each load cost ~15 cycles of
+//     MFMA issue apiece (8441 shader cycles per 256-MFMA chunk against 8226 here and 8199 with no loads at all --
+//     in-kernel s_memtime stamps, scripts/w1_gemm.hip, profiles/r03_w1_gemm.txt);
+//   * the MFMAs are inline asm with the accumulators tied in place ("+a"): left to the register allocator the loop
+//     carried ~1100 v_accvgpr moves.  Loads stay ordinary builtins, so hipcc still counts vmcnt for them.
+// Traffic per flop is that of the 128 x 128 LDS tile (each wave reads a 128-row slice of both operands once per
+// chunk); with one wave per SIMD nothing overlaps the epilogue, so the fp64 add-back of the fit runs on the fp64
+// MATRIX pipe: a 128 x 128 x 16 product of the row vectors with the coefficient vectors (256 v_mfma_f64_16x16x4_f64,
+// ~one chunk's worth of time) instead of 3584 fp64 FMAs per lane.
+// Short k-loops (small models) keep the LDS tiles: there the epilogue and the first loads are not amortised.
+#include "gpx_internal.hpp"
+
+namespace gpx {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+struct VarW1Dev {
+    const float *X;
+    long ldx;
+    const float *Kq;
+    long ldk;
+    const float *dinv;       // plain epilogue: 1/D in fp32
+    float *partial;          // plain epilogue
+    double *partial64;       // fp64 epilogue
+    long ldp;
+    const double *rowcorr, *colcoef, *dinv64;
+    long ldrc, ldcc;
+};
+
+template <bool CORR>
+__global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_kernel(VarW1Dev g)
+{
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy row tiles first
+    const int m0 = mt * 128, n0 = nt * 128;
+    const int r16 = lane & 15, lg = lane >> 4;
+    const int nch = (m0 + 128) / 16;  // 16-deep k chunks (X is lower triangular: k < m0 + 128); a multiple of 8
+    char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.X + (size_t)m0 * g.ldx));
+    char *bbase = const_cast<char *>(reinterpret_cast<const char *>(g.Kq + (size_t)n0 * g.ldk));
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(abase, 0, (int)(128 * g.ldx * 4), 0x00020000);
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(bbase, 0, (int)(128 * g.ldk * 4), 0x00020000);
+    const unsigned aoff = (unsigned)(r16 * g.ldx * 4 + lg * 16);
+    const unsigned boff = (unsigned)(r16 * g.ldk * 4 + lg * 16);
+    const int astep = (int)(16 * g.ldx * 4), bstep = (int)(16 * g.ldk * 4);
+
+    f4v acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+    // one piece = one 16-byte load per lane of the next chunk: pieces 0-7 are the A fragments, 8-15 the B fragments
+    // (the builtin's result is bit-cast as a whole: indexing its elements mis-compiles to a one-dword load on ROCm 7.2)
+    float4 a0[8], b0[8], a1[8], b1[8];
+#define W1_PIECE(A_, B_, KB_, P_)                                                                                  \
+    {                                                                                                              \
+        if ((P_) < 8)                                                                                              \
+            A_[(P_) & 7] = __builtin_bit_cast(                                                                     \
+                float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(aoff + (KB_)), ((P_) & 7) * astep, 0)); \
+        else                                                                                                       \
+            B_[(P_) & 7] = __builtin_bit_cast(                                                                     \
+                float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(boff + (KB_)), ((P_) & 7) * bstep, 0)); \
+    }
+#define W1_ROW(A_, B_, S_, I_)                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) \
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[I_][j_]) : "v"(A_[I_].S_), "v"(B_[j_].S_));
+    // 256 MFMAs on (A_, B_); the 16 pieces of (AN_, BN_) go out one per 8 MFMAs over the first half, so the last one has
+    // 128 MFMAs (~4000 cycles) to land
+#define W1_COMPUTE_LD(A_, B_, AN_, BN_, KB_)                                                                       \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, i_) W1_ROW(A_, B_, x, i_) }     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, 8 + i_) W1_ROW(A_, B_, y, i_) } \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, z, i_) }                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, w, i_) }                                 \
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+        W1_PIECE(a0, b0, 0u, p)
+    asm volatile(".p2align 6");
+    for (int c = 0; c < nch; c += 2) {
+        // (the last trip re-loads its own second chunk: nothing in the loop is conditional)
+        const unsigned kb1 = (unsigned)(c + 1) * 64u, kb2 = (unsigned)min(c + 2, nch - 1) * 64u;
+        W1_COMPUTE_LD(a0, b0, a1, b1, kb1);
+        W1_COMPUTE_LD(a1, b1, a0, b0, kb2);
+    }
+#undef W1_PIECE
+#undef W1_ROW
+#undef W1_COMPUTE_LD
+    // the asm MFMAs are opaque to hipcc's hazard recogniser: let the last ones retire before the accumulators are read
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+
+    // acc[i][j][r] is row 16 i + 4 lg + r, column 16 j + r16 of the tile
+    if constexpr (!CORR) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 w = *reinterpret_cast<const float4 *>(g.dinv + m0 + 16 * i + 4 * lg);
+                s = fmaf(acc[i][j][0] * acc[i][j][0], w.x, s);
+                s = fmaf(acc[i][j][1] * acc[i][j][1], w.y, s);
+                s = fmaf(acc[i][j][2] * acc[i][j][2], w.z, s);
+                s = fmaf(acc[i][j][3] * acc[i][j][3], w.w, s);
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lg == 0)
+                g.partial[(size_t)mt * g.ldp + n0 + 16 * j + r16] = s;
+        }
+    } else {
+        // Low-rank fit added back in fp64 (gpx_eval.hip, "centred kernel operand"): w = acc + sum_c rowcorr[c][m] colcoef[c][n],
+        // then w^2 / D and the column sums, all fp64.  The rank-14 sum is a 128 x 128 x 16 fp64 product on the matrix
+        // pipe.  v_mfma_f64_16x16x4_f64 returns rows lg, lg + 4, lg + 8, lg + 12 of a fragment to a lane where the fp32
+        // form returned rows 4 lg .. 4 lg + 3, so the A operand is fed with its rows permuted: operand row rho carries
+        // tile row 4 (rho & 3) + (rho >> 2), and result register r of a lane is then row 4 lg + r -- acc's layout.
+        const int prow = 4 * (r16 & 3) + (r16 >> 2);
+        double ra[8][4], cb[8][4];  // step s of a fragment uses vector c = 4 s + lg (c >= VAR_NCORR: zero)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = 4 * s + lg;
+            const bool live = c < VAR_NCORR;
+            const double *rp = g.rowcorr + (size_t)(live ? c : 0) * g.ldrc + m0 + prow;
+            const double *cp = g.colcoef + (size_t)(live ? c : 0) * g.ldcc + n0 + r16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ra[i][s] = live ? rp[16 * i] : 0.0;
+                cb[i][s] = live ? cp[16 * i] : 0.0;
+            }
+        }
+        double rw[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rw[i][r] = g.dinv64[m0 + 16 * i + 4 * lg + r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double sj = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                d4v d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i][s], cb[j][s], d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double w = (double)acc[i][j][r] + d[r];
+                    sj = fma(w * w, rw[i][r], sj);
+                }
+            }
+            sj += __shfl_xor(sj, 16);
+            sj += __shfl_xor(sj, 32);
+            if (lg == 0)
+                g.partial64[(size_t)mt * g.ldp + n0 + 16 * j + r16] = sj;
+        }
+    }
+}
+
+bool var_w1_fits(const GemmArgs &a)
+{
+    // 128-row slices of both operands must fit a buffer descriptor's 32-bit range; 16-byte aligned rows
+    return a.epi == EPI_COLSQ && !a.nn && a.a_lower && !a.b_lower && !a.lower_only && a.batch == 1 && a.M_last < 0 &&
+           a.M > 0 && a.N > 0 && a.M % 128 == 0 && a.N % 128 == 0 && a.K >= a.M && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+           a.lda >= a.M && a.ldb >= a.M && 128 * a.lda * 4 < (1L << 31) && 128 * a.ldb * 4 < (1L << 31);
+}
+
+void launch_var_w1(const GemmArgs &a, hipStream_t st)
+{
+    VarW1Dev g;
+    g.X = (const float *)a.A, g.ldx = a.lda;
+    g.Kq = (const float *)a.B, g.ldk = a.ldb;
+    g.dinv = (const float *)a.rowweight;
+    g.partial = (float *)a.partial, g.partial64 = (double *)a.partial, g.ldp = a.ldp;
+    g.rowcorr = a.rowcorr, g.colcoef = a.colcoef, g.dinv64 = a.rowweight64;
+    g.ldrc = a.ldrc, g.ldcc = a.ldcc;
+    const dim3 grid(a.N / 128, a.M / 128);
+    if (a.colcoef)
+        hipLaunchKernelGGL(var_w1_kernel<true>, grid, dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(var_w1_kernel<false>, grid, dim3(64), 0, st, g);
+}
+
+}  // namespace gpx

@@ -1,7 +1,8 @@
 // gemm_bench.hip -- development harness: times the GEMM core on the two hot shapes (variance contraction with / without
 // the low-rank correction in its epilogue; trailing update of the LDL^T for K = 128 .. 2048).
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gaussian-object-modelling_amd/csrc scripts/gemm_bench.hip \
-//          gaussian-object-modelling_amd/csrc/gpx_gemm.hip -o scripts/gemm_bench.bin       [-DGEMM_WAVES_PER_EU=1|2]
+//          gaussian-object-modelling_amd/csrc/gpx_gemm.hip gaussian-object-modelling_amd/csrc/gpx_vargemm.hip \
+//          gaussian-object-modelling_amd/csrc/gpx_host.cpp -o scripts/gemm_bench.bin       [-DGEMM_WAVES_PER_EU=1|2]
 //   (compiled TOGETHER with the GEMM source, not linked to libgpx.so: struct GemmArgs is internal to the library and a
 //   harness built against another revision of it passes garbage pointers -- the round-1 faults)
 //   run  : scripts/gemm_bench.bin N NQ prec(0 = f32, 1 = f64) [with_correction = 1] [inverse-assembly shapes = 0] [variance only = 0]
@@ -60,7 +61,9 @@ int main(int argc, char **argv)
 #ifdef GEMM_BENCH_M32
     for (int cfg : {0, 2, 3, 4, 5}) {
 #else
-    for (int cfg : {0, 2, 3}) {
+    for (int cfg : {0, 2, 3, 6}) {
+        if (cfg == 6 && prec)
+            continue;
 #endif
         GemmArgs a;
         a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;

@@ -1,0 +1,29 @@
+"""Variance-product tile by model size: evaluate(f, v) on 2^19 lattice queries for N = 512 .. 16384 with the LDS tile
+(GPX_VAR_TILE=3) and the one-wave tile (GPX_VAR_TILE=6, GPX_VAR_W1_MIN_ROWS=128 so that it is used at every size); the
+switches are read once per process, so this script re-runs itself per setting.  Prints ms per evaluate and the GEMM's share."""
+import importlib, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1:
+    import numpy as np, torch
+    gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    dev = torch.device("cuda:0")
+    g = 80
+    t = torch.linspace(-1.01, 1.01, g, dtype=torch.float64, device=dev)
+    idx = torch.arange(0, 2 ** 19, device=dev)
+    q = [t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()]
+    nq = int(idx.numel())
+    f = torch.empty(nq, dtype=torch.float64, device=dev); v = torch.empty_like(f)
+    for n in (512, 1024, 2048, 3072, 4096, 8192, 16384):
+        x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+        m = gpx.Model(gpx.make_kernel("matern52", 1.0, 1.0), x, y, z, lab, s2, precision=gpx.F32, prepare_variance=True)
+        for _ in range(2):
+            m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr()); m.sync()
+        st = m.stats
+        print("%s N=%5d: evaluate %.2f ms  (variance GEMM %.2f ms)" % (sys.argv[1], n, st["t_mean_ms"] + st["t_var_ms"], st["t_var_gemm_ms"]), flush=True)
+        m.close()
+else:
+    for tile, name in (("3", "LDS tile 3   "), ("6", "one-wave tile")):
+        env = dict(os.environ, GPX_VAR_TILE=tile, GPX_VAR_W1_MIN_ROWS="128")
+        subprocess.run([sys.executable, os.path.abspath(__file__), name], env=env, check=True)
