@@ -58,6 +58,24 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
     const unsigned boff = (unsigned)(r16 * g.ldk * 4 + lg * 16);
     const int astep = (int)(16 * g.ldx * 4), bstep = (int)(16 * g.ldk * 4);
 
+    // fp64 epilogue: this tile's slices of the 14 row vectors (+ a zero row), the 14 coefficient vectors and 1/D go to
+    // LDS now, so that the epilogue -- which nothing overlaps with one wave per SIMD -- reads them at LDS latency
+    __shared__ double epi_rowc[CORR ? (VAR_NCORR + 1) * 128 : 1];  // row VAR_NCORR: zeros (steps past the last vector)
+    __shared__ double epi_colc[CORR ? VAR_NCORR * 128 : 1];
+    __shared__ double epi_roww[CORR ? 128 : 1];
+    __shared__ float4 epi_acc[CORR ? 8 * 64 : 1];                  // one row block of accumulator fragments
+    if constexpr (CORR) {
+#pragma unroll
+        for (int c = 0; c < VAR_NCORR; ++c) {
+            const double2 rv = *reinterpret_cast<const double2 *>(g.rowcorr + (size_t)c * g.ldrc + m0 + 2 * lane);
+            const double2 cv = *reinterpret_cast<const double2 *>(g.colcoef + (size_t)c * g.ldcc + n0 + 2 * lane);
+            *reinterpret_cast<double2 *>(epi_rowc + c * 128 + 2 * lane) = rv;
+            *reinterpret_cast<double2 *>(epi_colc + c * 128 + 2 * lane) = cv;
+        }
+        *reinterpret_cast<double2 *>(epi_rowc + VAR_NCORR * 128 + 2 * lane) = double2{0.0, 0.0};
+        *reinterpret_cast<double2 *>(epi_roww + 2 * lane) = *reinterpret_cast<const double2 *>(g.dinv64 + m0 + 2 * lane);
+    }
+
     f4v acc[8][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -129,45 +147,87 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
         // pipe.  v_mfma_f64_16x16x4_f64 returns rows lg, lg + 4, lg + 8, lg + 12 of a fragment to a lane where the fp32
         // form returned rows 4 lg .. 4 lg + 3, so the A operand is fed with its rows permuted: operand row rho carries
         // tile row 4 (rho & 3) + (rho >> 2), and result register r of a lane is then row 4 lg + r -- acc's layout.
+        // Step s of a fragment uses vector c = 4 s + lg; c >= VAR_NCORR reads the zero row (and any finite coefficient).
+        //
+        // Shape of the code.  A ROLLED loop over the eight row blocks whose body hipcc compiles once, at the register
+        // pressure of one block; the accumulators reach it through LDS, written from their AGPRs by the asm of the switch
+        // (8 KiB per block).  Any C++ read of acc[][] -- or the MFMA builtin, whose result wants AGPRs -- makes hipcc copy
+        // all 256 accumulators to VGPRs at the top of the epilogue and spill most of them.  The fp64 MFMAs are inline asm
+        // with VGPR results for the same reason; asm is opaque to the hazard recogniser, hence the explicit wait states
+        // (tied to the results, so that no consumer is scheduled above them) and eight independent chains (dependent
+        // MFMAs 8 x 32 cycles apart).  One wave is the whole workgroup and a wave's LDS operations execute in order:
+        // no barrier anywhere, only lgkmcnt waits.
+        const unsigned epi_lane = (unsigned)(size_t)(epi_acc + lane);  // low half of the flat address = the LDS offset
         const int prow = 4 * (r16 & 3) + (r16 >> 2);
-        double ra[8][4], cb[8][4];  // step s of a fragment uses vector c = 4 s + lg (c >= VAR_NCORR: zero)
+        int crow[4], ccol[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int c = 4 * s + lg;
-            const bool live = c < VAR_NCORR;
-            const double *rp = g.rowcorr + (size_t)(live ? c : 0) * g.ldrc + m0 + prow;
-            const double *cp = g.colcoef + (size_t)(live ? c : 0) * g.ldcc + n0 + r16;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                ra[i][s] = live ? rp[16 * i] : 0.0;
-                cb[i][s] = live ? cp[16 * i] : 0.0;
-            }
+            crow[s] = min(4 * s + lg, VAR_NCORR) * 128 + prow;
+            ccol[s] = min(4 * s + lg, VAR_NCORR - 1) * 128 + r16;
         }
-        double rw[8][4];
+        double sj[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j)
+            sj[j] = 0.0;
+#define W1_DUMP(I_)                                                                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                                   \
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(epi_lane), "a"(acc[I_][j_]), "n"(1024 * j_) : "memory");
+#pragma nounroll
+        for (int i = 0; i < 8; ++i) {
+            switch (i) {
+            case 0: W1_DUMP(0) break;
+            case 1: W1_DUMP(1) break;
+            case 2: W1_DUMP(2) break;
+            case 3: W1_DUMP(3) break;
+            case 4: W1_DUMP(4) break;
+            case 5: W1_DUMP(5) break;
+            case 6: W1_DUMP(6) break;
+            default: W1_DUMP(7) break;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double ra[4], rw[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                ra[s] = epi_rowc[crow[s] + 16 * i];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                rw[i][r] = g.dinv64[m0 + 16 * i + 4 * lg + r];
+                rw[r] = epi_roww[16 * i + 4 * lg + r];
+            d4v d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double cb = epi_colc[ccol[0] + 16 * j];
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(d[j]) : "v"(ra[0]), "v"(cb));
+            }
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double cb = epi_colc[ccol[s] + 16 * j];
+                    asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(d[j]) : "v"(ra[s]), "v"(cb));
+                }
+            asm volatile("s_nop 15\n s_nop 15"
+                         : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 av = epi_acc[64 * j + lane];
+                double w = (double)av.x + d[j][0];
+                sj[j] = fma(w * w, rw[0], sj[j]);
+                w = (double)av.y + d[j][1];
+                sj[j] = fma(w * w, rw[1], sj[j]);
+                w = (double)av.z + d[j][2];
+                sj[j] = fma(w * w, rw[2], sj[j]);
+                w = (double)av.w + d[j][3];
+                sj[j] = fma(w * w, rw[3], sj[j]);
+            }
+        }
+#undef W1_DUMP
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            double sj = 0.0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                d4v d = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i][s], cb[j][s], d, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double w = (double)acc[i][j][r] + d[r];
-                    sj = fma(w * w, rw[i][r], sj);
-                }
-            }
-            sj += __shfl_xor(sj, 16);
-            sj += __shfl_xor(sj, 32);
+            double t = sj[j];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
             if (lg == 0)
-                g.partial64[(size_t)mt * g.ldp + n0 + 16 * j + r16] = sj;
+                g.partial64[(size_t)mt * g.ldp + n0 + 16 * j + r16] = t;
         }
     }
 }
