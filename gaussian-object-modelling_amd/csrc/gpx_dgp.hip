@@ -380,6 +380,7 @@ extern "C" int gpx_dgp_evaluate(const gpx_dgp *cg, size_t nq, const double *qx, 
             a.epi = EPI_COLSQ;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
+            a.cfg = 6;  // the one-wave fp64 tile (gpx_vargemm.hip); launch_gemm falls back to the LDS tile if it does not fit
             launch_gemm(GPX_PREC_F64, a, s);
             launch_var_finish(GPX_PREC_F64, g->k0, np_rows / gemm_rows_per_partial(GPX_PREC_F64, a), (long)qb, m->ws_partial,
                               (long)nv, dvar + q0, s);

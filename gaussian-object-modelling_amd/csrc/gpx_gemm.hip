@@ -663,6 +663,10 @@ void launch_gemm(int prec, const GemmArgs &g, hipStream_t st)
             launch_var_w1(g, st);
             return;
         }
+        if (prec == GPX_PREC_F64 && var_w1_f64_fits(g)) {
+            launch_var_w1_f64(g, st);
+            return;
+        }
         GemmArgs h = g;
         h.cfg = 3;
         launch_gemm(prec, h, st);

@@ -204,6 +204,8 @@ void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
 // straight into the MFMA fragments -- gpx_vargemm.hip.  launch_gemm routes cfg 6 there when var_w1_fits(), else to cfg 3.
 bool var_w1_fits(const GemmArgs &g);
 void launch_var_w1(const GemmArgs &g, hipStream_t st);
+bool var_w1_f64_fits(const GemmArgs &g);   // the fp64 form: 128 x 64 tile per wave, plain epilogue
+void launch_var_w1_f64(const GemmArgs &g, hipStream_t st);
 constexpr int VAR_W1_MIN_ROWS = 128;  // i.e. always: measured faster than the LDS tiles from 512 rows up (scripts/var_tile_sweep.py)
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
 int gemm_tile_m(int cfg);

@@ -232,6 +232,133 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
     }
 }
 
+// ---- the same structure in fp64 (GPX_PREC_F64 models; the derivative-observation GP) ------------------------------------
+// v_mfma_f64_16x16x4_f64 accumulates a 16 x 16 fragment in 8 registers, so 256 AGPRs hold 8 x 4 fragments: a 128 x 64 tile
+// per wave.  A lane's operand for an 8-deep chunk is again 16 contiguous bytes of one row -- k = 2 g, 2 g + 1 for lane
+// group g -- and the two MFMA steps of the chunk take its two halves; 64 MFMAs of 64 cycles and 12 loads per chunk.
+// Plain epilogue only (fp64 models carry no fit).  Result rows of a lane: g, g + 4, g + 8, g + 12 of each fragment.
+struct VarW1F64Dev {
+    const double *X;
+    long ldx;
+    const double *Kq;
+    long ldk;
+    const double *dinv;
+    double *partial;
+    long ldp;
+};
+
+__global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f64_kernel(VarW1F64Dev g)
+{
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy row tiles first
+    const int m0 = mt * 128, n0 = nt * 64;
+    const int r16 = lane & 15, lg = lane >> 4;
+    const int nch = (m0 + 128) / 8;  // 8-deep k chunks; a multiple of 16
+    char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.X + (size_t)m0 * g.ldx));
+    char *bbase = const_cast<char *>(reinterpret_cast<const char *>(g.Kq + (size_t)n0 * g.ldk));
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(abase, 0, (int)(128 * g.ldx * 8), 0x00020000);
+    const auto brsrc = __builtin_amdgcn_make_buffer_rsrc(bbase, 0, (int)(64 * g.ldk * 8), 0x00020000);
+    const unsigned aoff = (unsigned)(r16 * g.ldx * 8 + lg * 16);
+    const unsigned boff = (unsigned)(r16 * g.ldk * 8 + lg * 16);
+    const int astep = (int)(16 * g.ldx * 8), bstep = (int)(16 * g.ldk * 8);
+
+    d4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = d4v{0.0, 0.0, 0.0, 0.0};
+
+    double2 a0[8], b0[4], a1[8], b1[4];
+    // pieces 0-7: the A fragments, 8-11: the B fragments
+#define W1D_PIECE(A_, B_, KB_, P_)                                                                                  \
+    {                                                                                                               \
+        if ((P_) < 8)                                                                                               \
+            A_[(P_) & 7] = __builtin_bit_cast(                                                                      \
+                double2, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(aoff + (KB_)), ((P_) & 7) * astep, 0)); \
+        else                                                                                                        \
+            B_[(P_) & 3] = __builtin_bit_cast(                                                                      \
+                double2, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(boff + (KB_)), ((P_) & 3) * bstep, 0)); \
+    }
+#define W1D_ROW(A_, B_, S_, I_)                      \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) \
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[I_][j_]) : "v"(A_[I_].S_), "v"(B_[j_].S_));
+    // 64 MFMAs on (A_, B_); the 12 pieces of the next chunk go out one per 4 MFMAs (first 48 MFMAs = 3000 cycles)
+#define W1D_COMPUTE_LD(A_, B_, AN_, BN_, KB_)                                                                        \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1D_PIECE(AN_, BN_, KB_, i_) W1D_ROW(A_, B_, x, i_) }     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { W1D_PIECE(AN_, BN_, KB_, 8 + i_) W1D_ROW(A_, B_, y, i_) } \
+        _Pragma("unroll") for (int i_ = 4; i_ < 8; ++i_) { W1D_ROW(A_, B_, y, i_) }                                  \
+    }
+#pragma unroll
+    for (int p = 0; p < 12; ++p)
+        W1D_PIECE(a0, b0, 0u, p)
+    asm volatile(".p2align 6");
+    for (int c = 0; c < nch; c += 2) {
+        const unsigned kb1 = (unsigned)(c + 1) * 64u, kb2 = (unsigned)min(c + 2, nch - 1) * 64u;
+        W1D_COMPUTE_LD(a0, b0, a1, b1, kb1);
+        W1D_COMPUTE_LD(a1, b1, a0, b0, kb2);
+    }
+#undef W1D_PIECE
+#undef W1D_ROW
+#undef W1D_COMPUTE_LD
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+
+    // acc[i][j][r] is row 16 i + lg + 4 r, column 16 j + r16 of the tile.  A ROLLED loop over the row blocks with the block's
+    // fragments picked by a switch: unrolled, hipcc copies all 256 accumulator registers to VGPRs at once and spills.
+    double sj[4] = {0.0, 0.0, 0.0, 0.0};
+#define W1D_PICK(I_) t[0] = acc[I_][0], t[1] = acc[I_][1], t[2] = acc[I_][2], t[3] = acc[I_][3]
+#pragma nounroll
+    for (int i = 0; i < 8; ++i) {
+        d4v t[4];
+        switch (i) {
+        case 0: W1D_PICK(0); break;
+        case 1: W1D_PICK(1); break;
+        case 2: W1D_PICK(2); break;
+        case 3: W1D_PICK(3); break;
+        case 4: W1D_PICK(4); break;
+        case 5: W1D_PICK(5); break;
+        case 6: W1D_PICK(6); break;
+        default: W1D_PICK(7); break;
+        }
+        double w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            w[r] = g.dinv[m0 + 16 * i + lg + 4 * r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sj[j] = fma(t[j][r] * t[j][r], w[r], sj[j]);
+    }
+#undef W1D_PICK
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double s = sj[j];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lg == 0)
+            g.partial[(size_t)mt * g.ldp + n0 + 16 * j + r16] = s;
+    }
+}
+
+bool var_w1_f64_fits(const GemmArgs &a)
+{
+    return a.epi == EPI_COLSQ && !a.nn && a.a_lower && !a.b_lower && !a.lower_only && a.batch == 1 && a.M_last < 0 &&
+           a.M > 0 && a.N > 0 && a.M % 128 == 0 && a.N % 64 == 0 && a.K >= a.M && a.lda % 2 == 0 && a.ldb % 2 == 0 &&
+           a.lda >= a.M && a.ldb >= a.M && 128 * a.lda * 8 < (1L << 31) && 64 * a.ldb * 8 < (1L << 31) && !a.colcoef;
+}
+
+void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
+{
+    VarW1F64Dev g;
+    g.X = (const double *)a.A, g.ldx = a.lda;
+    g.Kq = (const double *)a.B, g.ldk = a.ldb;
+    g.dinv = (const double *)a.rowweight;
+    g.partial = (double *)a.partial, g.ldp = a.ldp;
+    hipLaunchKernelGGL(var_w1_f64_kernel, dim3(a.N / 64, a.M / 128), dim3(64), 0, st, g);
+}
+
 bool var_w1_fits(const GemmArgs &a)
 {
     // 128-row slices of both operands must fit a buffer descriptor's 32-bit range; 16-byte aligned rows

@@ -62,7 +62,7 @@ int main(int argc, char **argv)
     for (int cfg : {0, 2, 3, 4, 5}) {
 #else
     for (int cfg : {0, 2, 3, 6}) {
-        if (cfg == 6 && prec)
+        if (cfg == 2 && prec)
             continue;
 #endif
         GemmArgs a;
