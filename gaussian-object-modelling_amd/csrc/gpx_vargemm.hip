@@ -121,7 +121,13 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
 #undef W1_ROW
 #undef W1_COMPUTE_LD
     // the asm MFMAs are opaque to hipcc's hazard recogniser: let the last ones retire before the accumulators are read
-    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    // (tied to the last row of fragments, so that no read of them can be scheduled above the wait states; every other
+    // fragment's last MFMA is at least 8 MFMAs = 256 cycles older)
+    asm volatile("s_nop 15\n s_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
+                   "+a"(acc[7][6]), "+a"(acc[7][7])
+                 :
+                 : "memory");
 
     // acc[i][j][r] is row 16 i + 4 lg + r, column 16 j + r16 of the tile
     if constexpr (!CORR) {
@@ -302,7 +308,11 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f6
 #undef W1D_PIECE
 #undef W1D_ROW
 #undef W1D_COMPUTE_LD
-    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    // (as in the fp32 kernel: wait states tied to the last MFMAs' fragments; the others are >= 4 x 64 cycles older)
+    asm volatile("s_nop 15\n s_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3])
+                 :
+                 : "memory");
 
     // acc[i][j][r] is row 16 i + lg + 4 r, column 16 j + r16 of the tile.  A ROLLED loop over the row blocks with the block's
     // fragments picked by a switch: unrolled, hipcc copies all 256 accumulator registers to VGPRs at once and spills.
