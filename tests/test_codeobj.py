@@ -51,3 +51,18 @@ def test_gemm_tiles_leave_room_for_two_workgroups_per_cu(kernels):
             seen += 1
             assert k["vgpr_count"] + k["agpr_count"] <= 256, (k["name"], k["vgpr_count"], k["agpr_count"])
     assert seen >= 4
+
+
+def test_one_wave_variance_tiles_own_a_simd(kernels):
+    """gpx_vargemm.hip: one 64-lane workgroup per SIMD with the whole accumulator file (256 AGPRs: 8 x 8 fp32 / 8 x 4 fp64
+    fragments) and at most 512 registers in all; four of them must fit a CU's 160 KiB of LDS (the fp64 epilogue of the
+    fp32 tile stages its operands and one block of accumulators there)."""
+    seen = 0
+    for k in kernels:
+        if "var_w1_" in k["name"]:
+            seen += 1
+            assert k["max_flat_workgroup_size"] == 64, k["name"]
+            assert k["agpr_count"] == 256, (k["name"], k["agpr_count"])
+            assert k["vgpr_count"] <= 512, (k["name"], k["vgpr_count"])  # (the unified count: arch + accumulator registers)
+            assert 4 * k["group_segment_fixed_size"] <= 160 * 1024, (k["name"], k["group_segment_fixed_size"])
+    assert seen == 3  # fp32 with the fit, fp32 plain, fp64
