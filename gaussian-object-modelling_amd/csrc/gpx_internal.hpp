@@ -206,6 +206,10 @@ bool var_w1_fits(const GemmArgs &g);
 void launch_var_w1(const GemmArgs &g, hipStream_t st);
 bool var_w1_f64_fits(const GemmArgs &g);   // the fp64 form: 128 x 64 tile per wave, plain epilogue
 void launch_var_w1_f64(const GemmArgs &g, hipStream_t st);
+// Rows of the variance operand K' are np + KQP_LDPAD elements apart: with the power-of-two stride np the 128 rows of a
+// tile's K' slab and of its X slab fall on the same L2 sets and evict each other (N = 16384: 19.9 GB of L2 misses per
+// launch against 7.6 GB with the padded stride, paired launch; profiles/r03_w1_traffic.txt)
+constexpr int KQP_LDPAD = 32;
 constexpr int VAR_W1_MIN_ROWS = 128;  // i.e. always: measured faster than the LDS tiles from 512 rows up (scripts/var_tile_sweep.py)
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
 int gemm_tile_m(int cfg);

@@ -22,6 +22,7 @@
 // MATRIX pipe: a 128 x 128 x 16 product of the row vectors with the coefficient vectors (256 v_mfma_f64_16x16x4_f64,
 // ~one chunk's worth of time) instead of 3584 fp64 FMAs per lane.
 // Short k-loops (small models) keep the LDS tiles: there the epilogue and the first loads are not amortised.
+#include <cstdlib>
 #include "gpx_internal.hpp"
 
 namespace gpx {
@@ -40,16 +41,28 @@ struct VarW1Dev {
     long ldp;
     const double *rowcorr, *colcoef, *dinv64;
     long ldrc, ldcc;
+    int paired;  // 1: gridDim.y = row tiles / 2 and a workgroup does tile MT - 1 - y, then tile y walked in descending k
 };
 
 template <bool CORR>
 __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_kernel(VarW1Dev g)
 {
     const int lane = threadIdx.x;
-    const int nt = blockIdx.x, mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy row tiles first
-    const int m0 = mt * 128, n0 = nt * 128;
+    const int nt = blockIdx.x, n0 = nt * 128;
     const int r16 = lane & 15, lg = lane >> 4;
+    // Which row tile(s).  Plain launch: one tile per workgroup, heavy row tiles first (a tile of row block mt has mt + 1
+    // units of k).  Paired launch (launch_var_w1 picks it when the pairs fill the chip's SIMDs in whole rounds): tile
+    // MT - 1 - y and then tile y, so that EVERY workgroup has MT + 1 units and the workgroups of a round run in step --
+    // the heavy tiles at k = t, the light ones walked in DESCENDING k at k = T - 1 - t whatever their length -- and the
+    // row slices of X and K' they share are fetched from HBM once per round instead of once per workgroup.
+    const int nphase = g.paired ? 2 : 1;
+    const int MT = g.paired ? 2 * (int)gridDim.y : (int)gridDim.y;
+#pragma nounroll
+    for (int ph = 0; ph < nphase; ++ph) {
+    const int mt = (ph == 0) ? MT - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int m0 = mt * 128;
     const int nch = (m0 + 128) / 16;  // 16-deep k chunks (X is lower triangular: k < m0 + 128); a multiple of 8
+    const int cfirst = (ph == 0) ? 0 : nch - 1, cdir = (ph == 0) ? 1 : -1;  // chunk j of the walk is cfirst + cdir * j
     char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.X + (size_t)m0 * g.ldx));
     char *bbase = const_cast<char *>(reinterpret_cast<const char *>(g.Kq + (size_t)n0 * g.ldk));
     const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(abase, 0, (int)(128 * g.ldx * 4), 0x00020000);
@@ -107,13 +120,17 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, z, i_) }                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, w, i_) }                                 \
     }
+    {
+        const unsigned kb0 = (unsigned)cfirst * 64u;
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-        W1_PIECE(a0, b0, 0u, p)
+        for (int p = 0; p < 16; ++p)
+            W1_PIECE(a0, b0, kb0, p)
+    }
     asm volatile(".p2align 6");
     for (int c = 0; c < nch; c += 2) {
         // (the last trip re-loads its own second chunk: nothing in the loop is conditional)
-        const unsigned kb1 = (unsigned)(c + 1) * 64u, kb2 = (unsigned)min(c + 2, nch - 1) * 64u;
+        const unsigned kb1 = (unsigned)(cfirst + cdir * (c + 1)) * 64u;
+        const unsigned kb2 = (unsigned)(cfirst + cdir * min(c + 2, nch - 1)) * 64u;
         W1_COMPUTE_LD(a0, b0, a1, b1, kb1);
         W1_COMPUTE_LD(a1, b1, a0, b0, kb2);
     }
@@ -236,6 +253,7 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
                 g.partial64[(size_t)mt * g.ldp + n0 + 16 * j + r16] = t;
         }
     }
+    }  // phase (row tile of the pair)
 }
 
 // ---- the same structure in fp64 (GPX_PREC_F64 models; the derivative-observation GP) ------------------------------------
@@ -251,15 +269,23 @@ struct VarW1F64Dev {
     const double *dinv;
     double *partial;
     long ldp;
+    int paired;  // as in VarW1Dev
 };
 
 __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f64_kernel(VarW1F64Dev g)
 {
     const int lane = threadIdx.x;
-    const int nt = blockIdx.x, mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy row tiles first
-    const int m0 = mt * 128, n0 = nt * 64;
+    const int nt = blockIdx.x, n0 = nt * 64;
     const int r16 = lane & 15, lg = lane >> 4;
+    // plain launch: heavy row tiles first; paired launch: tile MT - 1 - y, then tile y in descending k (see var_w1_kernel)
+    const int nphase = g.paired ? 2 : 1;
+    const int MT = g.paired ? 2 * (int)gridDim.y : (int)gridDim.y;
+#pragma nounroll
+    for (int ph = 0; ph < nphase; ++ph) {
+    const int mt = (ph == 0) ? MT - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int m0 = mt * 128;
     const int nch = (m0 + 128) / 8;  // 8-deep k chunks; a multiple of 16
+    const int cfirst = (ph == 0) ? 0 : nch - 1, cdir = (ph == 0) ? 1 : -1;
     char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.X + (size_t)m0 * g.ldx));
     char *bbase = const_cast<char *>(reinterpret_cast<const char *>(g.Kq + (size_t)n0 * g.ldk));
     const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(abase, 0, (int)(128 * g.ldx * 8), 0x00020000);
@@ -296,12 +322,16 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f6
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { W1D_PIECE(AN_, BN_, KB_, 8 + i_) W1D_ROW(A_, B_, y, i_) } \
         _Pragma("unroll") for (int i_ = 4; i_ < 8; ++i_) { W1D_ROW(A_, B_, y, i_) }                                  \
     }
+    {
+        const unsigned kb0 = (unsigned)cfirst * 64u;
 #pragma unroll
-    for (int p = 0; p < 12; ++p)
-        W1D_PIECE(a0, b0, 0u, p)
+        for (int p = 0; p < 12; ++p)
+            W1D_PIECE(a0, b0, kb0, p)
+    }
     asm volatile(".p2align 6");
     for (int c = 0; c < nch; c += 2) {
-        const unsigned kb1 = (unsigned)(c + 1) * 64u, kb2 = (unsigned)min(c + 2, nch - 1) * 64u;
+        const unsigned kb1 = (unsigned)(cfirst + cdir * (c + 1)) * 64u;
+        const unsigned kb2 = (unsigned)(cfirst + cdir * min(c + 2, nch - 1)) * 64u;
         W1D_COMPUTE_LD(a0, b0, a1, b1, kb1);
         W1D_COMPUTE_LD(a1, b1, a0, b0, kb2);
     }
@@ -350,6 +380,7 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f6
         if (lg == 0)
             g.partial[(size_t)mt * g.ldp + n0 + 16 * j + r16] = s;
     }
+    }  // phase (row tile of the pair)
 }
 
 bool var_w1_f64_fits(const GemmArgs &a)
@@ -359,6 +390,25 @@ bool var_w1_f64_fits(const GemmArgs &a)
            a.lda >= a.M && a.ldb >= a.M && 128 * a.lda * 8 < (1L << 31) && 64 * a.ldb * 8 < (1L << 31) && !a.colcoef;
 }
 
+// Paired launch (see var_w1_kernel) when the row tiles pair up and the pairs fill the SIMDs in whole rounds -- equal-length
+// workgroups would otherwise leave a partly filled last round that nothing balances.  GPX_VAR_PAIR=0/1 overrides.
+static bool var_w1_paired(int MT, int NT)
+{
+    static const int pair_env = [] {
+        const char *e = std::getenv("GPX_VAR_PAIR");
+        return e ? std::atoi(e) : -1;
+    }();
+    if (MT < 2 || MT % 2)
+        return false;
+    if (pair_env >= 0)
+        return pair_env != 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    const long slots = 4L * cus;  // one wave per SIMD
+    return slots > 0 && ((long)(MT / 2) * NT) % slots == 0;
+}
+
 void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
 {
     VarW1F64Dev g;
@@ -366,7 +416,10 @@ void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
     g.Kq = (const double *)a.B, g.ldk = a.ldb;
     g.dinv = (const double *)a.rowweight;
     g.partial = (double *)a.partial, g.ldp = a.ldp;
-    hipLaunchKernelGGL(var_w1_f64_kernel, dim3(a.N / 64, a.M / 128), dim3(64), 0, st, g);
+    const int MT = a.M / 128, NT = a.N / 64;
+    const bool paired = var_w1_paired(MT, NT);
+    g.paired = paired ? 1 : 0;
+    hipLaunchKernelGGL(var_w1_f64_kernel, dim3(NT, paired ? MT / 2 : MT), dim3(64), 0, st, g);
 }
 
 bool var_w1_fits(const GemmArgs &a)
@@ -386,7 +439,10 @@ void launch_var_w1(const GemmArgs &a, hipStream_t st)
     g.partial = (float *)a.partial, g.partial64 = (double *)a.partial, g.ldp = a.ldp;
     g.rowcorr = a.rowcorr, g.colcoef = a.colcoef, g.dinv64 = a.rowweight64;
     g.ldrc = a.ldrc, g.ldcc = a.ldcc;
-    const dim3 grid(a.N / 128, a.M / 128);
+    const int MT = a.M / 128, NT = a.N / 128;
+    const bool paired = var_w1_paired(MT, NT);
+    g.paired = paired ? 1 : 0;
+    const dim3 grid(NT, paired ? MT / 2 : MT);
     if (a.colcoef)
         hipLaunchKernelGGL(var_w1_kernel<true>, grid, dim3(64), 0, st, g);
     else

@@ -37,10 +37,14 @@ int main(int argc, char **argv)
     const int NQ = argc > 2 ? atoi(argv[2]) : 8192;  // queries per launch
     const int prec = argc > 3 ? atoi(argv[3]) : 0;
     const size_t e = prec ? 8 : 4;
+    // GEMM_BENCH_LDPAD=p: leading dimension N + p of X and Kqp in the variance shape (is the power-of-two row stride a cache problem?)
+    const int ldpad = getenv("GEMM_BENCH_LDPAD") ? atoi(getenv("GEMM_BENCH_LDPAD")) : 0;
+    const long LDV = N + ldpad;
+    const long LDA = getenv("GEMM_BENCH_NOPAD_A") ? N : LDV, LDB = getenv("GEMM_BENCH_NOPAD_B") ? N : LDV;
     void *X, *Kqp, *dinv, *partial, *C, *W, *rowcorr, *colcoef;
     const bool with_corr = argc > 4 ? atoi(argv[4]) != 0 : true;  // the low-rank correction in the COLSQ epilogue
-    CK(hipMalloc(&X, e * (size_t)N * N));
-    CK(hipMalloc(&Kqp, e * (size_t)NQ * N));
+    CK(hipMalloc(&X, e * (size_t)N * (N + ldpad)));
+    CK(hipMalloc(&Kqp, e * (size_t)NQ * (N + ldpad)));
     CK(hipMalloc(&dinv, e * N));
     CK(hipMalloc(&partial, 8 * (size_t)NQ * (N / 128)));  // doubles with the fp64 epilogue (low-rank correction)
     CK(hipMalloc(&C, e * (size_t)N * N));
@@ -53,8 +57,8 @@ int main(int argc, char **argv)
     fill((double *)rowcorr, (size_t)N * VAR_NCORR, 5, 1e-2);
     fill((double *)colcoef, (size_t)NQ * VAR_NCORR, 6, 1.0);
     fill((double *)dinv64, N, 7, 1.0);
-    if (prec) { fill((double *)X, (size_t)N * N, 1, 1e-2); fill((double *)Kqp, (size_t)NQ * N, 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
-    else { fill((float *)X, (size_t)N * N, 1, 1e-2); fill((float *)Kqp, (size_t)NQ * N, 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
+    if (prec) { fill((double *)X, (size_t)N * (N + ldpad), 1, 1e-2); fill((double *)Kqp, (size_t)NQ * (N + ldpad), 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
+    else { fill((float *)X, (size_t)N * (N + ldpad), 1, 1e-2); fill((float *)Kqp, (size_t)NQ * (N + ldpad), 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
     CK(hipMemset(C, 0, e * (size_t)N * N));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -66,7 +70,7 @@ int main(int argc, char **argv)
             continue;
 #endif
         GemmArgs a;
-        a.A = X, a.lda = N; a.B = Kqp, a.ldb = N; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
+        a.A = X, a.lda = LDA; a.B = Kqp, a.ldb = LDB; a.M = N, a.N = NQ, a.K = N; a.a_lower = 1; a.epi = EPI_COLSQ;
         a.rowweight = dinv; a.partial = partial, a.ldp = NQ; a.cfg = cfg;
         if (with_corr && !prec) { a.rowcorr = (const double *)rowcorr, a.ldrc = N; a.colcoef = (const double *)colcoef, a.ldcc = NQ; a.rowweight64 = (const double *)dinv64; }
         launch_gemm(prec, a, st);
