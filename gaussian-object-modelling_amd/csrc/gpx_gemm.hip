@@ -12,6 +12,7 @@
 // permutation is applied to B, so the products pair up.  Global -> register -> LDS staging is
 // double-buffered with one barrier per k-tile.  All dimensions are multiples of the tile by
 // construction (matrices are padded to 256), so there is no edge handling in the hot loop.
+#include <cstdlib>
 #include "gpx_internal.hpp"
 
 namespace gpx {
@@ -672,10 +673,19 @@ void launch_gemm(int prec, const GemmArgs &g, hipStream_t st)
         launch_gemm(prec, h, st);
         return;
     }
-    if (prec == GPX_PREC_F64)
+    if (prec == GPX_PREC_F64) {
+        static const int w1_nn = [] {
+            const char *e = std::getenv("GPX_W1_NN");
+            return e ? std::atoi(e) : 1;
+        }();
+        if (w1_nn && w1_f64_nn_fits(g)) {
+            launch_w1_f64_nn(g, st);
+            return;
+        }
         gemm_t<double>(g, st);
-    else
+    } else {
         gemm_t<float>(g, st);
+    }
 }
 
 }  // namespace gpx

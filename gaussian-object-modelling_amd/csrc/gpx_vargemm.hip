@@ -22,6 +22,7 @@
 // MATRIX pipe: a 128 x 128 x 16 product of the row vectors with the coefficient vectors (256 v_mfma_f64_16x16x4_f64,
 // ~one chunk's worth of time) instead of 3584 fp64 FMAs per lane.
 // Short k-loops (small models) keep the LDS tiles: there the epilogue and the first loads are not amortised.
+#include <atomic>
 #include <cstdlib>
 #include "gpx_internal.hpp"
 
@@ -402,9 +403,16 @@ static bool var_w1_paired(int MT, int NT)
         return false;
     if (pair_env >= 0)
         return pair_env != 0;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    static std::atomic<int> cu_count[MAX_DEVICES];  // per device, 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)
         return false;
+    int cus = cu_count[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return false;
+        cu_count[dev].store(cus, std::memory_order_relaxed);
+    }
     const long slots = 4L * cus;  // one wave per SIMD
     return slots > 0 && ((long)(MT / 2) * NT) % slots == 0;
 }
@@ -420,6 +428,161 @@ void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
     const bool paired = var_w1_paired(MT, NT);
     g.paired = paired ? 1 : 0;
     hipLaunchKernelGGL(var_w1_f64_kernel, dim3(NT, paired ? MT / 2 : MT), dim3(64), 0, st, g);
+}
+
+// ---- C = alpha A B with B in [k][n] form, fp64: the large products of the inverse-factor assembly -----------------------
+// (T = L21 X11 with X11 lower triangular, X21 = -X22 T with X22 lower triangular; gpx_build.hip trtri_levels / _combine.)
+// Same one-wave structure, 128 x 64 tile.  A's fragments are fetched as in the kernels above (16 bytes = k = 2 g, 2 g + 1 of
+// one row).  B's rows run along n, so a lane's 16 bytes are TWO COLUMNS of one k: the lane of column index c fetches columns
+// n0 + 32 jj + 2 c and + 1 of row k = 2 g + s and hands them to fragments 2 jj and 2 jj + 1 -- fragment j = 2 jj + p
+// therefore holds the columns n0 + 32 jj + 2 c + p, a permutation the store undoes for free (a lane's results for fragments
+// 2 jj, 2 jj + 1 are two adjacent columns of C: one 16-byte store).  B is walked by moving the descriptor's base (a row
+// block of k is ld * 64 bytes: a 32-bit offset from the matrix corner would not reach the far rows of a large model).
+struct W1NNDev {
+    const double *A, *B;
+    double *C;
+    long lda, ldb, ldc;
+    int M, K;
+    long sA, sB, sC;
+    int batch, M_last, k_eq_m;
+    double alpha;
+    int a_lower, b_lower;
+};
+
+__global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void w1_f64_nn_kernel(W1NNDev g)
+{
+    const int lane = threadIdx.x;
+    const int r16 = lane & 15, lg = lane >> 4;
+    // heavy tiles first: k < m0 + 128 for a lower-triangular A (large mt first), k >= n0 for a lower-triangular B (small nt
+    // first, the column index slowest so that neighbours in launch order share the k range)
+    int mt, nt;
+    if (g.b_lower)
+        mt = blockIdx.x, nt = blockIdx.y;
+    else
+        nt = blockIdx.x, mt = g.a_lower ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int z = blockIdx.z;
+    int Mz = g.M, Kz = g.K;
+    if (g.M_last >= 0 && z == g.batch - 1) {
+        Mz = g.M_last;
+        if (g.k_eq_m)
+            Kz = g.M_last;
+    }
+    const int m0 = mt * 128, n0 = nt * 64;
+    if (m0 >= Mz)
+        return;
+    const int klo = g.b_lower ? n0 : 0;
+    const int khi = g.a_lower ? min(Kz, m0 + 128) : Kz;
+    const int nch = (khi - klo) / 8;  // 8-deep chunks; klo is a multiple of 64 and khi of 128: a multiple of 8
+    double *C = g.C + (size_t)z * g.sC;  // (an empty k range -- not a shape of the assembly -- stores zeros: the loop does not run)
+    char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.A + (size_t)z * g.sA + (size_t)m0 * g.lda + klo));
+    const char *bcorner = reinterpret_cast<const char *>(g.B + (size_t)z * g.sB + (size_t)klo * g.ldb + n0);
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(abase, 0, (int)(128 * g.lda * 8), 0x00020000);
+    const unsigned aoff = (unsigned)(r16 * g.lda * 8 + lg * 16);
+    const int astep = (int)(16 * g.lda * 8);
+    const size_t bchunk = (size_t)8 * g.ldb * 8;          // bytes from one chunk of B to the next
+    const int brange = (int)(8 * g.ldb * 8);              // one chunk of rows
+    const unsigned boff0 = (unsigned)((2 * lg) * g.ldb * 8 + r16 * 16), boff1 = boff0 + (unsigned)(g.ldb * 8);
+
+    d4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = d4v{0.0, 0.0, 0.0, 0.0};
+
+    // operands of a chunk: a[i] = {A[row][k], A[row][k + 1]}; b[2 s + jj] = {B[k + s][col pair jj]} for step s
+    double2 a0[8], b0[4], a1[8], b1[4];
+#define NN_APIECE(A_, KB_, P_) \
+    A_[P_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(aoff + (KB_)), (P_) * astep, 0));
+#define NN_BPIECE(B_, RS_, P_) \
+    B_[P_] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(RS_, (int)(((P_) >> 1) ? boff1 : boff0), ((P_) & 1) * 256, 0));
+#define NN_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_));
+    // step s = 0 (k = 2 g): A_.x with b[0], b[1]; step 1 (k = 2 g + 1): A_.y with b[2], b[3]
+#define NN_ROW0(A_, B_, I_) \
+    NN_MFMA(acc[I_][0], A_[I_].x, B_[0].x) NN_MFMA(acc[I_][1], A_[I_].x, B_[0].y) NN_MFMA(acc[I_][2], A_[I_].x, B_[1].x) NN_MFMA(acc[I_][3], A_[I_].x, B_[1].y)
+#define NN_ROW1(A_, B_, I_) \
+    NN_MFMA(acc[I_][0], A_[I_].y, B_[2].x) NN_MFMA(acc[I_][1], A_[I_].y, B_[2].y) NN_MFMA(acc[I_][2], A_[I_].y, B_[3].x) NN_MFMA(acc[I_][3], A_[I_].y, B_[3].y)
+#define NN_COMPUTE_LD(A_, B_, AN_, BN_, KB_, RS_)                                                              \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { NN_APIECE(AN_, KB_, i_) NN_ROW0(A_, B_, i_) }       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { NN_BPIECE(BN_, RS_, i_) NN_ROW1(A_, B_, i_) }       \
+        _Pragma("unroll") for (int i_ = 4; i_ < 8; ++i_) { NN_ROW1(A_, B_, i_) }                               \
+    }
+    {
+        const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bcorner), 0, brange, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            NN_APIECE(a0, 0u, p)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            NN_BPIECE(b0, brs, p)
+    }
+    asm volatile(".p2align 6");
+    for (int c = 0; c < nch; c += 2) {
+        const int c1 = c + 1, c2 = min(c + 2, nch - 1);
+        const auto brs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bcorner + c1 * bchunk), 0, brange, 0x00020000);
+        const auto brs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bcorner + c2 * bchunk), 0, brange, 0x00020000);
+        NN_COMPUTE_LD(a0, b0, a1, b1, (unsigned)c1 * 64u, brs1);
+        NN_COMPUTE_LD(a1, b1, a0, b0, (unsigned)c2 * 64u, brs2);
+    }
+#undef NN_APIECE
+#undef NN_BPIECE
+#undef NN_MFMA
+#undef NN_ROW0
+#undef NN_ROW1
+#undef NN_COMPUTE_LD
+    asm volatile("s_nop 15\n s_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3])
+                 :
+                 : "memory");
+
+    // acc[i][j][r] is row 16 i + lg + 4 r, column 32 (j >> 1) + 2 r16 + (j & 1): rolled over the row blocks (see above)
+    const double alpha = g.alpha;
+#define NN_PICK(I_) t[0] = acc[I_][0], t[1] = acc[I_][1], t[2] = acc[I_][2], t[3] = acc[I_][3]
+#pragma nounroll
+    for (int i = 0; i < 8; ++i) {
+        d4v t[4];
+        switch (i) {
+        case 0: NN_PICK(0); break;
+        case 1: NN_PICK(1); break;
+        case 2: NN_PICK(2); break;
+        case 3: NN_PICK(3); break;
+        case 4: NN_PICK(4); break;
+        case 5: NN_PICK(5); break;
+        case 6: NN_PICK(6); break;
+        default: NN_PICK(7); break;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *row = C + (size_t)(m0 + 16 * i + lg + 4 * r) * g.ldc + n0 + 2 * r16;
+            *reinterpret_cast<double2 *>(row) = double2{alpha * t[0][r], alpha * t[1][r]};
+            *reinterpret_cast<double2 *>(row + 32) = double2{alpha * t[2][r], alpha * t[3][r]};
+        }
+    }
+#undef NN_PICK
+}
+
+bool w1_f64_nn_fits(const GemmArgs &a)
+{
+    return a.epi == EPI_STORE && a.nn && a.beta == 0 && !a.lower_only && !(a.a_lower && a.b_lower) && a.batch >= 1 &&
+           a.M > 0 && a.N > 0 && a.M % 128 == 0 && a.N % 64 == 0 && a.K % 128 == 0 && (a.M_last < 0 || a.M_last % 128 == 0) &&
+           a.K >= W1_NN_MIN_K && a.lda % 2 == 0 && a.ldb % 2 == 0 && a.ldc % 2 == 0 && a.sA % 2 == 0 && a.sB % 2 == 0 &&
+           a.sC % 2 == 0 && 128 * a.lda * 8 < (1L << 31) && 8 * a.ldb * 8 < (1L << 31);
+}
+
+void launch_w1_f64_nn(const GemmArgs &a, hipStream_t st)
+{
+    W1NNDev g;
+    g.A = (const double *)a.A, g.B = (const double *)a.B, g.C = (double *)a.C;
+    g.lda = a.lda, g.ldb = a.ldb, g.ldc = a.ldc;
+    g.M = a.M, g.K = a.K;
+    g.sA = a.sA, g.sB = a.sB, g.sC = a.sC;
+    g.batch = a.batch, g.M_last = a.M_last, g.k_eq_m = a.k_eq_m;
+    g.alpha = a.alpha;
+    g.a_lower = a.a_lower, g.b_lower = a.b_lower;
+    const int mt = a.M / 128, nt = a.N / 64;
+    const dim3 grid = a.b_lower ? dim3(mt, nt, a.batch) : dim3(nt, mt, a.batch);
+    hipLaunchKernelGGL(w1_f64_nn_kernel, grid, dim3(64), 0, st, g);
 }
 
 bool var_w1_fits(const GemmArgs &a)

@@ -8,6 +8,7 @@ import subprocess
 import msgpack
 
 OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
@@ -66,4 +67,24 @@ def kernels(lib_path, tmp_dir):
                             "private_segment_fixed_size": k.get(".private_segment_fixed_size", 0),
                             "group_segment_fixed_size": k.get(".group_segment_fixed_size", 0),
                             "max_flat_workgroup_size": k.get(".max_flat_workgroup_size", 0)})
+    return out
+
+
+def disassemble(lib_path, tmp_dir, name_part):
+    """{kernel symbol: [instruction text, ...]} for the gfx950 kernels of lib_path whose symbol contains name_part
+    (llvm-objdump -d of the device ELFs; branch targets keep their '<symbol+0xoffset>' form)."""
+    out = {}
+    for n, elf in enumerate(_device_elfs(_fatbin(lib_path, tmp_dir))):
+        path = "%s/dev%d.elf" % (tmp_dir, n)
+        open(path, "wb").write(elf)
+        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", path], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in txt.splitlines():
+            if line.endswith(">:") and "<" in line:
+                sym = line[line.index("<") + 1:-2]
+                cur = sym if name_part in sym else None
+                if cur:
+                    out[cur] = []
+            elif cur and line.strip():
+                out[cur].append(line.strip())
     return out

@@ -66,3 +66,29 @@ def test_one_wave_variance_tiles_own_a_simd(kernels):
             assert k["vgpr_count"] <= 512, (k["name"], k["vgpr_count"])  # (the unified count: arch + accumulator registers)
             assert 4 * k["group_segment_fixed_size"] <= 160 * 1024, (k["name"], k["group_segment_fixed_size"])
     assert seen == 3  # fp32 with the fit, fp32 plain, fp64
+
+
+def test_one_wave_main_loops_hold_nothing_but_mfmas_and_loads(gpx, tmp_path):
+    """The main loops of gpx_vargemm.hip issue their MFMAs from inline asm, which hipcc's hazard recogniser and register
+    allocator cannot see into: an accumulator copy (v_accvgpr_*) or a spill next to them would read a result that is
+    still in flight (one build of the [k][n] kernel carried 64 such moves per trip until an early-return path was removed).
+    Every backward branch of these kernels whose body holds >= 128 MFMAs must hold only MFMAs, buffer loads, waits and
+    scalar / address arithmetic."""
+    dis = codeobj.disassemble(gpx.LIB_PATH, tmp_path, "w1_")
+    assert len(dis) == 4, sorted(dis)  # var_w1_kernel<true|false>, var_w1_f64_kernel, w1_f64_nn_kernel
+    for sym, lines in dis.items():
+        # 'mnemonic operands   // ADDRESS: ENCODING [<symbol+0xOFFSET>]'
+        ins = [(int(l.split("//")[1].split(":")[0], 16), l.split("//")[0].strip(), l) for l in lines if "//" in l]
+        first = ins[0][0]
+        spans = []  # backward branches whose body holds the MFMAs; the innermost one is the main loop (the paired launch wraps it)
+        for a, text, raw in ins:
+            if not text.startswith("s_cbranch") or "+0x" not in raw:
+                continue
+            target = first + int(raw[raw.rindex("+0x") + 3:raw.rindex(">")], 16)
+            if target < a and sum(t.startswith("v_mfma") for b, t, _ in ins if target <= b <= a) >= 128:
+                spans.append((a - target, target, a))
+        assert spans, sym
+        _, lo, hi = min(spans)
+        body = [t for b, t, _ in ins if lo <= b <= hi]
+        bad = [t for t in body if t.startswith(("v_accvgpr", "scratch_", "v_mov_b", "ds_"))]
+        assert not bad, (sym, bad[:5])
