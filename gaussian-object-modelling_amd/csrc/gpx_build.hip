@@ -1178,7 +1178,25 @@ void set_query_batch(gpx_model *m)
     // launch still fills the chip (N = 724: 131072 queries -> 6 x 1024 tiles)
     size_t qb = ((size_t)512 << 20) / ((size_t)m->npad * 4);
     qb = std::min<size_t>(std::max<size_t>(qb, 8192), 131072);
-    m->qbatch = (int)(qb / 256 * 256);
+    qb = qb / 256 * 256;
+    // The one-wave variance tiles run their paired launch (equal-length workgroups in step: a quarter of the L2-miss
+    // traffic, gpx_vargemm.hip) when (row tiles / 2) x (query tiles) fills the SIMDs in whole rounds: round the batch down
+    // to the nearest size that does, if there is one within a factor of two.
+    const long mt = ((long)m->n + TILE - 1) / TILE;
+    int cus = 0;
+    if (mt >= 2 && mt % 2 == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess &&
+        cus > 0) {
+        const long slots = 4L * cus;
+        long a = mt / 2, b = slots;
+        while (b) {
+            const long t = a % b;
+            a = b, b = t;
+        }
+        const size_t step = (size_t)TILE * (size_t)(slots / a);  // queries per whole round of pairs
+        if (step <= qb && qb / step * step >= qb / 2)
+            qb = qb / step * step;
+    }
+    m->qbatch = (int)qb;
 }
 
 }  // namespace gpxh
