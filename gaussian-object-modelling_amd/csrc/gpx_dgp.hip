@@ -178,6 +178,11 @@ struct gpx_dgp {
     std::vector<double> h_alpha, h_y;
     double loglik = 0;
     int n_negative = 0;
+    // what create was given (gpx_dgp_add rebuilds on the union)
+    gpx_kernel kernel{};
+    double noise = 0;
+    gpx_options opt{};
+    std::vector<double> in_x, in_y, in_z, in_t, in_n;  // n, n, n, n, 3 n (zeros where no normals were given)
 };
 
 extern "C" void gpx_dgp_destroy(gpx_dgp *g)
@@ -326,7 +331,44 @@ extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, 
     }
     g->loglik = -0.5 * quad - 0.5 * logdet - 0.5 * n4 * std::log(2.0 * M_PI);
     m->ready = true;
+    g->kernel = *kernel, g->noise = noise, g->opt = o;
+    g->in_x.assign(x, x + n), g->in_y.assign(y, y + n), g->in_z.assign(z, z + n), g->in_t.assign(target, target + n);
+    g->in_n.assign(3 * n, 0.0);
+    if (normals)
+        std::copy(normals, normals + 3 * n, g->in_n.begin());
     *out = g;
+    return GPX_OK;
+}
+
+// add_patterns (GaussianProcess.h:340-374).  The reference appends rows to its Cholesky factor from cf->get() alone, i.e.
+// it treats the new samples as value observations and leaves the derivative blocks of compute() (:545-567) out -- a
+// factor that no longer belongs to the matrix f() and var() assume.  Here the model is rebuilt on the union of the old
+// and the new samples, which is what compute() would give for that sample set: the results equal those of
+// gpx_dgp_create on the concatenated data bit for bit.  On failure the model is unchanged.
+extern "C" int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const double *y, const double *z,
+                           const double *target, const double *normals)
+{
+    if (!g || !g->m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (n_new == 0)
+        return fail(GPX_E_EMPTY, "All input data is empty!");
+    if (!x || !y || !z || !target)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    const size_t n0 = (size_t)g->n_pts, n = n0 + n_new;
+    std::vector<double> ux(g->in_x), uy(g->in_y), uz(g->in_z), ut(g->in_t), un(g->in_n);
+    ux.insert(ux.end(), x, x + n_new), uy.insert(uy.end(), y, y + n_new), uz.insert(uz.end(), z, z + n_new);
+    ut.insert(ut.end(), target, target + n_new);
+    un.resize(3 * n, 0.0);
+    if (normals)
+        std::copy(normals, normals + 3 * n_new, un.begin() + 3 * n0);
+    gpx_dgp *fresh = nullptr;
+    gpx_options o = g->opt;
+    o.device = g->m->device;
+    const int rc = gpx_dgp_create(&g->kernel, g->noise, n, ux.data(), uy.data(), uz.data(), ut.data(), un.data(), &o, &fresh);
+    if (rc)
+        return rc;
+    std::swap(*g, *fresh);
+    gpx_dgp_destroy(fresh);  // (the old model)
     return GPX_OK;
 }
 

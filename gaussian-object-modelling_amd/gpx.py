@@ -70,7 +70,7 @@ EXPORTS = [
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
     "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_dgp_create", "gpx_dgp_evaluate", "gpx_dgp_get",
-    "gpx_dgp_destroy", "gpx_pcd_read", "gpx_node_training_set",
+    "gpx_dgp_add", "gpx_dgp_destroy", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
 _lib = None
@@ -161,6 +161,8 @@ def lib():
     L.gpx_dgp_create.argtypes = [C.POINTER(Kernel), C.c_double, C.c_size_t, dp, dp, dp, dp, dp, C.POINTER(Options), C.POINTER(vp)]
     L.gpx_dgp_evaluate.restype = C.c_int
     L.gpx_dgp_evaluate.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp]
+    L.gpx_dgp_add.restype = C.c_int
+    L.gpx_dgp_add.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, dp]
     L.gpx_dgp_get.restype = C.c_int
     L.gpx_dgp_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.gpx_dgp_destroy.restype = None
@@ -447,6 +449,20 @@ class DerivativeGP:
         self.n = len(x)
         _check(self._L.gpx_dgp_create(C.byref(kernel), float(noise), len(x), _dptr(x), _dptr(y), _dptr(z), _dptr(target),
                                       _dptr(nr) if nr is not None else None, C.byref(opt), C.byref(self._h)))
+
+    def add(self, x, y, z, target, normals=None):
+        """add_patterns: append samples and rebuild on the union (include/gp/GaussianProcess.h:340-374)."""
+        x, y, z, target = _as_d(x), _as_d(y), _as_d(z), _as_d(target)
+        if not (len(x) == len(y) == len(z) == len(target)):
+            raise GpxError(E_SIZE_MISMATCH, "coordinate / target length mismatch")
+        nr = None
+        if normals is not None:
+            nr = _as_d(np.asarray(normals, dtype=np.float64).reshape(-1))
+            if len(nr) != 3 * len(x):
+                raise GpxError(E_SIZE_MISMATCH, "normals must be n x 3")
+        _check(self._L.gpx_dgp_add(self._h, len(x), _dptr(x), _dptr(y), _dptr(z), _dptr(target),
+                                   _dptr(nr) if nr is not None else None))
+        self.n += len(x)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

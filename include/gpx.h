@@ -279,6 +279,11 @@ int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const doubl
                    const double *target, const double *normals, const gpx_options *opt, gpx_dgp **out);
 int gpx_dgp_evaluate(const gpx_dgp *g, size_t nq, const double *qx, const double *qy, const double *qz, double *f4,
                      double *var);
+/* add_patterns (GaussianProcess.h:340-374): append n_new samples (normals NULL = zeros) and rebuild on the union -- the
+ * results equal gpx_dgp_create on the concatenated data (the reference's own row append ignores the derivative blocks of
+ * its compute(); see csrc/gpx_dgp.hip).  External exclusion against evaluate, as for gpx_model_update. */
+int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const double *y, const double *z, const double *target,
+                const double *normals);
 int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes);
 void gpx_dgp_destroy(gpx_dgp *g);
 

@@ -93,3 +93,41 @@ def test_derivative_gp_reconstructs_a_sphere_from_points_and_normals(gpu):
     inn = gg.evaluate(0.8 * d[:, 0], 0.8 * d[:, 1], 0.8 * d[:, 2], want_v=False)
     assert out["f"].min() > 0.1 and inn["f"].max() < -0.1  # signed: positive outside, negative inside
     gg.close()
+
+
+@pytest.mark.parametrize("kern", [("se", 1.2, 0.8), ("thinplate", 4.0)])
+def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern):
+    """gpx_dgp_add (add_patterns, GaussianProcess.h:340-374): after two appends -- one with normals, one without -- alpha,
+    the log-likelihood and evaluate equal a model created on the concatenated samples bit for bit, and the oracle on the
+    union to the usual tolerance; a failing append (non-finite sample) leaves the model as it was."""
+    P, t, nr = _cloud(300, 77)
+    gk = gpu.make_kernel("se", kern[1], kern[2]) if kern[0] == "se" else gpu.make_kernel("thinplate", kern[1])
+    a, b = 120, 230
+    nr_u = nr.copy()
+    nr_u[b:] = 0.0  # the last append passes no normals
+    gg = gpu.DerivativeGP(gk, 0.05, P[:a, 0], P[:a, 1], P[:a, 2], t[:a], nr[:a])
+    gg.add(P[a:b, 0], P[a:b, 1], P[a:b, 2], t[a:b], nr[a:b])
+    before = gg.alpha.copy()
+    bad = P[b:, 0].copy()
+    bad[3] = np.nan
+    with pytest.raises(gpu.GpxError) as ei:
+        gg.add(bad, P[b:, 1], P[b:, 2], t[b:], None)
+    assert ei.value.code == gpu.E_NAN_INPUT
+    assert gg.n == b
+    np.testing.assert_array_equal(gg.alpha, before)
+    gg.add(P[b:, 0], P[b:, 1], P[b:, 2], t[b:], None)
+    assert gg.n == 300 and gg.stats["n"] == 1200
+    fresh = gpu.DerivativeGP(gk, 0.05, P[:, 0], P[:, 1], P[:, 2], t, nr_u)
+    np.testing.assert_array_equal(gg.alpha, fresh.alpha)
+    assert gg.loglik == fresh.loglik
+    Q = np.random.default_rng(5).uniform(-1.3, 1.3, size=(500, 3))
+    o1, o2 = gg.evaluate(Q[:, 0], Q[:, 1], Q[:, 2]), fresh.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
+    for key in ("f", "grad", "v"):
+        np.testing.assert_array_equal(o1[key], o2[key])
+    og = orc.DerivativeGP(kern, 0.05, P[:, 0], P[:, 1], P[:, 2], t, nr_u)
+    tol = 1e-10 if kern[0] == "se" else 1e-8
+    assert nerr(gg.alpha, og.alpha) < tol
+    ref = og.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
+    assert np.max(np.abs(o1["f"] - ref["f"])) / max(np.max(np.abs(ref["f"])), 0.1) < tol
+    gg.close()
+    fresh.close()

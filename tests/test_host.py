@@ -140,6 +140,7 @@ def test_derivative_gp_argument_validation(gpx):
     nan = (C.c_double * 1)(float("nan"))
     assert lib.gpx_dgp_create(C.byref(k), 0.1, 1, nan, one, one, one, None, None, C.byref(h)) == gpx.E_NAN_INPUT
     assert lib.gpx_dgp_get(None, 0, one, 8) == gpx.E_NULL
+    assert lib.gpx_dgp_add(None, 1, one, one, one, one, None) == gpx.E_NULL
     lib.gpx_dgp_destroy(None)
     assert h.value is None
 
