@@ -435,6 +435,14 @@ def main():
                     "timed_launches": fg, "timed_flops": st["factor_gemm_flops"], "timed_ms": st["t_factor_gemm_ms"],
                     "whole_ldlt": {"what": "N^3/3 flop / t_factor_ms (diagonal blocks, panel solves, strip and trailing updates)",
                                    "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
+            if want_v and st["t_inverse_ms"] > 0:
+                # the inverse factor X = L^-1 (recursive doubling, assembled in fp64 in every mode when the fp64 temporaries
+                # fit): N^3/3 flop over the whole stage, casts and the small levels on the LDS tiles included
+                inv = (n_train ** 3 / 3.0) / (st["t_inverse_ms"] * 1e-3) / 1e12
+                out["roofline_inverse"] = {
+                    "bound": "mfma", "kernel": "w1_f64_nn_kernel (levels with K >= 1024) + gemm_kernel<f64,NN,STORE> (small levels), fp64",
+                    "achieved": inv, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": inv / PEAK_F64_MFMA_TFLOPS,
+                    "ms": st["t_inverse_ms"], "what": "N^3/3 flop / t_inverse_ms"}
         esz = 8 if prec == gpx.F64 else 4
         npad = int(st["n_padded"])
         k0 = 64.0 if args.kernel == "thinplate" else (2.0 if args.kernel == "laplace" else 1.0)
