@@ -1,8 +1,10 @@
-// gpx_vargemm.hip -- the fp32 variance contraction as ONE WAVE PER WORKGROUP (round 3, GPX_VAR_TILE = 6).
+// gpx_vargemm.hip -- the long-k products as ONE WAVE PER WORKGROUP (round 3): the fp32 variance contraction
+// (GPX_VAR_TILE = 6, var_w1_kernel), its fp64 form (var_w1_f64_kernel) and the large fp64 [k][n] products of the
+// inverse-factor assembly (w1_f64_nn_kernel).  The variance contraction
 //
 //   partial[mt][n] = sum_{m in row tile mt} w[m][n]^2 / D_m ,   w = X[m][:] . K'[n][:]  (+ the low-rank fit, fp64)
 //
-// replaces, for large models, the LDS-staged 4-wave tiles of gpx_gemm.hip on this one product (the reference's
+// replaces the LDS-staged 4-wave tiles of gpx_gemm.hip on this one product (the reference's
 // `cholesker.solve(Kqp^T)` + `Kqp * V` + `diagonal()`, gp_regressor.hpp:316-319, restated as a column sum of squares of
 // L^-1 K'^T).  Why a different structure: the 4-wave tiles hold the MFMA pipe 88-91 % busy whatever their shape
 // (DESIGN.md section 4); what they lose is the per-k-tile barrier that couples four SIMDs each shared by three
@@ -20,8 +22,12 @@
 // Traffic per flop is that of the 128 x 128 LDS tile (each wave reads a 128-row slice of both operands once per
 // chunk); with one wave per SIMD nothing overlaps the epilogue, so the fp64 add-back of the fit runs on the fp64
 // MATRIX pipe: a 128 x 128 x 16 product of the row vectors with the coefficient vectors (256 v_mfma_f64_16x16x4_f64,
-// ~one chunk's worth of time) instead of 3584 fp64 FMAs per lane.
-// Short k-loops (small models) keep the LDS tiles: there the epilogue and the first loads are not amortised.
+// two chunks' worth of time) instead of 3584 fp64 FMAs per lane.
+// Measured faster than the LDS tiles at every model size (scripts/var_tile_sweep.py), although for a few hundred rows
+// the epilogue and the first loads are 20-30 % of a tile; it does NOT pay for read-modify-write products with K = 256
+// (the trailing updates of the LDL^T: DESIGN.md section 4).
+// tests/test_codeobj.py disassembles the main loops of this file: nothing but MFMAs, buffer loads, waits and scalar
+// arithmetic may appear in them (asm MFMAs are invisible to hipcc's hazard recogniser).
 #include <atomic>
 #include <cstdlib>
 #include "gpx_internal.hpp"
