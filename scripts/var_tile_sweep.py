@@ -15,7 +15,7 @@ if len(sys.argv) > 1:
     q = [t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()]
     nq = int(idx.numel())
     f = torch.empty(nq, dtype=torch.float64, device=dev); v = torch.empty_like(f)
-    for n in (512, 1024, 2048, 3072, 4096, 8192, 16384):
+    for n in (277, 512, 724, 1024, 1536, 2048, 3072, 4096, 8192, 16384):
         x, y, z, lab, s2 = ds.fibonacci_training_set(n)
         m = gpx.Model(gpx.make_kernel("matern52", 1.0, 1.0), x, y, z, lab, s2, precision=gpx.F32, prepare_variance=True)
         for _ in range(2):
