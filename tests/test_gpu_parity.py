@@ -868,6 +868,22 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         r = subprocess.run([sys.executable, "-c", child, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tile, fit] = np.load(path)
+    # the same one-wave tiles launched the other way round (paired row tiles <-> plain heavy-first order: the light tile of a
+    # pair walks k downwards, so the fp32 sums differ in order only), and the inverse factor assembled without the one-wave
+    # [k][n] kernel (the 2305-point models have a K = 1024 level): same results to rounding
+    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("nn0", {"GPX_W1_NN": "0"})):
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", child, path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        alt = np.load(path)
+        for key in alt.files:
+            n, kn, prec = key.split("/")
+            vmax = np.max(np.abs(res["6", "1"]["%s/%s/%d" % (n, kn, gpu.F64)]))
+            # (a thin-plate operand is ~k(0) / max|v| = 60 times larger than the variance it contributes to: the order of
+            # the fp32 sums shows there first)
+            tol = 1e-12 if int(prec) == gpu.F64 else (3e-6 if kn == "thinplate" else 5e-7)
+            assert np.max(np.abs(alt[key] - res["6", "1"][key])) / vmax < tol, (name, key)
+            assert np.max(np.abs(alt[key] - res["6", "1"]["%s/%s/%d" % (n, kn, gpu.F64)])) / vmax < 1e-5, (name, key)
     keys = sorted(res["6", "1"].files)
     assert len(keys) == 12
     for key in keys:
