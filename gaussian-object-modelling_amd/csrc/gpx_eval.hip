@@ -59,7 +59,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         // ~0.13 ms of HBM-write / VALU work) is built on the second stream into a second buffer while the GEMM of batch i
         // (15.6 ms of MFMA work at N = 16384) runs on the caller's stream.  Measured: the 3.4 ms per step it hides come
         // back as a GEMM that runs 0.15 ms longer per launch beside the kqp (2098.2 vs 2099.3 ms per step) -- no gain, so
-        // the default stays one stream and one buffer.
+        // the default stays one stream and one buffer.  (Round 3, one-wave variance tiles: a loss -- 2421 vs 1950 ms per
+        // step; the operand kernel's workgroups take SIMDs out of the rounds of equal-length tiles, 18.4 vs 14.6 ms per launch.)
         const char *pipe_env = std::getenv("GPX_VAR_PIPE");  // read per call
         const bool pipe_on = pipe_env && std::atoi(pipe_env) != 0;
         bool pipe = pipe_on && nq > qb;
