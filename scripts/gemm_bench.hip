@@ -47,7 +47,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&Kqp, e * (size_t)NQ * (N + ldpad)));
     CK(hipMalloc(&dinv, e * N));
     CK(hipMalloc(&partial, 8 * (size_t)NQ * (N / 128)));  // doubles with the fp64 epilogue (low-rank correction)
-    CK(hipMalloc(&C, e * (size_t)N * N));
+    CK(hipMalloc(&C, e * (size_t)N * (N + ldpad)));
     CK(hipMalloc(&W, e * (size_t)N * 2048));
     // the low-rank correction is fp64 data whatever the product's type (round 3: fp64 epilogue)
     void *dinv64;
@@ -59,7 +59,7 @@ int main(int argc, char **argv)
     fill((double *)dinv64, N, 7, 1.0);
     if (prec) { fill((double *)X, (size_t)N * (N + ldpad), 1, 1e-2); fill((double *)Kqp, (size_t)NQ * (N + ldpad), 2, 1.0); fill((double *)dinv, N, 3, 1.0); fill((double*)W, (size_t)N*2048, 4, 1e-2); }
     else { fill((float *)X, (size_t)N * (N + ldpad), 1, 1e-2); fill((float *)Kqp, (size_t)NQ * (N + ldpad), 2, 1.0); fill((float *)dinv, N, 3, 1.0); fill((float*)W, (size_t)N*2048, 4, 1e-2); }
-    CK(hipMemset(C, 0, e * (size_t)N * N));
+    CK(hipMemset(C, 0, e * (size_t)N * (N + ldpad)));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 #ifdef GEMM_BENCH_M32
@@ -99,7 +99,7 @@ int main(int argc, char **argv)
     for (int cfg = 0; cfg < 1; cfg += 2) {
         const int M = N - 256;
         GemmArgs s;
-        s.A = W, s.lda = 2048; s.B = X, s.ldb = N; s.C = C, s.ldc = N; s.M = M, s.N = M, s.K = KK; s.alpha = -1, s.beta = 1; s.lower_only = 1; s.cfg = cfg;
+        s.A = W, s.lda = 2048; s.B = X, s.ldb = LDV; s.C = C, s.ldc = LDV; s.M = M, s.N = M, s.K = KK; s.alpha = -1, s.beta = 1; s.lower_only = 1; s.cfg = cfg;
         launch_gemm(prec, s, st);
         CK(hipStreamSynchronize(st));
         const int reps = 5;
