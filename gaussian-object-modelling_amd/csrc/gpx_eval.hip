@@ -119,7 +119,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->var_fit && m->op64, m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, m->d_x, m->d_y,
                                  m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, fab,
-                                 (long)qb);
+                                 (long)qb, (long)np + KQP_LDPAD);
                 if (kev)
                     (void)hipEventRecord(kev[1], sp);
                 if (pipe) {
@@ -131,7 +131,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                     (void)hipEventRecord(ev2[0], s);
                 launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, 2, s,
                                    np_rows, m->var_fit ? m->d_corr : nullptr, np,
-                                   m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3);
+                                   m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3,
+                                   (long)np + KQP_LDPAD);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;

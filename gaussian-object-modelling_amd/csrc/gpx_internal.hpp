@@ -231,13 +231,13 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
 void launch_kqp_split(bool compute64, const CovHost &cov, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       const double *px64, const double *py64, const double *pz64, const double *cen, long nq_valid,
                       long nq_tile, const double *qx, const double *qy, const double *qz, void *P, hipStream_t st,
-                      const double *fab = nullptr, long ldcc = 0);
+                      const double *fab = nullptr, long ldcc = 0, long ldk = 0);
 // colcoef != null: fp64 epilogue (rowcorr, colcoef, dinv64, inv_scale as above; partial holds doubles); else the plain
 // fp32 epilogue with the scaled weights w
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial, long ldp,
                         int prefetch, hipStream_t st, int m_rows = 0, const double *rowcorr = nullptr, long ldrc = 0,
                         const double *colcoef = nullptr, long ldcc = 0, const double *dinv64 = nullptr,
-                        const double *inv_scale = nullptr);
+                        const double *inv_scale = nullptr, long ldk = 0);
 
 // ---- factorisation helpers : gpx_factor.hip -------------------------------------------------
 // LDL^T of one TILE x TILE diagonal block in place (strict lower = L, diagonal = D), its unit-lower

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<TC> cov, float sk, i
                                                         long nq_valid, const double *__restrict__ qx,
                                                         const double *__restrict__ qy,
                                                         const double *__restrict__ qz, half_t *__restrict__ P,
-                                                        const double *__restrict__ fab, long ldcc)
+                                                        const double *__restrict__ fab, long ldcc, long ldk)
 {
     __shared__ TC rx[TILE], ry[TILE], rz[TILE], rfa[TILE], rfb[TILE], rfc[TILE];
     const int tid = threadIdx.x;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<TC> cov, float sk, i
         }
         half8 hi, lo;
         split8(v, sk, hi, lo);
-        half_t *dst = P + (size_t)q * (2 * (size_t)npad) + (gj0 / 32) * 64 + (gj0 % 32);
+        half_t *dst = P + (size_t)q * (2 * (size_t)ldk) + (gj0 / 32) * 64 + (gj0 % 32);  // ldk >= npad: row stride, fp32-equivalent elements
         *reinterpret_cast<half8 *>(dst) = hi;
         *reinterpret_cast<half8 *>(dst + 32) = lo;
     }
@@ -198,6 +198,7 @@ struct VsplitDev {
     const unsigned char *A;  // P16 X,   row stride 4 K bytes
     const unsigned char *B;  // P16 Kqp, row stride 4 K bytes
     int M, N, K;             // rows of X, queries (multiples of 128), K (multiple of 32)
+    long ldkB;               // row stride of Kqp in fp32-equivalent elements (>= K; off the power of two: L2 sets)
     const float *w;          // per-row weight (1/D, scales folded in): plain epilogue
     float *partial;
     long ldp;
@@ -243,24 +244,26 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
     // staging: chunk c = tid + 256 i -> row = (tid >> 3) + 32 i, 16-byte chunk (tid & 7) of the 128-byte block
     const int s_row = tid >> 3, s_kc = tid & 7;
     const unsigned char *a_src = g.A + (size_t)(m0 + s_row) * ldb + s_kc * 16;
-    const unsigned char *b_src = g.B + (size_t)(n0 + s_row) * ldb + s_kc * 16;
+    const size_t ldbB = (size_t)g.ldkB * 4;
+    const unsigned char *b_src = g.B + (size_t)(n0 + s_row) * ldbB + s_kc * 16;
     const int s_lds = s_row * ROWP + s_kc * 16;
     // two register slots of 4 + 4 chunks, as NAMED scalars: hipcc demotes (even 1-D) uint4 arrays that live across
     // the two halves of the unrolled loop to scratch memory, which serialises the loads behind the MFMAs
     uint4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3;
     uint4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;
 #define VS_LD1(DST, SRC, I, KO) DST = *reinterpret_cast<const uint4 *>((SRC) + (size_t)(32 * (I)) * ldb + (KO))
+#define VS_LD1B(DST, SRC, I, KO) DST = *reinterpret_cast<const uint4 *>((SRC) + (size_t)(32 * (I)) * ldbB + (KO))
 #define VS_GLOAD(SLOT, KT)                                  \
     {                                                       \
         const size_t ko_ = (size_t)(KT) * ROWB;             \
         VS_LD1(ra##SLOT##_0, a_src, 0, ko_);                \
-        VS_LD1(rb##SLOT##_0, b_src, 0, ko_);                \
+        VS_LD1B(rb##SLOT##_0, b_src, 0, ko_);                \
         VS_LD1(ra##SLOT##_1, a_src, 1, ko_);                \
-        VS_LD1(rb##SLOT##_1, b_src, 1, ko_);                \
+        VS_LD1B(rb##SLOT##_1, b_src, 1, ko_);                \
         VS_LD1(ra##SLOT##_2, a_src, 2, ko_);                \
-        VS_LD1(rb##SLOT##_2, b_src, 2, ko_);                \
+        VS_LD1B(rb##SLOT##_2, b_src, 2, ko_);                \
         VS_LD1(ra##SLOT##_3, a_src, 3, ko_);                \
-        VS_LD1(rb##SLOT##_3, b_src, 3, ko_);                \
+        VS_LD1B(rb##SLOT##_3, b_src, 3, ko_);                \
     }
 #define VS_ST1(BASE, BUF, I, V) *reinterpret_cast<uint4 *>((BASE) + (BUF) * TILE_B + s_lds + 32 * (I) * ROWP) = V
 #define VS_SSTORE(SLOT, BUF)                    \
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
 #undef VS_GLOAD
 #undef VS_SSTORE
 #undef VS_LD1
+#undef VS_LD1B
 #undef VS_ST1
 
     // ---- epilogue: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
@@ -438,24 +442,26 @@ void launch_split_prepare(float *X, int np, float *dinv_to_w, float sk, unsigned
 void launch_kqp_split(bool compute64, const CovHost &h, float sk, int n, int npad, const void *px, const void *py, const void *pz,
                       const double *px64, const double *py64, const double *pz64, const double *cen, long nq_valid,
                       long nq_tile, const double *qx, const double *qy, const double *qz, void *P, hipStream_t st,
-                      const double *fab, long ldcc)
+                      const double *fab, long ldcc, long ldk)
 {
+    if (ldk <= 0)
+        ldk = npad;
     dim3 grid(npad / TILE, (unsigned)(nq_tile / TILE));
     if (compute64) {
         Cov<double> c = lower_cov<double>(h);
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<double, KID>), grid, dim3(256), 0, st, c, sk, n, npad,
-                                                  px64, py64, pz64, cen, nq_valid, qx, qy, qz, (half_t *)P, fab, ldcc));
+                                                  px64, py64, pz64, cen, nq_valid, qx, qy, qz, (half_t *)P, fab, ldcc, ldk));
     } else {
         Cov<float> c = lower_cov<float>(h);
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_split_kernel<float, KID>), grid, dim3(256), 0, st, c, sk, n, npad,
                                                   (const float *)px, (const float *)py, (const float *)pz, cen, nq_valid,
-                                                  qx, qy, qz, (half_t *)P, fab, ldcc));
+                                                  qx, qy, qz, (half_t *)P, fab, ldcc, ldk));
     }
 }
 
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial,
                         long ldp, int prefetch, hipStream_t st, int m_rows, const double *rowcorr, long ldrc,
-                        const double *colcoef, long ldcc, const double *dinv64, const double *inv_scale)
+                        const double *colcoef, long ldcc, const double *dinv64, const double *inv_scale, long ldk)
 {
     VsplitDev g;
     const bool corr = rowcorr && colcoef && dinv64 && inv_scale;
@@ -465,6 +471,7 @@ void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, con
     g.A = (const unsigned char *)Xp;
     g.B = (const unsigned char *)Kp;
     g.M = np, g.N = nq_tile, g.K = np;
+    g.ldkB = ldk > 0 ? ldk : np;
     g.w = w;
     g.partial = (float *)partial, g.partial64 = (double *)partial, g.ldp = ldp;
     constexpr size_t shmem = 4 * (size_t)TILE * (128 + 16);
