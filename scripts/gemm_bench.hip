@@ -122,7 +122,7 @@ int main(int argc, char **argv)
             {"same size     (NT, full)           ", 0, 0, 0}, {"same size     (NN, full)           ", 1, 0, 0}};
         for (auto &c : cases) {
             GemmArgs g;
-            g.A = X, g.lda = N; g.B = Kqp, g.ldb = N; g.C = C, g.ldc = N; g.M = h, g.N = h, g.K = h;
+            g.A = X, g.lda = LDV; g.B = Kqp, g.ldb = LDV; g.C = C, g.ldc = LDV; g.M = h, g.N = h, g.K = h;
             g.nn = c.nn, g.a_lower = c.a_lower, g.b_lower = c.b_lower;
             launch_gemm(prec, g, st);
             CK(hipStreamSynchronize(st));
