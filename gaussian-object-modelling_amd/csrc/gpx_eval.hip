@@ -4,6 +4,18 @@
 // AtlasBase::project.
 #include "gpx_model.hpp"
 
+namespace gpx {
+int kqp_ldpad()
+{
+    static const int pad = [] {
+        const char *e = std::getenv("GPX_KQP_LDPAD");
+        const int v = e ? std::atoi(e) : KQP_LDPAD;
+        return v >= 0 && v % 4 == 0 ? v : KQP_LDPAD;
+    }();
+    return pad;
+}
+}  // namespace gpx
+
 namespace gpxh {
 
 // ---- evaluate ------------------------------------------------------------------------------------
@@ -31,7 +43,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         if (rc)
             return rc;
         const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
-        if ((rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + KQP_LDPAD))))
+        if ((rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + kqp_ldpad()))))
             return rc;
         // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
         if ((rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
@@ -75,7 +87,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 m->pipe_ev[i] = nullptr;
                 pipe = false;
             }
-        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * (np + KQP_LDPAD)) != GPX_OK ||
+        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * (np + kqp_ldpad())) != GPX_OK ||
                      (m->var_fit && ensure(m, &m->ws_coef2, &m->ws_coef2_bytes, sizeof(double) * qb * VAR_NCOEF) != GPX_OK))) {
             (void)hipGetLastError();
             pipe = false;  // no room for the second operand buffer: one stream, one buffer
@@ -119,7 +131,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->var_fit && m->op64, m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, m->d_x, m->d_y,
                                  m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, fab,
-                                 (long)qb, (long)np + KQP_LDPAD);
+                                 (long)qb, (long)np + kqp_ldpad());
                 if (kev)
                     (void)hipEventRecord(kev[1], sp);
                 if (pipe) {
@@ -132,7 +144,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, 2, s,
                                    np_rows, m->var_fit ? m->d_corr : nullptr, np,
                                    m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3,
-                                   (long)np + KQP_LDPAD);
+                                   (long)np + kqp_ldpad());
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
@@ -146,8 +158,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 // fp64 models and the fp64-formed fp32 operand read the model's fp64 points (differences do not depend
                 // on where the cloud sits); the fp32-formed operand reads the centred fp32 points
                 const bool c64 = m->prec == GPX_PREC_F64 || (m->var_fit && m->op64);
-                // (row stride np + KQP_LDPAD: the kernel uses its n_padded argument only as the stride of the operand's rows)
-                launch_kqp(c64, m->prec, m->prec == GPX_PREC_F64, m->cov, m->n, np + KQP_LDPAD, c64 ? (const void *)m->d_x : m->t_x,
+                // (row stride np + kqp_ldpad(): the kernel uses its n_padded argument only as the stride of the operand's rows)
+                launch_kqp(c64, m->prec, m->prec == GPX_PREC_F64, m->cov, m->n, np + kqp_ldpad(), c64 ? (const void *)m->d_x : m->t_x,
                            c64 ? (const void *)m->d_y : m->t_y, c64 ? (const void *)m->d_z : m->t_z, m->d_meta, (long)nv,
                            (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, np_rows, fab, (long)qb);
             }
@@ -159,7 +171,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             }
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
-            a.B = kqp_buf, a.ldb = np + KQP_LDPAD;
+            a.B = kqp_buf, a.ldb = np + kqp_ldpad();
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;

@@ -210,6 +210,7 @@ void launch_var_w1_f64(const GemmArgs &g, hipStream_t st);
 // tile's K' slab and of its X slab fall on the same L2 sets and evict each other (N = 16384: 19.9 GB of L2 misses per
 // launch against 7.6 GB with the padded stride, paired launch; profiles/r03_w1_traffic.txt)
 constexpr int KQP_LDPAD = 32;
+int kqp_ldpad();  // KQP_LDPAD, or GPX_KQP_LDPAD (a multiple of 4, read once): gpx_eval.hip
 // fp64 C = alpha A B (B in [k][n] form, EPI_STORE, beta = 0) with K >= W1_NN_MIN_K goes to the one-wave kernel as well
 // (the three largest levels of the inverse-factor assembly carry 98 % of its flops); GPX_W1_NN=0 keeps the LDS tiles
 constexpr int W1_NN_MIN_K = 1024;
