@@ -175,6 +175,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
+            a.m_valid = m->n;
             // Tile of the fp32 product (GPX_VAR_TILE).  6 (default for VAR_W1_MIN_ROWS rows and more): one wave per
             // workgroup, a 128 x 128 tile per wave, no LDS, no barrier (gpx_vargemm.hip) -- 152 TFLOP/s against 139-140 for
             // the LDS tiles at N = 16384.  The LDS tiles: 3 = 128 x 128 with 64-byte k rows at three workgroups per CU

@@ -182,6 +182,8 @@ struct GemmArgs {
     int nn = 0;                     // 0: C = A * B^T (B is [n][k]); 1: C = A * B (B is [k][n])
     int lower_only = 0;             // square C: compute only tiles with m-tile >= n-tile
     int a_lower = 0;                // A lower-triangular: k < m0 + TILE
+    int m_valid = 0;                // EPI_COLSQ, cfg 6: rows of A (= columns of B) that hold data, the rest being the identity / zero
+                                    // padding (0 = all): the one-wave fp32 tile leaves the padding's share of the work out
     int b_lower = 0;                // B lower-triangular: nn: k >= n0 ; nt: k < n0 + TILE
     int epi = EPI_STORE;
     int cfg = 0;                    // preferred tile: 0 = 128x128, 2 = 256x256 (falls back if it does not divide); EPI_COLSQ fp32

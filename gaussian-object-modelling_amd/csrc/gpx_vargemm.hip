@@ -28,6 +28,7 @@
 // (the trailing updates of the LDL^T: DESIGN.md section 4).
 // tests/test_codeobj.py disassembles the main loops of this file: nothing but MFMAs, buffer loads, waits and scalar
 // arithmetic may appear in them (asm MFMAs are invisible to hipcc's hazard recogniser).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include "gpx_internal.hpp"
@@ -49,9 +50,15 @@ struct VarW1Dev {
     const double *rowcorr, *colcoef, *dinv64;
     long ldrc, ldcc;
     int paired;  // 1: gridDim.y = row tiles / 2 and a workgroup does tile MT - 1 - y, then tile y walked in descending k
+    int mt_base;  // first row tile of this launch (0 unless the last row tile runs on its own)
+    int k_limit;  // columns of K' that can be non-zero, rounded up to 32
 };
 
-template <bool CORR>
+// NI = row fragments that hold data: 8 for every full tile; 2, 4 or 6 for the LAST row tile of a model whose row count
+// leaves most of that tile to the identity padding (N = 266 pads to 384 rows: the last tile holds 10 rows) -- rows of the
+// padding give w = 0 exactly (X is the identity there and K', the row vectors of the fit too are zero), so their MFMAs,
+// loads and epilogue blocks are simply left out.  launch_var_w1 runs such a tile as a launch of its own.
+template <bool CORR, int NI>
 __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_kernel(VarW1Dev g)
 {
     const int lane = threadIdx.x;
@@ -66,9 +73,11 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
     const int MT = g.paired ? 2 * (int)gridDim.y : (int)gridDim.y;
 #pragma nounroll
     for (int ph = 0; ph < nphase; ++ph) {
-    const int mt = (ph == 0) ? MT - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int mt = g.mt_base + ((ph == 0) ? MT - 1 - (int)blockIdx.y : (int)blockIdx.y);
     const int m0 = mt * 128;
-    const int nch = (m0 + 128) / 16;  // 16-deep k chunks (X is lower triangular: k < m0 + 128); a multiple of 8
+    // 16-deep k chunks: X is lower triangular (k < m0 + 128) and K' is zero from the first padding column on (k_limit, a
+    // multiple of 32); an even number of chunks
+    const int nch = min(m0 + 128, g.k_limit) / 16;
     const int cfirst = (ph == 0) ? 0 : nch - 1, cdir = (ph == 0) ? 1 : -1;  // chunk j of the walk is cfirst + cdir * j
     char *abase = const_cast<char *>(reinterpret_cast<const char *>(g.X + (size_t)m0 * g.ldx));
     char *bbase = const_cast<char *>(reinterpret_cast<const char *>(g.Kq + (size_t)n0 * g.ldk));
@@ -103,34 +112,43 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
         for (int j = 0; j < 8; ++j)
             acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-    // one piece = one 16-byte load per lane of the next chunk: pieces 0-7 are the A fragments, 8-15 the B fragments
-    // (the builtin's result is bit-cast as a whole: indexing its elements mis-compiles to a one-dword load on ROCm 7.2)
-    float4 a0[8], b0[8], a1[8], b1[8];
-#define W1_PIECE(A_, B_, KB_, P_)                                                                                  \
-    {                                                                                                              \
-        if ((P_) < 8)                                                                                              \
-            A_[(P_) & 7] = __builtin_bit_cast(                                                                     \
-                float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(aoff + (KB_)), ((P_) & 7) * astep, 0)); \
-        else                                                                                                       \
-            B_[(P_) & 7] = __builtin_bit_cast(                                                                     \
-                float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(boff + (KB_)), ((P_) & 7) * bstep, 0)); \
+    // one piece = one 16-byte load per lane of the next chunk: pieces 0 .. NI - 1 are the A fragments, NI .. NI + 7 the B
+    // fragments (the builtin's result is bit-cast as a whole: indexing its elements mis-compiles to a one-dword load on ROCm 7.2)
+    float4 a0[NI], b0[8], a1[NI], b1[8];
+#define W1_PIECE(A_, B_, KB_, P_)                                                                                      \
+    {                                                                                                                  \
+        if ((P_) < NI)                                                                                                 \
+            A_[(P_) < NI ? (P_) : 0] = __builtin_bit_cast(                                                             \
+                float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)(aoff + (KB_)), (P_) * astep, 0));           \
+        else                                                                                                           \
+            B_[((P_) - NI) & 7] = __builtin_bit_cast(                                                                  \
+                float4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(boff + (KB_)), (((P_) - NI) & 7) * bstep, 0)); \
     }
 #define W1_ROW(A_, B_, S_, I_)                       \
     _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) \
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[I_][j_]) : "v"(A_[I_].S_), "v"(B_[j_].S_));
     // 256 MFMAs on (A_, B_); the 16 pieces of (AN_, BN_) go out one per 8 MFMAs over the first half, so the last one has
     // 128 MFMAs (~4000 cycles) to land
+    // (partial tiles, NI < 8: the NI + 8 pieces at the top of the chunk -- where the loads sit was measured not to matter)
 #define W1_COMPUTE_LD(A_, B_, AN_, BN_, KB_)                                                                       \
     {                                                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, i_) W1_ROW(A_, B_, x, i_) }     \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, 8 + i_) W1_ROW(A_, B_, y, i_) } \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, z, i_) }                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, w, i_) }                                 \
+        if constexpr (NI == 8) {                                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, i_) W1_ROW(A_, B_, x, i_) }     \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_PIECE(AN_, BN_, KB_, 8 + i_) W1_ROW(A_, B_, y, i_) } \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, z, i_) }                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { W1_ROW(A_, B_, w, i_) }                             \
+        } else {                                                                                                   \
+            _Pragma("unroll") for (int p_ = 0; p_ < NI + 8; ++p_) W1_PIECE(AN_, BN_, KB_, p_)                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) { W1_ROW(A_, B_, x, i_) }                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) { W1_ROW(A_, B_, y, i_) }                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) { W1_ROW(A_, B_, z, i_) }                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) { W1_ROW(A_, B_, w, i_) }                            \
+        }                                                                                                          \
     }
     {
         const unsigned kb0 = (unsigned)cfirst * 64u;
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < NI + 8; ++p)
             W1_PIECE(a0, b0, kb0, p)
     }
     asm volatile(".p2align 6");
@@ -148,8 +166,8 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
     // (tied to the last row of fragments, so that no read of them can be scheduled above the wait states; every other
     // fragment's last MFMA is at least 8 MFMAs = 256 cycles older)
     asm volatile("s_nop 15\n s_nop 15"
-                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
-                   "+a"(acc[7][6]), "+a"(acc[7][7])
+                 : "+a"(acc[NI - 1][0]), "+a"(acc[NI - 1][1]), "+a"(acc[NI - 1][2]), "+a"(acc[NI - 1][3]),
+                   "+a"(acc[NI - 1][4]), "+a"(acc[NI - 1][5]), "+a"(acc[NI - 1][6]), "+a"(acc[NI - 1][7])
                  :
                  : "memory");
 
@@ -159,7 +177,7 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
         for (int j = 0; j < 8; ++j) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const float4 w = *reinterpret_cast<const float4 *>(g.dinv + m0 + 16 * i + 4 * lg);
                 s = fmaf(acc[i][j][0] * acc[i][j][0], w.x, s);
                 s = fmaf(acc[i][j][1] * acc[i][j][1], w.y, s);
@@ -203,7 +221,7 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
     _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                                   \
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(epi_lane), "a"(acc[I_][j_]), "n"(1024 * j_) : "memory");
 #pragma nounroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {  // (row blocks past NI hold zeros and rows of the padding: nothing to add)
             switch (i) {
             case 0: W1_DUMP(0) break;
             case 1: W1_DUMP(1) break;
@@ -599,6 +617,15 @@ bool var_w1_fits(const GemmArgs &a)
            a.lda >= a.M && a.ldb >= a.M && 128 * a.lda * 4 < (1L << 31) && 128 * a.ldb * 4 < (1L << 31);
 }
 
+template <int NI>
+static void var_w1_launch_ni(const VarW1Dev &g, bool corr, dim3 grid, hipStream_t st)
+{
+    if (corr)
+        hipLaunchKernelGGL((var_w1_kernel<true, NI>), grid, dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL((var_w1_kernel<false, NI>), grid, dim3(64), 0, st, g);
+}
+
 void launch_var_w1(const GemmArgs &a, hipStream_t st)
 {
     VarW1Dev g;
@@ -608,14 +635,29 @@ void launch_var_w1(const GemmArgs &a, hipStream_t st)
     g.partial = (float *)a.partial, g.partial64 = (double *)a.partial, g.ldp = a.ldp;
     g.rowcorr = a.rowcorr, g.colcoef = a.colcoef, g.dinv64 = a.rowweight64;
     g.ldrc = a.ldrc, g.ldcc = a.ldcc;
+    const bool corr = a.colcoef != nullptr;
     const int MT = a.M / 128, NT = a.N / 128;
-    const bool paired = var_w1_paired(MT, NT);
-    g.paired = paired ? 1 : 0;
-    const dim3 grid(NT, paired ? MT / 2 : MT);
-    if (a.colcoef)
-        hipLaunchKernelGGL(var_w1_kernel<true>, grid, dim3(64), 0, st, g);
-    else
-        hipLaunchKernelGGL(var_w1_kernel<false>, grid, dim3(64), 0, st, g);
+    // rows that hold data (the rest of the last tile is the identity padding): columns of K' past them are zero
+    const int mv = (a.m_valid > 0 && a.m_valid <= a.M) ? a.m_valid : a.M;
+    g.k_limit = std::min(a.M, (mv + 31) / 32 * 32);
+    const int r_last = mv - (MT - 1) * 128;  // data rows of the last row tile
+    const int ni_last = r_last <= 0 ? 8 : (r_last <= 32 ? 2 : (r_last <= 64 ? 4 : (r_last <= 96 ? 6 : 8)));
+    int mt_main = MT;
+    if (ni_last < 8) {  // the last row tile (the longest k range) as a launch of its own, first
+        g.paired = 0, g.mt_base = MT - 1;
+        if (ni_last == 2)
+            var_w1_launch_ni<2>(g, corr, dim3(NT, 1), st);
+        else if (ni_last == 4)
+            var_w1_launch_ni<4>(g, corr, dim3(NT, 1), st);
+        else
+            var_w1_launch_ni<6>(g, corr, dim3(NT, 1), st);
+        mt_main = MT - 1;
+    }
+    if (mt_main <= 0)
+        return;
+    const bool paired = var_w1_paired(mt_main, NT);
+    g.paired = paired ? 1 : 0, g.mt_base = 0;
+    var_w1_launch_ni<8>(g, corr, dim3(NT, paired ? mt_main / 2 : mt_main), st);
 }
 
 }  // namespace gpx
