@@ -13,7 +13,7 @@ static void release_inv_ahead(gpx_model *m)
     big_free(ia.L64);
     big_free(ia.X64);
     if (ia.linv64)
-        (void)hipFree(ia.linv64);
+        big_free(ia.linv64);
     if (ia.start)
         (void)hipEventDestroy(ia.start);
     if (ia.done)
@@ -25,7 +25,7 @@ void free_dev(gpx_model *m)
 {
     quiesce(m);
     release_inv_ahead(m);
-    auto F = [](void *p) { big_free(p); };  // parks buffers of 64 MiB and more, hipFree otherwise
+    auto F = [](void *p) { big_free(p); };  // parks the buffers that came from big_alloc (>= BIG_POOL_MIN), hipFree otherwise
     F(m->dvecs);
     F(m->blob0);
     F(m->tvecs);
@@ -121,7 +121,7 @@ int alloc_blob0(gpx_model *m, size_t esz, void **blob, size_t *bytes)
 {
     const size_t np = (size_t)m->npad;
     *bytes = sizeof(double) * np * (5 + VAR_NCORR) + esz * np * 4 + sizeof(double) * BLOB_META;
-    HIPCHK(hipMalloc(blob, *bytes));
+    HIPCHK(big_alloc(blob, *bytes));
     return GPX_OK;
 }
 
@@ -149,13 +149,13 @@ int alloc_model(gpx_model *m)
     if (rc)
         return rc;
     carve_blob0(m);
-    HIPCHK(hipMalloc((void **)&m->dvecs, sizeof(double) * (np * 4 + 8)));
+    HIPCHK(big_alloc((void **)&m->dvecs, sizeof(double) * (np * 4 + 8)));
     m->d_lab = m->dvecs;
     m->d_s2 = m->d_lab + np;
     m->d_r = m->d_s2 + np;
     m->d_f = m->d_r + np;
     m->d_rmax = m->d_f + np;
-    HIPCHK(hipMalloc(&m->tvecs, e * np * 6));
+    HIPCHK(big_alloc(&m->tvecs, e * np * 6));
     char *b = (char *)m->tvecs;
     m->t_s2 = b;
     m->t_d = b + e * np;
@@ -315,7 +315,7 @@ static void prepare_inverse_ahead(gpx_model *m)
     if (ok && ia.f64) {
         ok = big_alloc(&ia.L64, sizeof(double) * nn) == hipSuccess && big_alloc(&ia.X64, sizeof(double) * nn) == hipSuccess &&
              big_alloc(&ia.Tws, sizeof(double) * nn) == hipSuccess &&
-             hipMalloc(&ia.linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) == hipSuccess;
+             big_alloc(&ia.linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) == hipSuccess;
     } else if (ok) {
         ok = big_alloc(&ia.Tws, e * nn) == hipSuccess &&
              hipMemsetAsync(m->X, 0, e * nn, m->stream) == hipSuccess;  // structural zeros above the block diagonal
@@ -613,8 +613,8 @@ int alloc_factor_buffers(gpx_model *m)
 {
     const size_t np = (size_t)m->npad, e = m->esz;
     HIPCHK(big_alloc(&m->Kmat, e * np * np));
-    HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
-    HIPCHK(hipMalloc(&m->Wp, e * np * WIDE_PANEL));
+    HIPCHK(big_alloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
+    HIPCHK(big_alloc(&m->Wp, e * np * WIDE_PANEL));
     return GPX_OK;
 }
 void factorize_matrix(gpx_model *m)
@@ -700,7 +700,7 @@ int build_inverse(gpx_model *m)
         HIPCHK(big_alloc(&m->X, e * (size_t)np * np));
     (void)hipEventRecord(m->ev[EV_INV0], m->stream);
     // temporaries behind guards: every early return below (HIPCHK) releases them
-    DevGuard gTws(nullptr, true), gL64(nullptr, true), gX64(nullptr, true), glinv64(nullptr, false);
+    DevGuard gTws(nullptr, true), gL64(nullptr, true), gX64(nullptr, true), glinv64(nullptr, true);
     bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
     // the part that was started inside the factorisation (its buffers pass to the guards here)
     inv_ahead &ia = m->ia;
@@ -722,7 +722,7 @@ int build_inverse(gpx_model *m)
         const size_t nn = (size_t)np * np;
         if (big_alloc(&gL64.p, sizeof(double) * nn) != hipSuccess || big_alloc(&gX64.p, sizeof(double) * nn) != hipSuccess ||
             big_alloc(&gTws.p, sizeof(double) * nn) != hipSuccess ||
-            hipMalloc(&glinv64.p, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
+            big_alloc(&glinv64.p, sizeof(double) * (size_t)m->nblk * TILE * TILE) != hipSuccess) {
             (void)hipGetLastError();
             gL64.reset(), gX64.reset(), gTws.reset(), glinv64.reset();
             assemble64 = false;
@@ -868,7 +868,7 @@ static int demote_to_f32(gpx_model *m)
     int rc = alloc_blob0(m, 4, &nb, &nbytes);
     if (rc)
         return rc;
-    DevGuard gnb(nb, false), gnX(nullptr, true);  // released if a call below fails
+    DevGuard gnb(nb, true), gnX(nullptr, true);  // released if a call below fails
     HIPCHK(big_alloc(&gnX.p, sizeof(float) * np * np));
     nX = gnX.p;
     // the fp64 part (points, alpha, 1/D, row-correction vectors) and the meta block as they are; the T part rounded
@@ -885,12 +885,12 @@ static int demote_to_f32(gpx_model *m)
         }
     }
     (void)gnb.release(), (void)gnX.release();  // the model owns them from here on
-    HIPCHK(hipFree(m->blob0));
+    big_free(m->blob0);
     big_free(m->X);
     big_free(m->Kmat);
-    HIPCHK(hipFree(m->linv));
-    HIPCHK(hipFree(m->Wp));
-    HIPCHK(hipFree(m->tvecs));
+    big_free(m->linv);
+    big_free(m->Wp);
+    big_free(m->tvecs);
     m->Kmat = m->linv = m->Wp = m->tvecs = nullptr;
     m->t_s2 = m->t_d = m->t_b = m->t_yv = m->t_xs = m->t_alpha = nullptr;
     m->blob0 = nb;
@@ -929,8 +929,8 @@ int build_model(gpx_model *m, kept_factor *keep)
         if (rc)
             return rc;
         HIPCHK(big_alloc(&m->Kmat, e * (size_t)np * np));
-        HIPCHK(hipMalloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
-        HIPCHK(hipMalloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
+        HIPCHK(big_alloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
+        HIPCHK(big_alloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
         const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
         HIPCHK(hipMalloc((void **)&m->d_tmax, sizeof(float) * ntiles));
         HIPCHK(hipMalloc((void **)&m->d_tij, sizeof(int) * 2 * ntiles));

@@ -72,7 +72,7 @@ void BigPool::release(void *p)
                 live_.erase(live_.begin() + i);
                 break;
             }
-        if (b.p && parked_ + b.bytes <= cap_) {
+        if (b.p && parked_ + b.bytes <= cap_ && free_.size() < BIG_POOL_MAX_PARKED) {
             free_.push_back(b);
             parked_ += b.bytes;
             park = true;

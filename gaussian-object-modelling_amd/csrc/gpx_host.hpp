@@ -30,7 +30,10 @@ void set_device_backend(const DeviceBackend *b);  // must be called before any o
 const DeviceBackend *device_backend();
 
 // ---- pool of large device buffers ------------------------------------------------------------------------------------
-constexpr size_t BIG_POOL_MIN = (size_t)64 << 20;
+// (4 KiB since round 3, 64 MiB before: a model of a few hundred points is ~15 buffers of 10 KiB .. 2 MiB, and their
+// hipMalloc / hipFree calls were half of its create + destroy time; at most BIG_POOL_MAX_PARKED buffers are kept)
+constexpr size_t BIG_POOL_MIN = (size_t)4 << 10;
+constexpr size_t BIG_POOL_MAX_PARKED = 512;
 class BigPool {
 public:
     explicit BigPool(size_t cap_bytes) : cap_(cap_bytes) {}

@@ -157,7 +157,10 @@ namespace gpxh {
 // scripts/la_check.py, create() wall 49 ms or 300-710 ms for 25 ms of device work).  Buffers of at least
 // BIG_POOL_MIN bytes released by one model are therefore parked in a per-process pool (per device, best fit within
 // 25 %) and handed to the next; GPX_POOL_MB caps the parked bytes (default 16384, 0 disables), gpx_trim() empties
-// the pool.  big_free() does NOT synchronise: the caller has waited for the work that used the buffer (quiesce(model):
+// the pool.  Since round 3 BIG_POOL_MIN is 4 KiB, so the ~15 buffers of a model of a few hundred points are recycled too:
+// create + destroy of an N = 277 model 1.84 -> 1.19 ms wall, N = 724 2.5 -> 1.66 ms (their device work is 0.6 / 1.07 ms).
+// A recycled buffer holds its previous owner's data: nothing in the library may assume a fresh allocation reads as zeros
+// (the whole GPU suite runs hundreds of models through the pool in one process).  big_free() does NOT synchronise: the caller has waited for the work that used the buffer (quiesce(model):
 // the model's own streams and workspace event -- not the whole device, which would stall every other model and thread).
 hipError_t big_alloc(void **p, size_t bytes);  // BigPool of gpx_host.hpp over the HIP backend
 void big_free(void *p);
@@ -197,10 +200,11 @@ struct kept_factor {
     void *X = nullptr;  // the old inverse factor (leading dimension np_old) when it had been built, else null
     void release()
     {
-        for (void *p : {linv, d, dinv})
+        for (void *p : {d, dinv})  // hipMalloc'ed by gpx_model_update
             if (p)
                 (void)hipFree(p);
-        big_free(K);  // from big_alloc, like every kernel matrix / inverse factor
+        big_free(K);  // from big_alloc, like every kernel matrix / inverse factor / diagonal-block inverse
+        big_free(linv);
         big_free(X);
         K = linv = d = dinv = X = nullptr;
     }
