@@ -76,6 +76,40 @@ hipError_t big_alloc(void **p, size_t bytes)
 }
 
 void big_free(void *p) { pool().release(p); }
+
+static std::mutex g_stream_mtx;
+static std::vector<hipStream_t> g_stream_pool[MAX_DEVICES];
+constexpr size_t STREAM_POOL_MAX = 64;  // per device
+
+hipError_t stream_acquire(int device, hipStream_t *s)
+{
+    if (device >= 0 && device < MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_stream_mtx);
+        std::vector<hipStream_t> &v = g_stream_pool[device];
+        if (!v.empty()) {
+            *s = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+void stream_release(int device, hipStream_t s)
+{
+    if (!s)
+        return;
+    (void)hipStreamSynchronize(s);
+    if (device >= 0 && device < MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_stream_mtx);
+        std::vector<hipStream_t> &v = g_stream_pool[device];
+        if (v.size() < STREAM_POOL_MAX) {
+            v.push_back(s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
 }  // namespace gpxh
 
 extern "C" void gpx_trim(void)
@@ -83,6 +117,17 @@ extern "C" void gpx_trim(void)
     gpxh::pool().trim();
     int prev = -1;
     (void)hipGetDevice(&prev);
+    {
+        std::lock_guard<std::mutex> lk(gpxh::g_stream_mtx);
+        for (int d = 0; d < MAX_DEVICES; ++d) {
+            if (gpxh::g_stream_pool[d].empty())
+                continue;
+            (void)hipSetDevice(d);
+            for (hipStream_t s : gpxh::g_stream_pool[d])
+                (void)hipStreamDestroy(s);
+            gpxh::g_stream_pool[d].clear();
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(gpxh::g_kb_mtx);
         for (int d = 0; d < MAX_DEVICES; ++d) {
@@ -166,10 +211,9 @@ extern "C" void gpx_model_destroy(gpx_model *m)
     for (auto &e : m->pipe_ev)
         if (e)
             (void)hipEventDestroy(e);
-    if (m->stream2)
-        (void)hipStreamDestroy(m->stream2);
-    if (m->stream)
-        (void)hipStreamDestroy(m->stream);
+    gpxh::stream_release(m->device, m->stream3);
+    gpxh::stream_release(m->device, m->stream2);
+    gpxh::stream_release(m->device, m->stream);
     if (prev >= 0)
         (void)hipSetDevice(prev);
     delete m;
@@ -226,7 +270,7 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     if (const char *vo = std::getenv("GPX_VAR_OP64"))
         m->op64 = std::atoi(vo) != 0;
     m->var_fit_opt = m->var_fit;
-    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (gpxh::stream_acquire(m->device, &m->stream) != hipSuccess) {
         delete m;
         return fail(GPX_E_HIP, "hipStreamCreate failed");
     }

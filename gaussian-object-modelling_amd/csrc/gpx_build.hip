@@ -309,7 +309,7 @@ static void prepare_inverse_ahead(gpx_model *m)
     if (!m->X)
         ok = big_alloc(&m->X, e * nn) == hipSuccess;
     if (!m->stream3)
-        ok = ok && hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && stream_acquire(m->device, &m->stream3) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&ia.start, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&ia.done, hipEventDisableTiming) == hipSuccess;
     if (ok && ia.f64) {
@@ -436,7 +436,7 @@ static void factorize(gpx_model *m, int c_start = 0)
     const bool la_window = m->prec == GPX_PREC_F64 ? (np >= 24 * PANEL && np < 128 * PANEL) : np >= 32 * PANEL;
     const bool la_env = (!la_e || la_forced) && wide_env != WIDE_PANEL && (la_forced ? np >= 2 * PANEL : la_window);
     if (la_env && c_start == 0 && !m->stream2 &&
-        hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
+        stream_acquire(m->device, &m->stream2) != hipSuccess) {
         (void)hipGetLastError();
         m->stream2 = nullptr;
     }

@@ -76,7 +76,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         const char *pipe_env = std::getenv("GPX_VAR_PIPE");  // read per call
         const bool pipe_on = pipe_env && std::atoi(pipe_env) != 0;
         bool pipe = pipe_on && nq > qb;
-        if (pipe && !m->stream2 && hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess) {
+        if (pipe && !m->stream2 && stream_acquire(m->device, &m->stream2) != hipSuccess) {
             (void)hipGetLastError();
             m->stream2 = nullptr;
             pipe = false;

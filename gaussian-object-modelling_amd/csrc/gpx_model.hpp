@@ -158,10 +158,16 @@ namespace gpxh {
 // BIG_POOL_MIN bytes released by one model are therefore parked in a per-process pool (per device, best fit within
 // 25 %) and handed to the next; GPX_POOL_MB caps the parked bytes (default 16384, 0 disables), gpx_trim() empties
 // the pool.  Since round 3 BIG_POOL_MIN is 4 KiB, so the ~15 buffers of a model of a few hundred points are recycled too:
-// create + destroy of an N = 277 model 1.84 -> 1.19 ms wall, N = 724 2.5 -> 1.66 ms (their device work is 0.6 / 1.07 ms).
+// create + destroy of an N = 277 model 1.84 -> 1.19 ms wall, N = 724 2.5 -> 1.66 ms (their device work is 0.6 / 1.07 ms;
+// 0.80 / 1.26 ms with the stream pool above).
 // A recycled buffer holds its previous owner's data: nothing in the library may assume a fresh allocation reads as zeros
 // (the whole GPU suite runs hundreds of models through the pool in one process).  big_free() does NOT synchronise: the caller has waited for the work that used the buffer (quiesce(model):
 // the model's own streams and workspace event -- not the whole device, which would stall every other model and thread).
+// hipStreamCreateWithFlags costs 0.37 ms and hipStreamDestroy 0.44 ms on this stack (rocprofv3 --hip-trace of
+// scripts/create_small.py): more than the device work of a 277-point model.  A model's streams therefore come from, and
+// go back (synchronised) to, a per-device pool of non-blocking streams; gpx_trim() destroys the pooled ones.
+hipError_t stream_acquire(int device, hipStream_t *s);  // the current device must be `device`
+void stream_release(int device, hipStream_t s);
 hipError_t big_alloc(void **p, size_t bytes);  // BigPool of gpx_host.hpp over the HIP backend
 void big_free(void *p);
 // releases a device allocation when the scope is left on an error path (HIPCHK returns early); release() hands it on
