@@ -38,15 +38,40 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         if (rc)
             return rc;
     }
+    // Small models (the reference's own sizes): every row of the product resident in one wave, the triangle of X skipped per
+    // 16-row fragment, the fp64 epilogue inside the triangle, v written directly; where the operand's arithmetic is fp32
+    // the wave forms it in registers and neither launch_kqp nor an operand buffer is needed (gpx_varcols.hip) -- the
+    // query batch is then bounded only by the fit's coefficient array (136 bytes per query).
+    static const bool var_cols_on = [] {
+        const char *ev = std::getenv("GPX_VAR_COLS");
+        return !ev || std::atoi(ev) != 0;
+    }();
+    const bool use_cols = v && var_cols_on && m->var_fit && !m->x_packed && m->prec != GPX_PREC_F64 &&
+                          var_cols_fits(m->n, np, np, np + kqp_ldpad());
+    VarColsArgs vc;
+    if (use_cols) {
+        vc.X = (const float *)m->X, vc.ldx = np, vc.n = m->n, vc.np = np;
+        vc.ldk = np + kqp_ldpad();
+        vc.rowcorr = m->d_corr, vc.ldrc = np;
+        vc.dinv64 = m->d_dinv64, vc.k0 = m->cov.k0;
+        vc.cov = m->cov, vc.op64 = m->op64;
+        vc.px = (const float *)m->t_x, vc.py = (const float *)m->t_y, vc.pz = (const float *)m->t_z;
+        vc.qx = qx, vc.qy = qy, vc.qz = qz;  // (set per batch below)
+        vc.cen[0] = m->cen[0], vc.cen[1] = m->cen[1], vc.cen[2] = m->cen[2];
+    }
+    const bool cols_gen = use_cols && var_cols_gen(vc);
+    const size_t nq_tiles = ((nq + TILE - 1) / TILE) * TILE;
+    const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, (size_t)1 << 21) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
     if (v) {
         int rc = build_inverse(m);
         if (rc)
             return rc;
-        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
-        if ((rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + kqp_ldpad()))))
+        const size_t qb = qbatch;
+        // (+ 64 rows: the 48-query waves of gpx_varcols.hip read -- and discard -- up to 47 operand rows past the last tile)
+        if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * (qb + 64) * (np + kqp_ldpad()))))
             return rc;
         // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
-        if ((rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
+        if (!use_cols && (rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
             return rc;
         if (m->var_fit && (rc = ensure(m, &m->ws_coef, &m->ws_coef_bytes, sizeof(double) * qb * VAR_NCOEF)))
             return rc;
@@ -65,7 +90,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     (void)hipEventRecord(m->ev[EV_M1], s);
     m->gemm_ev_used_var = 0;
     if (v) {
-        const size_t qb = (size_t)std::min<size_t>((size_t)m->qbatch, ((nq + TILE - 1) / TILE) * TILE);
+        const size_t qb = qbatch;
         const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
         // Opt-in (GPX_VAR_PIPE=1) two-deep pipeline over the query batches: the kernel operand of batch i+1 (fit + kqp,
         // ~0.13 ms of HBM-write / VALU work) is built on the second stream into a second buffer while the GEMM of batch i
@@ -87,7 +112,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 m->pipe_ev[i] = nullptr;
                 pipe = false;
             }
-        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * (np + kqp_ldpad())) != GPX_OK ||
+        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * (qb + 64) * (np + kqp_ldpad())) != GPX_OK ||
                      (m->var_fit && ensure(m, &m->ws_coef2, &m->ws_coef2_bytes, sizeof(double) * qb * VAR_NCOEF) != GPX_OK))) {
             (void)hipGetLastError();
             pipe = false;  // no room for the second operand buffer: one stream, one buffer
@@ -154,7 +179,13 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 launch_var_finish(part_prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
             }
-            {
+            if (use_cols) {
+                vc.Kq = (const float *)kqp_buf;
+                vc.colcoef = (const double *)coef_buf, vc.ldcc = (long)qb;
+                vc.nq_valid = (long)nv, vc.nq_tile = (long)ntile, vc.v = v + q0;
+                vc.qx = qx + q0, vc.qy = qy + q0, vc.qz = qz + q0;
+            }
+            if (!cols_gen) {
                 // fp64 models and the fp64-formed fp32 operand read the model's fp64 points (differences do not depend
                 // on where the cloud sits); the fp32-formed operand reads the centred fp32 points
                 const bool c64 = m->prec == GPX_PREC_F64 || (m->var_fit && m->op64);
@@ -168,6 +199,19 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             if (pipe) {
                 (void)hipEventRecord(m->pipe_ev[1 + buf], sp);
                 (void)hipStreamWaitEvent(s, m->pipe_ev[1 + buf], 0);
+            }
+            if (use_cols) {
+                hipEvent_t *evc = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
+                if (evc)
+                    (void)hipEventRecord(evc[0], s);
+                launch_var_cols(vc, s);
+                if (evc) {
+                    (void)hipEventRecord(evc[1], s);
+                    ++gi;
+                }
+                if (pipe)
+                    (void)hipEventRecord(m->pipe_ev[3 + buf], s);
+                continue;
             }
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;

@@ -223,6 +223,33 @@ int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launc
 int gemm_tile_m(int cfg);
 int gemm_tile_n(int cfg);
 
+// ---- variance contraction of small models : gpx_varcols.hip ----------------------------------------
+// One wave per workgroup holds every row fragment of w = X K'^T for 16 CF queries (all rows resident in the AGPRs, the
+// triangle of X skipped per 16-row fragment, ONE fp64 epilogue per accumulator fragment) and writes v = k(0) - sum w^2 / D
+// directly: no partial sums, no var_finish.  For fp32 contractions with the fit (var_fit) of up to VARCOLS_MAX_N points.
+constexpr int VARCOLS_MAX_N = 1024;
+struct VarColsArgs {
+    const float *X = nullptr;  // inverse factor [np][ldx]
+    long ldx = 0;
+    int n = 0, np = 0;
+    const float *Kq = nullptr;  // operand K' = k - fit of the batch, [nq_tile][ldk] (only read when the wave cannot form it itself)
+    long ldk = 0;
+    const double *rowcorr = nullptr, *colcoef = nullptr, *dinv64 = nullptr;
+    long ldrc = 0, ldcc = 0;
+    double k0 = 0;
+    long nq_valid = 0, nq_tile = 0;
+    double *v = nullptr;
+    // for the operand formed inside the wave (fp32 arithmetic): covariance function, centred fp32 points, queries, centre
+    CovHost cov{};
+    bool op64 = false;  // the model's operand is formed in fp64 (thin plate): read it from Kq
+    const float *px = nullptr, *py = nullptr, *pz = nullptr;
+    const double *qx = nullptr, *qy = nullptr, *qz = nullptr;
+    double cen[3] = {0, 0, 0};
+};
+bool var_cols_fits(int n, int np, long ldx, long ldk);
+bool var_cols_gen(const VarColsArgs &a);  // true: launch_var_cols forms the operand itself -- no launch_kqp needed
+void launch_var_cols(const VarColsArgs &a, hipStream_t st);
+
 // ---- split-fp16 variance contraction : gpx_vsplit.hip ------------------------------------------
 // in place: X (fp32, np x np) -> packed hi/lo halves with a device-chosen power-of-two scale sx;
 // dinv -> w = dinv / (sx sk)^2 (the weights of the plain epilogue); *inv_scale = 1 / (sx sk) (the fp64 epilogue
