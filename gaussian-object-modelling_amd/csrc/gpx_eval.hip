@@ -38,6 +38,11 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         if (rc)
             return rc;
     }
+    if (v) {  // the inverse factor first: it decides the representation of X (build_inverse packs the split operands)
+        int rc = build_inverse(m);
+        if (rc)
+            return rc;
+    }
     // Small models (the reference's own sizes): every row of the product resident in one wave, the triangle of X skipped per
     // 16-row fragment, the fp64 epilogue inside the triangle, v written directly; where the operand's arithmetic is fp32
     // the wave forms it in registers and neither launch_kqp nor an operand buffer is needed (gpx_varcols.hip) -- the
@@ -63,12 +68,9 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     const size_t nq_tiles = ((nq + TILE - 1) / TILE) * TILE;
     const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, (size_t)1 << 21) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
     if (v) {
-        int rc = build_inverse(m);
-        if (rc)
-            return rc;
+        int rc;
         const size_t qb = qbatch;
-        // (+ 64 rows: the 48-query waves of gpx_varcols.hip read -- and discard -- up to 47 operand rows past the last tile)
-        if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * (qb + 64) * (np + kqp_ldpad()))))
+        if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + kqp_ldpad()))))
             return rc;
         // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
         if (!use_cols && (rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
@@ -112,7 +114,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 m->pipe_ev[i] = nullptr;
                 pipe = false;
             }
-        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * (qb + 64) * (np + kqp_ldpad())) != GPX_OK ||
+        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * (np + kqp_ldpad())) != GPX_OK ||
                      (m->var_fit && ensure(m, &m->ws_coef2, &m->ws_coef2_bytes, sizeof(double) * qb * VAR_NCOEF) != GPX_OK))) {
             (void)hipGetLastError();
             pipe = false;  // no room for the second operand buffer: one stream, one buffer

@@ -97,3 +97,52 @@ def test_one_wave_main_loops_hold_nothing_but_mfmas_and_loads(gpx, tmp_path):
         body = [t for b, t, _ in ins if lo <= b <= hi]
         bad = [t for t in body if t.startswith(("v_accvgpr", "scratch_", "v_mov_b", "ds_"))]
         assert not bad, (sym, bad[:5])
+
+
+def test_small_model_variance_kernels_run_two_waves_per_simd(kernels):
+    """gpx_varcols_kernel.hpp: one 64-lane workgroup per wave, 12 x 2 accumulator fragments (96 AGPRs) and at most 256
+    registers in all, so that two waves share a SIMD; eight workgroups must fit a CU's 160 KiB of LDS (the training points,
+    the lane's queries and the column side of the fp64 add-back live there)."""
+    seen = 0
+    for k in kernels:
+        if "var_cols_kernel" in k["name"]:
+            seen += 1
+            assert k["max_flat_workgroup_size"] == 64, k["name"]
+            assert k["vgpr_count"] <= 256, (k["name"], k["vgpr_count"])  # (the unified count: arch + accumulator registers)
+            assert k["agpr_count"] >= 96, (k["name"], k["agpr_count"])
+            assert 8 * k["group_segment_fixed_size"] <= 160 * 1024, (k["name"], k["group_segment_fixed_size"])
+    assert seen == 4  # operand formed in the wave for Gaussian / Laplace, Matern-3/2, Matern-5/2; operand read from the buffer
+
+
+def test_small_model_variance_kernels_read_no_accumulator_in_flight(gpx, tmp_path):
+    """The fp32 MFMAs of gpx_varcols_kernel.hpp are inline asm: hipcc neither sees their latency nor pads the hazards around
+    them.  The epilogue of a row fragment reads its accumulators (v_accvgpr_read) from compiler-generated code placed behind
+    later MFMAs; a read scheduled right behind the fragment's own last MFMA would fetch a result still in the pipe.  Every
+    v_accvgpr_read of the kernels must therefore lie at least 4 MFMAs (128 cycles; the result is written after 8 passes = 32)
+    or an explicit run of wait states behind the last MFMA that wrote the register."""
+    import re
+    dis = codeobj.disassemble(gpx.LIB_PATH, tmp_path, "var_cols_kernel")
+    assert len(dis) == 4, sorted(dis)
+    for sym, lines in dis.items():
+        last_write = {}  # accumulator register -> index (in MFMAs) of the last MFMA that wrote it
+        nops_since = {}  # accumulator register -> wait states (s_nop) seen since that MFMA
+        n_mfma = reads = 0
+        for l in lines:
+            text = l.split("//")[0].strip()
+            if text.startswith("v_mfma_f32"):
+                m = re.match(r"v_mfma_f32\S*\s+a\[(\d+):(\d+)\]", text)
+                assert m, text
+                for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                    last_write[r] = n_mfma
+                    nops_since[r] = 0
+                n_mfma += 1
+            elif text.startswith("s_nop"):
+                w = int(text.split()[1]) + 1
+                for r in nops_since:
+                    nops_since[r] += w
+            elif text.startswith("v_accvgpr_read"):
+                r = int(re.search(r"\ba(\d+)\b", text).group(1))
+                if r in last_write:  # (registers the compiler parks values in are never MFMA destinations)
+                    reads += 1
+                    assert n_mfma - last_write[r] >= 4 or nops_since[r] >= 16, (sym, text, n_mfma - last_write[r], nops_since[r])
+        assert n_mfma >= 500 and reads >= 96, (sym, n_mfma, reads)

@@ -837,6 +837,51 @@ def test_round1_and_round2_diagonal_block_kernels_agree(gpu, ds, tmp_path, monke
         assert np.max(np.abs(a - b)) / scale < tol, key
 
 
+def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
+    """Models of up to 1024 points take the variance contraction of gpx_varcols_kernel.hpp (every row fragment resident in one
+    wave, the triangle of X skipped per 16-row fragment, fp64 add-back inside the triangle, operand formed in the wave).
+    Against the general path (GPX_VAR_COLS=0: kqp_kernel -> 128 x 128 tiles -> var_finish) and against its own form that
+    reads the operand buffer (GPX_VAR_COLS_GEN=0) the fp32 contraction is the same k-ordered sum: 5e-7 of max|v|; each
+    within 1e-5 of the fp64 oracle.  Sizes: one pass (<= 192 rows), 2 .. 6 passes, a last fragment with 1 and with 15
+    padding rows, a cloud translated by (10, -7, 3); every covariance function (the thin plate's operand is formed in fp64
+    and always read from the buffer)."""
+    import subprocess, sys
+    child = (
+        "import sys, importlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "gpx = importlib.import_module('gaussian-object-modelling_amd.gpx')\n"
+        "ds = importlib.import_module('gaussian-object-modelling_amd.datasets')\n"
+        "out = {}\n"
+        "qx, qy, qz = ds.query_grid(9)\n"
+        "for n, off in ((17, 0), (100, 0), (193, 0), (277, 0), (300, 1), (511, 0), (724, 0), (1024, 0)):\n"
+        "    x, y, z, lab, s2 = ds.fibonacci_training_set(n)\n"
+        "    o = (10.0, -7.0, 3.0) if off else (0.0, 0.0, 0.0)\n"
+        "    for kn, par in (('matern52', (1.0, 1.0)), ('matern32', (1.0, 0.7)), ('gaussian', (1.0, 1.0)), ('laplace', (0.8, 1.3)), ('thinplate', (4.0,))):\n"
+        "        gm = gpx.Model(gpx.make_kernel(kn, *par), x + o[0], y + o[1], z + o[2], lab, s2, precision=gpx.F32)\n"
+        "        out['%%d/%%s' %% (n, kn)] = gm.evaluate(qx + o[0], qy + o[1], qz + o[2], want_v=True)['v']\n"
+        "        gm.close()\n"
+        "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base_env = {k: v for k, v in os.environ.items() if not k.startswith("GPX_VAR_")}
+    res = {}
+    for name, extra in (("cols", {}), ("general", {"GPX_VAR_COLS": "0"}), ("buffer", {"GPX_VAR_COLS_GEN": "0"})):
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", child, path], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = np.load(path)
+    qx, qy, qz = ds.query_grid(9)
+    assert len(res["cols"].files) == 40
+    for key in res["cols"].files:
+        n, kn = key.split("/")
+        vmax = np.max(np.abs(res["general"][key]))
+        for other in ("general", "buffer"):
+            assert np.max(np.abs(res["cols"][key] - res[other][key])) / vmax < 5e-7, (key, other)
+    # the fp64 oracle on a subset (it is the slow side)
+    for n, kn, par in ((277, "matern52", (1.0, 1.0)), (724, "gaussian", (1.0, 1.0)), (193, "matern32", (1.0, 0.7)), (511, "thinplate", (4.0,))):
+        x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+        ref = orc.Model(orc.make_kernel(kn, *par), x, y, z, lab, s2).evaluate(qx, qy, qz, want_v=True)["v"]
+        assert np.max(np.abs(res["cols"]["%d/%s" % (n, kn)] - ref)) / np.max(np.abs(ref)) < 1e-5, (n, kn)
+
+
 def test_variance_tiles_agree(gpu, ds, tmp_path):
     """The one-wave variance tile (gpx_vargemm.hip, GPX_VAR_TILE=6, default) against the LDS-staged tiles 0, 2 and 3 of
     gpx_gemm.hip (the switch is read once per process, hence the children): the same contraction
