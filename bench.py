@@ -85,14 +85,24 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
 
     ns1, nq1 = 3072, 1024
     c1, q1, full1 = sample(ns1, nq1, False)
+    # The same one-core path timed ONCE at the full size in the build container (scripts/cpu_full_size.py ->
+    # profiles/r04_cpu_full_size.txt): measured / extrapolated from N = 3072 there
+    FULL_SIZE = {"n_train": 16384, "create_s": 1443.4, "ms_per_query": 360.158, "create_ratio": 1.834, "query_ratio": 1.599,
+                 "where": "profiles/r04_cpu_full_size.txt (build container, one core, 256 queries)"}
     out = {
         "value": nq / full1, "unit": "query-points/s", "cores": 1, "kind": "port",
         "sample": ("oracle/gp_oracle.c (fp64 restatement of gp_regressor.hpp, unblocked LDL^T, per-query solve) "
                    "timed at N_train=%d (create %.2fs) and %d queries (%.2f ms/query), scaled by N^3 / N^2 to "
                    "N_train=%d, N_query=%d -> %.0f s per step.  The sample's 72 MiB matrix is cache-resident, the "
-                   "2 GiB one of N_train=%d is not: the scaling flatters the CPU" %
-                   (ns1, c1, nq1, q1 * 1e3, n_train, nq, full1, n_train)),
+                   "2 GiB one of N_train=%d is not: the scaling flatters the CPU -- timed once at the full size on "
+                   "the build container's core the create took %.2fx and a query %.2fx the extrapolation from the "
+                   "same sample there (%s)" %
+                   (ns1, c1, nq1, q1 * 1e3, n_train, nq, full1, n_train, FULL_SIZE["create_ratio"],
+                    FULL_SIZE["query_ratio"], FULL_SIZE["where"])),
     }
+    if n_train == FULL_SIZE["n_train"]:
+        out["full_size_measured"] = dict(FULL_SIZE, value=nq / (FULL_SIZE["create_s"] + FULL_SIZE["ms_per_query"] * 1e-3 * nq),
+                                         unit="query-points/s at the measured one-core rates (create once + N_query per-query solves)")
     try:
         nsa, nqa = 6144, 1024
         ca, qa, fulla = sample(nsa, nqa, True)
@@ -108,8 +118,7 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
 
 # committed PMC passes per variance tile (GPX_VAR_TILE): file, kernel-name prefix of that tile's instantiation
 PMC_TRAFFIC = {"6": ("r03_pmc_traffic_w1.json", "gpx::var_w1_kernel<true"),    # one-wave tile (default)
-               "3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64"),   # 64-byte k rows, LDS-staged
-               "0": ("r02_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 128")}  # 128-byte k rows
+               "3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64")}   # LDS-staged fallback
 
 
 def pmc_traffic(args, n_train, q_per_launch):
@@ -117,7 +126,7 @@ def pmc_traffic(args, n_train, q_per_launch):
     --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_pass.sh; FETCH_SIZE doubled as the MI355X guide prescribes for wide
     streaming reads, + WRITE_SIZE) -- counters cannot be collected inside an un-profiled run, so this figure is NOT
     measured by the run that prints it; only valid for the shape and the tile those passes were taken on."""
-    tile = os.environ.get("GPX_VAR_TILE", "6")
+    tile = "3" if os.environ.get("GPX_VAR_TILE") == "3" else "6"
     if not (args.precision == "f32" and n_train == N_TRAIN and q_per_launch == 8192 and tile in PMC_TRAFFIC):
         return None, None
     fn, prefix = PMC_TRAFFIC[tile]
@@ -142,6 +151,93 @@ def accuracy_record(torch, f_a, v_a, f_ref, v_ref, k0):
             "v_err_mean_over_max_v": float(dv.mean().item()) / vmax, "max_abs_v_ref": vmax, "min_v_ref": float(v_ref.min().item()),
             "k0": k0, "f_err_over_max_f": float(df.max().item()) / fmax,
             "tolerance": "1e-5 (north star, SURVEY 8d: max|dv| / max|v_ref|)"}
+
+
+def eigen_on_box():
+    """Is Eigen 3 -- the third-party library the reference's arithmetic lives in (gp_regressor.hpp:9-12, CMakeLists.txt:25) --
+    installed on this box?  Decides whether the oracle's LDL^T can be pinned to the real Eigen::LDLT (BASELINE.md section 4
+    item 4): header search in the usual prefixes plus what the compiler itself finds."""
+    import glob
+    import tempfile
+    cands = []
+    for pat in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/*/include/eigen3", "/usr/include/Eigen",
+                "/usr/local/include/Eigen", "/opt/rocm*/include/eigen3", "/usr/share/eigen3"):
+        cands += [d for d in glob.glob(pat) if os.path.exists(os.path.join(d, "Eigen", "Core")) or os.path.exists(os.path.join(d, "Core"))]
+    rec = {"present": bool(cands), "path": cands[0] if cands else None, "version": None}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "e.cpp")
+            open(src, "w").write("#include <Eigen/Core>\n#include <cstdio>\nint main(){std::printf(\"%d.%d.%d\", EIGEN_WORLD_VERSION, "
+                                 "EIGEN_MAJOR_VERSION, EIGEN_MINOR_VERSION);}\n")
+            inc = ["-I" + cands[0]] if cands else []
+            r = subprocess.run(["g++", "-std=c++14"] + inc + [src, "-o", os.path.join(td, "e")], capture_output=True, text=True, timeout=60)
+            if r.returncode == 0:
+                rec["present"] = True
+                rec["version"] = subprocess.run([os.path.join(td, "e")], capture_output=True, text=True, timeout=10).stdout
+            else:
+                rec["compiler"] = (r.stderr.strip().splitlines() or ["?"])[0][-160:]
+    except Exception as e:
+        rec["probe_error"] = str(e)
+    return rec
+
+
+def small_model_roofline(torch, gpx, ds, dev, local_rank):
+    """The variance contraction at the reference's own model sizes (N = 166 .. 724): Matern-5/2 fp32-mode
+    models of 277 / 512 / 724 points on the Fibonacci cloud, evaluate(f, v) on 2^19 lattice queries; the kernel's HIP-event time
+    against the fp32 MFMA peak on the ALGORITHMIC N^2 flop per query, and the whole variance stage (fit + kernel) beside it."""
+    g = 80
+    t = torch.linspace(-1.01, 1.01, g, dtype=torch.float64, device=dev)
+    idx = torch.arange(0, 2 ** 19, device=dev)
+    q = [t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()]
+    nq = int(idx.numel())
+    f = torch.empty(nq, dtype=torch.float64, device=dev)
+    v = torch.empty_like(f)
+    out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "n_query": nq,
+           "kernel": "var_cols_kernel<2 x 12 fragments, operand formed in the wave> (gpx_varcols_kernel.hpp)",
+           "note": "the fp32-input MFMA issues on the vector ALU's slots (profiles/r04_mfma_filler_probe.txt): the fp64 add-back of "
+                   "the fit, the accumulator reads and the in-wave evaluation of the operand add to the MFMA time instead of hiding "
+                   "behind it -- at N = 277 they are as long as the algorithmic MFMAs (DESIGN.md section 4)", "sizes": {}}
+    for n in (277, 512, 724):
+        x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+        m = gpx.Model(gpx.make_kernel("matern52", 1.0, 1.0), x, y, z, lab, s2, precision=gpx.F32, prepare_variance=True, device=local_rank)
+        best = None
+        for _ in range(4):
+            m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+            m.sync()
+            st = m.stats
+            if best is None or st["t_var_gemm_ms"] < best["t_var_gemm_ms"]:
+                best = dict(st)
+        m.close()
+        flops = float(n) ** 2 * nq
+        a = flops / (best["t_var_gemm_ms"] * 1e-3) / 1e12
+        out["sizes"][str(n)] = {"kernel_ms": best["t_var_gemm_ms"], "launches": best["var_gemm_launches"], "achieved": a,
+                                "frac": a / PEAK_F32_MFMA_TFLOPS, "variance_stage_ms": best["t_var_ms"],
+                                "variance_stage_frac": flops / (best["t_var_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                "mean_ms": best["t_mean_ms"]}
+    return out
+
+
+def surface_config(torch, gpx, ds, dev, local_rank, kern, data, n_train):
+    """SURVEY 8f.2 on the headline model: the node's fakeDeterministicSampling (src/gp_node.cpp:998-1100) as ONE call --
+    gpx_model_sample_surface over the full 128^3 lattice: mean everywhere, |f| <= 0.01 compacted on the device, variance of
+    the survivors only.  Host arrays in and out (the C ABI's form), so the PCIe copies of 3 x 8 B per lattice point are in."""
+    import numpy as np
+    tt = np.linspace(-1.01, 1.01, GRID)
+    gx, gy, gz = np.meshgrid(tt, tt, tt, indexing="ij")
+    qx, qy, qz = gx.ravel(), gy.ravel(), gz.ravel()
+    m = gpx.Model(kern, *data, precision=gpx.F32, prepare_variance=True, device=local_rank)
+    m.sync()
+    m.sample_surface(qx[:4096], qy[:4096], qz[:4096], f_tol=0.01)
+    t0 = time.perf_counter()
+    o = m.sample_surface(qx, qy, qz, f_tol=0.01)
+    dt = time.perf_counter() - t0
+    st = m.stats
+    m.close()
+    ns = int(o["n_total"])
+    return {"workload": "C3 model (N=%d fp32 matern52) + gpx_model_sample_surface over the whole 128^3 lattice, |f| <= 0.01, "
+                        "variance on the survivors only (src/gp_node.cpp:1066-1100 as one call); host arrays in and out" % n_train,
+            "n_query": int(qx.size), "survivors": ns, "ms": dt * 1e3, "value": qx.size / dt, "unit": "lattice points/s",
+            "survivor_variance_ms": st["t_var_ms"], "survivor_mean_ms": st["t_mean_ms"]}
 
 
 def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
@@ -392,7 +488,7 @@ def main():
             flops_per_launch = float(n_train) ** 2 * q_per_launch  # N^2 flop per query
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             vkernel, vpeak = "gemm_kernel<%s,NT,COLSQ> (predict_var)" % gemm_t, peak
-            if prec != gpx.F64 and os.environ.get("GPX_VAR_TILE", "6") == "6":
+            if prec != gpx.F64 and os.environ.get("GPX_VAR_TILE", "6") != "3":
                 vkernel = "var_w1_kernel<fit added back in fp64> (predict_var; one wave per workgroup, 128x128 tile, no LDS)"
             if prec == gpx.F32_SPLIT:  # three fp16 MFMA products per algorithmic multiply-add: price against the fp16 peak
                 vkernel, vpeak, achieved = "vsplit_gemm_kernel (3 fp16 MFMA products per fp32 product)", PEAK_F16_MFMA_TFLOPS, 3 * achieved
@@ -614,6 +710,18 @@ def main():
                 out["configs"] = extra_configs(torch, gpx, ds, sharding, dev, local_rank)
             except Exception as e:
                 out["configs"] = {"error": str(e)}
+            try:  # the node-shaped end-to-end number on the headline model (informative, after the timed region)
+                full_variance_ms = st["t_var_ms"] * (GRID ** 3 / float(nq_local)) if want_v else None
+                out["configs"]["C3_surface"] = surface_config(torch, gpx, ds, dev, local_rank, kern, (x, y, z, lab, s2), n_train)
+                out["configs"]["C3_surface"]["full_variance_equivalent_ms"] = full_variance_ms
+            except Exception as e:
+                out["configs"]["C3_surface"] = {"error": str(e)}
+            try:
+                out["roofline_small"] = small_model_roofline(torch, gpx, ds, dev, local_rank)
+            except Exception as e:
+                out["roofline_small"] = {"error": str(e)}
+        if world == 1:
+            out["eigen_on_box"] = eigen_on_box()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_train, nq, args.kernel, kpar)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

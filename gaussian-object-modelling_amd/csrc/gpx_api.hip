@@ -208,10 +208,6 @@ extern "C" void gpx_model_destroy(gpx_model *m)
             (void)hipEventDestroy(e);
     for (auto &e : m->la_ev)
         (void)hipEventDestroy(e);
-    for (auto &e : m->pipe_ev)
-        if (e)
-            (void)hipEventDestroy(e);
-    gpxh::stream_release(m->device, m->stream3);
     gpxh::stream_release(m->device, m->stream2);
     gpxh::stream_release(m->device, m->stream);
     if (prev >= 0)

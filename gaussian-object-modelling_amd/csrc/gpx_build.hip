@@ -6,25 +6,9 @@
 
 namespace gpxh {
 
-static void release_inv_ahead(gpx_model *m)
-{
-    inv_ahead &ia = m->ia;
-    big_free(ia.Tws);
-    big_free(ia.L64);
-    big_free(ia.X64);
-    if (ia.linv64)
-        big_free(ia.linv64);
-    if (ia.start)
-        (void)hipEventDestroy(ia.start);
-    if (ia.done)
-        (void)hipEventDestroy(ia.done);
-    ia = inv_ahead{};
-}
-
 void free_dev(gpx_model *m)
 {
     quiesce(m);
-    release_inv_ahead(m);
     auto F = [](void *p) { big_free(p); };  // parks the buffers that came from big_alloc (>= BIG_POOL_MIN), hipFree otherwise
     F(m->dvecs);
     F(m->blob0);
@@ -40,10 +24,6 @@ void free_dev(gpx_model *m)
     F(m->ws_kqp);
     F(m->ws_partial);
     F(m->ws_coef);
-    F(m->ws_kqp2);
-    F(m->ws_coef2);
-    m->ws_kqp2 = m->ws_coef2 = nullptr;
-    m->ws_kqp2_bytes = m->ws_coef2_bytes = 0;
     F(m->ws_grad);
     F(m->ws_host_io);
     F(m->ws_small);
@@ -96,8 +76,6 @@ void quiesce(gpx_model *m)
         (void)hipStreamSynchronize(m->stream);
     if (m->stream2)
         (void)hipStreamSynchronize(m->stream2);
-    if (m->stream3)
-        (void)hipStreamSynchronize(m->stream3);
     if (m->ws_in_flight && m->ev[EV_WS])
         (void)hipEventSynchronize(m->ev[EV_WS]);
     m->ws_in_flight = false;
@@ -238,96 +216,6 @@ static void trtri_levels(int prec, size_t e, char *L, char *X, char *Tw, int np,
     }
 }
 
-// one combine step with an arbitrary split: X = inverse of the np x np unit-lower L whose leading h x h and trailing
-// (np - h) x (np - h) inverses are already in X:  X21 = -X22 * (L21 * X11)
-static void trtri_combine(int prec, size_t e, char *L, char *X, char *Tw, int np, int h, hipStream_t st, long ld)
-{
-    auto off = [&](size_t r, size_t c) { return (r * ld + c) * e; };
-    const int m2 = np - h;
-    if (m2 <= 0 || h <= 0)
-        return;
-    GemmArgs g1;  // T = L21 * X11   (B lower, [k][n])
-    g1.A = L + off(h, 0), g1.lda = ld;
-    g1.B = X + off(0, 0), g1.ldb = ld;
-    g1.C = Tw + off(h, 0), g1.ldc = ld;
-    g1.M = m2, g1.N = h, g1.K = h;
-    g1.nn = 1, g1.b_lower = 1;
-    launch_gemm(prec, g1, st);
-    GemmArgs g2;  // X21 = -X22 * T  (A lower)
-    g2.A = X + off(h, h), g2.lda = ld;
-    g2.B = Tw + off(h, 0), g2.ldb = ld;
-    g2.C = X + off(h, 0), g2.ldc = ld;
-    g2.M = m2, g2.N = h, g2.K = m2;
-    g2.nn = 1, g2.a_lower = 1;
-    g2.alpha = -1.0;
-    launch_gemm(prec, g2, st);
-}
-
-// The part of the inverse-factor assembly that only needs the first h columns of the factor, enqueued on the model's
-// third stream behind an event of the stream `after` (the factorisation has just passed column h there).
-static void launch_inverse_left(gpx_model *m, hipStream_t after)
-{
-    inv_ahead &ia = m->ia;
-    if (!ia.active || ia.launched)
-        return;
-    ia.launched = true;
-    const int np = m->npad, h = ia.h;
-    hipStream_t s3 = m->stream3;
-    (void)hipEventRecord(ia.start, after);
-    (void)hipStreamWaitEvent(s3, ia.start, 0);
-    if (ia.f64) {
-        launch_cast_lower_f2d(np, (const float *)m->Kmat, (double *)ia.L64, false, s3, 0, h);
-        launch_cast_f2d((size_t)(h / TILE) * TILE * TILE, (const float *)m->linv, (double *)ia.linv64, s3);
-        launch_place_diag(GPX_PREC_F64, h / TILE, ia.linv64, ia.X64, np, s3);
-        trtri_levels(GPX_PREC_F64, 8, (char *)ia.L64, (char *)ia.X64, (char *)ia.Tws, h, s3, np);
-    } else {
-        launch_place_diag(m->prec, h / TILE, m->linv, m->X, np, s3);
-        trtri_levels(m->prec, m->esz, (char *)m->Kmat, (char *)m->X, (char *)ia.Tws, h, s3, np);
-    }
-    (void)hipEventRecord(ia.done, s3);
-}
-
-// Decide and prepare (buffers, stream, events) the ahead-of-time part of the inverse factor; any failure just leaves it off.
-static void prepare_inverse_ahead(gpx_model *m)
-{
-    release_inv_ahead(m);
-    // Built and measured in round 3 (profiles/r03_create_timeline.txt, N = 16384): the assembly that remains is 3.1 ms
-    // shorter, the factorisation 3.3 ms (fp32) / 3.8 ms (fp64) longer -- its chain-bound tail shares CUs with the fp64 GEMM
-    // tiles of X11 and runs ~2x slower there, exactly the co-residency effect of DESIGN.md section 4 -- create wall 46.0-47.2
-    // vs 46.3-46.9 ms.  No gain: OFF unless GPX_INV_AHEAD=1 (same factor, the inverse to fp64 rounding; tested).
-    const char *env = std::getenv("GPX_INV_AHEAD");  // read per call (tests switch it)
-    const int on = env ? std::atoi(env) : 0;
-    const int np = m->npad;
-    const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);
-    const int h = np_rows / 2 / PANEL * PANEL;
-    if (!on || h < 4 * PANEL || m->has_inverse)
-        return;
-    inv_ahead &ia = m->ia;
-    const size_t nn = (size_t)np * np, e = m->esz;
-    ia.f64 = m->prec == GPX_PREC_F32 && m->inv64;
-    bool ok = true;
-    if (!m->X)
-        ok = big_alloc(&m->X, e * nn) == hipSuccess;
-    if (!m->stream3)
-        ok = ok && stream_acquire(m->device, &m->stream3) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&ia.start, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&ia.done, hipEventDisableTiming) == hipSuccess;
-    if (ok && ia.f64) {
-        ok = big_alloc(&ia.L64, sizeof(double) * nn) == hipSuccess && big_alloc(&ia.X64, sizeof(double) * nn) == hipSuccess &&
-             big_alloc(&ia.Tws, sizeof(double) * nn) == hipSuccess &&
-             big_alloc(&ia.linv64, sizeof(double) * (size_t)m->nblk * TILE * TILE) == hipSuccess;
-    } else if (ok) {
-        ok = big_alloc(&ia.Tws, e * nn) == hipSuccess &&
-             hipMemsetAsync(m->X, 0, e * nn, m->stream) == hipSuccess;  // structural zeros above the block diagonal
-    }
-    if (!ok) {
-        (void)hipGetLastError();
-        release_inv_ahead(m);
-        return;
-    }
-    ia.h = h;
-    ia.active = true;
-}
 
 // ---- blocked right-looking LDL^T -----------------------------------------------------------------
 // Outer panels of 256 columns = 2 diagonal blocks of 128 (GPX_PANEL=512: 4 blocks): per block the diagonal LDL^T
@@ -442,9 +330,7 @@ static void factorize(gpx_model *m, int c_start = 0)
     }
     if (la_env && c_start == 0 && m->stream2) {
         hipStream_t sa = m->stream, sb = m->stream2;
-        int la_tail_rows = 4096;  // GPX_LA_TAIL: remaining rows from which on the plain order is used (0: never)
-        if (const char *te = std::getenv("GPX_LA_TAIL"))
-            la_tail_rows = std::atoi(te);
+        constexpr int la_tail_rows = 4096;  // remaining rows from which on one trailing update on the chain stream is the faster order
         size_t ev_used = 0;
         auto next_event = [&]() -> hipEvent_t {
             if (ev_used == m->la_ev.size()) {
@@ -464,13 +350,10 @@ static void factorize(gpx_model *m, int c_start = 0)
                     half_update(cc, wofs + h * TILE, c0 + nb * TILE, st);
             }
         };
-        int la_mode = 2;  // GPX_LA_MODE=1: the round-1 schedule (strip on the main stream, two hops per panel on the chain)
-        if (const char *me = std::getenv("GPX_LA_MODE"))
-            la_mode = std::atoi(me);
-        if (la_mode == 2) {
+        {
             // The chain stream owns everything the NEXT panel waits for -- diagonal blocks, panel solves, half update AND the
             // 256-column strip of the trailing update -- so no cross-stream hop lies on the serial chain any more (the
-            // round-1 schedule had strip + two hops = 44 of the ~190 us per panel there, rocprofv3 timeline in
+            // round-1 schedule, removed in round 4, had strip + two hops = 44 of the ~190 us per panel there, rocprofv3 timeline in
             // profiles/r02_create_stages.txt); the main stream only runs the rest of each trailing update:
             //   chain stream:  chain_p -> [eP_p] -> wait eR_{p-1} -> strip_p -> chain_{p+1} ...
             //   main stream :  wait eP_p -> rest_p -> [eR_p]
@@ -500,8 +383,6 @@ static void factorize(gpx_model *m, int c_start = 0)
                     const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
                     const int sw = std::min(PANEL, np - r0);
                     const bool tail = np - r0 <= la_tail_rows || r0 + sw >= np;
-                    if (m->ia.active && !m->ia.launched && c0 >= m->ia.h)
-                        launch_inverse_left(m, sb);  // the chain of panel c0 is enqueued on sb: columns < c0 + 256 are final
                     // the rest update is released as soon as chain_p is done -- BEFORE the chain stream waits for rest_{p-1}:
                     // in the update-bound part the chain finishes long before that, and rest_p then follows rest_{p-1} on the
                     // main stream without a hop (was: hop + start of the strip = ~37 us per panel between two rest updates)
@@ -541,44 +422,7 @@ static void factorize(gpx_model *m, int c_start = 0)
                 return;
             }
         }
-        chain(0, 0, sa);
-        int p = 0;
-        for (int c0 = 0; c0 + PANEL < np; c0 += PANEL, ++p) {
-            const int wofs = (p & 1) * PANEL, r0 = c0 + PANEL;
-            const int sw = std::min(PANEL, np - r0);  // width of the strip = of the next panel
-            // Deep in the tail the whole trailing update is shorter than the strip launch plus the two cross-stream
-            // hops that the split costs (timeline at N = 16384: strip 23 us + 2 x ~10 us against a trailing update of
-            // 27 us at 2816 rows): there the plain order -- one trailing update, then the chain on the same stream --
-            // is the faster one.  Same tiles, same k order: bit-identical either way.
-            if (np - r0 <= la_tail_rows) {
-                trailing(c0, r0, PANEL, wofs);
-                chain(r0, wofs ^ PANEL, sa);
-                continue;
-            }
-            GemmArgs s;  // strip: C[r0:, r0:r0+sw] -= W_p L_p^T (the tile above the diagonal is computed too, nobody reads it)
-            s.A = Wpp(r0, wofs), s.lda = WIDE_PANEL;
-            s.B = Kp(r0, c0), s.ldb = ldk;
-            s.C = Kp(r0, r0), s.ldc = ldk;
-            s.M = np - r0, s.N = sw, s.K = PANEL;
-            s.alpha = -1.0, s.beta = 1;
-            launch_gemm(m->prec, s, sa);
-            hipEvent_t e1 = nullptr, e2 = nullptr;
-            const bool overlap = r0 + sw < np && (e1 = next_event()) && (e2 = next_event());
-            if (overlap) {
-                (void)hipEventRecord(e1, sa);
-                (void)hipStreamWaitEvent(sb, e1, 0);
-                chain(r0, wofs ^ PANEL, sb);
-                (void)hipEventRecord(e2, sb);
-                trailing(c0, r0 + sw, PANEL, wofs);
-                (void)hipStreamWaitEvent(sa, e2, 0);
-            } else {
-                if (r0 + sw < np)
-                    trailing(c0, r0 + sw, PANEL, wofs);
-                chain(r0, wofs ^ PANEL, sa);
-            }
-        }
-        m->gemm_ev_used_factor = gemm_idx;
-        return;
+        // (no events: the plain order below)
     }
     int c0 = c_start;
     if (c0 % PANEL) {  // start in the middle of a 256-column unit: a lone 128-wide step
@@ -591,8 +435,6 @@ static void factorize(gpx_model *m, int c_start = 0)
     const int wide = wide_env == WIDE_PANEL ? WIDE_PANEL
                                             : (wide_env == PANEL ? PANEL : (m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL));
     while (c0 < np) {
-        if (m->ia.active && !m->ia.launched && c0 >= m->ia.h)
-            launch_inverse_left(m, m->stream);  // columns < c0 are final
         const int pw = std::min(wide, np - c0), nb = pw / TILE;
         for (int h = 0; h < nb; ++h) {
             const int cc = c0 + h * TILE, r0 = cc + TILE;
@@ -702,22 +544,7 @@ int build_inverse(gpx_model *m)
     // temporaries behind guards: every early return below (HIPCHK) releases them
     DevGuard gTws(nullptr, true), gL64(nullptr, true), gX64(nullptr, true), glinv64(nullptr, true);
     bool assemble64 = m->prec == GPX_PREC_F32 && m->inv64;
-    // the part that was started inside the factorisation (its buffers pass to the guards here)
-    inv_ahead &ia = m->ia;
-    const bool ahead = ia.active && ia.launched && ia.f64 == assemble64;
-    const int h = ahead ? ia.h : 0;
-    if (ia.active) {
-        if (ia.launched)
-            (void)hipStreamWaitEvent(m->stream, ia.done, 0);  // X11 is ready (or: nothing below touches buffers in use)
-        if (ahead) {
-            gTws.p = ia.Tws, gL64.p = ia.L64, gX64.p = ia.X64, glinv64.p = ia.linv64;
-            ia.Tws = ia.L64 = ia.X64 = ia.linv64 = nullptr;
-        } else if (ia.launched) {
-            (void)hipStreamSynchronize(m->stream3);
-        }
-        release_inv_ahead(m);
-    }
-    if (assemble64 && !ahead) {
+    if (assemble64) {
         // three N x N fp64 temporaries: at very large N they may not fit next to K and X -- assemble in fp32 then
         const size_t nn = (size_t)np * np;
         if (big_alloc(&gL64.p, sizeof(double) * nn) != hipSuccess || big_alloc(&gX64.p, sizeof(double) * nn) != hipSuccess ||
@@ -728,8 +555,6 @@ int build_inverse(gpx_model *m)
             assemble64 = false;
         }
     }
-    // With the leading h x h inverse already there (h > 0): the trailing block's own inverse, then one combine step
-    // X21 = -X22 (L21 X11) -- the same products as the top level of the recursive doubling.
     if (assemble64) {
         double *L64 = (double *)gL64.p, *X64 = (double *)gX64.p, *linv64 = (double *)glinv64.p;
         char *Tws = (char *)gTws.p;
@@ -737,32 +562,23 @@ int build_inverse(gpx_model *m)
         // rounded once.  Measured at N = 16384 (variance error / k(0) vs the fp64 pipeline): Matern-5/2 1.0e-5 ->
         // 4.5e-6, Gaussian 1.1e-5 -> 2.3e-6, thin-plate R=4 1.05e-4 -> 2.1e-5, i.e. the level of an fp64 factor:
         // the log2(N/128) levels of products of inverses, not the LDL^T, are where fp32 loses the accuracy.
-        launch_cast_lower_f2d(np, (const float *)m->Kmat, L64, false, m->stream, h, -1);  // the upper tiles are never read
-        const size_t lb = (size_t)(h / TILE) * TILE * TILE;
-        launch_cast_f2d((size_t)m->nblk * TILE * TILE - lb, (const float *)m->linv + lb, linv64 + lb, m->stream);
+        launch_cast_lower_f2d(np, (const float *)m->Kmat, L64, false, m->stream, 0, -1);  // the upper tiles are never read
+        launch_cast_f2d((size_t)m->nblk * TILE * TILE, (const float *)m->linv, linv64, m->stream);
         // (no memset of X64: the assembly reads and writes only tiles on / below the block diagonal -- place_diag
         // supplies the diagonal tiles, zeros above the diagonal inside them -- and the final cast writes the zeros of
         // the upper tiles of X without reading them)
-        launch_place_diag(GPX_PREC_F64, m->nblk - h / TILE, linv64 + lb, X64 + (size_t)h * np + h, np, m->stream);
-        trtri_levels(GPX_PREC_F64, 8, (char *)(L64 + (size_t)h * np + h), (char *)(X64 + (size_t)h * np + h),
-                     Tws + ((size_t)h * np + h) * 8, np - h, m->stream, np);
-        if (h > 0)
-            trtri_combine(GPX_PREC_F64, 8, (char *)L64, (char *)X64, Tws, np, h, m->stream, np);
+        launch_place_diag(GPX_PREC_F64, m->nblk, linv64, X64, np, m->stream);
+        trtri_levels(GPX_PREC_F64, 8, (char *)L64, (char *)X64, Tws, np, m->stream, np);
         launch_cast_lower_d2f(np, X64, (float *)m->X, true, m->stream);
         if (m->var_fit)  // from the un-rounded rows: the rounding of X then only meets the small fit residual
             launch_var_rowcorr(true, m->op64, m->n, np, X64, np, m->d_x, m->d_y, m->d_z, m->d_meta, m->d_corr, m->stream);
     } else {
         if (!gTws.p)
             HIPCHK(big_alloc(&gTws.p, e * (size_t)np * np));
-        // blocks above the diagonal are structural zeros: the 256-row variance tiles read the upper-right
-        // 128-block of every 256-diagonal block (with the ahead-of-time part the memset ran before the factorisation)
-        if (!ahead)
-            HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
-        const size_t lb = (size_t)(h / TILE) * TILE * TILE, dg = ((size_t)h * np + h) * e;
-        launch_place_diag(m->prec, m->nblk - h / TILE, (char *)m->linv + lb * e, (char *)m->X + dg, np, m->stream);
-        trtri_levels(m->prec, e, (char *)m->Kmat + dg, (char *)m->X + dg, (char *)gTws.p + dg, np - h, m->stream, np);
-        if (h > 0)
-            trtri_combine(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)gTws.p, np, h, m->stream, np);
+        // blocks above the diagonal are structural zeros (the LDS-staged variance tiles read them)
+        HIPCHK(hipMemsetAsync(m->X, 0, e * (size_t)np * np, m->stream));
+        launch_place_diag(m->prec, m->nblk, m->linv, m->X, np, m->stream);
+        trtri_levels(m->prec, e, (char *)m->Kmat, (char *)m->X, (char *)gTws.p, np, m->stream, np);
         if (m->var_fit)
             launch_var_rowcorr(m->prec == GPX_PREC_F64, m->op64, m->n, np, m->X, np, m->d_x, m->d_y, m->d_z, m->d_meta,
                                m->d_corr, m->stream);
@@ -986,9 +802,7 @@ int build_model(gpx_model *m, kept_factor *keep)
         const int nmax = launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
         launch_reduce_tilemax(nmax, m->d_tmax, m->d_tij, m->d_info + 2, s);
         (void)hipEventRecord(m->ev[EV_KBUILD], s);
-        // ---- factorisation (with the finished half of the inverse factor assembled beside its tail, if one is wanted) ----
-        if (m->opt.prepare_variance || m->train64)
-            prepare_inverse_ahead(m);
+        // ---- factorisation ----
         factorize(m);
     }
     (void)hipEventRecord(m->ev[EV_FACTOR], s);

@@ -4,17 +4,6 @@
 // AtlasBase::project.
 #include "gpx_model.hpp"
 
-namespace gpx {
-int kqp_ldpad()
-{
-    static const int pad = [] {
-        const char *e = std::getenv("GPX_KQP_LDPAD");
-        const int v = e ? std::atoi(e) : KQP_LDPAD;
-        return v >= 0 && v % 4 == 0 ? v : KQP_LDPAD;
-    }();
-    return pad;
-}
-}  // namespace gpx
 
 namespace gpxh {
 
@@ -52,11 +41,11 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         return !ev || std::atoi(ev) != 0;
     }();
     const bool use_cols = v && var_cols_on && m->var_fit && !m->x_packed && m->prec != GPX_PREC_F64 &&
-                          var_cols_fits(m->n, np, np, np + kqp_ldpad());
+                          var_cols_fits(m->n, np, np, np + KQP_LDPAD);
     VarColsArgs vc;
     if (use_cols) {
         vc.X = (const float *)m->X, vc.ldx = np, vc.n = m->n, vc.np = np;
-        vc.ldk = np + kqp_ldpad();
+        vc.ldk = np + KQP_LDPAD;
         vc.rowcorr = m->d_corr, vc.ldrc = np;
         vc.dinv64 = m->d_dinv64, vc.k0 = m->cov.k0;
         vc.cov = m->cov, vc.op64 = m->op64;
@@ -70,7 +59,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     if (v) {
         int rc;
         const size_t qb = qbatch;
-        if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + kqp_ldpad()))))
+        if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + KQP_LDPAD))))
             return rc;
         // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
         if (!use_cols && (rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
@@ -94,45 +83,17 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     if (v) {
         const size_t qb = qbatch;
         const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
-        // Opt-in (GPX_VAR_PIPE=1) two-deep pipeline over the query batches: the kernel operand of batch i+1 (fit + kqp,
-        // ~0.13 ms of HBM-write / VALU work) is built on the second stream into a second buffer while the GEMM of batch i
-        // (15.6 ms of MFMA work at N = 16384) runs on the caller's stream.  Measured: the 3.4 ms per step it hides come
-        // back as a GEMM that runs 0.15 ms longer per launch beside the kqp (2098.2 vs 2099.3 ms per step) -- no gain, so
-        // the default stays one stream and one buffer.  (Round 3, one-wave variance tiles: a loss -- 2421 vs 1950 ms per
-        // step; the operand kernel's workgroups take SIMDs out of the rounds of equal-length tiles, 18.4 vs 14.6 ms per launch.)
-        const char *pipe_env = std::getenv("GPX_VAR_PIPE");  // read per call
-        const bool pipe_on = pipe_env && std::atoi(pipe_env) != 0;
-        bool pipe = pipe_on && nq > qb;
-        if (pipe && !m->stream2 && stream_acquire(m->device, &m->stream2) != hipSuccess) {
-            (void)hipGetLastError();
-            m->stream2 = nullptr;
-            pipe = false;
-        }
-        for (int i = 0; pipe && i < 5; ++i)
-            if (!m->pipe_ev[i] && hipEventCreateWithFlags(&m->pipe_ev[i], hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                m->pipe_ev[i] = nullptr;
-                pipe = false;
-            }
-        if (pipe && (ensure(m, &m->ws_kqp2, &m->ws_kqp2_bytes, e * qb * (np + kqp_ldpad())) != GPX_OK ||
-                     (m->var_fit && ensure(m, &m->ws_coef2, &m->ws_coef2_bytes, sizeof(double) * qb * VAR_NCOEF) != GPX_OK))) {
-            (void)hipGetLastError();
-            pipe = false;  // no room for the second operand buffer: one stream, one buffer
-        }
-        hipStream_t sp = pipe ? m->stream2 : s;  // producer of the kernel operand
-        if (pipe) {
-            (void)hipEventRecord(m->pipe_ev[0], s);  // queries, model state and the workspaces are ready on s
-            (void)hipStreamWaitEvent(sp, m->pipe_ev[0], 0);
-        }
-        size_t gi = 0, bi = 0;
-        for (size_t q0 = 0; q0 < nq; q0 += qb, ++bi) {
+        const long ldk = (long)np + KQP_LDPAD;  // row stride of the operand buffer (not the power of two X's is)
+        // One stream, one operand buffer.  (A two-deep pipeline over the query batches -- operand of batch i + 1 built on a
+        // second stream beside the GEMM of batch i -- was measured in rounds 1 and 3 and removed: no gain with the LDS
+        // tiles, 2421 against 1950 ms per step with the one-wave tiles, whose rounds of equal-length workgroups the operand
+        // kernel's workgroups break up.)
+        size_t gi = 0;
+        for (size_t q0 = 0; q0 < nq; q0 += qb) {
             const size_t nv = std::min(qb, nq - q0);
             const size_t ntile = ((nv + TILE - 1) / TILE) * TILE;
-            const int buf = pipe ? (int)(bi & 1) : 0;
-            void *kqp_buf = buf ? m->ws_kqp2 : m->ws_kqp;
-            void *coef_buf = buf ? m->ws_coef2 : m->ws_coef;
-            if (pipe && bi >= 2)
-                (void)hipStreamWaitEvent(sp, m->pipe_ev[3 + buf], 0);  // the GEMM of batch bi - 2 has read this buffer
+            void *kqp_buf = m->ws_kqp;
+            void *coef_buf = m->ws_coef;
             // The kernel operand holds k - fit with a per-query fit that is rank 14 in (q, p); the GEMM epilogue adds
             // X * fit back, in fp64, from the model's 14 row-correction vectors (gpx_internal.hpp, "low-rank fit").
             hipEvent_t *kev = nullptr;  // brackets the Kqp launch of this batch (stats; only on the model's own stream)
@@ -149,102 +110,78 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             const double *fab = nullptr;  // rows a_q, b_q, c_q of the batch's coefficient array
             if (m->var_fit) {
                 launch_var_fit(m->op64, m->cov, m->n, m->d_x, m->d_y, m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0,
-                               qy + q0, qz + q0, (double *)coef_buf, (long)qb, sp);
+                               qy + q0, qz + q0, (double *)coef_buf, (long)qb, s);
                 fab = (const double *)coef_buf + qb * VAR_NCORR;
             }
             const int part_prec = m->var_fit ? GPX_PREC_F64 : m->prec;  // type of the partial sums
             if (kev)
-                (void)hipEventRecord(kev[0], sp);
+                (void)hipEventRecord(kev[0], s);
             if (m->x_packed) {  // F32_SPLIT: fp16 hi/lo operands, three MFMA products per k-step
                 launch_kqp_split(m->var_fit && m->op64, m->cov, m->sk, m->n, np, m->t_x, m->t_y, m->t_z, m->d_x, m->d_y,
-                                 m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, fab,
-                                 (long)qb, (long)np + kqp_ldpad());
+                                 m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, s, fab,
+                                 (long)qb, ldk);
                 if (kev)
-                    (void)hipEventRecord(kev[1], sp);
-                if (pipe) {
-                    (void)hipEventRecord(m->pipe_ev[1 + buf], sp);
-                    (void)hipStreamWaitEvent(s, m->pipe_ev[1 + buf], 0);
-                }
+                    (void)hipEventRecord(kev[1], s);
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
                 launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, 2, s,
                                    np_rows, m->var_fit ? m->d_corr : nullptr, np,
-                                   m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3,
-                                   (long)np + kqp_ldpad());
+                                   m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3, ldk);
                 if (ev2) {
                     (void)hipEventRecord(ev2[1], s);
                     ++gi;
                 }
-                if (pipe)
-                    (void)hipEventRecord(m->pipe_ev[3 + buf], s);
                 launch_var_finish(part_prec, m->cov.k0, np_rows / TILE, (long)qb, m->ws_partial, (long)nv, v + q0, s);
                 continue;
-            }
-            if (use_cols) {
-                vc.Kq = (const float *)kqp_buf;
-                vc.colcoef = (const double *)coef_buf, vc.ldcc = (long)qb;
-                vc.nq_valid = (long)nv, vc.nq_tile = (long)ntile, vc.v = v + q0;
-                vc.qx = qx + q0, vc.qy = qy + q0, vc.qz = qz + q0;
             }
             if (!cols_gen) {
                 // fp64 models and the fp64-formed fp32 operand read the model's fp64 points (differences do not depend
                 // on where the cloud sits); the fp32-formed operand reads the centred fp32 points
                 const bool c64 = m->prec == GPX_PREC_F64 || (m->var_fit && m->op64);
-                // (row stride np + kqp_ldpad(): the kernel uses its n_padded argument only as the stride of the operand's rows)
-                launch_kqp(c64, m->prec, m->prec == GPX_PREC_F64, m->cov, m->n, np + kqp_ldpad(), c64 ? (const void *)m->d_x : m->t_x,
+                // (the kernel uses its n_padded argument only as the stride of the operand's rows)
+                launch_kqp(c64, m->prec, m->prec == GPX_PREC_F64, m->cov, m->n, (int)ldk, c64 ? (const void *)m->d_x : m->t_x,
                            c64 ? (const void *)m->d_y : m->t_y, c64 ? (const void *)m->d_z : m->t_z, m->d_meta, (long)nv,
-                           (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, sp, np_rows, fab, (long)qb);
+                           (long)ntile, qx + q0, qy + q0, qz + q0, kqp_buf, s, np_rows, fab, (long)qb);
             }
             if (kev)
-                (void)hipEventRecord(kev[1], sp);
-            if (pipe) {
-                (void)hipEventRecord(m->pipe_ev[1 + buf], sp);
-                (void)hipStreamWaitEvent(s, m->pipe_ev[1 + buf], 0);
-            }
+                (void)hipEventRecord(kev[1], s);
+            hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (use_cols) {
-                hipEvent_t *evc = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
-                if (evc)
-                    (void)hipEventRecord(evc[0], s);
+                vc.Kq = (const float *)kqp_buf;
+                vc.colcoef = (const double *)coef_buf, vc.ldcc = (long)qb;
+                vc.nq_valid = (long)nv, vc.nq_tile = (long)ntile, vc.v = v + q0;
+                vc.qx = qx + q0, vc.qy = qy + q0, vc.qz = qz + q0;
+                if (ev)
+                    (void)hipEventRecord(ev[0], s);
                 launch_var_cols(vc, s);
-                if (evc) {
-                    (void)hipEventRecord(evc[1], s);
+                if (ev) {
+                    (void)hipEventRecord(ev[1], s);
                     ++gi;
                 }
-                if (pipe)
-                    (void)hipEventRecord(m->pipe_ev[3 + buf], s);
                 continue;
             }
             GemmArgs a;  // partial[mt][q] = sum_rows (X * Kqp^T)^2 / D
             a.A = m->X, a.lda = np;
-            a.B = kqp_buf, a.ldb = np + kqp_ldpad();
+            a.B = kqp_buf, a.ldb = ldk;
             a.M = np_rows, a.N = (int)ntile, a.K = np;  // rows of X in the identity padding see only zeros of Kqp
             a.a_lower = 1;
             a.epi = EPI_COLSQ;
             a.m_valid = m->n;
-            // Tile of the fp32 product (GPX_VAR_TILE).  6 (default for VAR_W1_MIN_ROWS rows and more): one wave per
-            // workgroup, a 128 x 128 tile per wave, no LDS, no barrier (gpx_vargemm.hip) -- 152 TFLOP/s against 139-140 for
-            // the LDS tiles at N = 16384.  The LDS tiles: 3 = 128 x 128 with 64-byte k rows at three workgroups per CU
-            // (what 6 falls back to for small models), 0 = the same tile with 128-byte k rows at two per CU, 2 = 256 x 256
-            // at one per CU; those three are within 1-2 % of each other (profiles/r03_var_gemm_variants.txt).
+            // Tile of the fp32 product: 6 = one wave per workgroup, a 128 x 128 tile per wave, no LDS, no barrier
+            // (gpx_vargemm.hip; 152 TFLOP/s at N = 16384).  GPX_VAR_TILE=3 selects the documented fallback, the LDS-staged
+            // 128 x 128 tile with 64-byte k rows at three workgroups per CU (139-140 TFLOP/s) -- also what 6 falls back to
+            // for a shape the one-wave kernel does not take.
             static const int var_tile = [] {
                 const char *e = std::getenv("GPX_VAR_TILE");
-                return e ? std::atoi(e) : 6;
+                return e && std::atoi(e) == 3 ? 3 : 6;
             }();
-            static const int w1_min_rows = [] {
-                const char *e = std::getenv("GPX_VAR_W1_MIN_ROWS");
-                return e ? std::atoi(e) : VAR_W1_MIN_ROWS;
-            }();
-            if (var_tile == 6)
-                a.cfg = np_rows >= w1_min_rows ? 6 : 3;
-            else
-                a.cfg = (var_tile == 2 && np_rows % 256 == 0 && (size_t)(np_rows / 256) * (ntile / 256) >= 1024) ? 2 : (var_tile == 3 ? 3 : 0);
+            a.cfg = var_tile;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)
                 a.rowcorr = m->d_corr, a.ldrc = np, a.colcoef = (const double *)coef_buf, a.ldcc = (long)qb,
                 a.rowweight64 = m->d_dinv64;
-            hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (ev)
                 (void)hipEventRecord(ev[0], s);
             launch_gemm(m->prec, a, s);
@@ -252,8 +189,6 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 (void)hipEventRecord(ev[1], s);
                 ++gi;
             }
-            if (pipe)
-                (void)hipEventRecord(m->pipe_ev[3 + buf], s);
             const int bm = gemm_rows_per_partial(m->prec, a);
             launch_var_finish(part_prec, m->cov.k0, np_rows / bm, (long)qb, m->ws_partial, (long)nv, v + q0, s);
         }

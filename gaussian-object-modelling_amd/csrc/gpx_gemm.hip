@@ -634,25 +634,13 @@ static void gemm_t(const GemmArgs &a, hipStream_t st)
             GPX_GEMM_CFG(false, EPI_STORE);
     } else if (a.epi == EPI_TRSM) {
         GPX_GEMM_CFG(false, EPI_TRSM);
-    } else if (sizeof(T) == 4 && a.cfg == 3) {
-        // GPX_VAR_TILE=3 (default since round 3): 64-byte k rows, 40 KiB of LDS per workgroup, compiled for 3 workgroups per CU
-        if constexpr (sizeof(T) == 4)
-            gemm_launch_cfg<T, false, EPI_COLSQ, 4, 4, 2, 2, 64>(g, a, st);
-#ifdef GEMM_BENCH_M32
-    } else if (sizeof(T) == 4 && (a.cfg == 4 || a.cfg == 5)) {
-        // harness only: the same 128 x 128 tile on v_mfma_f32_32x32x2_f32 (2 x 2 fragments of 32 x 32 per wave)
-        if constexpr (sizeof(T) == 4) {
-            if (a.cfg == 4)
-                gemm_launch_cfg<T, false, EPI_COLSQ, 2, 2, 2, 2, 128, true>(g, a, st);
-            else
-                gemm_launch_cfg<T, false, EPI_COLSQ, 2, 2, 2, 2, 64, true>(g, a, st);
-        }
-#endif
+    } else if constexpr (sizeof(T) == 8) {  // EPI_COLSQ, fp64: the LDS-staged 128 x 128 tile (what the one-wave fp64 tile falls back to)
+        gemm_launch_cfg<T, false, EPI_COLSQ, 4, 2, 2, 4>(g, a, st);
     } else {
-        // Measured on the variance shape (N = 16384, 8192 queries), all within 1.5 %: 128x128 tile 135-136 TF,
-        // 256x256 tile 134-135 TF, 64-byte k rows at 3 workgroups/CU (KBYTES = 64) 136.6 TF, 32x32x2 MFMA
-        // (M32 = true) 133-134 TF.  MFMA pipe ~88 % busy at 2.29 GHz in every variant: not tile-shape limited.
-        GPX_GEMM_CFG(false, EPI_COLSQ);
+        // EPI_COLSQ, fp32: the documented fallback of the one-wave tiles (GPX_VAR_TILE=3) -- 128 x 128 with 64-byte k rows,
+        // 40 KiB of LDS per workgroup, compiled for 3 workgroups per CU.  The 128-byte-k and 256 x 256 variants measured
+        // within 1.5 % of it on the variance shape (profiles/r03_var_gemm_variants.txt) and were removed in round 4.
+        gemm_launch_cfg<T, false, EPI_COLSQ, 4, 4, 2, 2, 64>(g, a, st);
     }
 #undef GPX_GEMM_CFG
 }

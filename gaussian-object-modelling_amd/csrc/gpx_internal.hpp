@@ -16,7 +16,6 @@ constexpr int TILE = 128;   // order of a diagonal block / GEMM tile edge
 constexpr int PANEL = 256;  // padding unit of N, and the narrow outer panel of the factorisation (2 diagonal blocks)
 constexpr int WIDE_PANEL = 512;  // optional wider outer panel (GPX_PANEL=512, 4 diagonal blocks) and the workspace width
 constexpr int WAVE = 64;
-constexpr int PAIR_WIDE_DEFAULT = 0, PAIR_NT_DEFAULT = 0, KBUILD_WIDE_DEFAULT = 0;  // store pattern of the operand kernel (gpx_pairwise.hip: kqp_t)
 // Terms of the low-rank fit taken out of the kernel operand of the variance contraction.  The fit is a polynomial of
 // degree two in s = |q - p|^2, which is rank 14 in (q, p): basis functions of the training point, relative to the
 // model's centre c (p' = p - c):  1 | p'_x p'_y p'_z | p'_x^2 p'_y^2 p'_z^2 p'_x p'_y p'_x p'_z p'_y p'_z |
@@ -212,13 +211,11 @@ void launch_var_w1_f64(const GemmArgs &g, hipStream_t st);
 // tile's K' slab and of its X slab fall on the same L2 sets and evict each other (N = 16384: 19.9 GB of L2 misses per
 // launch against 7.6 GB with the padded stride, paired launch; profiles/r03_w1_traffic.txt)
 constexpr int KQP_LDPAD = 32;
-int kqp_ldpad();  // KQP_LDPAD, or GPX_KQP_LDPAD (a multiple of 4, read once): gpx_eval.hip
 // fp64 C = alpha A B (B in [k][n] form, EPI_STORE, beta = 0) with K >= W1_NN_MIN_K goes to the one-wave kernel as well
 // (the three largest levels of the inverse-factor assembly carry 98 % of its flops); GPX_W1_NN=0 keeps the LDS tiles
 constexpr int W1_NN_MIN_K = 1024;
 bool w1_f64_nn_fits(const GemmArgs &g);
 void launch_w1_f64_nn(const GemmArgs &g, hipStream_t st);
-constexpr int VAR_W1_MIN_ROWS = 128;  // i.e. always: measured faster than the LDS tiles from 512 rows up (scripts/var_tile_sweep.py)
 int gemm_rows_per_partial(int prec, const GemmArgs &g);  // BM of the tile launch_gemm will pick for g
 int gemm_tile_m(int cfg);
 int gemm_tile_n(int cfg);

@@ -48,17 +48,6 @@ struct gpx_pending {
     std::string err;
 };
 
-// Inverse-factor assembly started INSIDE the factorisation (round 3): once the LDL^T has passed column h,
-// the leading h x h part of L is final and X11 = L11^-1 (1/8 of the assembly's flops for h = N/2) is assembled on a
-// third stream while the chain-bound tail of the factorisation runs; build_inverse() does the rest.
-struct inv_ahead {
-    bool active = false, launched = false;
-    bool f64 = false;  // fp64 assembly of an fp32 factor: L64 / X64 / linv64 in use (else the model's own Kmat / X / linv)
-    int h = 0;
-    void *Tws = nullptr, *L64 = nullptr, *X64 = nullptr, *linv64 = nullptr;
-    hipEvent_t start = nullptr, done = nullptr;
-};
-
 struct gpx_model {
     int device = 0, prec = 0;
     size_t esz = 4;
@@ -76,8 +65,6 @@ struct gpx_model {
     double R = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;         // look-ahead of the factorisation: the next panel beside the trailing update
-    hipStream_t stream3 = nullptr;         // inverse-factor assembly of the finished part beside the factorisation's tail
-    inv_ahead ia;
     std::vector<hipEvent_t> la_ev;         // its cross-stream events (no timing), reused
     hipEvent_t ev[EV_COUNT] = {};
     std::vector<hipEvent_t> gemm_ev;  // pairs bracketing GEMM launches (stats)
@@ -124,10 +111,6 @@ struct gpx_model {
     size_t ws_partial_bytes = 0;
     void *ws_coef = nullptr;  // doubles [VAR_NCOEF][qbatch]: query-side coefficients of the fit, then a_q, b_q, c_q
     size_t ws_coef_bytes = 0;
-    // second set for the two-deep pipeline of the variance batches (operand of batch i+1 built beside the GEMM of batch i)
-    void *ws_kqp2 = nullptr, *ws_coef2 = nullptr;
-    size_t ws_kqp2_bytes = 0, ws_coef2_bytes = 0;
-    hipEvent_t pipe_ev[5] = {};  // start | operand ready (2) | operand consumed (2); no timing
     double *ws_grad = nullptr;
     size_t ws_grad_doubles = 0;
     void *ws_small = nullptr;      // partial sums + counters of the one-launch path for a handful of queries

@@ -25,26 +25,18 @@ struct Vec4 {
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 using f64x2_t = __attribute__((ext_vector_type(2))) double;
 
-// NT: non-temporal stores (the matrix is re-read only after all of it exists; GPX_PAIR_NT=1 selects them -- measured, see
-// launch_kqp)
-template <typename T, bool NT = false>
+// (Measured and closed in round 3, profiles/r03_kqp_store_patterns.txt: non-temporal stores and 1-KiB row segments per wave
+// store -- 128 x 256 blocks -- change the traffic pattern, not the time, of kbuild and kqp; the variants were removed.)
+template <typename T>
 __device__ __forceinline__ void store4(T *dst, const T (&o)[4])
 {
     if constexpr (sizeof(T) == 4) {
         const f32x4_t v = {o[0], o[1], o[2], o[3]};
-        if constexpr (NT)
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t *>(dst));
-        else
-            *reinterpret_cast<f32x4_t *>(dst) = v;
+        *reinterpret_cast<f32x4_t *>(dst) = v;
     } else {
         const f64x2_t v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
-        if constexpr (NT) {
-            __builtin_nontemporal_store(v0, reinterpret_cast<f64x2_t *>(dst));
-            __builtin_nontemporal_store(v1, reinterpret_cast<f64x2_t *>(dst + 2));
-        } else {
-            *reinterpret_cast<f64x2_t *>(dst) = v0;
-            *reinterpret_cast<f64x2_t *>(dst + 2) = v1;
-        }
+        *reinterpret_cast<f64x2_t *>(dst) = v0;
+        *reinterpret_cast<f64x2_t *>(dst + 2) = v1;
     }
 }
 
@@ -134,105 +126,6 @@ __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad
         tmax[tile] = best;
         tij[2 * tile] = bi;
         tij[2 * tile + 1] = bj;
-    }
-}
-
-// The same matrix with 1-KiB row segments per wave store: a block covers 128 rows x 256 columns = the tiles (ti, 2 bx) and
-// (ti, 2 bx + 1) of the lower block triangle (grid: ceil(nt / 2) x nt; blocks right of the diagonal leave at once; on
-// the diagonal of an even row tile the right half lies above it and is written all the same -- nobody reads it).  A pure
-// fill of this shape reaches 5.99 instead of 5.71 TB/s (profiles/r03_fill_bench.txt).  tmax / tij: one entry per block,
-// -1 for the idle ones.
-template <typename T, int KID, bool NT>
-__global__ __launch_bounds__(256) void kbuild_wide_kernel(Cov<T> cov, int n, int npad, const T *__restrict__ x,
-                                                          const T *__restrict__ y, const T *__restrict__ z,
-                                                          const T *__restrict__ s2, T *__restrict__ K,
-                                                          float *__restrict__ tmax, int *__restrict__ tij)
-{
-    __shared__ T rx[TILE], ry[TILE], rz[TILE], rs[TILE];
-    __shared__ float wbest[4];
-    __shared__ int wbi[4], wbj[4];
-    const int ti = blockIdx.y, bx = blockIdx.x;
-    const int blk = ti * (int)gridDim.x + bx;
-    const int tid = threadIdx.x;
-    if (2 * bx > ti) {
-        if (tid == 0) {
-            tmax[blk] = -1.0f;
-            tij[2 * blk] = tij[2 * blk + 1] = 0;
-        }
-        return;
-    }
-    if (tid < TILE) {
-        int gi = ti * TILE + tid;
-        rx[tid] = x[gi];
-        ry[tid] = y[gi];
-        rz[tid] = z[gi];
-        rs[tid] = s2[gi];
-    }
-    const int tx = tid & 63, ty = tid >> 6;
-    const int gj0 = bx * 2 * TILE + tx * 4;
-    T cx[4], cy[4], cz[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        cx[c] = x[gj0 + c];
-        cy[c] = y[gj0 + c];
-        cz[c] = z[gj0 + c];
-    }
-    __syncthreads();
-    float best = -1.0f;
-    int bi = 0, bj = 0;
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-        const int li = ty + 4 * r;
-        const int gi = ti * TILE + li;
-        const T ax = rx[li], ay = ry[li], az = rz[li];
-        T out[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int gj = gj0 + c;
-            T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
-            T d2 = dx * dx + dy * dy + dz * dz;
-            T kv = cov_k<T, KID>(cov, d2);
-            if (gi == gj)
-                kv += rs[li];
-            if (gi < n && gj < n) {
-                if ((float)d2 > best) {
-                    best = (float)d2;
-                    bi = gi;
-                    bj = gj;
-                }
-            } else {
-                kv = (gi == gj) ? T(1) : T(0);  // identity on the padding
-            }
-            out[c] = kv;
-        }
-        store4<T, NT>(K + (size_t)gi * npad + gj0, out);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float ob = __shfl_xor(best, off);
-        int oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
-        if (ob > best) {
-            best = ob;
-            bi = oi;
-            bj = oj;
-        }
-    }
-    if ((tid & 63) == 0) {
-        wbest[tid >> 6] = best;
-        wbi[tid >> 6] = bi;
-        wbj[tid >> 6] = bj;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (wbest[w] > best) {
-                best = wbest[w];
-                bi = wbi[w];
-                bj = wbj[w];
-            }
-        tmax[blk] = best;
-        tij[2 * blk] = bi;
-        tij[2 * blk + 1] = bj;
     }
 }
 
@@ -417,9 +310,7 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
 // With TC = double, TO = float the residual k - fit is formed in fp64 and rounded ONCE: its error is 6e-8 of the
 // (small) residual, where forming k and the fit separately in fp32 costs 6e-8 of k(0) each (measured: 1.2e-7 k(0) of
 // variance error from the operand alone at N = 16384 thin-plate, against 2e-9 -- profiles/r03_tp_fit_probe.txt).
-// WIDE: a wave writes ONE row segment of 256 columns (64 lanes x 16 B = 1 KiB contiguous per store instruction; the
-// block covers 128 queries x 256 columns) instead of two 512-byte pieces in two rows (128 x 128 block).
-template <typename TC, typename TO, int KID, typename M, bool WIDE, bool NT>
+template <typename TC, typename TO, int KID, typename M>
 __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, const TC *__restrict__ px,
                                                   const TC *__restrict__ py, const TC *__restrict__ pz,
                                                   const double *__restrict__ cen, long nq_valid,
@@ -443,7 +334,7 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, 
         rfb[tid] = fab ? (TC)fab[ldcc + q] : TC(0);
         rfc[tid] = fab ? (TC)fab[2 * ldcc + q] : TC(0);
     }
-    constexpr int LANES_X = WIDE ? 64 : 32, ROWS_PER_PASS = 256 / LANES_X, PASSES = TILE / ROWS_PER_PASS;
+    constexpr int LANES_X = 32, ROWS_PER_PASS = 256 / LANES_X, PASSES = TILE / ROWS_PER_PASS;
     const int tx = tid & (LANES_X - 1), ty = tid / LANES_X;
     const int gj0 = blockIdx.x * (4 * LANES_X) + tx * 4;
     TC cx[4], cy[4], cz[4];
@@ -472,7 +363,7 @@ __global__ __launch_bounds__(256) void kqp_kernel(Cov<TC> cov, int n, int npad, 
             kv -= fa + d2 * (fb + fc * d2);
             out[c] = (q < nq_valid && gj0 + c < n) ? (TO)kv : TO(0);
         }
-        store4<TO, NT>(Kqp + (size_t)q * npad + gj0, out);
+        store4<TO>(Kqp + (size_t)q * npad + gj0, out);
     }
 }
 
@@ -560,20 +451,6 @@ static int kbuild_t(const CovHost &h, int n, int npad, const void *x, const void
     if (tile0 >= ntiles)
         return 0;
     Cov<T> c = lower_cov<T>(h);
-    // store pattern of a fresh build (read once): GPX_KBUILD_WIDE=1: 1-KiB row segments per wave store; GPX_PAIR_NT=1: non-temporal
-    static const int wide = [] { const char *e = std::getenv("GPX_KBUILD_WIDE"); return e ? std::atoi(e) : KBUILD_WIDE_DEFAULT; }();
-    static const int nt_st = [] { const char *e = std::getenv("GPX_PAIR_NT"); return e ? std::atoi(e) : PAIR_NT_DEFAULT; }();
-    if (wide && first_tile_row == 0) {
-        const dim3 grid((nt + 1) / 2, nt);
-        if (nt_st) {
-            GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_wide_kernel<T, KID, true>), grid, dim3(256), 0, st, c, n, npad,
-                                                      (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K, tmax, tij));
-        } else {
-            GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_wide_kernel<T, KID, false>), grid, dim3(256), 0, st, c, n, npad,
-                                                      (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K, tmax, tij));
-        }
-        return (int)(grid.x * grid.y);
-    }
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kbuild_kernel<T, KID>), dim3(ntiles - tile0), dim3(256), 0, st, c, n,
                                               npad, (const T *)x, (const T *)y, (const T *)z, (const T *)s2, (T *)K,
                                               tmax, tij, tile0));
@@ -599,26 +476,10 @@ static void kqp_t(const CovHost &h, int n, int npad, const void *px, const void 
                   hipStream_t st, int ncols, const double *fab, long ldcc)
 {
     Cov<TC> c = lower_cov<TC>(h);
-    // experiment switches (read once): GPX_PAIR_WIDE=1: 1-KiB row segments per wave store; GPX_PAIR_NT=1: non-temporal stores
-    static const int wide = [] { const char *e = std::getenv("GPX_PAIR_WIDE"); return e ? std::atoi(e) : PAIR_WIDE_DEFAULT; }();
-    static const int nt = [] { const char *e = std::getenv("GPX_PAIR_NT"); return e ? std::atoi(e) : PAIR_NT_DEFAULT; }();
     const int cols = ncols > 0 ? ncols : npad;
-#define GPX_KQP_LAUNCH(WIDE_, NT_)                                                                                    \
-    {                                                                                                                 \
-        dim3 grid((cols + (WIDE_ ? 255 : 127)) / (WIDE_ ? 256 : 128), (unsigned)(nq_tile / TILE));                    \
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<TC, TO, KID, M, WIDE_, NT_>), grid, dim3(256), 0, st, c, n, \
-                                                  npad, (const TC *)px, (const TC *)py, (const TC *)pz, cen, nq_valid, \
-                                                  qx, qy, qz, (TO *)Kqp, fab, ldcc));                                 \
-    }
-    if (wide && nt)
-        GPX_KQP_LAUNCH(true, true)
-    else if (wide)
-        GPX_KQP_LAUNCH(true, false)
-    else if (nt)
-        GPX_KQP_LAUNCH(false, true)
-    else
-        GPX_KQP_LAUNCH(false, false)
-#undef GPX_KQP_LAUNCH
+    const dim3 grid((cols + 127) / 128, (unsigned)(nq_tile / TILE));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((kqp_kernel<TC, TO, KID, M>), grid, dim3(256), 0, st, c, n, npad, (const TC *)px,
+                                              (const TC *)py, (const TC *)pz, cen, nq_valid, qx, qy, qz, (TO *)Kqp, fab, ldcc));
 }
 
 void launch_kqp(bool compute64, int out_prec, bool accurate_math, const CovHost &cov, int n, int npad, const void *px,

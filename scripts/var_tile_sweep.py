@@ -1,6 +1,8 @@
-"""Variance-product tile by model size: evaluate(f, v) on 2^19 lattice queries for N = 512 .. 16384 with the LDS tile
-(GPX_VAR_TILE=3) and the one-wave tile (GPX_VAR_TILE=6, GPX_VAR_W1_MIN_ROWS=128 so that it is used at every size); the
-switches are read once per process, so this script re-runs itself per setting.  Prints ms per evaluate and the GEMM's share."""
+"""Variance contraction by model size: evaluate(f, v) on 2^19 lattice queries for N = 277 .. 16384, fp32-mode Matern-5/2 models
+on the Fibonacci cloud.  Up to 1024 points the small-model kernel (gpx_varcols_kernel.hpp), above the one-wave 128 x 128 tile
+(GPX_VAR_TILE=3: its LDS-staged fallback; GPX_VAR_COLS=0: the tiles at every size); the switches are read once per
+process, so this script re-runs itself per setting.  Prints ms per evaluate, the variance kernel's time and its share of
+the fp32 MFMA peak on N^2 flop per query."""
 import importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,9 +23,10 @@ if len(sys.argv) > 1:
         for _ in range(2):
             m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr()); m.sync()
         st = m.stats
-        print("%s N=%5d: evaluate %.2f ms  (variance GEMM %.2f ms)" % (sys.argv[1], n, st["t_mean_ms"] + st["t_var_ms"], st["t_var_gemm_ms"]), flush=True)
+        tf = float(n) ** 2 * nq / (st["t_var_gemm_ms"] * 1e-3) / 1e12
+        print("%s N=%5d: evaluate %.2f ms  (variance kernel %.3f ms in %d launch(es) = %.1f TFLOP/s = %.1f %% of 157.3; whole variance stage %.2f ms)" % (
+            sys.argv[1], n, st["t_mean_ms"] + st["t_var_ms"], st["t_var_gemm_ms"], st["var_gemm_launches"], tf, 100 * tf / 157.3, st["t_var_ms"]), flush=True)
         m.close()
 else:
-    for tile, name in (("3", "LDS tile 3   "), ("6", "one-wave tile")):
-        env = dict(os.environ, GPX_VAR_TILE=tile, GPX_VAR_W1_MIN_ROWS="128")
-        subprocess.run([sys.executable, os.path.abspath(__file__), name], env=env, check=True)
+    for env_add, name in (({}, "default            "), ({"GPX_VAR_COLS": "0"}, "128 x 128 tiles    "), ({"GPX_VAR_COLS": "0", "GPX_VAR_TILE": "3"}, "LDS-staged fallback")):
+        subprocess.run([sys.executable, os.path.abspath(__file__), name], env=dict(os.environ, **env_add), check=True)

@@ -731,21 +731,21 @@ def test_march_surface_follows_the_reference_walk(gpu, orc, ds, prec):
 
 
 @pytest.mark.parametrize("prec", [1, 0, 3])
-def test_pipelined_variance_batches_are_bit_identical(gpu, ds, prec, monkeypatch):
-    """GPX_VAR_PIPE=1 (opt-in): the kernel operand of batch i+1 is built on a second stream into a second buffer while
-    the GEMM of batch i runs.  Same kernels on the same operands: bit-identical variance, also over many small batches
-    and a ragged last one."""
-    x, y, z, lab, s2 = ds.fibonacci_training_set(700)
+@pytest.mark.parametrize("n", [700, 1500])
+def test_variance_batches_are_bit_identical(gpu, ds, prec, n):
+    """The variance is evaluated per batch of queries (operand buffer / coefficient array of bounded size): many small
+    batches with a ragged last one give bit-identical values to one batch, call after call.  700 points: the small-model
+    kernel (gpx_varcols_kernel.hpp) for the fp32 mode; 1500: the 128 x 128 tiles."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     qx, qy, qz = ds.query_grid(11)  # 1331 queries
     kern = gpu.make_kernel("matern52", 1.0, 1.0)
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("GPX_VAR_PIPE", mode)
-        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, query_batch=256)
-        res[mode] = [gm.evaluate(qx, qy, qz, want_v=True)["v"] for _ in range(2)]
+    for qb in (256, 0):
+        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, query_batch=qb)
+        res[qb] = [gm.evaluate(qx, qy, qz, want_v=True)["v"] for _ in range(2)]
         gm.close()
-    for a in res["0"] + res["1"]:
-        np.testing.assert_array_equal(a, res["0"][0])
+    for a in res[256] + res[0]:
+        np.testing.assert_array_equal(a, res[0][0])
 
 
 def test_sample_surface_matches_filtered_evaluate(gpu, orc, ds):
@@ -883,13 +883,14 @@ def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
 
 
 def test_variance_tiles_agree(gpu, ds, tmp_path):
-    """The one-wave variance tile (gpx_vargemm.hip, GPX_VAR_TILE=6, default) against the LDS-staged tiles 0, 2 and 3 of
-    gpx_gemm.hip (the switch is read once per process, hence the children): the same contraction
+    """The one-wave variance tile (gpx_vargemm.hip, default) against its documented fallback, the LDS-staged tile of
+    gpx_gemm.hip (GPX_VAR_TILE=3; the switch is read once per process, hence the children): the same contraction
     (gp_regressor.hpp:316-319) with the same k-to-lane assignment, so the fp32 accumulators agree to rounding and the
     variances to 5e-7 of max|v| (3e-6 with the plain fp32 epilogue); each tile within 1e-5 of the fp64 pipeline in the survey's metric.  F32 with the fit
     (fp64 epilogue on the fp64 matrix pipe in tile 6), F32 without it (GPX_VAR_FIT=0: plain fp32 epilogue), MIXED, and F64
     (one-wave 128 x 64 fp64 tile against the LDS-staged fp64 tile: 1e-12);
-    thin-plate included; 700 rows (3 row tiles, the last partly padding) and 2305 (10 row tiles)."""
+    thin-plate included; 1100 rows (9 row tiles, the last partly padding) and 2305 (19 row tiles).  (Models of up to 1024
+    points never reach these tiles in the fp32 modes: test_small_model_variance_paths_agree.)"""
     import subprocess, sys
     child = (
         "import sys, importlib, numpy as np\n"
@@ -897,7 +898,7 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         "gpx = importlib.import_module('gaussian-object-modelling_amd.gpx')\n"
         "ds = importlib.import_module('gaussian-object-modelling_amd.datasets')\n"
         "out = {}\n"
-        "for n in (700, 2305):\n"
+        "for n in (1100, 2305):\n"
         "    x, y, z, lab, s2 = ds.fibonacci_training_set(n)\n"
         "    qx, qy, qz = ds.query_grid(7)\n"
         "    for kn, par in (('matern52', (1.0, 1.0)), ('thinplate', (4.0,))):\n"
@@ -907,8 +908,8 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         "            gm.close()\n"
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_W1_NN", "GPX_KQP_LDPAD", "GPX_VAR_TILE", "GPX_VAR_FIT")}
-    for tile, fit in (("6", "1"), ("3", "1"), ("0", "1"), ("2", "1"), ("6", "0"), ("3", "0")):
+    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_W1_NN", "GPX_VAR_TILE", "GPX_VAR_FIT")}
+    for tile, fit in (("6", "1"), ("3", "1"), ("6", "0"), ("3", "0")):
         path = str(tmp_path / ("tile%s_%s.npz" % (tile, fit)))
         env = dict(base_env, GPX_VAR_TILE=tile, GPX_VAR_FIT=fit)
         r = subprocess.run([sys.executable, "-c", child, path], env=env, capture_output=True, text=True, timeout=300)
@@ -1051,28 +1052,3 @@ def test_replicas_on_a_second_device(gpu, ds, prec):
     np.testing.assert_array_equal(out["v"], ref["v"])
     m1.close()
     src.close()
-
-
-@pytest.mark.parametrize("prec", [1, 0, 2])
-@pytest.mark.parametrize("n", [2305, 4096, 5000])
-def test_inverse_factor_started_inside_the_factorisation(gpu, ds, prec, n, monkeypatch):
-    """GPX_INV_AHEAD=1 assembles X11 = L11^-1 (the leading half) on a third stream while the factorisation
-    works on the trailing columns, and build_inverse() adds the trailing block's inverse and one combine step
-    X21 = -X22 (L21 X11).  The factorisation itself is untouched (alpha, D bit-identical); the inverse factor is the same
-    matrix assembled through a different tree of block products (split at N/2 rounded to 256 instead of at powers of
-    two), so the variance agrees to fp64 rounding (1e-12), bit for bit where the trees coincide.  Measured: no time
-    gain, so it is off by default -- the test keeps the path alive.  F64, F32 (fp64 assembly of the fp32 factor), MIXED."""
-    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
-    kern = gpu.make_kernel("matern52", 1.0, 1.0)
-    qx, qy, qz = ds.query_grid(6)
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("GPX_INV_AHEAD", mode)
-        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=True)
-        o = gm.evaluate(qx, qy, qz, want_v=True)
-        res[mode] = (gm.alpha.copy(), gm.D.copy(), o["f"].copy(), o["v"].copy())
-        gm.close()
-    for a, b in zip(res["1"][:3], res["0"][:3]):
-        np.testing.assert_array_equal(a, b)
-    # fp32 state: X is rounded to fp32 after the fp64 assembly, a 1e-16 difference can flip a last bit here and there
-    assert verr_v(res["1"][3], res["0"][3]) < (1e-12 if prec == 1 else 1e-7)
