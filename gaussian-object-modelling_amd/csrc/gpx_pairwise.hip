@@ -10,6 +10,7 @@
 // (fp32) / two 16-byte (fp64) stores, a wave writes 2 x 512 contiguous bytes per instruction.
 // Distances are direct differences (dx^2+dy^2+dz^2): exact 0 on the diagonal, never negative
 // (documented deviation from the reference's norm expansion).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -293,7 +294,12 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
         const int v = e ? std::atoi(e) : VAR_FIT_SAMPLES_DEFAULT;
         return v < 16 ? 16 : (v > VAR_FIT_SAMPLES ? VAR_FIT_SAMPLES : v);
     }();
-    const int stride = (n + nsamp - 1) / nsamp;
+    // Small models (the small-model variance kernel's range): 32 samples.  The fit kernel's time is proportional to the
+    // samples and independent of N -- 0.74 ms for 2^21 queries at 64 samples, which is 7 % of the variance stage at N = 724
+    // but a quarter of it at N = 277 (profiles/r04_c5_kernel_stats.txt) -- while the accuracy is not (see gpx_internal.hpp:
+    // 3.6 / 3.7e-6 and 1.5 / 1.2e-6 at 32 / 64 samples).
+    const int ns = n <= VARCOLS_MAX_N ? std::min(nsamp, 32) : nsamp;
+    const int stride = (n + ns - 1) / ns;
     Cov<double> c = lower_cov<double>(h);
     if (op64) {
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), grid, dim3(256), 0, st, c, n, stride, px,

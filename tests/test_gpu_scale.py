@@ -2,6 +2,8 @@
 (a) against the oracle on a sub-sample of the queries at C2 (N = 4096, fp64), and (b) at N = 16384 by
 size-independent properties: the interpolation identity f(p_i) = y_i - sigma2_i alpha_i, linearity of
 alpha in the labels, 0 <= v <= k(0), and agreement of the fp32 pipeline with the fp64 pipeline."""
+import os
+
 import numpy as np
 import pytest
 
@@ -207,3 +209,50 @@ def test_c4_slab_of_the_256_cubed_grid_on_a_committed_shell(gpu, ds):
     assert qx[0] == t[rank * (G // world)] and qx[-1] == t[(rank + 1) * (G // world) - 1] and qz[-1] == t[-1]
     src.close()
     dst.close()
+
+
+def test_state_blobs_go_through_rccl_at_world_size_one(gpu, ds, tmp_path):
+    """SURVEY 8e on the one GPU a test box has: torch.distributed with the "nccl" backend (= RCCL) at world size 1, and
+    BOTH state blobs of an N = 2305 model pushed through sharding.broadcast_state on the zero-copy device_blob_as_tensor
+    views of libgpx's own allocations -- the exact call bench.py --mode shard --state broadcast makes on every rank.  RCCL
+    must accept those views (memory it did not allocate) and leave the bytes as they are; a shell that then receives the
+    same bytes and is committed predicts bit-identically to the model.  (What stays unverified without a second GPU: the
+    transport between devices.)  Runs in a child: the process group is created and destroyed there."""
+    import subprocess, sys
+    child = (
+        "import sys, os, importlib, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "gpx = importlib.import_module('gaussian-object-modelling_amd.gpx')\n"
+        "ds = importlib.import_module('gaussian-object-modelling_amd.datasets')\n"
+        "sh = importlib.import_module('gaussian-object-modelling_amd.sharding')\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "n = 2305\n"
+        "x, y, z, lab, s2 = ds.fibonacci_training_set(n)\n"
+        "qx, qy, qz = ds.query_grid(12)\n"
+        "out = {}\n"
+        "for kn, par, prec in (('matern52', (1.0, 1.0), gpx.F32), ('thinplate', (4.0,), gpx.F32), ('matern52', (1.0, 1.0), gpx.F64)):\n"
+        "    kern = gpx.make_kernel(kn, *par)\n"
+        "    src = gpx.Model(kern, x, y, z, lab, s2, precision=prec, prepare_variance=True)\n"
+        "    dst = gpx.Model.shell(kern, n, precision=prec)\n"
+        "    a = [sh.device_blob_as_tensor(torch, *src.state_blob(p), dev) for p in (0, 1)]\n"
+        "    before = [t.clone() for t in a]\n"
+        "    sh.broadcast_state(dist, a, src=0)  # RCCL on memory owned by libgpx\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert all(torch.equal(t, u) for t, u in zip(a, before)), 'broadcast changed the source blobs'\n"
+        "    b = [sh.device_blob_as_tensor(torch, *dst.state_blob(p), dev) for p in (0, 1)]\n"
+        "    for t, u in zip(b, a):\n"
+        "        t.copy_(u)\n"
+        "    sh.broadcast_state(dist, b, src=0)  # ... and on the shell's receive buffers\n"
+        "    torch.cuda.synchronize()\n"
+        "    dst.commit(with_variance=True)\n"
+        "    o1, o2 = src.evaluate(qx, qy, qz, want_v=True), dst.evaluate(qx, qy, qz, want_v=True)\n"
+        "    assert np.array_equal(o1['f'], o2['f']) and np.array_equal(o1['v'], o2['v']), (kn, prec)\n"
+        "    out['%%s/%%d' %% (kn, prec)] = int(sum(t.numel() for t in a))\n"
+        "    src.close(); dst.close()\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('rccl world-1 ok', out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
