@@ -75,7 +75,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
     // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
     launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g,
-                   m->ws_pred, s);
+                   m->ws_pred, s, m->n);
     if (want_basis)
         launch_tangent_basis((long)nq, g, tx, ty, s);
     (void)hipEventRecord(m->ev[EV_M1], s);

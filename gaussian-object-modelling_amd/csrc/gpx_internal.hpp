@@ -126,7 +126,8 @@ void launch_var_rowcorr(bool x_is_f64, bool op64, int n, int np, const void *X, 
 size_t predict_ws_doubles(long nq, int n_chunk_src, bool grad);
 void launch_predict(int prec, const CovHost &cov, int n_pad_pts, const void *px, const void *py, const void *pz,
                     const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
-                    double *grad /*nq x 3 row-major or null*/, double *ws, hipStream_t st);
+                    double *grad /*nq x 3 row-major or null*/, double *ws, hipStream_t st,
+                    int nvalid = 0);  // > 0: points from nvalid on are padding with alpha = 0 and are skipped
 // v[q] = k0 - sum_m partial[m][q]
 void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *partial, long nq, double *v,
                        hipStream_t st);

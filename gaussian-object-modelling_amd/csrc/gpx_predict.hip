@@ -47,7 +47,7 @@ size_t predict_ws_doubles(long nq, int npts, bool grad)
 // parameter is a positive finite number -- anything else (infinite or negative length scales: whatever the reference's
 // formula gives for them) takes the general path
 template <typename T, int KID, bool GRAD, bool FASTEXP>
-__global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int chunk_len,
+__global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int nlim, int chunk_len,
                                                       const T *__restrict__ px, const T *__restrict__ py,
                                                       const T *__restrict__ pz, const T *__restrict__ alpha,
                                                       long nq, const double *__restrict__ qx,
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
     const T ax = va ? (T)qx[qa] : T(0), ay = va ? (T)qy[qa] : T(0), az = va ? (T)qz[qa] : T(0);
     const T bx = vb ? (T)qx[qb] : T(0), by = vb ? (T)qy[qb] : T(0), bz = vb ? (T)qz[qb] : T(0);
     const int j0 = blockIdx.y * chunk_len;
-    const int j1 = min(npts, j0 + chunk_len);
+    // nlim <= npts: points from nlim on are padding (alpha = 0) -- the last tile stops there, in steps of the unroll (a
+    // model of 277 points is padded to 512: without the limit every query pays 512 pair evaluations for 277)
+    const int j1 = min(min(npts, nlim), j0 + chunk_len);
     double fa = 0, fb = 0, gax = 0, gay = 0, gaz = 0, gbx = 0, gby = 0, gbz = 0;
     // the amplitude of the exponential kernels rides on alpha (one multiply per point and tile instead of one per pair)
     const T amp = KID == GPX_KERNEL_THINPLATE ? T(1) : cov.a;
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(256) void predict_kernel(Cov<T> cov, int npts, int 
         tile[tid] = P4<T>{px[jt + tid], py[jt + tid], pz[jt + tid], alpha[jt + tid] * amp};
         __syncthreads();
         T sa = 0, sb = 0, tax = 0, tay = 0, taz = 0, tbx = 0, tby = 0, tbz = 0;
+        const int jn = min(PT, j1 - jt);  // a multiple of 4
 #pragma unroll 4
-        for (int jj = 0; jj < PT; ++jj) {
+        for (int jj = 0; jj < jn; ++jj) {
             const P4<T> p = tile[jj];
             T dxa = ax - p.x, dya = ay - p.y, dza = az - p.z;
             T dxb = bx - p.x, dyb = by - p.y, dzb = bz - p.z;
@@ -185,8 +188,9 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(int chunks, long nq
 template <typename T, bool GRAD>
 static void predict_t(const CovHost &h, int npts, const void *px, const void *py, const void *pz,
                       const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
-                      double *grad, double *ws, hipStream_t st)
+                      double *grad, double *ws, hipStream_t st, int nvalid)
 {
+    const int nlim = nvalid > 0 ? std::min(npts, (nvalid + 3) / 4 * 4) : npts;
     int chunks, chunk_len;
     predict_plan(nq, npts, chunks, chunk_len);
     Cov<T> c = lower_cov<T>(h);
@@ -196,11 +200,11 @@ static void predict_t(const CovHost &h, int npts, const void *px, const void *py
     int direct = chunks > 1 ? 0 : 1;
     if (h.s > 0 && h.s < 1e100) {
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((predict_kernel<T, KID, GRAD, true>), grid, dim3(256), 0, st, c, npts,
-                                                  chunk_len, (const T *)px, (const T *)py, (const T *)pz,
+                                                  nlim, chunk_len, (const T *)px, (const T *)py, (const T *)pz,
                                                   (const T *)alpha, nq, qx, qy, qz, pf, pg, direct));
     } else {
         GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((predict_kernel<T, KID, GRAD, false>), grid, dim3(256), 0, st, c, npts,
-                                                  chunk_len, (const T *)px, (const T *)py, (const T *)pz,
+                                                  nlim, chunk_len, (const T *)px, (const T *)py, (const T *)pz,
                                                   (const T *)alpha, nq, qx, qy, qz, pf, pg, direct));
     }
     if (chunks > 1)
@@ -210,13 +214,13 @@ static void predict_t(const CovHost &h, int npts, const void *px, const void *py
 
 void launch_predict(int prec, const CovHost &cov, int npts, const void *px, const void *py, const void *pz,
                     const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
-                    double *grad, double *ws, hipStream_t st)
+                    double *grad, double *ws, hipStream_t st, int nvalid)
 {
     (void)prec;  // fp64 only (see the header of this file); px, py, pz, alpha are fp64 arrays
     if (grad)
-        predict_t<double, true>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st);
+        predict_t<double, true>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid);
     else
-        predict_t<double, false>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st);
+        predict_t<double, false>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid);
 }
 
 // ---- variance epilogue: v[q] = k(0) - sum_m partial[m][q]  (gp_regressor.hpp:318-319, diagonal only)
