@@ -886,6 +886,38 @@ def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
         assert np.max(np.abs(res["cols"]["%d/%s" % (n, kn)] - ref)) / np.max(np.abs(ref)) < 1e-5, (n, kn)
 
 
+def test_small_model_variance_over_more_than_one_whole_call_batch(gpu, ds):
+    """The small-model kernel takes a whole evaluate call as ONE launch up to 2^21 queries (its only per-query workspace is the
+    fit's coefficient array); a longer call is cut there.  2^21 + 77 device-resident queries on a 150-point model: the two
+    pieces (second one: 77 queries in a single 128-query tile, columns past the last query computed and discarded) equal
+    separate calls on the same points bit for bit, on the model's own stream and on a caller's stream."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    x, y, z, lab, s2 = ds.fibonacci_training_set(150)
+    gm = gpu.Model(gpu.make_kernel("matern52", 1.0, 1.0), x, y, z, lab, s2, precision=gpu.F32, prepare_variance=True)
+    nq = (1 << 21) + 77
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    q = [(torch.rand(nq, generator=gen, dtype=torch.float64) * 2.4 - 1.2).to(dev) for _ in range(3)]
+    f = torch.empty(nq, dtype=torch.float64, device=dev)
+    v = torch.empty_like(f)
+    gm.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+    gm.sync()
+    assert gm.stats["var_gemm_launches"] == 2
+    side = torch.cuda.Stream(device=dev)
+    for lo, hi in ((0, 1000), ((1 << 21) - 50, (1 << 21) + 77), (nq - 77, nq), (12345, 12345 + 4097)):
+        n1 = hi - lo
+        f1 = torch.empty(n1, dtype=torch.float64, device=dev)
+        v1 = torch.empty_like(f1)
+        qq = [t[lo:hi].contiguous() for t in q]
+        torch.cuda.synchronize()
+        gm.evaluate_device(n1, qq[0].data_ptr(), qq[1].data_ptr(), qq[2].data_ptr(), f1.data_ptr(), v1.data_ptr(),
+                           stream=side.cuda_stream)
+        side.synchronize()
+        assert torch.equal(f1, f[lo:hi]) and torch.equal(v1, v[lo:hi]), (lo, hi)
+    assert float(v.min()) > -1e-6 and float(v.max()) <= 1.0 + 1e-9
+    gm.close()
+
+
 def test_variance_tiles_agree(gpu, ds, tmp_path):
     """The one-wave variance tile (gpx_vargemm.hip, default) against its documented fallback, the LDS-staged tile of
     gpx_gemm.hip (GPX_VAR_TILE=3; the switch is read once per process, hence the children): the same contraction
