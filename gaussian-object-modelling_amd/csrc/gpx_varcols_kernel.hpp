@@ -86,6 +86,11 @@ constexpr int VC_MAX_FRAG = VARCOLS_MAX_N / 16;
 // MFMA number M_ (0 .. 4 CF - 1) of row fragment IL_ on the current chunk: k step outermost, so that an accumulator is
 // touched again CF MFMAs later
 #define VC_MFMA1(IL_, M_) VC_MFMA(acc[IL_][(M_) % CF], a[IL_][(M_) / CF], bq[(M_) % CF][(M_) / CF])
+// the first MFMA of a chunk: its B operand may have been written by a VALU move a moment ago (bq = bn at the end of the
+// previous chunk), and hipcc pads no hazard whose consumer sits inside an asm string -- the two wait states between a VALU
+// write and the MFMA that reads it go inside the string, behind every instruction hipcc can place in front of the statement
+#define VC_MFMA1_FIRST(IL_) \
+    asm volatile("s_nop 1\n v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[IL_][0]) : "v"(a[IL_][0]), "v"(bq[0][0]))
 // ties: nothing that reads the named registers may be scheduled above the statement (asm statements keep their order)
 #define VC_TIE_ACC(IL_, NOPS_)                                                                                \
     {                                                                                                         \
@@ -298,7 +303,10 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, (FS * CF <= 24 ? 
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     const int mm = il * NM + m;
-                    VC_MFMA1(il, m);
+                    if (mm == 0)
+                        VC_MFMA1_FIRST(il);
+                    else
+                        VC_MFMA1(il, m);
                     if (mm == 0) {  // the next chunk's points / operand fragments, behind the chunk's first MFMA
                         if constexpr (GEN) {
                             load_points(c + 1);
@@ -356,11 +364,10 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, (FS * CF <= 24 ? 
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
                         const int mm = gi * NM + m;
-                        if (mm == 0 && cs > 0) {
-                            // (bq was written by v_mov just now: wait states between a VALU write and the MFMA that reads it)
-                            asm volatile("s_nop 1");
-                        }
-                        VC_MFMA1(il, m);
+                        if (mm == 0)
+                            VC_MFMA1_FIRST(il);
+                        else
+                            VC_MFMA1(il, m);
                         if (mm == 0 && has_next) {
                             if constexpr (GEN) {
                                 load_points(kc + 1);
@@ -480,6 +487,7 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, (FS * CF <= 24 ? 
 }
 #undef VC_MFMA
 #undef VC_MFMA1
+#undef VC_MFMA1_FIRST
 #undef VC_TIE_ACC
 #undef VC_TIE_D
 
