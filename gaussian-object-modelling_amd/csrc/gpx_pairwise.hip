@@ -213,9 +213,9 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
 // px.. are the model's fp64 points.  R32 = false: p' = p - cen, q' = q - cen in fp64.  R32 = true (fp32 operand kernel):
 // p' = (float)(p - cen) -- the stored centred fp32 points --, q' = (float)(q - cen), and a, b, c are rounded to fp32:
 // exactly the numbers that kernel works with, so that fit = sum_c coef_c b_c holds for what it subtracts.
-constexpr int FIT_PER_LANE = VAR_FIT_SAMPLES / 16;
 
-template <bool R32, int KID>
+// NPER: samples per lane (16 lanes per query): 2, 4 or 8 -- the loops run over exactly the samples in use
+template <bool R32, int KID, int NPER>
 __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, int stride, const double *__restrict__ px,
                                                       const double *__restrict__ py, const double *__restrict__ pz,
                                                       const double *__restrict__ cen, long nq_valid,
@@ -234,10 +234,10 @@ __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, in
         ax = qx[q] - cen[0], ay = qy[q] - cen[1], az = qz[q] - cen[2];
         if constexpr (!P64)
             ax = (double)(float)ax, ay = (double)(float)ay, az = (double)(float)az;
-        double sv[FIT_PER_LANE], kv[FIT_PER_LANE], wv[FIT_PER_LANE];
+        double sv[NPER], kv[NPER], wv[NPER];
         double sw = 0, sws = 0, swk = 0;
 #pragma unroll
-        for (int i = 0; i < FIT_PER_LANE; ++i) {
+        for (int i = 0; i < NPER; ++i) {
             const int l = (sub + 16 * i) * stride;
             sv[i] = kv[i] = wv[i] = 0.0;
             if (l < n) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, in
         const double m1 = sws / sw, a0 = swk / sw;
         double s11 = 0, s1k = 0, s21 = 0, s20 = 0;
 #pragma unroll
-        for (int i = 0; i < FIT_PER_LANE; ++i) {
+        for (int i = 0; i < NPER; ++i) {
             const double p1 = sv[i] - m1, w = wv[i];
             s11 = fma(w * p1, p1, s11);
             s1k = fma(w * p1, kv[i], s1k);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, in
         const double b1 = ok1 ? s1k / s11 : 0.0, al = ok1 ? s21 / s11 : 0.0, be = s20 / sw;
         double s22 = 0, s2k = 0;
 #pragma unroll
-        for (int i = 0; i < FIT_PER_LANE; ++i) {
+        for (int i = 0; i < NPER; ++i) {
             const double p2 = sv[i] * sv[i] - al * (sv[i] - m1) - be, w = wv[i];
             s22 = fma(w * p2, p2, s22);
             s2k = fma(w * p2, kv[i], s2k);
@@ -342,13 +342,28 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
     const int ns = n <= VARCOLS_MAX_N ? std::min(nsamp, 32) : nsamp;
     const int stride = (n + ns - 1) / ns;
     Cov<double> c = lower_cov<double>(h);
+    const int nper = (ns + 15) / 16;  // samples per lane
+#define GPX_FIT_LAUNCH(R32_, NPER_)                                                                                          \
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<R32_, KID, NPER_>), grid, dim3(256), 0, st, c, n, stride, px, py, \
+                                              pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc))
     if (op64) {
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), grid, dim3(256), 0, st, c, n, stride, px,
-                                                  py, pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
+        if (nper <= 2) {
+            GPX_FIT_LAUNCH(false, 2);
+        } else if (nper <= 4) {
+            GPX_FIT_LAUNCH(false, 4);
+        } else {
+            GPX_FIT_LAUNCH(false, 8);
+        }
     } else {
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID>), grid, dim3(256), 0, st, c, n, stride, px,
-                                                  py, pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
+        if (nper <= 2) {
+            GPX_FIT_LAUNCH(true, 2);
+        } else if (nper <= 4) {
+            GPX_FIT_LAUNCH(true, 4);
+        } else {
+            GPX_FIT_LAUNCH(true, 8);
+        }
     }
+#undef GPX_FIT_LAUNCH
 }
 
 // ---- the kernel operand of one variance batch ---------------------------------------------------------------------
