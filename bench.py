@@ -193,6 +193,8 @@ def small_model_roofline(torch, gpx, ds, dev, local_rank):
     f = torch.empty(nq, dtype=torch.float64, device=dev)
     v = torch.empty_like(f)
     out = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "n_query": nq,
+           "traffic": "0.35 GB per 2^21-query launch (queries + fit coefficients read, v written; the operand never exists in memory): "
+                      "profiles/r04_pmc_var_cols.txt (committed rocprofv3 --pmc passes of scripts/c5_stages.py, not this run)",
            "kernel": "var_cols_kernel<2 x 12 fragments, operand formed in the wave> (gpx_varcols_kernel.hpp)",
            "note": "the fp32-input MFMA issues on the vector ALU's slots (profiles/r04_mfma_filler_probe.txt): the fp64 add-back of "
                    "the fit, the accumulator reads and the in-wave evaluation of the operand add to the MFMA time instead of hiding "
