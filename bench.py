@@ -493,7 +493,7 @@ def main():
             if prec != gpx.F64 and os.environ.get("GPX_VAR_TILE", "6") != "3":
                 vkernel = "var_w1_kernel<fit added back in fp64> (predict_var; one wave per workgroup, 128x128 tile, no LDS)"
             if prec == gpx.F32_SPLIT:  # three fp16 MFMA products per algorithmic multiply-add: price against the fp16 peak
-                vkernel, vpeak, achieved = "vsplit_gemm_kernel (3 fp16 MFMA products per fp32 product)", PEAK_F16_MFMA_TFLOPS, 3 * achieved
+                vkernel, vpeak, achieved = "vsplit_gemm_kernel (3 fp16 MFMA products per fp32 product, LDS-DMA staged)", PEAK_F16_MFMA_TFLOPS, 3 * achieved
             roof = {"bound": "mfma", "kernel": vkernel,
                     "achieved": achieved, "peak": vpeak, "unit": "TFLOP/s", "frac": achieved / vpeak,
                     "traffic": pmc_traffic(args, n_train, q_per_launch)[0],

@@ -125,7 +125,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 hipEvent_t *ev2 = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
                 if (ev2)
                     (void)hipEventRecord(ev2[0], s);
-                launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, 2, s,
+                launch_vsplit_gemm(m->X, kqp_buf, np, (int)ntile, (const float *)m->t_dinv, m->ws_partial, (long)qb, s,
                                    np_rows, m->var_fit ? m->d_corr : nullptr, np,
                                    m->var_fit ? (const double *)coef_buf : nullptr, (long)qb, m->d_dinv64, m->d_meta + 3, ldk);
                 if (ev2) {

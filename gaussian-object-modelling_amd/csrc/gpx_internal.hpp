@@ -263,7 +263,7 @@ void launch_kqp_split(bool compute64, const CovHost &cov, float sk, int n, int n
 // colcoef != null: fp64 epilogue (rowcorr, colcoef, dinv64, inv_scale as above; partial holds doubles); else the plain
 // fp32 epilogue with the scaled weights w
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial, long ldp,
-                        int prefetch, hipStream_t st, int m_rows = 0, const double *rowcorr = nullptr, long ldrc = 0,
+                        hipStream_t st, int m_rows = 0, const double *rowcorr = nullptr, long ldrc = 0,
                         const double *colcoef = nullptr, long ldcc = 0, const double *dinv64 = nullptr,
                         const double *inv_scale = nullptr, long ldk = 0);
 

@@ -3,13 +3,14 @@
 //     hi = fp16(s x) on a per-group grid,   lo = fp16(2^11 (s x - hi))      (s: a power of two bringing max|x| below 1)
 // and
 //     x y  ~  hi_x hi_y  +  2^-11 (hi_x lo_y + lo_x hi_y)
-// runs as three v_mfma_f32_32x32x16_f16 into TWO fp32 accumulator sets (main, correction) that are combined
+// runs as three v_mfma_f32_16x16x32_f16 into TWO fp32 accumulator sets (main, correction) that are combined
 // once in the epilogue; the dropped lo*lo term is below 2^-22 relative.  Three fp16 MFMAs move 16x more
 // flops per cycle than one fp32 MFMA, so the contraction costs ~5x fewer matrix-pipe cycles; what remains
 // is a staging problem (the operands are as many bytes as in fp32).
 //
 // Accuracy hinges on how the matrix core adds: the 8 products one lane feeds (8 consecutive k) are summed in
-// fixed point, aligned to the LARGEST of them and truncated 24 bits below it (scripts/mfma_tree_probe.hip), so the
+// fixed point, aligned to the LARGEST of them and truncated 24 bits below it (scripts/mfma_tree_probe.hip, on the
+// 32x32x16 form; the 16x16x32 form shipped since round 4 gives the same errors on the headline workload), so the
 // error scales with the largest product, not with the sum -- and the rows of the inverse factor times the kernel
 // values cancel by 2-3 orders of magnitude (sum|x k| / |sum x k| ~ 700 at N = 1500).  With free-floating fp16 hi
 // parts that cost 7x the native fp32 error (3e-5 k(0) at N = 16384).  Therefore the hi parts of each such group of
@@ -19,7 +20,7 @@
 //
 // Packed layout "P16" of a [rows][K] matrix (K a multiple of 32): per row, per block of 32 k, 64 halves =
 // [hi(32) | lo(32)] = 128 bytes.  A row is exactly as long as in fp32, and one k-tile of a row is one
-// 128-byte line -- so global->register->LDS staging is byte-for-byte the one of gpx_gemm.hip.
+// 128-byte line: eight lanes of one LDS-DMA instruction bring it in.
 //
 //   split_absmax / split_pack : X (fp32, inverse factor)  -> P16, scale chosen on the device
 //   kqp_split                 : Kqp[q][j] = k(|q-p_j|)     -> P16 directly (never stored in fp32)
@@ -30,7 +31,6 @@ namespace gpx {
 
 using half_t = _Float16;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
-using f32x16v = __attribute__((ext_vector_type(16))) float;
 
 // ---- scale + split of the inverse factor ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_absmax_kernel(const float *__restrict__ X, size_t n,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *
         *inv_scale = (double)inv;
 }
 
-// One call = the 8 consecutive k that ONE lane feeds to v_mfma_f32_32x32x16_f16.  The matrix core adds the 8
+// One call = the 8 consecutive k that ONE lane feeds to the fp16 MFMA (32x32x16 and 16x16x32 alike).  The matrix core adds the 8
 // products of such a group in fixed point, aligned to the largest of them and TRUNCATED 24 bits below it
 // (scripts/mfma_tree_probe.hip), i.e. with an error relative to the largest product, not to the (here heavily
 // cancelling) sum.  So the hi halves of a group share one quantum q = ulp_fp16(max |x|): every hi is an integer
@@ -193,7 +193,6 @@ __global__ __launch_bounds__(256) void kqp_split_kernel(Cov<TC> cov, float sk, i
     }
 }
 
-// ---- the contraction -----------------------------------------------------------------------------------
 struct VsplitDev {
     const unsigned char *A;  // P16 X,   row stride 4 K bytes
     const unsigned char *B;  // P16 Kqp, row stride 4 K bytes
@@ -209,350 +208,36 @@ struct VsplitDev {
     long ldrc, ldcc;
 };
 
-// ---- epilogue of both contraction kernels: partial[mt][q] = sum over the tile's 128 rows of acc^2 * w[row] ----
-// (the caller has passed a barrier after its last LDS read: vs_smem is reused here)
-__device__ __forceinline__ void vsplit_epilogue(const VsplitDev &g, const f32x16v (&acc)[2][2], const f32x16v (&cor)[2][2],
-                                                unsigned char *vs_smem, int m0, int n0, int mt, int wm, int wn,
-                                                int lane, int tid)
-{
-    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    if (g.colcoef == nullptr) {
-        float *red = reinterpret_cast<float *>(vs_smem);  // [2][TILE]
-        float colsum[2] = {0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float wr = g.w[row];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float wv = acc[i][j][r] + cor[i][j][r] * (1.0f / 2048.0f);
-                    colsum[j] += wv * wv * wr;
-                }
-            }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float s = colsum[j];
-            s += __shfl_xor(s, 32);
-            if (lane < 32)
-                red[wm * TILE + wn * 64 + j * 32 + lane] = s;
-        }
-        __syncthreads();
-        if (tid < TILE)
-            g.partial[(size_t)mt * g.ldp + n0 + tid] = red[tid] + red[TILE + tid];
-        return;
+// ---- the contraction -----------------------------------------------------------------------------------
+// 128 x 128 tile per workgroup, 4 waves of 64 x 64 = 4 x 4 fragments of v_mfma_f32_16x16x32_f16 (one instruction per
+// 32-deep k-tile and fragment pair; lane l feeds row (l & 15), k = 8 (l >> 4) .. + 8 -- the 8 consecutive k of one
+// split8 group), two accumulator sets (hi*hi; hi*lo + lo*hi), two workgroups per CU.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): a k-tile (one 128-byte P16 block per row) goes from L2 straight into
+// LDS, 1 KiB = 8 rows per wave-instruction, no staging registers and no ds_write_b128 -- which at 13 LDS-path cycles
+// per wave-instruction (MI355X_MICROARCH.md, LDS table) cost the register-staged round-2 kernel 54 % of a CU's LDS time
+// on top of the 33 % its fragment reads take (profiles/r04_pmc_vsplit.txt).  An LDS-DMA write is lane-linear, so rows
+// cannot be padded against bank conflicts; instead the eight 16-byte chunks of a row are permuted: chunk c of row r sits
+// at c ^ ((r >> 1) & 7), applied on the per-lane SOURCE address when writing and on the LDS address when reading.  The 16
+// lanes of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper halves) then fall on
+// 16 distinct 16-byte slots of the 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0).
+//
+// Schedule: two LDS buffers; at the top of k-tile kt the wait + barrier says that tile kt has landed and that everybody
+// is done reading the other buffer; tile kt + 1 is issued into that one and has the whole compute phase (768 matrix-pipe
+// cycles per wave, twice that with the CU's second workgroup) to arrive.  The kernel runs at the chip's power limit
+// (1.7 GHz under it; section 4.3 of DESIGN.md): a software-pipelined form that keeps every LDS read a group ahead of its
+// MFMAs raised the matrix-pipe duty from 68 to 72 % and the clock fell by the same factor.
+//
+// An LDS-DMA write is ordered for the other waves' ds_reads only by the issuing wave's vmcnt wait followed by a barrier;
+// hipcc adds that wait to __syncthreads() for the DMAs it sees in straight-line code but not for those issued before a
+// loop's back-edge, so it is spelled out.
+#define VD_SYNC()                                        \
+    {                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        __syncthreads();                                 \
     }
-    // low-rank correction, as in the COLSQ epilogue of gemm_kernel (gpx_gemm.hip): the B operand holds k - fit, the
-    // product of X with the fit comes back in fp64 from the model's 14 row vectors and the batch's 14 coefficient
-    // vectors; the accumulators return to true units first (inv_scale = 1 / (sx sk), a power of two)
-    double *ds = reinterpret_cast<double *>(vs_smem);
-    double *rowc = ds;                       // [VAR_NCORR][TILE]
-    double *colc = rowc + VAR_NCORR * TILE;  // [VAR_NCORR][TILE]
-    double *roww = colc + VAR_NCORR * TILE;  // [TILE]
-    double *red64 = roww + TILE;             // [2][TILE]
-        const double inv = *g.inv_scale;
-    for (int e = tid; e < 2 * VAR_NCORR * TILE + TILE; e += 256) {
-        double v;
-        if (e < VAR_NCORR * TILE) {
-            v = g.rowcorr[(size_t)(e / TILE) * g.ldrc + m0 + e % TILE];
-        } else if (e < 2 * VAR_NCORR * TILE) {
-            const int e2 = e - VAR_NCORR * TILE;
-            v = g.colcoef[(size_t)(e2 / TILE) * g.ldcc + n0 + e2 % TILE];
-        } else {
-            v = g.dinv64[m0 + e - 2 * VAR_NCORR * TILE];
-        }
-        ds[e] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int lcol = wn * 64 + j * 32 + (lane & 31);
-        double ca[VAR_NCORR];
-#pragma unroll
-        for (int c = 0; c < VAR_NCORR; ++c)
-            ca[c] = colc[c * TILE + lcol];
-        double sj = 0.0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                double w = ((double)acc[i][j][r] + (double)cor[i][j][r] * (1.0 / 2048.0)) * inv;
-#pragma unroll
-                for (int c = 0; c < VAR_NCORR; ++c)
-                    w = fma(ca[c], rowc[c * TILE + lrow], w);
-                sj = fma(w * w, roww[lrow], sj);
-            }
-        sj += __shfl_xor(sj, 32);
-        if (lane < 32)
-            red64[wm * TILE + lcol] = sj;
-    }
-    __syncthreads();
-    if (tid < TILE)
-        g.partial64[(size_t)mt * g.ldp + n0 + tid] = red64[tid] + red64[TILE + tid];
-}
-
-// 128 x 128 tile, 4 waves of 64 x 64 = 2 x 2 fragments of v_mfma_f32_32x32x16_f16; k-tile = 32 (one
-// 128-byte P16 block per row); PF k-tiles of global loads are kept in flight in registers (the matrix work
-// per k-tile is only 768 cycles per wave, far less than a memory round trip).
-template <int PF>
-__global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
-{
-    constexpr int ROWB = 128;          // bytes of one k-tile of a row
-    constexpr int ROWP = ROWB + 16;    // padded LDS row
-    constexpr int TILE_B = TILE * ROWP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char vs_smem[];
-    unsigned char *As = vs_smem;               // [2][TILE][ROWP]
-    unsigned char *Bs = vs_smem + 2 * TILE_B;  // [2][TILE][ROWP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nt = blockIdx.x;
-    const int mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy (long-k) row tiles first
-    const int m0 = mt * TILE, n0 = nt * TILE;
-    const int kt1 = min(g.K, m0 + TILE) / 32;  // X is lower-triangular
-    const size_t ldb = (size_t)g.K * 4;        // bytes per P16 row
-
-    f32x16v acc[2][2], cor[2][2];  // main (hi*hi) and correction (hi*lo + lo*hi, scaled by 2^11) sums
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.0f;
-                cor[i][j][r] = 0.0f;
-            }
-
-    // staging: chunk c = tid + 256 i -> row = (tid >> 3) + 32 i, 16-byte chunk (tid & 7) of the 128-byte block
-    const int s_row = tid >> 3, s_kc = tid & 7;
-    const unsigned char *a_src = g.A + (size_t)(m0 + s_row) * ldb + s_kc * 16;
-    const size_t ldbB = (size_t)g.ldkB * 4;
-    const unsigned char *b_src = g.B + (size_t)(n0 + s_row) * ldbB + s_kc * 16;
-    const int s_lds = s_row * ROWP + s_kc * 16;
-    // two register slots of 4 + 4 chunks, as NAMED scalars: hipcc demotes (even 1-D) uint4 arrays that live across
-    // the two halves of the unrolled loop to scratch memory, which serialises the loads behind the MFMAs
-    uint4 ra0_0, ra0_1, ra0_2, ra0_3, rb0_0, rb0_1, rb0_2, rb0_3;
-    uint4 ra1_0, ra1_1, ra1_2, ra1_3, rb1_0, rb1_1, rb1_2, rb1_3;
-#define VS_LD1(DST, SRC, I, KO) DST = *reinterpret_cast<const uint4 *>((SRC) + (size_t)(32 * (I)) * ldb + (KO))
-#define VS_LD1B(DST, SRC, I, KO) DST = *reinterpret_cast<const uint4 *>((SRC) + (size_t)(32 * (I)) * ldbB + (KO))
-#define VS_GLOAD(SLOT, KT)                                  \
-    {                                                       \
-        const size_t ko_ = (size_t)(KT) * ROWB;             \
-        VS_LD1(ra##SLOT##_0, a_src, 0, ko_);                \
-        VS_LD1B(rb##SLOT##_0, b_src, 0, ko_);                \
-        VS_LD1(ra##SLOT##_1, a_src, 1, ko_);                \
-        VS_LD1B(rb##SLOT##_1, b_src, 1, ko_);                \
-        VS_LD1(ra##SLOT##_2, a_src, 2, ko_);                \
-        VS_LD1B(rb##SLOT##_2, b_src, 2, ko_);                \
-        VS_LD1(ra##SLOT##_3, a_src, 3, ko_);                \
-        VS_LD1B(rb##SLOT##_3, b_src, 3, ko_);                \
-    }
-#define VS_ST1(BASE, BUF, I, V) *reinterpret_cast<uint4 *>((BASE) + (BUF) * TILE_B + s_lds + 32 * (I) * ROWP) = V
-#define VS_SSTORE(SLOT, BUF)                    \
-    {                                           \
-        VS_ST1(As, BUF, 0, ra##SLOT##_0);       \
-        VS_ST1(Bs, BUF, 0, rb##SLOT##_0);       \
-        VS_ST1(As, BUF, 1, ra##SLOT##_1);       \
-        VS_ST1(Bs, BUF, 1, rb##SLOT##_1);       \
-        VS_ST1(As, BUF, 2, ra##SLOT##_2);       \
-        VS_ST1(Bs, BUF, 2, rb##SLOT##_2);       \
-        VS_ST1(As, BUF, 3, ra##SLOT##_3);       \
-        VS_ST1(Bs, BUF, 3, rb##SLOT##_3);       \
-    }
-
-    // fragment addresses: lane l -> row (l & 31), k = 8 (l >> 5) + j  (16 bytes), second MFMA k-step +32 bytes;
-    // the lo halves sit 64 bytes further in the block
-    const int f_off = (lane & 31) * ROWP + (lane >> 5) * 16;
-    const int a_frag = (wm * 64) * ROWP + f_off;
-    const int b_frag = (wn * 64) * ROWP + f_off;
-
-#define VS_COMPUTE(BUF)                                                                                      \
-    {                                                                                                        \
-        const unsigned char *as = As + (BUF) * TILE_B + a_frag;                                              \
-        const unsigned char *bs = Bs + (BUF) * TILE_B + b_frag;                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
-        {                                                                                                    \
-            half8 ah[2], al[2], bh[2], bl[2];                                                                \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                    \
-            {                                                                                                \
-                ah[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWP + kk * 32);                      \
-                al[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWP + kk * 32 + 64);                 \
-                bh[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWP + kk * 32);                      \
-                bl[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWP + kk * 32 + 64);                 \
-            }                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
-            {                                                                                                \
-                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);        \
-                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);        \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-
-    // kt1 is a multiple of 4 (K and the tile are multiples of 128), so the 2-deep variant can be unrolled by
-    // two without a remainder and every register-slot index stays a compile-time constant.
-    if (kt1 > 0) {
-        VS_GLOAD(0, 0);
-        if constexpr (PF == 2)
-            VS_GLOAD(1, 1);
-        VS_SSTORE(0, 0);
-        __syncthreads();
-        if constexpr (PF == 1) {
-            int buf = 0;
-            for (int kt = 0; kt < kt1; ++kt) {
-                VS_GLOAD(0, min(kt + 1, kt1 - 1));
-                VS_COMPUTE(buf);
-                VS_SSTORE(0, buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
-        } else {
-            for (int kt = 0; kt < kt1; kt += 2) {
-                // even tile kt: LDS buffer 0; slot 0 is free -> tile kt+2; slot 1 holds tile kt+1
-                VS_GLOAD(0, min(kt + 2, kt1 - 1));
-                VS_COMPUTE(0);
-                VS_SSTORE(1, 1);
-                __syncthreads();
-                // odd tile kt+1: LDS buffer 1; slot 1 is free -> tile kt+3; slot 0 holds tile kt+2
-                VS_GLOAD(1, min(kt + 3, kt1 - 1));
-                VS_COMPUTE(1);
-                VS_SSTORE(0, 0);
-                __syncthreads();
-            }
-        }
-    }
-#undef VS_COMPUTE
-#undef VS_GLOAD
-#undef VS_SSTORE
-#undef VS_LD1
-#undef VS_LD1B
-#undef VS_ST1
-
-    vsplit_epilogue(g, acc, cor, vs_smem, m0, n0, mt, wm, wn, lane, tid);
-}
-
-// The same tile with the staging done by LDS-DMA (global_load_lds_dwordx4): a k-tile goes from L2 straight into LDS,
-// 1 KiB = 8 rows x 128 bytes per wave-instruction, no staging registers and no ds_write_b128 -- which at 13 LDS-path
-// cycles per wave-instruction (MI355X_MICROARCH.md, LDS table) cost the register-staged kernel above 54 % of the LDS
-// time of a CU, on top of the 33 % its fragment reads take.  An LDS-DMA write is lane-linear, so the rows cannot be padded
-// against bank conflicts; instead the eight 16-byte chunks of a row are permuted, chunk c of row r sits at c ^ ((r >> 1) & 7)
-// -- applied on the per-lane SOURCE address when writing and on the LDS address when reading: the 16 lanes of every
-// ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper halves) then fall on 16 distinct
-// 16-byte slots of the 256-byte bank row.
-// Schedule: two LDS buffers; at the top of k-tile kt the barrier (with the vmcnt(0) hipcc puts in front of it) says that
-// tile kt has landed and that everybody is done reading the other buffer, tile kt + 1 is issued into that one and has
-// the whole compute phase (768 matrix-pipe cycles per wave, twice that with the second workgroup of the CU) to arrive.
-__global__ __launch_bounds__(256, 2) void vsplit_dma_kernel(VsplitDev g)
-{
-    constexpr int ROWB = 128;
-    constexpr int TILE_B = TILE * ROWB;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char vs_smem[];
-    unsigned char *As = vs_smem;               // [2][TILE][ROWB]
-    unsigned char *Bs = vs_smem + 2 * TILE_B;  // [2][TILE][ROWB]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (M0 of the LDS-DMA: scalar)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nt = blockIdx.x;
-    const int mt = (int)(gridDim.y - 1 - blockIdx.y);  // heavy (long-k) row tiles first
-    const int m0 = mt * TILE, n0 = nt * TILE;
-    const int kt1 = min(g.K, m0 + TILE) / 32;  // X is lower-triangular
-    const size_t ldb = (size_t)g.K * 4, ldbB = (size_t)g.ldkB * 4;
-
-    f32x16v acc[2][2], cor[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.0f;
-                cor[i][j][r] = 0.0f;
-            }
-
-    // staging: wave w brings rows 32 w .. 32 w + 31 of both operands, 8 rows per instruction; lane l writes bytes
-    // 16 l of the piece = row (l >> 3), physical chunk (l & 7), and reads the logical chunk that belongs there
-    const int r_loc = lane >> 3;
-    const int c_even = (lane & 7) ^ (r_loc >> 1);  // pieces starting at a row = 0 mod 16; the others: ^ 4
-    const unsigned char *a_src = g.A + (size_t)(m0 + 32 * wave + r_loc) * ldb;
-    const unsigned char *b_src = g.B + (size_t)(n0 + 32 * wave + r_loc) * ldbB;
-    using gptr_t = const __attribute__((address_space(1))) void *;
-    using lptr_t = __attribute__((address_space(3))) void *;
-    const unsigned lds_a = (unsigned)(uintptr_t)As + (unsigned)(32 * wave) * ROWB;  // LDS byte address, wave-uniform
-    const unsigned lds_b = (unsigned)(uintptr_t)Bs + (unsigned)(32 * wave) * ROWB;
-#define VD_STAGE(BUF, KT)                                                                                              \
-    {                                                                                                                  \
-        const size_t ko_ = (size_t)(KT) * ROWB;                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-        {                                                                                                              \
-            const int co_ = (c_even ^ (4 * (i & 1))) * 16;                                                             \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src + (size_t)(8 * i) * ldb + ko_ + co_),                     \
-                                             (lptr_t)(uintptr_t)(lds_a + (BUF) * TILE_B + 8 * i * ROWB), 16, 0, 0);    \
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src + (size_t)(8 * i) * ldbB + ko_ + co_),                    \
-                                             (lptr_t)(uintptr_t)(lds_b + (BUF) * TILE_B + 8 * i * ROWB), 16, 0, 0);    \
-        }                                                                                                              \
-    }
-
-    // fragment addresses: lane l -> row (l & 31), logical chunk (l >> 5) + 2 kk (+ 4: the lo halves), at physical chunk
-    // logical ^ ((l >> 1) & 7); the fragments' row offsets are multiples of 32, which the permutation does not see
-    const int sw = (lane >> 1) & 7;
-    const int row_off = (lane & 31) * ROWB;
-    int f_off[2][2];  // [kk][hi / lo]
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            f_off[kk][h] = row_off + ((((lane >> 5) + 2 * kk + 4 * h) ^ sw) * 16);
-    const int a_frag = (wm * 64) * ROWB, b_frag = (wn * 64) * ROWB;
-
-#define VD_COMPUTE(BUF)                                                                                      \
-    {                                                                                                        \
-        const unsigned char *as = As + (BUF) * TILE_B + a_frag;                                              \
-        const unsigned char *bs = Bs + (BUF) * TILE_B + b_frag;                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
-        {                                                                                                    \
-            half8 ah[2], al[2], bh[2], bl[2];                                                                \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                    \
-            {                                                                                                \
-                ah[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWB + f_off[kk][0]);                 \
-                al[f] = *reinterpret_cast<const half8 *>(as + f * 32 * ROWB + f_off[kk][1]);                 \
-                bh[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWB + f_off[kk][0]);                 \
-                bl[f] = *reinterpret_cast<const half8 *>(bs + f * 32 * ROWB + f_off[kk][1]);                 \
-            }                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
-            {                                                                                                \
-                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cor[i][j], 0, 0, 0);        \
-                cor[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cor[i][j], 0, 0, 0);        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);        \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-
-    // kt1 is a multiple of 4: unrolled by two, so the buffer index is a compile-time constant
-    if (kt1 > 0) {
-        VD_STAGE(0, 0);
-        for (int kt = 0; kt < kt1; kt += 2) {
-            __syncthreads();
-            VD_STAGE(1, kt + 1);
-            VD_COMPUTE(0);
-            __syncthreads();
-            VD_STAGE(0, min(kt + 2, kt1 - 1));  // (past the end: the last tile once more, into the buffer nobody reads again)
-            VD_COMPUTE(1);
-        }
-    }
-#undef VD_STAGE
-#undef VD_COMPUTE
-    __syncthreads();  // the epilogue reuses the buffers
-    vsplit_epilogue(g, acc, cor, vs_smem, m0, n0, mt, wm, wn, lane, tid);
-}
-
-// The same kernel on v_mfma_f32_16x16x32_f16 (one instruction per 32-deep k-tile and fragment pair; a wave's 64 x 64 are
-// 4 x 4 fragments): equal matrix-pipe cycles and LDS reads, but under the chip's power limit this shape holds a higher
-// clock (MI355X_MICROARCH.md, DVFS give-back (7)).  Lane l feeds row (l & 15), k = 8 (l >> 4) .. + 8: still the 8
-// consecutive k of one split8 group.
 using f32x4v = __attribute__((ext_vector_type(4))) float;
-__global__ __launch_bounds__(256, 2) void vsplit_dma16_kernel(VsplitDev g)
+__global__ __launch_bounds__(256, 2) void vsplit_gemm_kernel(VsplitDev g)
 {
     constexpr int ROWB = 128;
     constexpr int TILE_B = TILE * ROWB;
@@ -630,20 +315,18 @@ __global__ __launch_bounds__(256, 2) void vsplit_dma16_kernel(VsplitDev g)
         }                                                                                                    \
     }
 
-    if (kt1 > 0) {
-        VD_STAGE(0, 0);
-        for (int kt = 0; kt < kt1; kt += 2) {
-            __syncthreads();
-            VD_STAGE(1, kt + 1);
-            VD_COMPUTE(0);
-            __syncthreads();
-            VD_STAGE(0, min(kt + 2, kt1 - 1));
-            VD_COMPUTE(1);
-        }
+    VD_STAGE(0, 0);
+    for (int kt = 0; kt < kt1; kt += 2) {  // kt1 is a multiple of 4: the buffer index stays a compile-time constant
+        VD_SYNC();
+        VD_STAGE(1, kt + 1);
+        VD_COMPUTE(0);
+        VD_SYNC();
+        VD_STAGE(0, min(kt + 2, kt1 - 1));  // (past the end: the last tile once more, into the buffer nobody reads again)
+        VD_COMPUTE(1);
     }
 #undef VD_STAGE
 #undef VD_COMPUTE
-    __syncthreads();
+    VD_SYNC();
 
     // ---- epilogue; C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + r ----
     if (g.colcoef == nullptr) {
@@ -668,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void vsplit_dma16_kernel(VsplitDev g)
             if (lane < 16)
                 red[wm * TILE + wn * 64 + j * 16 + lane] = s;
         }
-        __syncthreads();
+        VD_SYNC();
         if (tid < TILE)
             g.partial[(size_t)mt * g.ldp + n0 + tid] = red[tid] + red[TILE + tid];
         return;
@@ -691,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void vsplit_dma16_kernel(VsplitDev g)
         }
         ds[e] = v;
     }
-    __syncthreads();
+    VD_SYNC();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int lcol = wn * 64 + j * 16 + (lane & 15);
@@ -716,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void vsplit_dma16_kernel(VsplitDev g)
         if (lane < 16)
             red64[wm * TILE + lcol] = sj;
     }
-    __syncthreads();
+    VD_SYNC();
     if (tid < TILE)
         g.partial64[(size_t)mt * g.ldp + n0 + tid] = red64[tid] + red64[TILE + tid];
 }
@@ -755,7 +438,7 @@ void launch_kqp_split(bool compute64, const CovHost &h, float sk, int n, int npa
 }
 
 void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, const float *w, void *partial,
-                        long ldp, int prefetch, hipStream_t st, int m_rows, const double *rowcorr, long ldrc,
+                        long ldp, hipStream_t st, int m_rows, const double *rowcorr, long ldrc,
                         const double *colcoef, long ldcc, const double *dinv64, const double *inv_scale, long ldk)
 {
     VsplitDev g;
@@ -769,31 +452,15 @@ void launch_vsplit_gemm(const void *Xp, const void *Kp, int np, int nq_tile, con
     g.ldkB = ldk > 0 ? ldk : np;
     g.w = w;
     g.partial = (float *)partial, g.partial64 = (double *)partial, g.ldp = ldp;
-    constexpr size_t shmem = 4 * (size_t)TILE * (128 + 16), shmem_dma = 4 * (size_t)TILE * 128;
+    constexpr size_t shmem = 4 * (size_t)TILE * 128;  // 2 buffers x 2 operands x 128 rows x 128 bytes
+    static_assert(sizeof(double) * (2 * VAR_NCORR * TILE + 3 * TILE) <= shmem, "the fp64 epilogue reuses the staging buffers");
     static PerDeviceOnce attr_once;  // per device, see gpx_internal.hpp
     attr_once.run([&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_dma_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_dma);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_dma16_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_dma);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel<2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vsplit_gemm_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     });
     dim3 grid(nq_tile / TILE, (m_rows > 0 ? m_rows : np) / TILE);  // rows in the identity padding contribute nothing
-    static const int dma = [] {  // GPX_SPLIT_DMA=0: the register-staged kernel, 2: 16x16x32 fragments
-        const char *e = std::getenv("GPX_SPLIT_DMA");
-        return e ? std::atoi(e) : 2;
-    }();
-    if (dma == 2)
-        hipLaunchKernelGGL(vsplit_dma16_kernel, grid, dim3(256), shmem_dma, st, g);
-    else if (dma)
-        hipLaunchKernelGGL(vsplit_dma_kernel, grid, dim3(256), shmem_dma, st, g);
-    else if (prefetch >= 2)
-        hipLaunchKernelGGL(vsplit_gemm_kernel<2>, grid, dim3(256), shmem, st, g);
-    else
-        hipLaunchKernelGGL(vsplit_gemm_kernel<1>, grid, dim3(256), shmem, st, g);
+    hipLaunchKernelGGL(vsplit_gemm_kernel, grid, dim3(256), shmem, st, g);
 }
 
 }  // namespace gpx

@@ -146,3 +146,36 @@ def test_small_model_variance_kernels_read_no_accumulator_in_flight(gpx, tmp_pat
                     reads += 1
                     assert n_mfma - last_write[r] >= 4 or nops_since[r] >= 16, (sym, text, n_mfma - last_write[r], nops_since[r])
         assert n_mfma >= 500 and reads >= 96, (sym, n_mfma, reads)
+
+
+def test_split_contraction_stages_by_lds_dma_behind_a_vmcnt_wait(gpx, tmp_path, kernels):
+    """gpx_vsplit.hip: the k-tiles of the F32_SPLIT contraction arrive by LDS-DMA (global_load_lds_dwordx4), 8 per wave and
+    tile, with no ds_write in the main loop; two workgroups must fit a CU (<= 256 registers, 64 KiB of LDS each).  An
+    LDS-DMA write becomes visible to the other waves' ds_reads only through the issuing wave's `s_waitcnt vmcnt(0)` before
+    the barrier -- hipcc left that wait out of one of the loop's two barriers until it was written into the source, so every
+    s_barrier of the main loop must have one in the instructions in front of it."""
+    ks = [k for k in kernels if "vsplit_gemm_kernel" in k["name"]]
+    assert len(ks) == 1
+    assert ks[0]["vgpr_count"] + ks[0]["agpr_count"] <= 256, ks[0]
+    dis = codeobj.disassemble(gpx.LIB_PATH, tmp_path, "vsplit_gemm_kernel")
+    assert len(dis) == 1, sorted(dis)
+    lines = next(iter(dis.values()))
+    ins = [(int(l.split("//")[1].split(":")[0], 16), l.split("//")[0].strip(), l) for l in lines if "//" in l]
+    first = ins[0][0]
+    spans = []
+    for a, text, raw in ins:
+        if text.startswith("s_cbranch") and "+0x" in raw:
+            target = first + int(raw[raw.rindex("+0x") + 3:raw.rindex(">")], 16)
+            if target < a and sum(t.startswith("v_mfma") for b, t, _ in ins if target <= b <= a) >= 96:
+                spans.append((a - target, target, a))
+    assert spans
+    _, lo, hi = min(spans)
+    body = [t for b, t, _ in ins if lo <= b <= hi]
+    assert sum(t.startswith("v_mfma_f32_16x16x32_f16") for t in body) == 96   # 2 k-tiles x 16 fragment pairs x 3 products
+    assert sum(t.startswith("global_load_lds_dwordx4") for t in body) == 16  # 2 k-tiles x 2 operands x 4 pieces per wave
+    assert sum(t.startswith("ds_read_b128") for t in body) == 32
+    assert not [t for t in body if t.startswith(("ds_write", "scratch_", "global_load_dword", "buffer_load"))]
+    barriers = [i for i, t in enumerate(body) if t.startswith("s_barrier")]
+    assert len(barriers) == 2
+    for i in barriers:
+        assert any("vmcnt(0)" in t for t in body[max(0, i - 3):i]), body[max(0, i - 3):i + 1]
