@@ -166,6 +166,119 @@ __global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int n, int n4, i
     }
 }
 
+// ---- logLikelihoodGradient (GaussianProcess.h:387-410), CovSE only (the other classes of the reference have no grad()) ----
+// d/d log(l) of entry (a, b), from CovSE::grad's d k / d log(l) = k z, z = r^2 / l^2 (CovSE.h:96-101), carried through the
+// derivative blocks: g = -k / l^2 -> g (z - 2), h = k / l^4 -> h (z - 4).  No noise term: sn does not depend on l.
+__device__ __forceinline__ double dgp_entry_dlogl(const DCov &c, int n, int a, int b, const double *__restrict__ x,
+                                                  const double *__restrict__ y, const double *__restrict__ z)
+{
+    const int ia = a < n ? a : (a - n) / 3, da = a < n ? -1 : (a - n) % 3;
+    const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+    const double u[3] = {x[ia] - x[ib], y[ia] - y[ib], z[ia] - z[ib]};
+    const double r2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+    double k, g, h;
+    dcov_eval(c, r2, k, g, h);
+    const double zz = r2 * c.inv_l2;
+    if (da < 0 && db < 0)
+        return k * zz;
+    if (da >= 0 && db < 0)
+        return g * (zz - 2.0) * u[da];
+    if (da < 0)
+        return -g * (zz - 2.0) * u[db];
+    return -(da == db ? g * (zz - 2.0) : 0.0) - h * (zz - 4.0) * u[da] * u[db];
+}
+
+// the whole matrix dK / d log(l) (both triangles: it is the A operand of a plain product), zero on the padding
+__global__ __launch_bounds__(256) void dgp_dk_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
+                                                     const double *__restrict__ y, const double *__restrict__ z,
+                                                     double *__restrict__ dK)
+{
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll 2
+    for (int r = ty; r < TILE; r += 8) {
+        const int a = blockIdx.y * TILE + r;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int b = blockIdx.x * TILE + tx * 4 + cc;
+            dK[(size_t)a * npad + b] = (a < n4 && b < n4) ? dgp_entry_dlogl(c, n, a, b, x, y, z) : 0.0;
+        }
+    }
+}
+
+// out[a] = alpha_a (dK alpha)_a : one row per workgroup (the host adds the rows up: a fixed order)
+__global__ __launch_bounds__(256) void dgp_quad_rows_kernel(int n4, int npad, const double *__restrict__ dK,
+                                                            const double *__restrict__ alpha, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int a = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n4; b += 256)
+        s += dK[(size_t)a * npad + b] * alpha[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w)
+            red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[a] = alpha[a] * red[0];
+}
+
+// out[m] = (1 / D_m) sum_a X[m][a]^2 : the rows of tr(K^-1) = sum_m |X_m|^2 / D_m, X = L^-1 unit lower
+__global__ __launch_bounds__(256) void dgp_trkinv_rows_kernel(int npad, const double *__restrict__ X,
+                                                              const double *__restrict__ dinv, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int m = blockIdx.x;
+    double s = 0.0;
+    for (int a = threadIdx.x; a <= m; a += 256) {
+        const double v = X[(size_t)m * npad + a];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w)
+            red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[m] = red[0] * dinv[m];
+}
+
+// tr(K^-1 dK) = sum_m (1 / D_m) sum_a X[m][a] Z[a][m] with Z = dK X^T: one 32 x 32 tile (m, a) per workgroup, Z's tile
+// through LDS (it is read across its rows); out[tile] = the tile's share (zero above the diagonal of X)
+__global__ __launch_bounds__(256) void dgp_trace_tiles_kernel(int npad, const double *__restrict__ X,
+                                                              const double *__restrict__ Z, const double *__restrict__ dinv,
+                                                              double *__restrict__ out)
+{
+    __shared__ double zt[32][33];
+    __shared__ double red[256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * 32, a0 = blockIdx.x * 32;
+    double s = 0.0;
+    if (a0 <= m0 + 31) {
+        for (int rr = ty; rr < 32; rr += 8)
+            zt[rr][tx] = Z[(size_t)(a0 + rr) * npad + m0 + tx];  // zt[a - a0][m - m0]
+        __syncthreads();
+        for (int rr = ty; rr < 32; rr += 8) {
+            const int m = m0 + rr, a = a0 + tx;
+            if (a <= m)
+                s += X[(size_t)m * npad + a] * zt[tx][rr] * dinv[m];
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w)
+            red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
 }  // namespace gpx
 
 // ---- host ----------------------------------------------------------------------------------------------------------
@@ -370,6 +483,188 @@ extern "C" int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const doub
     std::swap(*g, *fresh);
     gpx_dgp_destroy(fresh);  // (the old model)
     return GPX_OK;
+}
+
+// ---- logLikelihoodGradient (GaussianProcess.h:387-410) ---------------------------------------------------------------
+// grad_j = 1/2 sum_ab W_ab dK_ab / d theta_j with W = alpha alpha^T - K^-1 (:398-400; the reference's loop over the lower
+// triangle with the diagonal halved, :402-408, is this sum), theta = CovSE's log hyper-parameters (log l, log sf) in
+// getLogHyper()'s order (CovSE.h:108-118).  Taken over the whole 4n x 4n covariance, i.e. the exact gradient of
+// GPX_DGP_FIELD_LOGLIK (the reference mixes the n x n value block with the 4n-long alpha; tests check against central
+// differences of the likelihood).  On the device:
+//   theta = log sf : dK = 2 (K - sn^2 I)  ->  grad = alpha.(y - sn^2 alpha) - (4n - sn^2 tr K^-1),  tr K^-1 = sum_m |X_m|^2 / D_m
+//   theta = log l  : dK built as a matrix (dgp_dk_kernel), Z = dK X^T on the fp64 matrix cores (X = L^-1),
+//                    grad = 1/2 alpha.dK alpha - 1/2 sum_m (X_m . Z_:,m) / D_m
+// Other covariances: GPX_E_BAD_ARG (BaseCovFunc::grad is empty for them, Covs.h:172).
+extern "C" int gpx_dgp_loglik_gradient(const gpx_dgp *cg, double *grad2)
+{
+    if (!cg || !cg->m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!grad2)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    if (cg->cov.id != GPX_KERNEL_SE)
+        return fail(GPX_E_BAD_ARG, "gpx_dgp_loglik_gradient: only GPX_KERNEL_SE has hyper-parameter derivatives (CovSE::grad)");
+    gpx_dgp *g = const_cast<gpx_dgp *>(cg);
+    gpx_model *m = g->m;
+    std::lock_guard<std::mutex> lk(m->mtx);
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int n = g->n_pts, n4 = 4 * n, np = m->npad;
+    const int np_rows = std::min(np, (n4 + TILE - 1) / TILE * TILE);
+    int rc;
+    if ((rc = build_inverse(m)))
+        return rc;
+    const int nt32 = np_rows / 32;
+    const size_t n_part = (size_t)2 * np_rows + (size_t)nt32 * nt32;
+    double *dK = nullptr, *Z = nullptr, *part = nullptr;
+    auto release = [&] {
+        for (double *p : {dK, Z, part})
+            if (p)
+                (void)hipFree(p);
+    };
+    hipError_t he;
+    if ((he = hipMalloc((void **)&dK, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
+        (he = hipMalloc((void **)&Z, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
+        (he = hipMalloc((void **)&part, sizeof(double) * n_part)) != hipSuccess) {
+        release();
+        (void)hipGetLastError();
+        return fail(he == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("gpx_dgp_loglik_gradient: ") + hipGetErrorString(he));
+    }
+    double *p_quad = part, *p_trk = part + np_rows, *p_tr = part + 2 * (size_t)np_rows;
+    hipLaunchKernelGGL(gpx::dgp_dk_kernel, dim3(np_rows / TILE, np_rows / TILE), dim3(256), 0, s, g->cov, n, n4, np, g->d_x,
+                       g->d_y, g->d_z, dK);
+    hipLaunchKernelGGL(gpx::dgp_quad_rows_kernel, dim3(n4), dim3(256), 0, s, n4, np, dK, g->d_alpha, p_quad);
+    hipLaunchKernelGGL(gpx::dgp_trkinv_rows_kernel, dim3(n4), dim3(256), 0, s, np, (const double *)m->X,
+                       (const double *)m->t_dinv, p_trk);
+    GemmArgs a;  // Z[a][m] = sum_b dK[a][b] X[m][b]
+    a.A = dK, a.lda = np;
+    a.B = m->X, a.ldb = np;
+    a.C = Z, a.ldc = np;
+    a.M = np_rows, a.N = np_rows, a.K = np_rows;
+    a.b_lower = 1;
+    launch_gemm(GPX_PREC_F64, a, s);
+    hipLaunchKernelGGL(gpx::dgp_trace_tiles_kernel, dim3(nt32, nt32), dim3(256), 0, s, np, (const double *)m->X, Z,
+                       (const double *)m->t_dinv, p_tr);
+    std::vector<double> h(n_part);
+    he = hipMemcpyAsync(h.data(), part, sizeof(double) * n_part, hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess)
+        he = hipStreamSynchronize(s);
+    if (he == hipSuccess)
+        he = hipGetLastError();
+    release();
+    if (he != hipSuccess)
+        return fail(GPX_E_HIP, std::string("gpx_dgp_loglik_gradient: ") + hipGetErrorString(he));
+    double quad_l = 0, trkinv = 0, tr_l = 0, ya = 0, aa = 0;
+    for (int i = 0; i < n4; ++i) {
+        quad_l += h[i];
+        trkinv += h[(size_t)np_rows + i];
+        ya += g->h_y[i] * g->h_alpha[i];
+        aa += g->h_alpha[i] * g->h_alpha[i];
+    }
+    // rows / columns of the identity padding inside the last 128-block: X = I, Z = 0 there, nothing to leave out
+    for (size_t t = 0; t < (size_t)nt32 * nt32; ++t)
+        tr_l += h[2 * (size_t)np_rows + t];
+    grad2[0] = 0.5 * quad_l - 0.5 * tr_l;
+    grad2[1] = (ya - g->sn2 * aa) - ((double)n4 - g->sn2 * trkinv);
+    return GPX_OK;
+}
+
+// the model again on its own samples with another kernel (the optimiser's setLogHyper + compute()); on failure unchanged
+static int dgp_refit(gpx_dgp *g, const gpx_kernel &k)
+{
+    gpx_dgp *fresh = nullptr;
+    gpx_options o = g->opt;
+    o.device = g->m->device;
+    const int rc = gpx_dgp_create(&k, g->noise, (size_t)g->n_pts, g->in_x.data(), g->in_y.data(), g->in_z.data(),
+                                  g->in_t.data(), g->in_n.data(), &o, &fresh);
+    if (rc)
+        return rc;
+    std::swap(*g, *fresh);
+    gpx_dgp_destroy(fresh);  // (the old model)
+    return GPX_OK;
+}
+
+// ---- Optimisation (RProp), GaussianProcess.h:41-160 ---------------------------------------------------------------------
+extern "C" void gpx_rprop_default(gpx_rprop *d)
+{
+    if (!d)
+        return;
+    d->delta0 = 0.1, d->delta_min = 1e-6, d->delta_max = 50, d->eta_minus = 0.5, d->eta_plus = 1.2;  // Desc::setToDefault :64-73
+    d->eps_stop = 1e-4;
+    d->max_iter = 100;
+}
+
+// Optimisation::find (:86-122) statement by statement, in CovSE's log hyper-parameters p = (log l, log sf): the step
+// sizes adapt on the sign of gradOld .* grad, a sign change zeroes that component of the gradient, the norm test comes
+// AFTER the step (so the step that meets it is never applied), the likelihood of every applied step is compared with
+// the best one and the model ends on the best parameters.  A step onto parameters whose covariance does not factorise
+// ends the search there (the reference's llt() would carry NaNs on); the model is left on the best parameters seen.
+extern "C" int gpx_dgp_optimise(gpx_dgp *g, const gpx_rprop *desc, gpx_rprop_result *res)
+{
+    if (!g || !g->m)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (g->cov.id != GPX_KERNEL_SE)
+        return fail(GPX_E_BAD_ARG, "gpx_dgp_optimise: only GPX_KERNEL_SE has hyper-parameter derivatives (CovSE::grad)");
+    gpx_rprop d;
+    gpx_rprop_default(&d);
+    if (desc)
+        d = *desc;
+    auto sign = [](double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); };
+    auto kernel_of = [](const double *p) {
+        gpx_kernel k{};
+        k.id = GPX_KERNEL_SE;
+        k.p[0] = std::exp(p[1]);  // sf  (sf2 = exp(2 p1), CovSE.h:111)
+        k.p[1] = std::exp(p[0]);  // l   (ell = exp(p0),   CovSE.h:110)
+        return k;
+    };
+    double delta[2] = {d.delta0, d.delta0}, grad_old[2] = {0, 0};
+    double params[2] = {std::log(g->kernel.p[1]), std::log(g->kernel.p[0])};
+    double best_params[2] = {params[0], params[1]};
+    double best = -INFINITY;
+    uint64_t done = 0;
+    int rc = GPX_OK;
+    bool at_best = true;  // the model currently holds best_params
+    for (uint64_t i = 0; i < d.max_iter; ++i) {
+        double grad[2];
+        if ((rc = gpx_dgp_loglik_gradient(g, grad)))
+            break;
+        grad[0] = -grad[0], grad[1] = -grad[1];
+        for (int j = 0; j < 2; ++j) {
+            grad_old[j] *= grad[j];
+            if (grad_old[j] > 0) {
+                delta[j] = std::min(delta[j] * d.eta_plus, d.delta_max);
+            } else if (grad_old[j] < 0) {
+                delta[j] = std::max(delta[j] * d.eta_minus, d.delta_min);
+                grad[j] = 0;
+            }
+            params[j] += -sign(grad[j]) * delta[j];
+        }
+        grad_old[0] = grad[0], grad_old[1] = grad[1];
+        if (std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]) < d.eps_stop)
+            break;
+        if ((rc = dgp_refit(g, kernel_of(params))))
+            break;
+        at_best = false;
+        ++done;
+        if (g->loglik > best) {
+            best = g->loglik;
+            best_params[0] = params[0], best_params[1] = params[1];
+            at_best = true;
+        }
+    }
+    const std::string keep = g_err;
+    if (!at_best) {
+        const int rc2 = dgp_refit(g, kernel_of(best_params));
+        if (!rc)
+            rc = rc2;
+        else
+            g_err = keep;
+    }
+    if (res) {
+        res->loghyper[0] = best_params[0], res->loghyper[1] = best_params[1];
+        res->loglik = done ? best : g->loglik;
+        res->iterations = done;
+    }
+    return rc;
 }
 
 extern "C" int gpx_dgp_evaluate(const gpx_dgp *cg, size_t nq, const double *qx, const double *qy, const double *qz,

@@ -70,7 +70,7 @@ EXPORTS = [
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
     "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
     "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_dgp_create", "gpx_dgp_evaluate", "gpx_dgp_get",
-    "gpx_dgp_add", "gpx_dgp_destroy", "gpx_pcd_read", "gpx_node_training_set",
+    "gpx_dgp_add", "gpx_dgp_destroy", "gpx_dgp_loglik_gradient", "gpx_rprop_default", "gpx_dgp_optimise", "gpx_pcd_read", "gpx_node_training_set",
 ]
 
 _lib = None
@@ -167,6 +167,12 @@ def lib():
     L.gpx_dgp_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.gpx_dgp_destroy.restype = None
     L.gpx_dgp_destroy.argtypes = [vp]
+    L.gpx_dgp_loglik_gradient.restype = C.c_int
+    L.gpx_dgp_loglik_gradient.argtypes = [vp, dp]
+    L.gpx_rprop_default.restype = None
+    L.gpx_rprop_default.argtypes = [vp]
+    L.gpx_dgp_optimise.restype = C.c_int
+    L.gpx_dgp_optimise.argtypes = [vp, vp, vp]
     L.gpx_pcd_read.restype = C.c_long
     L.gpx_pcd_read.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_size_t]
     L.gpx_node_training_set.restype = C.c_int
@@ -428,6 +434,16 @@ class Model:
         return reps
 
 
+class RProp(C.Structure):
+    """gpx_rprop = Optimisation::Desc (include/gp/GaussianProcess.h:49-62)."""
+    _fields_ = [("delta0", C.c_double), ("delta_min", C.c_double), ("delta_max", C.c_double), ("eta_minus", C.c_double),
+                ("eta_plus", C.c_double), ("eps_stop", C.c_double), ("max_iter", C.c_uint64)]
+
+
+class RPropResult(C.Structure):
+    _fields_ = [("loghyper", C.c_double * 2), ("loglik", C.c_double), ("iterations", C.c_uint64)]
+
+
 class DerivativeGP:
     """gpx_dgp_*: the first slice of the reference's second library, gp::GaussianProcess (values + gradients)."""
 
@@ -492,6 +508,25 @@ class DerivativeGP:
         s = Stats()
         _check(self._L.gpx_dgp_get(self._h, 3, C.byref(s), C.sizeof(s)))
         return s.as_dict()
+
+    def loglik_gradient(self):
+        """logLikelihoodGradient (include/gp/GaussianProcess.h:387-410): d loglik / d (log l, log sf); SE models only."""
+        g = np.zeros(2)
+        _check(self._L.gpx_dgp_loglik_gradient(self._h, _dptr(g)))
+        return g
+
+    def optimise(self, **desc):
+        """Optimisation::find (RProp, include/gp/GaussianProcess.h:86-122) in place; keyword arguments override
+        Optimisation::Desc's defaults (delta0, delta_min, delta_max, eta_minus, eta_plus, eps_stop, max_iter)."""
+        d = RProp()
+        self._L.gpx_rprop_default(C.byref(d))
+        for k, v in desc.items():
+            if not hasattr(d, k):
+                raise TypeError("unknown RProp field %r" % k)
+            setattr(d, k, v)
+        r = RPropResult()
+        _check(self._L.gpx_dgp_optimise(self._h, C.byref(d), C.byref(r)))
+        return {"loghyper": np.array([r.loghyper[0], r.loghyper[1]]), "loglik": float(r.loglik), "iterations": int(r.iterations)}
 
     def evaluate(self, qx, qy, qz, want_v=True):
         qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)

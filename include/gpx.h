@@ -286,6 +286,27 @@ int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const double *y, cons
                 const double *normals);
 int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes);
 void gpx_dgp_destroy(gpx_dgp *g);
+/* logLikelihoodGradient (GaussianProcess.h:387-410): grad2 = d logLikelihood / d (log l, log sf), CovSE's log
+ * hyper-parameters in getLogHyper()'s order (CovSE.h:96-118), = 1/2 sum_ab (alpha alpha^T - K^-1)_ab dK_ab (:398-408) over
+ * the whole 4n x 4n covariance -- the exact gradient of GPX_DGP_FIELD_LOGLIK.  GPX_KERNEL_SE models only (the other
+ * covariance classes of that library have an empty grad(), Covs.h:172): GPX_E_BAD_ARG otherwise. */
+int gpx_dgp_loglik_gradient(const gpx_dgp *g, double *grad2);
+/* Optimisation (RProp), GaussianProcess.h:41-160.  gpx_rprop = Optimisation::Desc (:49-62), gpx_rprop_default = its
+ * setToDefault (:64-73).  gpx_dgp_optimise = Optimisation::find (:86-122) on a GPX_KERNEL_SE model: at most max_iter
+ * steps in (log l, log sf), each one a gradient, a step, a refit (setLogHyper + compute()) and a likelihood; the model
+ * ends on the best parameters met (:120).  res (may be NULL): those parameters, their likelihood (the model's own if no
+ * step was applied) and the number of steps applied.  External exclusion against evaluate, as for gpx_dgp_add. */
+typedef struct {
+    double delta0, delta_min, delta_max, eta_minus, eta_plus, eps_stop;
+    uint64_t max_iter;
+} gpx_rprop;
+typedef struct {
+    double loghyper[2]; /* log l, log sf */
+    double loglik;
+    uint64_t iterations;
+} gpx_rprop_result;
+void gpx_rprop_default(gpx_rprop *d);
+int gpx_dgp_optimise(gpx_dgp *g, const gpx_rprop *desc, gpx_rprop_result *res);
 
 /* ---- stand-alone device stages (tests, bench roofline legs) -------------------------------
  * kbuild: K[i][j] = k(|p_i-p_j|) + sigma2_i*delta_ij on the lower block-triangle of an

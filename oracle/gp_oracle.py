@@ -338,6 +338,9 @@ class DerivativeGP:
             nr, pn = _d(np.asarray(normals, dtype=np.float64).reshape(-1))
         self._h = C.c_void_p(self._L.orc_dgp_create(kid, p0, p1, float(noise), self.n, px, py, pz, pt, pn))
         self.info = int(self._L.orc_dgp_info(self._h))
+        self._kernel, self._noise = (kernel[0], p0, p1), float(noise)
+        self._pts = np.stack([x, y, z], axis=1)
+        self._yv = np.concatenate([t, nr if normals is not None else np.zeros(3 * self.n)])
 
     def __del__(self):
         try:
@@ -363,6 +366,41 @@ class DerivativeGP:
     def loglik(self):
         return float(self._L.orc_dgp_loglik(self._h))
 
+    def dK_dlogl(self):
+        """d K / d log(l) of the 4n x 4n covariance of a CovSE model, block by block: CovSE::grad's d k / d log(l) = k z with
+        z = r^2 / l^2 (include/gp/CovSE.h:96-101) carried through the derivative blocks of compute() (GaussianProcess.h:545-567)
+        -- g = -k / l^2 -> g (z - 2), h = k / l^4 -> h (z - 4).  Plain NumPy; checked against central differences of K in
+        tests/test_oracle.py."""
+        assert self._kernel[0] == "se"
+        sf, l = self._kernel[1], self._kernel[2]
+        n, P = self.n, self._pts
+        U = P[:, None, :] - P[None, :, :]          # u = x_a - x_b
+        r2 = (U ** 2).sum(-1)
+        k = sf * sf * np.exp(-0.5 * r2 / l ** 2)
+        g, h, z = -k / l ** 2, k / l ** 4, r2 / l ** 2
+        D = np.zeros((4 * n, 4 * n))
+        D[:n, :n] = k * z
+        for d in range(3):
+            D[n + d::3, :n] = g * (z - 2) * U[:, :, d]           # cov(d_d f(x_a), f(x_b)) = g u_d
+            D[:n, n + d::3] = -g * (z - 2) * U[:, :, d]          # cov(f(x_a), d_e f(x_b)) = -g u_e
+            for e in range(3):
+                D[n + d::3, n + e::3] = -(g * (z - 2) if d == e else 0.0) - h * (z - 4) * U[:, :, d] * U[:, :, e]
+        return D
+
+    def loglik_gradient(self):
+        """logLikelihoodGradient (include/gp/GaussianProcess.h:387-410) in CovSE's log hyper-parameters (log l, log sf)
+        (getLogHyper's order, CovSE.h:108-118): W = alpha alpha^T - K^-1 (:398-400), grad_j = 1/2 sum_ab W_ab dK_ab / d theta_j
+        (:402-408 -- the lower triangle with the diagonal halved is that sum), over the whole 4n x 4n matrix, i.e. the
+        gradient of logLikelihood() :376-385 as this oracle defines it (the reference mixes n x n and 4n: it does not
+        build).  d K / d log(sf) = 2 (K - sn^2 I) (CovSE::grad's 2 k).  tests/test_oracle.py holds it to central differences
+        of loglik."""
+        K = self.K
+        a = self.alpha
+        W = np.outer(a, a) - np.linalg.inv(K)
+        dl = self.dK_dlogl()
+        ds = 2.0 * (K - self._noise ** 2 * np.eye(4 * self.n))
+        return np.array([0.5 * np.sum(W * dl), 0.5 * np.sum(W * ds)])
+
     def evaluate(self, qx, qy, qz, want_v=True):
         qx, px = _d(qx)
         qy, py = _d(qy)
@@ -376,3 +414,45 @@ class DerivativeGP:
         if want_v:
             out["v"] = v
         return out
+
+
+RPROP_DEFAULT = dict(delta0=0.1, delta_min=1e-6, delta_max=50.0, eta_minus=0.5, eta_plus=1.2, eps_stop=1e-4, max_iter=100)
+
+
+def rprop_find(sf, l, noise, x, y, z, target, normals=None, **desc):
+    """Optimisation::find (include/gp/GaussianProcess.h:86-122) restated statement by statement on a CovSE DerivativeGP,
+    in the log hyper-parameters p = (log l, log sf); Desc defaults :64-73.  Returns the best parameters, their likelihood,
+    the number of applied steps and the (params, lik) trace.  A step onto parameters whose matrix is not positive definite
+    ends the search (the reference's llt() would carry NaNs on)."""
+    d = dict(RPROP_DEFAULT, **desc)
+    sign = lambda v: 1.0 if v > 0 else (-1.0 if v < 0 else 0.0)
+    make = lambda p: DerivativeGP(("se", float(np.exp(p[1])), float(np.exp(p[0]))), noise, x, y, z, target, normals)
+    delta = np.ones(2) * d["delta0"]                      # :89
+    grad_old = np.zeros(2)                                # :90
+    params = np.array([np.log(l), np.log(sf)])            # :91 getLogHyper
+    best_params, best = params.copy(), -np.inf            # :92-93
+    gp = make(params)
+    start_lik = gp.loglik
+    trace, done = [], 0
+    for _ in range(int(d["max_iter"])):                   # :96
+        grad = -gp.loglik_gradient()                      # :97
+        grad_old = grad_old * grad                        # :98
+        for j in range(2):                                # :99-108
+            if grad_old[j] > 0:
+                delta[j] = min(delta[j] * d["eta_plus"], d["delta_max"])
+            elif grad_old[j] < 0:
+                delta[j] = max(delta[j] * d["eta_minus"], d["delta_min"])
+                grad[j] = 0.0
+            params[j] += -sign(grad[j]) * delta[j]
+        grad_old = grad.copy()                            # :109
+        if np.linalg.norm(grad_old) < d["eps_stop"]:      # :110
+            break
+        gp = make(params)                                 # :111 setLogHyper, :112 logLikelihood() -> compute()
+        if gp.info != 0:
+            break
+        done += 1
+        lik = gp.loglik
+        trace.append((params.copy(), lik))
+        if lik > best:                                    # :116-119
+            best, best_params = lik, params.copy()
+    return {"loghyper": best_params, "loglik": best if done else start_lik, "iterations": done, "trace": trace}

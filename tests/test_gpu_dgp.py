@@ -131,3 +131,61 @@ def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern):
     assert np.max(np.abs(o1["f"] - ref["f"])) / max(np.max(np.abs(ref["f"])), 0.1) < tol
     gg.close()
     fresh.close()
+
+
+@pytest.mark.parametrize("n", [5, 40, 150])
+def test_likelihood_gradient_against_oracle(gpu, orc, n):
+    """gpx_dgp_loglik_gradient (include/gp/GaussianProcess.h:387-410) against the oracle's NumPy restatement (itself held to
+    central differences of the likelihood in tests/test_oracle.py), and directly against central differences of the device
+    likelihood; models without hyper-parameter derivatives refuse."""
+    P, t, nr = _cloud(n, 500 + n)
+    sf, l, noise = 1.1, 0.7, 0.05
+    og = orc.DerivativeGP(("se", sf, l), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    gg = gpu.DerivativeGP(gpu.make_kernel("se", sf, l), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    ref, got = og.loglik_gradient(), gg.loglik_gradient()
+    assert np.abs(got - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), (got, ref)
+    np.testing.assert_array_equal(got, gg.loglik_gradient())  # fixed summation order: repeatable
+    eps = 1e-5
+    fd = np.zeros(2)
+    for j in range(2):
+        lik = []
+        for sgn in (+1, -1):
+            p = np.array([np.log(l), np.log(sf)])
+            p[j] += sgn * eps
+            gp = gpu.DerivativeGP(gpu.make_kernel("se", float(np.exp(p[1])), float(np.exp(p[0]))), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+            lik.append(gp.loglik)
+            gp.close()
+        fd[j] = (lik[0] - lik[1]) / (2 * eps)
+    assert np.abs(got - fd).max() < 1e-5 * max(1.0, np.abs(fd).max()), (got, fd)
+    gg.evaluate(P[:3, 0], P[:3, 1], P[:3, 2])  # the model is still usable
+    gg.close()
+    tp = gpu.DerivativeGP(gpu.make_kernel("thinplate", 4.0), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    with pytest.raises(gpu.GpxError) as e:
+        tp.loglik_gradient()
+    assert e.value.code == gpu.E_BAD_ARG
+    with pytest.raises(gpu.GpxError):
+        tp.optimise()
+    tp.close()
+
+
+def test_rprop_optimiser_follows_the_reference_loop(gpu, orc):
+    """gpx_dgp_optimise = Optimisation::find (include/gp/GaussianProcess.h:86-122) against the oracle's statement-by-statement
+    restatement: same best parameters, likelihood and number of applied steps (the step sizes are powers of 0.5 / 1.2 times
+    delta0 and only the SIGN of the gradient enters, so the two searches take identical steps unless a gradient component
+    is within rounding of zero), and the model ends refitted on the best parameters."""
+    P, t, nr = _cloud(60, 77)
+    sf, l, noise = 0.9, 0.5, 0.05
+    for kw in ({"max_iter": 12}, {"max_iter": 30, "delta0": 0.05, "eta_plus": 1.3}, {"max_iter": 0}):
+        ref = orc.rprop_find(sf, l, noise, P[:, 0], P[:, 1], P[:, 2], t, nr, **kw)
+        gg = gpu.DerivativeGP(gpu.make_kernel("se", sf, l), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+        start = gg.loglik
+        got = gg.optimise(**kw)
+        assert got["iterations"] == ref["iterations"], (kw, got, ref)
+        assert np.abs(got["loghyper"] - ref["loghyper"]).max() < 1e-12, (kw, got, ref)
+        assert abs(got["loglik"] - ref["loglik"]) < 1e-7 * max(1.0, abs(ref["loglik"]))
+        assert got["loglik"] >= start - 1e-9
+        assert abs(gg.loglik - got["loglik"]) < 1e-9 * max(1.0, abs(got["loglik"]))  # the model sits on the best parameters
+        best = orc.DerivativeGP(("se", float(np.exp(ref["loghyper"][1])), float(np.exp(ref["loghyper"][0]))), noise,
+                                P[:, 0], P[:, 1], P[:, 2], t, nr)
+        assert nerr(gg.alpha, best.alpha) < 1e-9
+        gg.close()

@@ -271,3 +271,38 @@ def test_derivative_gp_oracle_blocks_and_identities(orc, kern):
     # at the training points: the mean reproduces the targets and the gradient the normals (to the noise level)
     at = g.evaluate(P[:, 0], P[:, 1], P[:, 2], want_v=False)
     assert np.abs(at["f"] - t).max() < 5e-3 and np.abs(at["grad"] - nr).max() < 5e-2
+
+
+def test_derivative_gp_oracle_likelihood_gradient_and_rprop(orc):
+    """oracle/gp_oracle.py DerivativeGP.loglik_gradient / rprop_find (include/gp/GaussianProcess.h:387-410, :86-122) pinned
+    WITHOUT the reference (that class does not build): d K / d log l against central differences of K, the gradient
+    against central differences of the likelihood in (log l, log sf), and the RProp search against its own invariants --
+    the result is the best likelihood of the trace, never below the start, and repeatable."""
+    rng = np.random.default_rng(11)
+    n = 12
+    P = rng.normal(size=(n, 3))
+    P /= np.linalg.norm(P, axis=1)[:, None]
+    t, nr = 0.01 * rng.normal(size=n), P.copy()
+    sf, l, noise = 0.9, 0.6, 0.05
+    mk = lambda pl, ps: orc.DerivativeGP(("se", float(np.exp(ps)), float(np.exp(pl))), noise, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    p0 = np.array([np.log(l), np.log(sf)])
+    g = mk(*p0)
+    eps = 1e-6
+    fdK = (mk(p0[0] + eps, p0[1]).K - mk(p0[0] - eps, p0[1]).K) / (2 * eps)
+    assert np.abs(fdK - g.dK_dlogl()).max() < 1e-8 * np.abs(fdK).max()
+    grad = g.loglik_gradient()
+    fd = np.array([(mk(p0[0] + eps, p0[1]).loglik - mk(p0[0] - eps, p0[1]).loglik) / (2 * eps),
+                   (mk(p0[0], p0[1] + eps).loglik - mk(p0[0], p0[1] - eps).loglik) / (2 * eps)])
+    assert np.abs(grad - fd).max() < 1e-6 * max(1.0, np.abs(fd).max()), (grad, fd)
+    r = orc.rprop_find(sf, l, noise, P[:, 0], P[:, 1], P[:, 2], t, nr, max_iter=25)
+    assert r["iterations"] == len(r["trace"]) and 1 <= r["iterations"] <= 25
+    liks = [lk for _, lk in r["trace"]]
+    assert r["loglik"] == max(liks) and r["loglik"] > g.loglik
+    i_best = int(np.argmax(liks))
+    np.testing.assert_array_equal(r["loghyper"], r["trace"][i_best][0])
+    r2 = orc.rprop_find(sf, l, noise, P[:, 0], P[:, 1], P[:, 2], t, nr, max_iter=25)
+    np.testing.assert_array_equal(r["loghyper"], r2["loghyper"])
+    # a long search ends where the likelihood is flatter than at the start
+    r3 = orc.rprop_find(sf, l, noise, P[:, 0], P[:, 1], P[:, 2], t, nr, max_iter=100)
+    gb = mk(*r3["loghyper"]).loglik_gradient()
+    assert r3["loglik"] >= r["loglik"] and np.linalg.norm(gb) < 0.5 * np.linalg.norm(grad), (gb, grad)
