@@ -465,6 +465,15 @@ void factorize_matrix(gpx_model *m)
     factorize(m);
 }
 void solve_factored(gpx_model *m, void *b, void *ytmp, void *x) { solve_ldl(m, b, ytmp, x, false); }
+static void factor_append_rows(gpx_model *m, int t0);
+// the same on a matrix whose leading t0 rows / columns (a multiple of 128) already hold a factor -- L, D, 1/D and the
+// inverse diagonal blocks -- and whose rows behind them have just been filled: the rank-n append of gpx_model_update
+void factorize_matrix_append(gpx_model *m, int t0)
+{
+    factor_init(m->prec);
+    factor_append_rows(m, t0);
+    factorize(m, t0);
+}
 
 // Rank-n update, rows [t0, npad): the kernel rows have just been built; the columns [0, t0) hold the old factor.
 // Column block by column block: W = A_rows,j Linv_j^T (to the workspace), L_rows,j = W D_j^-1 (in place), then

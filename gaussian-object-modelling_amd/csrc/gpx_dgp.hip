@@ -46,12 +46,15 @@ __device__ __forceinline__ void dcov_eval(const DCov &c, double r2, double &k, d
     }
 }
 
-// entry (a, b) of the 4N x 4N covariance; index a: [0, n) values, n + 3 i + d derivative d of point i
-__device__ __forceinline__ double dgp_entry(const DCov &c, int n, int a, int b, const double *__restrict__ x,
+// A row of the covariance stands for one observation, coded 4 i + c: c = 0 the value at point i, c = 1..3 its derivative
+// d = c - 1.  A model made by gpx_dgp_create holds them in the reference's order [values (n) | d/dx d/dy d/dz of point 0 |
+// ...] (GaussianProcess.h:553-567); rows appended by gpx_dgp_add follow behind the old ones, so the order is kept as a
+// table (row[a], npad entries, -1 on the padding) and not as a formula.
+__device__ __forceinline__ double dgp_entry(const DCov &c, int ca, int cb, bool same_row, const double *__restrict__ x,
                                             const double *__restrict__ y, const double *__restrict__ z, double sn2)
 {
-    const int ia = a < n ? a : (a - n) / 3, da = a < n ? -1 : (a - n) % 3;
-    const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+    const int ia = ca >> 2, da = (ca & 3) - 1;
+    const int ib = cb >> 2, db = (cb & 3) - 1;
     const double u[3] = {x[ia] - x[ib], y[ia] - y[ib], z[ia] - z[ib]};
     double k, g, h;
     dcov_eval(c, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], k, g, h);
@@ -64,30 +67,44 @@ __device__ __forceinline__ double dgp_entry(const DCov &c, int n, int a, int b, 
         v = -g * u[db];  // d/dx_{b,e} k(x_a, x_b)
     else
         v = -(da == db ? g : 0.0) - h * u[da] * u[db];
-    return a == b ? v + sn2 : v;
+    return same_row ? v + sn2 : v;
 }
 
-__global__ __launch_bounds__(256) void dgp_kbuild_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
-                                                         const double *__restrict__ y, const double *__restrict__ z,
-                                                         double sn2, double *__restrict__ K)
+// tiles of the lower block triangle from tile row t_first on (0: the whole matrix; > 0: the rows of an append)
+__global__ __launch_bounds__(256) void dgp_kbuild_kernel(DCov c, int t_first, int npad, const int *__restrict__ row,
+                                                         const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, double sn2, double *__restrict__ K)
 {
     int ti, tj;
-    tri_decode((int)blockIdx.x, ti, tj);
+    tri_decode((int)blockIdx.x + t_first * (t_first + 1) / 2, ti, tj);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll 2
     for (int r = ty; r < TILE; r += 8) {
         const int a = ti * TILE + r;
+        const int ca = row[a];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int b = tj * TILE + tx * 4 + cc;
+            const int cb = row[b];
             double v;
-            if (a < n4 && b < n4)
-                v = dgp_entry(c, n, a, b, x, y, z, sn2);
+            if (ca >= 0 && cb >= 0)
+                v = dgp_entry(c, ca, cb, a == b, x, y, z, sn2);
             else
                 v = a == b ? 1.0 : 0.0;  // identity on the padding
             K[(size_t)a * npad + b] = v;
         }
     }
+}
+
+// alpha from the model's row order into the reference's layout [values | derivatives point by point] (what f() reads)
+__global__ __launch_bounds__(256) void dgp_alpha_layout_kernel(int n, int n4, const int *__restrict__ row,
+                                                               const double *__restrict__ a_rows, double *__restrict__ a_ref)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= n4)
+        return;
+    const int code = row[a], i = code >> 2, cmp = code & 3;
+    a_ref[cmp == 0 ? i : n + 3 * i + cmp - 1] = a_rows[a];
 }
 
 // value and gradient of the posterior mean at the queries: out[q][0..3] = k_star(q) (4 x 4N) alpha.
@@ -136,11 +153,11 @@ __global__ __launch_bounds__(256) void dgp_predict_kernel(DCov c, int n, const d
 }
 
 // operand of the variance contraction: row 0 of k_star for every query, Kq[q][b] = cov(f(q), observation b)
-__global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
-                                                        const double *__restrict__ y, const double *__restrict__ z,
-                                                        long nq_valid, const double *__restrict__ qx,
-                                                        const double *__restrict__ qy, const double *__restrict__ qz,
-                                                        double *__restrict__ Kq)
+__global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int npad, const int *__restrict__ row,
+                                                        const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, long nq_valid,
+                                                        const double *__restrict__ qx, const double *__restrict__ qy,
+                                                        const double *__restrict__ qz, double *__restrict__ Kq)
 {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long q0 = (long)blockIdx.y * TILE;
@@ -153,9 +170,10 @@ __global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int n, int n4, i
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int b = b0 + cc;
+            const int cb = row[b];
             double v = 0.0;
-            if (live && b < n4) {
-                const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+            if (live && cb >= 0) {
+                const int ib = cb >> 2, db = (cb & 3) - 1;
                 const double u[3] = {ax - x[ib], ay - y[ib], az - z[ib]};
                 double k, g, h;
                 dcov_eval(c, u[0] * u[0] + u[1] * u[1] + u[2] * u[2], k, g, h);
@@ -169,11 +187,11 @@ __global__ __launch_bounds__(256) void dgp_kstar_kernel(DCov c, int n, int n4, i
 // ---- logLikelihoodGradient (GaussianProcess.h:387-410), CovSE only (the other classes of the reference have no grad()) ----
 // d/d log(l) of entry (a, b), from CovSE::grad's d k / d log(l) = k z, z = r^2 / l^2 (CovSE.h:96-101), carried through the
 // derivative blocks: g = -k / l^2 -> g (z - 2), h = k / l^4 -> h (z - 4).  No noise term: sn does not depend on l.
-__device__ __forceinline__ double dgp_entry_dlogl(const DCov &c, int n, int a, int b, const double *__restrict__ x,
+__device__ __forceinline__ double dgp_entry_dlogl(const DCov &c, int ca, int cb, const double *__restrict__ x,
                                                   const double *__restrict__ y, const double *__restrict__ z)
 {
-    const int ia = a < n ? a : (a - n) / 3, da = a < n ? -1 : (a - n) % 3;
-    const int ib = b < n ? b : (b - n) / 3, db = b < n ? -1 : (b - n) % 3;
+    const int ia = ca >> 2, da = (ca & 3) - 1;
+    const int ib = cb >> 2, db = (cb & 3) - 1;
     const double u[3] = {x[ia] - x[ib], y[ia] - y[ib], z[ia] - z[ib]};
     const double r2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
     double k, g, h;
@@ -189,18 +207,20 @@ __device__ __forceinline__ double dgp_entry_dlogl(const DCov &c, int n, int a, i
 }
 
 // the whole matrix dK / d log(l) (both triangles: it is the A operand of a plain product), zero on the padding
-__global__ __launch_bounds__(256) void dgp_dk_kernel(DCov c, int n, int n4, int npad, const double *__restrict__ x,
-                                                     const double *__restrict__ y, const double *__restrict__ z,
-                                                     double *__restrict__ dK)
+__global__ __launch_bounds__(256) void dgp_dk_kernel(DCov c, int npad, const int *__restrict__ row,
+                                                     const double *__restrict__ x, const double *__restrict__ y,
+                                                     const double *__restrict__ z, double *__restrict__ dK)
 {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll 2
     for (int r = ty; r < TILE; r += 8) {
         const int a = blockIdx.y * TILE + r;
+        const int ca = row[a];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int b = blockIdx.x * TILE + tx * 4 + cc;
-            dK[(size_t)a * npad + b] = (a < n4 && b < n4) ? dgp_entry_dlogl(c, n, a, b, x, y, z) : 0.0;
+            const int cb = row[b];
+            dK[(size_t)a * npad + b] = (ca >= 0 && cb >= 0) ? dgp_entry_dlogl(c, ca, cb, x, y, z) : 0.0;
         }
     }
 }
@@ -287,11 +307,15 @@ struct gpx_dgp {
     int n_pts = 0;
     gpx::DCov cov{};
     double sn2 = 0, k0 = 0;
-    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_alpha = nullptr;  // n_pts, n_pts, n_pts, 4 n_pts
-    std::vector<double> h_alpha, h_y;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;  // n_pts each
+    double *d_alpha = nullptr;                               // 4 n_pts, the reference's layout (f() reads it)
+    int *d_row = nullptr;                                    // npad: observation code of every matrix row, -1 on the padding
+    std::vector<int> h_row;                                  // 4 n_pts
+    std::vector<double> h_alpha, h_alpha_rows, h_y;          // reference layout; row order; targets in row order (padded)
     double loglik = 0;
     int n_negative = 0;
-    // what create was given (gpx_dgp_add rebuilds on the union)
+    int appended_from = 0;  // rows the last gpx_dgp_add carried over from the old factor (0: built from scratch)
+    // what create / add were given (the optimiser refits on them)
     gpx_kernel kernel{};
     double noise = 0;
     gpx_options opt{};
@@ -307,7 +331,7 @@ extern "C" void gpx_dgp_destroy(gpx_dgp *g)
         (void)hipGetDevice(&prev);
         (void)hipSetDevice(g->m->device);
         (void)hipStreamSynchronize(g->m->stream);
-        for (double *p : {g->d_x, g->d_y, g->d_z, g->d_alpha})
+        for (void *p : {(void *)g->d_x, (void *)g->d_y, (void *)g->d_z, (void *)g->d_alpha, (void *)g->d_row})
             if (p)
                 (void)hipFree(p);
         if (prev >= 0)
@@ -317,28 +341,13 @@ extern "C" void gpx_dgp_destroy(gpx_dgp *g)
     delete g;
 }
 
-extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y,
-                              const double *z, const double *target, const double *normals, const gpx_options *opt,
-                              gpx_dgp **out)
+// Everything after the arguments are checked.  old == null: compute() from scratch on the n samples.  old != null (the
+// first old->n_pts samples are old's, in its row order): the leading t0 = 128 * floor(4 n_old / 128) rows and columns of old's
+// factor -- L, D and the inverse diagonal blocks -- are carried over, the rows behind them are built and appended to it
+// (factorize_matrix_append: the rank-n update of the first library), so the cost is that of the new rows only.
+static int dgp_build(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y, const double *z,
+                     const double *target, const double *normals, const gpx_options *opt, const gpx_dgp *old, gpx_dgp **out)
 {
-    if (!out)
-        return fail(GPX_E_NULL, "Empty Model pointer");
-    if (!kernel)
-        return fail(GPX_E_NULL, "Empty kernel pointer");
-    if (n == 0)
-        return fail(GPX_E_EMPTY, "No training data available");  // GaussianProcess.h:239
-    if (!x || !y || !z || !target)
-        return fail(GPX_E_NULL, "Empty data pointer");
-    if (kernel->id != GPX_KERNEL_SE && kernel->id != GPX_KERNEL_THINPLATE)
-        return fail(GPX_E_BAD_ARG, "gpx_dgp: kernel must be GPX_KERNEL_SE or GPX_KERNEL_THINPLATE");
-    if (!(noise >= 0.0) || !std::isfinite(noise))
-        return fail(GPX_E_BAD_ARG, "noise must be finite and non-negative");  // Desc::isValid, GaussianProcess.h:216-222
-    if (n > ((size_t)1 << 18))
-        return fail(GPX_E_BAD_ARG, "n too large");
-    for (size_t i = 0; i < n; ++i)
-        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i]) || !std::isfinite(target[i]) ||
-            (normals && (!std::isfinite(normals[3 * i]) || !std::isfinite(normals[3 * i + 1]) || !std::isfinite(normals[3 * i + 2]))))
-            return fail(GPX_E_NAN_INPUT, "non-finite value in the training data");
     // the engine: an fp64 shell of order 4n on the requested device (its kernel id is irrelevant: nothing of the first
     // library's kernel-specific code runs on it)
     gpx_options o{};
@@ -374,6 +383,8 @@ extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, 
         return code;
     };
     const int n4 = 4 * (int)n, np = m->npad;
+    const int n_old = old ? old->n_pts : 0;
+    const int t0 = old ? 4 * n_old / TILE * TILE : 0;
     hipStream_t s = m->stream;
 #define DGP_CHK(expr)                                                                                       \
     do {                                                                                                    \
@@ -388,37 +399,66 @@ extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, 
     DGP_CHK(hipMalloc((void **)&g->d_y, sizeof(double) * n));
     DGP_CHK(hipMalloc((void **)&g->d_z, sizeof(double) * n));
     DGP_CHK(hipMalloc((void **)&g->d_alpha, sizeof(double) * (size_t)np));
+    DGP_CHK(hipMalloc((void **)&g->d_row, sizeof(int) * (size_t)np));
     DGP_CHK(hipMemcpyAsync(g->d_x, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
     DGP_CHK(hipMemcpyAsync(g->d_y, y, sizeof(double) * n, hipMemcpyHostToDevice, s));
     DGP_CHK(hipMemcpyAsync(g->d_z, z, sizeof(double) * n, hipMemcpyHostToDevice, s));
-    // targets as SampleSet lays them out (src/gp/SampleSet.cpp:27-35): values, then the normals point by point
-    g->h_y.assign((size_t)np, 0.0);
-    for (size_t i = 0; i < n; ++i) {
-        g->h_y[i] = target[i];
-        if (normals)
+    // row order: old's rows first (a fresh model: none), then [values | derivatives point by point] of the other samples
+    // -- for a fresh model the layout of compute() (:553-567) and SampleSet (src/gp/SampleSet.cpp:27-35)
+    std::vector<int> hrow((size_t)np, -1);
+    if (old)
+        std::copy(old->h_row.begin(), old->h_row.end(), hrow.begin());
+    {
+        const int n_new = (int)n - n_old;
+        for (int i = 0; i < n_new; ++i) {
+            hrow[(size_t)4 * n_old + i] = 4 * (n_old + i);
             for (int d = 0; d < 3; ++d)
-                g->h_y[n + 3 * i + d] = normals[3 * i + d];
+                hrow[(size_t)4 * n_old + n_new + 3 * i + d] = 4 * (n_old + i) + 1 + d;
+        }
     }
+    g->h_row.assign(hrow.begin(), hrow.begin() + n4);
+    g->h_y.assign((size_t)np, 0.0);
+    for (int a = 0; a < n4; ++a) {
+        const int i = hrow[a] >> 2, c = hrow[a] & 3;
+        g->h_y[a] = c == 0 ? target[i] : (normals ? normals[3 * i + c - 1] : 0.0);
+    }
+    DGP_CHK(hipMemcpyAsync(g->d_row, hrow.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, s));
     DGP_CHK(hipMemcpyAsync(m->t_b, g->h_y.data(), sizeof(double) * (size_t)np, hipMemcpyHostToDevice, s));
     DGP_CHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
     // compute(): the covariance matrix (GaussianProcess.h:545-567) and its factorisation (:578)
-    const int nt = np / TILE;
+    const int nt = np / TILE, tf = t0 / TILE;
     (void)hipEventRecord(m->ev[EV_T0], s);
-    hipLaunchKernelGGL(gpx::dgp_kbuild_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, g->cov, (int)n, n4, np, g->d_x,
-                       g->d_y, g->d_z, g->sn2, (double *)m->Kmat);
+    if (t0 > 0) {
+        const gpx_model *mo = old->m;
+        DGP_CHK(hipStreamSynchronize(mo->stream));
+        DGP_CHK(hipMemcpy2DAsync(m->Kmat, sizeof(double) * np, mo->Kmat, sizeof(double) * mo->npad, sizeof(double) * t0, t0,
+                                 hipMemcpyDeviceToDevice, s));
+        DGP_CHK(hipMemcpyAsync(m->linv, mo->linv, sizeof(double) * (size_t)tf * TILE * TILE, hipMemcpyDeviceToDevice, s));
+        DGP_CHK(hipMemcpyAsync(m->t_d, mo->t_d, sizeof(double) * t0, hipMemcpyDeviceToDevice, s));
+        DGP_CHK(hipMemcpyAsync(m->t_dinv, mo->t_dinv, sizeof(double) * t0, hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(gpx::dgp_kbuild_kernel, dim3(nt * (nt + 1) / 2 - tf * (tf + 1) / 2), dim3(256), 0, s, g->cov, tf, np,
+                       g->d_row, g->d_x, g->d_y, g->d_z, g->sn2, (double *)m->Kmat);
     (void)hipEventRecord(m->ev[EV_KBUILD], s);
-    factorize_matrix(m);
+    if (t0 > 0)
+        factorize_matrix_append(m, t0);
+    else
+        factorize_matrix(m);
+    g->appended_from = t0;
     (void)hipEventRecord(m->ev[EV_FACTOR], s);
     // update_alpha(): alpha = K^-1 y (:505-528)
     solve_factored(m, m->t_b, m->t_yv, m->t_xs);
-    DGP_CHK(hipMemcpyAsync(g->d_alpha, m->t_xs, sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(gpx::dgp_alpha_layout_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, (int)n, n4, g->d_row,
+                       (const double *)m->t_xs, g->d_alpha);
     (void)hipEventRecord(m->ev[EV_SOLVE], s);
     int info[8];
     std::vector<double> hd((size_t)n4);
     g->h_alpha.assign((size_t)n4, 0.0);
+    g->h_alpha_rows.assign((size_t)n4, 0.0);
     DGP_CHK(hipMemcpyAsync(info, m->d_info, sizeof(info), hipMemcpyDeviceToHost, s));
     DGP_CHK(hipMemcpyAsync(hd.data(), m->t_d, sizeof(double) * (size_t)n4, hipMemcpyDeviceToHost, s));
     DGP_CHK(hipMemcpyAsync(g->h_alpha.data(), g->d_alpha, sizeof(double) * (size_t)n4, hipMemcpyDeviceToHost, s));
+    DGP_CHK(hipMemcpyAsync(g->h_alpha_rows.data(), m->t_xs, sizeof(double) * (size_t)n4, hipMemcpyDeviceToHost, s));
     DGP_CHK(hipStreamSynchronize(s));
     DGP_CHK(hipGetLastError());
 #undef DGP_CHK
@@ -439,7 +479,7 @@ extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, 
     // logLikelihood() (:376-385) with the determinant of the WHOLE matrix: -y.alpha / 2 - log det / 2 - 4n log(2 pi) / 2
     double quad = 0, logdet = 0;
     for (int i = 0; i < n4; ++i) {
-        quad += g->h_y[i] * g->h_alpha[i];
+        quad += g->h_y[i] * g->h_alpha_rows[i];
         logdet += std::log(hd[i]);
     }
     g->loglik = -0.5 * quad - 0.5 * logdet - 0.5 * n4 * std::log(2.0 * M_PI);
@@ -453,11 +493,39 @@ extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, 
     return GPX_OK;
 }
 
-// add_patterns (GaussianProcess.h:340-374).  The reference appends rows to its Cholesky factor from cf->get() alone, i.e.
-// it treats the new samples as value observations and leaves the derivative blocks of compute() (:545-567) out -- a
-// factor that no longer belongs to the matrix f() and var() assume.  Here the model is rebuilt on the union of the old
-// and the new samples, which is what compute() would give for that sample set: the results equal those of
-// gpx_dgp_create on the concatenated data bit for bit.  On failure the model is unchanged.
+extern "C" int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y,
+                              const double *z, const double *target, const double *normals, const gpx_options *opt,
+                              gpx_dgp **out)
+{
+    if (!out)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (!kernel)
+        return fail(GPX_E_NULL, "Empty kernel pointer");
+    if (n == 0)
+        return fail(GPX_E_EMPTY, "No training data available");  // GaussianProcess.h:239
+    if (!x || !y || !z || !target)
+        return fail(GPX_E_NULL, "Empty data pointer");
+    if (kernel->id != GPX_KERNEL_SE && kernel->id != GPX_KERNEL_THINPLATE)
+        return fail(GPX_E_BAD_ARG, "gpx_dgp: kernel must be GPX_KERNEL_SE or GPX_KERNEL_THINPLATE");
+    if (!(noise >= 0.0) || !std::isfinite(noise))
+        return fail(GPX_E_BAD_ARG, "noise must be finite and non-negative");  // Desc::isValid, GaussianProcess.h:216-222
+    if (n > ((size_t)1 << 18))
+        return fail(GPX_E_BAD_ARG, "n too large");
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i]) || !std::isfinite(target[i]) ||
+            (normals && (!std::isfinite(normals[3 * i]) || !std::isfinite(normals[3 * i + 1]) || !std::isfinite(normals[3 * i + 2]))))
+            return fail(GPX_E_NAN_INPUT, "non-finite value in the training data");
+    return dgp_build(kernel, noise, n, x, y, z, target, normals, opt, nullptr, out);
+}
+
+// add_patterns (GaussianProcess.h:340-374): the new samples' rows are appended to the existing factor, as the reference
+// appends rows to its Cholesky factor (:356-368: k = L^-1 k, L(j, :) = k^T, L(j, j) = sqrt(kappa - k.k)) -- here for ALL the
+// rows a sample brings (its value and its three derivatives; the reference appends value rows only, a factor that no
+// longer belongs to the matrix f() and var() assume) and block-wise on the matrix cores: the leading 128 * floor(4 n_old /
+// 128) rows and columns of the old factor stay, the rest is built and eliminated against them.  The model equals
+// gpx_dgp_create on the concatenated data to rounding (its rows stand in another order; alpha, f and var come back in the
+// reference's layout either way).  Fewer than 128 old rows, or GPX_DGP_APPEND=0: rebuilt from scratch.  On failure the
+// model is unchanged.
 extern "C" int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const double *y, const double *z,
                            const double *target, const double *normals)
 {
@@ -468,16 +536,28 @@ extern "C" int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const doub
     if (!x || !y || !z || !target)
         return fail(GPX_E_NULL, "Empty data pointer");
     const size_t n0 = (size_t)g->n_pts, n = n0 + n_new;
+    if (n > ((size_t)1 << 18))
+        return fail(GPX_E_BAD_ARG, "n too large");
+    for (size_t i = 0; i < n_new; ++i)
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i]) || !std::isfinite(target[i]) ||
+            (normals && (!std::isfinite(normals[3 * i]) || !std::isfinite(normals[3 * i + 1]) || !std::isfinite(normals[3 * i + 2]))))
+            return fail(GPX_E_NAN_INPUT, "non-finite value in the training data");
     std::vector<double> ux(g->in_x), uy(g->in_y), uz(g->in_z), ut(g->in_t), un(g->in_n);
     ux.insert(ux.end(), x, x + n_new), uy.insert(uy.end(), y, y + n_new), uz.insert(uz.end(), z, z + n_new);
     ut.insert(ut.end(), target, target + n_new);
     un.resize(3 * n, 0.0);
     if (normals)
         std::copy(normals, normals + 3 * n_new, un.begin() + 3 * n0);
+    const char *app_env = std::getenv("GPX_DGP_APPEND");  // 0: rebuild on the union (tests compare the two)
+    const bool append = (!app_env || std::atoi(app_env) != 0) && 4 * n0 >= (size_t)TILE;
     gpx_dgp *fresh = nullptr;
     gpx_options o = g->opt;
     o.device = g->m->device;
-    const int rc = gpx_dgp_create(&g->kernel, g->noise, n, ux.data(), uy.data(), uz.data(), ut.data(), un.data(), &o, &fresh);
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g->m->mtx);  // the old factor is read
+        rc = dgp_build(&g->kernel, g->noise, n, ux.data(), uy.data(), uz.data(), ut.data(), un.data(), &o, append ? g : nullptr, &fresh);
+    }
     if (rc)
         return rc;
     std::swap(*g, *fresh);
@@ -530,9 +610,9 @@ extern "C" int gpx_dgp_loglik_gradient(const gpx_dgp *cg, double *grad2)
         return fail(he == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("gpx_dgp_loglik_gradient: ") + hipGetErrorString(he));
     }
     double *p_quad = part, *p_trk = part + np_rows, *p_tr = part + 2 * (size_t)np_rows;
-    hipLaunchKernelGGL(gpx::dgp_dk_kernel, dim3(np_rows / TILE, np_rows / TILE), dim3(256), 0, s, g->cov, n, n4, np, g->d_x,
+    hipLaunchKernelGGL(gpx::dgp_dk_kernel, dim3(np_rows / TILE, np_rows / TILE), dim3(256), 0, s, g->cov, np, g->d_row, g->d_x,
                        g->d_y, g->d_z, dK);
-    hipLaunchKernelGGL(gpx::dgp_quad_rows_kernel, dim3(n4), dim3(256), 0, s, n4, np, dK, g->d_alpha, p_quad);
+    hipLaunchKernelGGL(gpx::dgp_quad_rows_kernel, dim3(n4), dim3(256), 0, s, n4, np, dK, (const double *)m->t_xs, p_quad);
     hipLaunchKernelGGL(gpx::dgp_trkinv_rows_kernel, dim3(n4), dim3(256), 0, s, np, (const double *)m->X,
                        (const double *)m->t_dinv, p_trk);
     GemmArgs a;  // Z[a][m] = sum_b dK[a][b] X[m][b]
@@ -557,8 +637,8 @@ extern "C" int gpx_dgp_loglik_gradient(const gpx_dgp *cg, double *grad2)
     for (int i = 0; i < n4; ++i) {
         quad_l += h[i];
         trkinv += h[(size_t)np_rows + i];
-        ya += g->h_y[i] * g->h_alpha[i];
-        aa += g->h_alpha[i] * g->h_alpha[i];
+        ya += g->h_y[i] * g->h_alpha_rows[i];
+        aa += g->h_alpha_rows[i] * g->h_alpha_rows[i];
     }
     // rows / columns of the identity padding inside the last 128-block: X = I, Z = 0 there, nothing to leave out
     for (size_t t = 0; t < (size_t)nt32 * nt32; ++t)
@@ -706,8 +786,8 @@ extern "C" int gpx_dgp_evaluate(const gpx_dgp *cg, size_t nq, const double *qx, 
             return rc;
         for (size_t q0 = 0; q0 < nq; q0 += qb) {
             const size_t nv = std::min(qb, nq - q0), ntile = ((nv + TILE - 1) / TILE) * TILE;
-            hipLaunchKernelGGL(gpx::dgp_kstar_kernel, dim3(np_rows / TILE, (unsigned)(ntile / TILE)), dim3(256), 0, s, g->cov, n,
-                               n4, np, g->d_x, g->d_y, g->d_z, (long)nv, dq[0] + q0, dq[1] + q0, dq[2] + q0,
+            hipLaunchKernelGGL(gpx::dgp_kstar_kernel, dim3(np_rows / TILE, (unsigned)(ntile / TILE)), dim3(256), 0, s, g->cov,
+                               np, g->d_row, g->d_x, g->d_y, g->d_z, (long)nv, dq[0] + q0, dq[1] + q0, dq[2] + q0,
                                (double *)m->ws_kqp);
             GemmArgs a;  // partial[mt][q] = sum_rows (X * k_star^T)^2 / D
             a.A = m->X, a.lda = np;
@@ -762,6 +842,11 @@ extern "C" int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes)
         if ((rc = need(sizeof(double))))
             return rc;
         *(double *)dst = g->loglik;
+        return GPX_OK;
+    case GPX_DGP_FIELD_APPENDED_FROM:
+        if ((rc = need(sizeof(int64_t))))
+            return rc;
+        *(int64_t *)dst = g->appended_from;
         return GPX_OK;
     case GPX_DGP_FIELD_STATS:
         if ((rc = need(sizeof(gpx_stats))))

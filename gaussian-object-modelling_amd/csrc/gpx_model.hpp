@@ -213,6 +213,7 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx);
 int build_inverse(gpx_model *m);
 int build_model(gpx_model *m, kept_factor *keep = nullptr);
 int alloc_factor_buffers(gpx_model *m);  // Kmat, linv, Wp for a model whose matrix is filled by the caller (gpx_dgp.hip)
+void factorize_matrix_append(gpx_model *m, int t0);
 void factorize_matrix(gpx_model *m);     // blocked LDL^T of m->Kmat in place (t_d, t_dinv, linv, d_info)
 void solve_factored(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x);  // x = (L D L^T)^-1 b on T vectors
 void set_query_batch(gpx_model *m);

@@ -509,6 +509,12 @@ class DerivativeGP:
         _check(self._L.gpx_dgp_get(self._h, 3, C.byref(s), C.sizeof(s)))
         return s.as_dict()
 
+    @property
+    def appended_from(self):
+        a = np.zeros(1, dtype=np.int64)
+        _check(self._L.gpx_dgp_get(self._h, 4, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return int(a[0])
+
     def loglik_gradient(self):
         """logLikelihoodGradient (include/gp/GaussianProcess.h:387-410): d loglik / d (log l, log sf); SE models only."""
         g = np.zeros(2)

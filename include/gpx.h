@@ -273,15 +273,19 @@ typedef enum {
     GPX_DGP_FIELD_N = 0,      /* int64: training points */
     GPX_DGP_FIELD_ALPHA = 1,  /* double[4n], layout as above */
     GPX_DGP_FIELD_LOGLIK = 2, /* double: logLikelihood() :376-385 over all 4n observations */
-    GPX_DGP_FIELD_STATS = 3   /* gpx_stats: t_kbuild_ms, t_factor_ms, t_solve_ms, t_mean_ms, t_var_ms, n = 4n, n_padded */
+    GPX_DGP_FIELD_STATS = 3,  /* gpx_stats: t_kbuild_ms, t_factor_ms, t_solve_ms, t_mean_ms, t_var_ms, n = 4n, n_padded */
+    GPX_DGP_FIELD_APPENDED_FROM = 4 /* int64: rows of the old factor the last gpx_dgp_add carried over (0: built from scratch) */
 } gpx_dgp_field;
 int gpx_dgp_create(const gpx_kernel *kernel, double noise, size_t n, const double *x, const double *y, const double *z,
                    const double *target, const double *normals, const gpx_options *opt, gpx_dgp **out);
 int gpx_dgp_evaluate(const gpx_dgp *g, size_t nq, const double *qx, const double *qy, const double *qz, double *f4,
                      double *var);
-/* add_patterns (GaussianProcess.h:340-374): append n_new samples (normals NULL = zeros) and rebuild on the union -- the
- * results equal gpx_dgp_create on the concatenated data (the reference's own row append ignores the derivative blocks of
- * its compute(); see csrc/gpx_dgp.hip).  External exclusion against evaluate, as for gpx_model_update. */
+/* add_patterns (GaussianProcess.h:340-374): append n_new samples (normals NULL = zeros).  Their rows -- the value and the
+ * three derivatives of every new sample; the reference appends value rows only, ignoring the derivative blocks of its own
+ * compute() -- are appended to the existing factor as :356-368 does row by row, here block-wise: the leading
+ * 128 * floor(4 n_old / 128) rows of the old factor are kept, the rest is built and eliminated against them.  The result
+ * equals gpx_dgp_create on the concatenated data to rounding (bit for bit with GPX_DGP_APPEND=0, which rebuilds; also taken
+ * when the old model has fewer than 128 rows).  External exclusion against evaluate, as for gpx_model_update. */
 int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const double *y, const double *z, const double *target,
                 const double *normals);
 int gpx_dgp_get(const gpx_dgp *g, int field, void *dst, size_t bytes);

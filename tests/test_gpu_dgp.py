@@ -95,11 +95,15 @@ def test_derivative_gp_reconstructs_a_sphere_from_points_and_normals(gpu):
     gg.close()
 
 
+@pytest.mark.parametrize("append", ["1", "0"])
 @pytest.mark.parametrize("kern", [("se", 1.2, 0.8), ("thinplate", 4.0)])
-def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern):
+def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern, append, monkeypatch):
     """gpx_dgp_add (add_patterns, GaussianProcess.h:340-374): after two appends -- one with normals, one without -- alpha,
-    the log-likelihood and evaluate equal a model created on the concatenated samples bit for bit, and the oracle on the
-    union to the usual tolerance; a failing append (non-finite sample) leaves the model as it was."""
+    the log-likelihood and evaluate equal a model created on the concatenated samples and the oracle on the union to the
+    usual tolerance: with the rows appended to the old factor (default; the first append carries 384 of 480 rows over, the
+    second 896 of 920, and the model says so) and, bit for bit, with GPX_DGP_APPEND=0 (rebuild on the union); a failing
+    append (non-finite sample) leaves the model as it was; a model with fewer than 128 rows is rebuilt."""
+    monkeypatch.setenv("GPX_DGP_APPEND", append)
     P, t, nr = _cloud(300, 77)
     gk = gpu.make_kernel("se", kern[1], kern[2]) if kern[0] == "se" else gpu.make_kernel("thinplate", kern[1])
     a, b = 120, 230
@@ -107,6 +111,7 @@ def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern):
     nr_u[b:] = 0.0  # the last append passes no normals
     gg = gpu.DerivativeGP(gk, 0.05, P[:a, 0], P[:a, 1], P[:a, 2], t[:a], nr[:a])
     gg.add(P[a:b, 0], P[a:b, 1], P[a:b, 2], t[a:b], nr[a:b])
+    assert gg.appended_from == (384 if append == "1" else 0)
     before = gg.alpha.copy()
     bad = P[b:, 0].copy()
     bad[3] = np.nan
@@ -117,20 +122,38 @@ def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern):
     np.testing.assert_array_equal(gg.alpha, before)
     gg.add(P[b:, 0], P[b:, 1], P[b:, 2], t[b:], None)
     assert gg.n == 300 and gg.stats["n"] == 1200
+    assert gg.appended_from == (896 if append == "1" else 0)
     fresh = gpu.DerivativeGP(gk, 0.05, P[:, 0], P[:, 1], P[:, 2], t, nr_u)
-    np.testing.assert_array_equal(gg.alpha, fresh.alpha)
-    assert gg.loglik == fresh.loglik
+    tol = 1e-10 if kern[0] == "se" else 1e-8
     Q = np.random.default_rng(5).uniform(-1.3, 1.3, size=(500, 3))
     o1, o2 = gg.evaluate(Q[:, 0], Q[:, 1], Q[:, 2]), fresh.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
-    for key in ("f", "grad", "v"):
-        np.testing.assert_array_equal(o1[key], o2[key])
+    k0 = kern[1] ** 2 if kern[0] == "se" else kern[1] ** 3
+    if append == "0":
+        np.testing.assert_array_equal(gg.alpha, fresh.alpha)
+        assert gg.loglik == fresh.loglik
+        for key in ("f", "grad", "v"):
+            np.testing.assert_array_equal(o1[key], o2[key])
+    else:
+        assert nerr(gg.alpha, fresh.alpha) < tol
+        assert abs(gg.loglik - fresh.loglik) < 1e-9 * abs(fresh.loglik)
+        assert np.max(np.abs(o1["f"] - o2["f"])) / max(np.max(np.abs(o2["f"])), 0.1) < tol
+        assert np.max(np.abs(o1["grad"] - o2["grad"])) / np.max(np.abs(o2["grad"])) < tol
+        assert np.max(np.abs(o1["v"] - o2["v"])) / k0 < tol
     og = orc.DerivativeGP(kern, 0.05, P[:, 0], P[:, 1], P[:, 2], t, nr_u)
-    tol = 1e-10 if kern[0] == "se" else 1e-8
     assert nerr(gg.alpha, og.alpha) < tol
     ref = og.evaluate(Q[:, 0], Q[:, 1], Q[:, 2])
     assert np.max(np.abs(o1["f"] - ref["f"])) / max(np.max(np.abs(ref["f"])), 0.1) < tol
+    assert np.max(np.abs(o1["v"] - ref["v"])) / k0 < tol
+    if kern[0] == "se":  # the likelihood gradient reads the appended row order too
+        assert np.abs(gg.loglik_gradient() - og.loglik_gradient()).max() < 1e-8 * np.abs(og.loglik_gradient()).max()
     gg.close()
     fresh.close()
+    small = gpu.DerivativeGP(gk, 0.05, P[:20, 0], P[:20, 1], P[:20, 2], t[:20], nr[:20])  # 80 rows: nothing to carry over
+    small.add(P[20:50, 0], P[20:50, 1], P[20:50, 2], t[20:50], nr[20:50])
+    assert small.appended_from == 0
+    og2 = orc.DerivativeGP(kern, 0.05, P[:50, 0], P[:50, 1], P[:50, 2], t[:50], nr[:50])
+    assert nerr(small.alpha, og2.alpha) < tol
+    small.close()
 
 
 @pytest.mark.parametrize("n", [5, 40, 150])
