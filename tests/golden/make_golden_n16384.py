@@ -7,6 +7,7 @@ f / v / grad at 64 queries (13 KB).  Run in the build container (~4 min on 8 cor
 
     python tests/golden/make_golden_n16384.py
     python tests/golden/make_golden_n16384.py random     # -> gp_golden_n16384_random.npz (round 3)
+    python tests/golden/make_golden_n16384.py dense      # -> gp_golden_n16384_dense.npz (round 4: all of alpha, 2048 queries)
 
 `random`: thin-plate R = 4 on an IRREGULAR cloud (datasets.random_shell_training_set: 16384 points uniform in the shell
 0.9 <= |p| <= 1.1) with 64 EXTRAPOLATING queries uniform in [-1.3, 1.3]^3 (three of them on training points) -- the
@@ -130,8 +131,40 @@ def main_random():
     print("wrote gp_golden_n16384_random.npz (%d arrays)" % len(out))
 
 
+def main_dense():
+    """Round 4: the same two models with EVERY alpha entry and 2048 queries (512 lattice points of [-1.01, 1.01]^3 + 1536
+    uniform in [-1.2, 1.2]^3), f and v only -- 0.4 MB; ~6 min on 8 cores."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(N)
+    P = np.stack([x, y, z], 1)
+    g = np.linspace(-1.01, 1.01, 8)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    rng = ds.MT19937_64(163840)
+    Qr = np.array([rng.uniform(-1.2, 1.2) for _ in range(3 * 1536)]).reshape(1536, 3)
+    Q = np.concatenate([np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1), Qr], 0)
+    out = {"n": np.array(N), "Q": Q}
+    D = pdist(P, P)
+    Dq = pdist(Q, P)
+    for kname, (kf, kd, k0) in KERNELS.items():
+        t0 = time.time()
+        K = kf(D)
+        K[np.diag_indices(N)] += s2
+        c = sl.cho_factor(K, lower=True, overwrite_a=True, check_finite=False)
+        alpha = sl.cho_solve(c, lab, check_finite=False)
+        Kq = kf(Dq)
+        f = Kq @ alpha
+        S = sl.cho_solve(c, Kq.T, check_finite=False)
+        v = k0 - np.einsum("ij,ji->i", Kq, S)
+        del K, c, S
+        out[kname + "/alpha"], out[kname + "/f"], out[kname + "/v"] = alpha, f, v
+        print("%s: %.1fs  max|alpha| %.4g  v in [%.3g, %.3g]" % (kname, time.time() - t0, np.abs(alpha).max(), v.min(), v.max()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "gp_golden_n16384_dense.npz"), **out)
+    print("wrote gp_golden_n16384_dense.npz (%d arrays)" % len(out))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "random":
+    if len(sys.argv) > 1 and sys.argv[1] == "dense":
+        main_dense()
+    elif len(sys.argv) > 1 and sys.argv[1] == "random":
         main_random()
     else:
         main()

@@ -115,7 +115,8 @@ def test_n16384_properties(gpu, ds, kn, par):
 @pytest.mark.parametrize("kkey,kn,par", [("matern52", "matern52", (1.0, 1.0)), ("thinplate4", "thinplate", (4.0,))])
 def test_n16384_against_independent_golden(gpu, ds, kkey, kn, par):
     """The headline size anchored OUTSIDE this repository's code: tests/golden/gp_golden_n16384.npz holds alpha at 256
-    training indices and f / v / grad at 64 queries from NumPy distances + LAPACK Cholesky in fp64
+    training indices and f / v / grad at 64 queries, gp_golden_n16384_dense.npz (round 4) all 16384 alpha entries and f / v at
+    2048 queries, from NumPy distances + LAPACK Cholesky in fp64
     (tests/golden/make_golden_n16384.py; residual of its solve 3e-15 / 9e-14).  fp64 pipeline at 1e-9 (the
     thin-plate system has cond > 1e6: two backward-stable fp64 solves agree to ~1e-10), every fp32 mode at the
     north-star 1e-5.  This also pins the paths that only engage at this size (look-ahead factorisation, the one-launch
@@ -128,11 +129,18 @@ def test_n16384_against_independent_golden(gpu, ds, kkey, kn, par):
     kern = gpu.make_kernel(kn, *par)
     k0 = 1.0 if kn != "thinplate" else par[0] ** 3
     Q, sel, pre = g["Q"], g["alpha_idx"], kkey + "/"
+    # round 4: the same models with EVERY alpha entry and 2048 queries (512 lattice + 1536 random in [-1.2, 1.2]^3), f and v
+    dense = np.load(os.path.join(GOLDEN_DIR, "gp_golden_n16384_dense.npz"))
+    Qd = dense["Q"]
     for prec, tol, atol in ((gpu.F64, 1e-9, 1e-9), (gpu.F32, 1e-5, 1e-5), (gpu.MIXED, 1e-5, 1e-9), (gpu.F32_SPLIT, 1e-5, 1e-5)):
         gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
         assert gm.stats["solve_fallbacks"] == 0
         out = gm.evaluate(Q[:, 0], Q[:, 1], Q[:, 2], want_v=True, want_grad=True)
         a = gm.alpha
+        od = gm.evaluate(Qd[:, 0], Qd[:, 1], Qd[:, 2], want_v=True)
+        assert np.max(np.abs(a - dense[pre + "alpha"])) / np.max(np.abs(dense[pre + "alpha"])) < atol, prec
+        assert nerr(od["f"], dense[pre + "f"]) < (tol if prec == gpu.F64 else (1e-9 if prec == gpu.MIXED else 1e-6)), prec
+        assert verr(od["v"], dense[pre + "v"], k0) < tol and verr_v(od["v"], dense[pre + "v"]) < tol, prec
         # alpha: norm-wise against max|alpha| of the whole vector (stored next to the sample)
         assert np.max(np.abs(a[sel] - g[pre + "alpha"])) / float(g[pre + "alpha_max"]) < atol, prec
         mtol = tol if prec in (gpu.F64,) else (1e-9 if prec == gpu.MIXED else 1e-6)  # mean / gradient are fp64 work
