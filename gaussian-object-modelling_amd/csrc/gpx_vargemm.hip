@@ -17,6 +17,8 @@
 //     no per-load address arithmetic.  With flat loads the 64-bit VALU adds in front of each load cost ~15 cycles of
 //     MFMA issue apiece (8441 shader cycles per 256-MFMA chunk against 8226 here and 8199 with no loads at all --
 //     in-kernel s_memtime stamps, scripts/w1_gemm.hip, profiles/r03_w1_gemm.txt);
+//   * the triangle of X is exploited per 128-row tile (k < m0 + 128) and, inside the tile's diagonal block, per 16-row
+//     fragment (round 4: W1_COMPUTE_DIAG; +0.6 % at N = 16384, +3.8 % at N = 1536);
 //   * the MFMAs are inline asm with the accumulators tied in place ("+a"): left to the register allocator the loop
 //     carried ~1100 v_accvgpr moves.  Loads stay ordinary builtins, so hipcc still counts vmcnt for them.
 // Traffic per flop is that of the 128 x 128 LDS tile (each wave reads a 128-row slice of both operands once per
@@ -52,6 +54,7 @@ struct VarW1Dev {
     int paired;  // 1: gridDim.y = row tiles / 2 and a workgroup does tile MT - 1 - y, then tile y walked in descending k
     int mt_base;  // first row tile of this launch (0 unless the last row tile runs on its own)
     int k_limit;  // columns of K' that can be non-zero, rounded up to 32
+    int diag_skip;  // leave the zero fragments of the diagonal block out (GPX_VAR_DIAG_SKIP=0: multiply them)
 };
 
 // NI = row fragments that hold data: 8 for every full tile; 2, 4 or 6 for the LAST row tile of a model whose row count
@@ -145,23 +148,63 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_ke
             _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) { W1_ROW(A_, B_, w, i_) }                            \
         }                                                                                                          \
     }
+    // A chunk of the tile's DIAGONAL 128-block (k = m0 + 16 cd .. + 15) meets zeros of the lower-triangular X in every row
+    // fragment i < cd: those MFMAs are left out (36 of the 64 fragment-chunks of the block remain; 0.7 % of a tile at
+    // N = 16384, 5 % at N = 2048).  cd is wave-uniform, so a row of 8 MFMAs sits behind one scalar branch; the loads of the
+    // next chunk all go out at the top.  Full tiles with the fp64 epilogue only.
+#define W1_COMPUTE_DIAG(A_, B_, AN_, BN_, KB_, CD_)                                                                \
+    {                                                                                                              \
+        _Pragma("unroll") for (int p_ = 0; p_ < 16; ++p_) W1_PIECE(AN_, BN_, KB_, p_)                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { if (i_ >= (CD_)) { W1_ROW(A_, B_, x, i_) } }            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { if (i_ >= (CD_)) { W1_ROW(A_, B_, y, i_) } }            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { if (i_ >= (CD_)) { W1_ROW(A_, B_, z, i_) } }            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { if (i_ >= (CD_)) { W1_ROW(A_, B_, w, i_) } }            \
+    }
     {
         const unsigned kb0 = (unsigned)cfirst * 64u;
 #pragma unroll
         for (int p = 0; p < NI + 8; ++p)
             W1_PIECE(a0, b0, kb0, p)
     }
+    // walk positions 0 .. nch - 1 stand for chunk cfirst + cdir * position; the nd chunks of the diagonal block are the last
+    // positions of an ascending walk and the first of a descending one (nd is even: m0 and k_limit are multiples of 32)
+    constexpr bool DIAG = NI == 8 && CORR;  // (the plain-epilogue variant has no registers to spare: it multiplies the zeros)
+    const int nd = (DIAG && g.diag_skip) ? max(0, nch - m0 / 16) : 0, ng = nch - nd;
+    int pos = 0;
+#define W1_KB(POS_) ((unsigned)(cfirst + cdir * min((POS_), nch - 1)) * 64u)
+    if constexpr (DIAG) {
+        if (ph != 0) {
+#pragma nounroll
+            for (int d = 0; d < nd; d += 2, pos += 2) {
+                const int cd = __builtin_amdgcn_readfirstlane(nd - 1 - d);
+                W1_COMPUTE_DIAG(a0, b0, a1, b1, W1_KB(pos + 1), cd);
+                W1_COMPUTE_DIAG(a1, b1, a0, b0, W1_KB(pos + 2), cd - 1);
+            }
+        }
+    }
     asm volatile(".p2align 6");
-    for (int c = 0; c < nch; c += 2) {
+    for (int c = 0; c < ng; c += 2, pos += 2) {
         // (the last trip re-loads its own second chunk: nothing in the loop is conditional)
-        const unsigned kb1 = (unsigned)(cfirst + cdir * (c + 1)) * 64u;
-        const unsigned kb2 = (unsigned)(cfirst + cdir * min(c + 2, nch - 1)) * 64u;
+        const unsigned kb1 = W1_KB(pos + 1);
+        const unsigned kb2 = W1_KB(pos + 2);
         W1_COMPUTE_LD(a0, b0, a1, b1, kb1);
         W1_COMPUTE_LD(a1, b1, a0, b0, kb2);
     }
+    if constexpr (DIAG) {
+        if (ph == 0) {
+#pragma nounroll
+            for (int d = 0; d < nd; d += 2, pos += 2) {
+                const int cd = __builtin_amdgcn_readfirstlane(d);
+                W1_COMPUTE_DIAG(a0, b0, a1, b1, W1_KB(pos + 1), cd);
+                W1_COMPUTE_DIAG(a1, b1, a0, b0, W1_KB(pos + 2), cd + 1);
+            }
+        }
+    }
+#undef W1_KB
 #undef W1_PIECE
 #undef W1_ROW
 #undef W1_COMPUTE_LD
+#undef W1_COMPUTE_DIAG
     // the asm MFMAs are opaque to hipcc's hazard recogniser: let the last ones retire before the accumulators are read
     // (tied to the last row of fragments, so that no read of them can be scheduled above the wait states; every other
     // fragment's last MFMA is at least 8 MFMAs = 256 cycles older)
@@ -640,6 +683,11 @@ void launch_var_w1(const GemmArgs &a, hipStream_t st)
     // rows that hold data (the rest of the last tile is the identity padding): columns of K' past them are zero
     const int mv = (a.m_valid > 0 && a.m_valid <= a.M) ? a.m_valid : a.M;
     g.k_limit = std::min(a.M, (mv + 31) / 32 * 32);
+    static const int diag_skip = [] {
+        const char *e = std::getenv("GPX_VAR_DIAG_SKIP");
+        return e ? std::atoi(e) : 1;
+    }();
+    g.diag_skip = diag_skip;
     const int r_last = mv - (MT - 1) * 128;  // data rows of the last row tile
     const int ni_last = r_last <= 0 ? 8 : (r_last <= 32 ? 2 : (r_last <= 64 ? 4 : (r_last <= 96 ? 6 : 8)));
     int mt_main = MT;

@@ -944,7 +944,7 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         "            gm.close()\n"
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_W1_NN", "GPX_VAR_TILE", "GPX_VAR_FIT")}
+    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_W1_NN", "GPX_VAR_TILE", "GPX_VAR_FIT", "GPX_VAR_DIAG_SKIP")}
     for tile, fit in (("6", "1"), ("3", "1"), ("6", "0"), ("3", "0")):
         path = str(tmp_path / ("tile%s_%s.npz" % (tile, fit)))
         env = dict(base_env, GPX_VAR_TILE=tile, GPX_VAR_FIT=fit)
@@ -954,12 +954,18 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
     # the same one-wave tiles launched the other way round (paired row tiles <-> plain heavy-first order: the light tile of a
     # pair walks k downwards, so the fp32 sums differ in order only), and the inverse factor assembled without the one-wave
     # [k][n] kernel (the 2305-point models have a K = 1024 level): same results to rounding
-    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("nn0", {"GPX_W1_NN": "0"})):
+    # and with the zero fragments of the diagonal block multiplied instead of skipped (GPX_VAR_DIAG_SKIP=0): they only ever
+    # added 0 * k to an accumulator, so every variance is the same bit for bit
+    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("nn0", {"GPX_W1_NN": "0"}),
+                        ("diag0", {"GPX_VAR_DIAG_SKIP": "0"})):
         path = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", child, path], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         alt = np.load(path)
         for key in alt.files:
+            if name == "diag0":
+                np.testing.assert_array_equal(alt[key], res["6", "1"][key], err_msg=key)
+                continue
             n, kn, prec = key.split("/")
             vmax = np.max(np.abs(res["6", "1"]["%s/%s/%d" % (n, kn, gpu.F64)]))
             # (a thin-plate operand is ~k(0) / max|v| = 60 times larger than the variance it contributes to: the order of
