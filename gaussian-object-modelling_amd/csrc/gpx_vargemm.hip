@@ -37,6 +37,16 @@
 
 namespace gpx {
 
+// GPX_VAR_DIAG_SKIP=0: the one-wave tiles multiply the zero fragments of their diagonal block (tests compare: bit-identical)
+static int var_diag_skip()
+{
+    static const int on = [] {
+        const char *e = std::getenv("GPX_VAR_DIAG_SKIP");
+        return e ? std::atoi(e) : 1;
+    }();
+    return on;
+}
+
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef double d4v __attribute__((ext_vector_type(4)));
 
@@ -338,6 +348,7 @@ struct VarW1F64Dev {
     double *partial;
     long ldp;
     int paired;  // as in VarW1Dev
+    int diag_skip;
 };
 
 __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f64_kernel(VarW1F64Dev g)
@@ -390,22 +401,52 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, 1) void var_w1_f6
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { W1D_PIECE(AN_, BN_, KB_, 8 + i_) W1D_ROW(A_, B_, y, i_) } \
         _Pragma("unroll") for (int i_ = 4; i_ < 8; ++i_) { W1D_ROW(A_, B_, y, i_) }                                  \
     }
+    // the diagonal 128-block (the last 16 chunks of an ascending walk): chunks 2 cd and 2 cd + 1 meet zeros of X in the row
+    // fragments i < cd -- left out, as in var_w1_kernel.  Here with cd a compile-time constant and the eight pairs written
+    // out: behind per-row branches hipcc renamed accumulators at the merges (v_accvgpr_read / _write next to the asm MFMAs,
+    // which its hazard recogniser cannot see: results read while still in flight, 1e-6 errors at N = 4096).
+#define W1D_COMPUTE_DIAG(A_, B_, AN_, BN_, KB_, CD_)                                           \
+    {                                                                                          \
+        _Pragma("unroll") for (int p_ = 0; p_ < 12; ++p_) W1D_PIECE(AN_, BN_, KB_, p_)         \
+        _Pragma("unroll") for (int i_ = (CD_); i_ < 8; ++i_) { W1D_ROW(A_, B_, x, i_) }        \
+        _Pragma("unroll") for (int i_ = (CD_); i_ < 8; ++i_) { W1D_ROW(A_, B_, y, i_) }        \
+    }
+#define W1D_DIAG_PAIR(CD_)                                          \
+    {                                                               \
+        W1D_COMPUTE_DIAG(a0, b0, a1, b1, W1D_KB(pos + 1), CD_);     \
+        W1D_COMPUTE_DIAG(a1, b1, a0, b0, W1D_KB(pos + 2), CD_);     \
+        pos += 2;                                                   \
+    }
     {
         const unsigned kb0 = (unsigned)cfirst * 64u;
 #pragma unroll
         for (int p = 0; p < 12; ++p)
             W1D_PIECE(a0, b0, kb0, p)
     }
+    const int nd = g.diag_skip ? 16 : 0, ng = nch - nd;
+    int pos = 0;
+#define W1D_KB(POS_) ((unsigned)(cfirst + cdir * min((POS_), nch - 1)) * 64u)
+    if (ph != 0 && nd) {
+        W1D_DIAG_PAIR(7) W1D_DIAG_PAIR(6) W1D_DIAG_PAIR(5) W1D_DIAG_PAIR(4)
+        W1D_DIAG_PAIR(3) W1D_DIAG_PAIR(2) W1D_DIAG_PAIR(1) W1D_DIAG_PAIR(0)
+    }
     asm volatile(".p2align 6");
-    for (int c = 0; c < nch; c += 2) {
-        const unsigned kb1 = (unsigned)(cfirst + cdir * (c + 1)) * 64u;
-        const unsigned kb2 = (unsigned)(cfirst + cdir * min(c + 2, nch - 1)) * 64u;
+    for (int c = 0; c < ng; c += 2, pos += 2) {
+        const unsigned kb1 = W1D_KB(pos + 1);
+        const unsigned kb2 = W1D_KB(pos + 2);
         W1D_COMPUTE_LD(a0, b0, a1, b1, kb1);
         W1D_COMPUTE_LD(a1, b1, a0, b0, kb2);
     }
+    if (ph == 0 && nd) {
+        W1D_DIAG_PAIR(0) W1D_DIAG_PAIR(1) W1D_DIAG_PAIR(2) W1D_DIAG_PAIR(3)
+        W1D_DIAG_PAIR(4) W1D_DIAG_PAIR(5) W1D_DIAG_PAIR(6) W1D_DIAG_PAIR(7)
+    }
+#undef W1D_DIAG_PAIR
+#undef W1D_KB
 #undef W1D_PIECE
 #undef W1D_ROW
 #undef W1D_COMPUTE_LD
+#undef W1D_COMPUTE_DIAG
     // (as in the fp32 kernel: wait states tied to the last MFMAs' fragments; the others are >= 4 x 64 cycles older)
     asm volatile("s_nop 15\n s_nop 15"
                  : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3])
@@ -494,6 +535,7 @@ void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
     const int MT = a.M / 128, NT = a.N / 64;
     const bool paired = var_w1_paired(MT, NT);
     g.paired = paired ? 1 : 0;
+    g.diag_skip = var_diag_skip();
     hipLaunchKernelGGL(var_w1_f64_kernel, dim3(NT, paired ? MT / 2 : MT), dim3(64), 0, st, g);
 }
 
@@ -683,11 +725,7 @@ void launch_var_w1(const GemmArgs &a, hipStream_t st)
     // rows that hold data (the rest of the last tile is the identity padding): columns of K' past them are zero
     const int mv = (a.m_valid > 0 && a.m_valid <= a.M) ? a.m_valid : a.M;
     g.k_limit = std::min(a.M, (mv + 31) / 32 * 32);
-    static const int diag_skip = [] {
-        const char *e = std::getenv("GPX_VAR_DIAG_SKIP");
-        return e ? std::atoi(e) : 1;
-    }();
-    g.diag_skip = diag_skip;
+    g.diag_skip = var_diag_skip();
     const int r_last = mv - (MT - 1) * 128;  // data rows of the last row tile
     const int ni_last = r_last <= 0 ? 8 : (r_last <= 32 ? 2 : (r_last <= 64 ? 4 : (r_last <= 96 ? 6 : 8)));
     int mt_main = MT;

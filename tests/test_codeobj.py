@@ -99,6 +99,29 @@ def test_one_wave_main_loops_hold_nothing_but_mfmas_and_loads(gpx, tmp_path):
         assert not bad, (sym, bad[:5])
 
 
+def test_one_wave_tiles_never_touch_an_accumulator_between_their_mfmas(gpx, tmp_path):
+    """Round 4 put the diagonal block of the one-wave tiles behind branches (zero fragments skipped).  At a merge hipcc may
+    rename accumulators -- v_accvgpr_read / _mov / spills right behind asm MFMAs it cannot see into, i.e. reads of results
+    still in flight (the first fp64 form did: 1e-6 errors at N = 4096).  From the first to the last accumulating MFMA of
+    var_w1_kernel<with the fit, 8 fragments> and var_w1_f64_kernel nothing may read or move an accumulator register."""
+    dis = codeobj.disassemble(gpx.LIB_PATH, tmp_path, "var_w1_")
+    seen = 0
+    for sym, lines in dis.items():
+        if "var_w1_f64_kernel" in sym:
+            mf, expect = "v_mfma_f64_16x16x4_f64 a", 128 + 2 * 576   # main loop + the diagonal pairs, ascending and descending
+        elif "var_w1_kernelILb1ELi8" in sym:
+            mf, expect = "v_mfma_f32_16x16x4_f32 a", 512 + 2 * 512   # main loop + one rolled pair of diagonal chunks per direction
+        else:
+            continue
+        seen += 1
+        text = [l.split("//")[0].strip() for l in lines]
+        idx = [i for i, t in enumerate(text) if t.startswith(mf)]
+        assert len(idx) == expect, (sym, len(idx))
+        bad = [t for t in text[idx[0]:idx[-1]] if t.startswith(("v_accvgpr_read", "v_accvgpr_mov", "scratch_"))]
+        assert not bad, (sym, bad[:5])
+    assert seen == 2
+
+
 def test_small_model_variance_kernels_run_two_waves_per_simd(kernels):
     """gpx_varcols_kernel.hpp: one 64-lane workgroup per wave, 12 x 2 accumulator fragments (96 AGPRs) and at most 256
     registers in all, so that two waves share a SIMD; eight workgroups must fit a CU's 160 KiB of LDS (the training points,
