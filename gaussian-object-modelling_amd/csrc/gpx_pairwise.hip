@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
 }
 
 // ---- the per-query fit of the variance contraction, once per query batch ------------------------------------------
-// (a, b, c) = weighted least-squares parabola of k against s = d^2 over every `stride`-th training point (<= 128 samples,
-// 16 lanes per query, the samples stay in registers), weights 1 / (s + wdelta) (wdelta <= 0: uniform): the rows of the
+// (a, b, c) = weighted least-squares parabola of k against s = d^2 over every `stride`-th training point (<= 128 samples),
+// weights 1 / (s + wdelta) (wdelta <= 0: uniform): the rows of the
 // inverse factor weigh a query's NEAREST training points most, so that is where the residual should be smallest
 // (measured at N = 16384, variance error / max|v_ref|, thin-plate R = 4: uniform 7.1e-6, wdelta = 0.05 3.8e-6;
 // Matern-5/2 1.8e-6 -> 8.5e-7; profiles/r03_fit_variants_*.txt).  wdelta is a per-model number (R_max^2 / 320).  The normal
@@ -213,97 +213,70 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
 // px.. are the model's fp64 points.  R32 = false: p' = p - cen, q' = q - cen in fp64.  R32 = true (fp32 operand kernel):
 // p' = (float)(p - cen) -- the stored centred fp32 points --, q' = (float)(q - cen), and a, b, c are rounded to fp32:
 // exactly the numbers that kernel works with, so that fit = sum_c coef_c b_c holds for what it subtracts.
-
-// NPER: samples per lane (16 lanes per query): 2, 4 or 8 -- the loops run over exactly the samples in use
-template <bool R32, int KID, int NPER>
-__global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, int stride, const double *__restrict__ px,
-                                                      const double *__restrict__ py, const double *__restrict__ pz,
-                                                      const double *__restrict__ cen, long nq_valid,
-                                                      long nq_tile, const double *__restrict__ qx,
-                                                      const double *__restrict__ qy, const double *__restrict__ qz,
-                                                      double *__restrict__ coef, long ldcc)
+// ONE lane per query: the samples are the same strided training points for every query, so their coordinates are scalar
+// loads and the eight weighted moments sum_w {1, s, s^2, s^3, s^4, k, k s, k s^2} accumulate in registers; the
+// orthogonal-polynomial solution is formed from the moments.  (Until round 4 sixteen lanes shared a query and orthogonalised
+// in three passes over their samples: 72 shuffles per query and coefficient stores from one lane in sixteen -- 3.8 instead
+// of 1.5 ms over the eight objects of C5.  What cancellation does to the expanded moments, a few digits of fp64, only moves
+// the fit, which any (a, b, c) may be; the variances agree to every printed digit, profiles/r04_fit_lane.txt.)
+template <bool R32, int KID>
+__global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, int stride, int ns,
+                                                           const double *__restrict__ px, const double *__restrict__ py,
+                                                           const double *__restrict__ pz, const double *__restrict__ cen,
+                                                           long nq_valid, long nq_tile, const double *__restrict__ qx,
+                                                           const double *__restrict__ qy, const double *__restrict__ qz,
+                                                           double *__restrict__ coef, long ldcc)
 {
     constexpr bool P64 = !R32;
-    const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int sub = threadIdx.x & 15;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= nq_tile)
         return;
     double fa = 0, fb = 0, fc = 0, ax = 0, ay = 0, az = 0;
-    const double wdelta = cen[4];  // meta block of the model: centre x y z, 1 / (sx sk), weight offset of this fit
+    const double c0 = cen[0], c1 = cen[1], c2c = cen[2], wdelta = cen[4];
     if (q < nq_valid) {
-        ax = qx[q] - cen[0], ay = qy[q] - cen[1], az = qz[q] - cen[2];
+        ax = qx[q] - c0, ay = qy[q] - c1, az = qz[q] - c2c;
         if constexpr (!P64)
             ax = (double)(float)ax, ay = (double)(float)ay, az = (double)(float)az;
-        double sv[NPER], kv[NPER], wv[NPER];
-        double sw = 0, sws = 0, swk = 0;
-#pragma unroll
-        for (int i = 0; i < NPER; ++i) {
-            const int l = (sub + 16 * i) * stride;
-            sv[i] = kv[i] = wv[i] = 0.0;
-            if (l < n) {
-                double bx = px[l] - cen[0], by = py[l] - cen[1], bz = pz[l] - cen[2];
-                if constexpr (!P64)
-                    bx = (double)(float)bx, by = (double)(float)by, bz = (double)(float)bz;
-                const double dx = ax - bx, dy = ay - by, dz = az - bz;
-                const double u = dx * dx + dy * dy + dz * dz;
-                sv[i] = u;
-                kv[i] = cov_k<double, KID, MathFast>(cov, u + 1e-300);
-                wv[i] = wdelta > 0.0 ? 1.0 / (u + wdelta) : 1.0;
-                sw += wv[i];
-                sws = fma(wv[i], u, sws);
-                swk = fma(wv[i], kv[i], swk);
-            }
+        double sw = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, K0 = 0, K1 = 0, K2 = 0;
+        for (int i = 0; i < ns; ++i) {
+            const int l = i * stride;  // (the 16-lane form visits (sub + 16 i) stride: the same set of points)
+            if (l >= n)
+                break;
+            double bx = px[l] - c0, by = py[l] - c1, bz = pz[l] - c2c;
+            if constexpr (!P64)
+                bx = (double)(float)bx, by = (double)(float)by, bz = (double)(float)bz;
+            const double dx = ax - bx, dy = ay - by, dz = az - bz;
+            const double u = dx * dx + dy * dy + dz * dz;
+            const double k = cov_k<double, KID, MathFast>(cov, u + 1e-300);
+            const double w = wdelta > 0.0 ? 1.0 / (u + wdelta) : 1.0;
+            const double wu = w * u, wu2 = wu * u, wk = w * k;
+            sw += w;
+            S1 += wu;
+            S2 += wu2;
+            S3 = fma(wu2, u, S3);
+            S4 = fma(wu2 * u, u, S4);
+            K0 += wk;
+            K1 = fma(wk, u, K1);
+            K2 = fma(wk * u, u, K2);
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            sw += __shfl_xor(sw, off);
-            sws += __shfl_xor(sws, off);
-            swk += __shfl_xor(swk, off);
-        }
-        // orthogonal polynomials under the weights: p0 = 1, p1 = s - m1, p2 = s^2 - al p1 - be
-        const double m1 = sws / sw, a0 = swk / sw;
-        double s11 = 0, s1k = 0, s21 = 0, s20 = 0;
-#pragma unroll
-        for (int i = 0; i < NPER; ++i) {
-            const double p1 = sv[i] - m1, w = wv[i];
-            s11 = fma(w * p1, p1, s11);
-            s1k = fma(w * p1, kv[i], s1k);
-            s21 = fma(w * p1, sv[i] * sv[i], s21);
-            s20 = fma(w, sv[i] * sv[i], s20);
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            s11 += __shfl_xor(s11, off);
-            s1k += __shfl_xor(s1k, off);
-            s21 += __shfl_xor(s21, off);
-            s20 += __shfl_xor(s20, off);
-        }
-        const double scale2 = sws * sws / sw;  // ~ sum w s^2: what s11 is compared against
+        // orthogonal polynomials under the weights: p0 = 1, p1 = s - m1, p2 = s^2 - al p1 - be, from the moments
+        const double m1 = S1 / sw, a0 = K0 / sw;
+        const double s11 = S2 - m1 * S1, s1k = K1 - m1 * K0, s21 = S3 - m1 * S2, s20 = S2;
+        const double scale2 = S1 * S1 / sw;
         const bool ok1 = s11 > 1e-10 * scale2 && s11 > 0.0;
         const double b1 = ok1 ? s1k / s11 : 0.0, al = ok1 ? s21 / s11 : 0.0, be = s20 / sw;
-        double s22 = 0, s2k = 0;
-#pragma unroll
-        for (int i = 0; i < NPER; ++i) {
-            const double p2 = sv[i] * sv[i] - al * (sv[i] - m1) - be, w = wv[i];
-            s22 = fma(w * p2, p2, s22);
-            s2k = fma(w * p2, kv[i], s2k);
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            s22 += __shfl_xor(s22, off);
-            s2k += __shfl_xor(s2k, off);
-        }
-        const bool ok2 = ok1 && s22 > 1e-10 * s20 * be && s22 > 0.0;
+        const double k0c = al * m1 - be;  // p2 = s^2 - al s + k0c
+        const double s22 = S4 + al * al * S2 + k0c * k0c * sw - 2.0 * al * S3 + 2.0 * k0c * S2 - 2.0 * al * k0c * S1;
+        const double s2k = K2 - al * K1 + k0c * K0;
+        // (s22 is a difference of O(S4) terms: below 1e-9 of them it is rounding, not a direction)
+        const bool ok2 = ok1 && s22 > 1e-10 * s20 * be && s22 > 1e-9 * S4 && s22 > 0.0;
         const double c2 = ok2 ? s2k / s22 : 0.0;
-        // a0 + b1 (s - m1) + c2 (s^2 - al (s - m1) - be) as a + b s + c s^2
         fa = a0 - b1 * m1 + c2 * (al * m1 - be);
         fb = b1 - c2 * al;
         fc = c2;
         if constexpr (!P64)
             fa = (double)(float)fa, fb = (double)(float)fb, fc = (double)(float)fc;
     }
-    if (sub != 0)
-        return;
     const double q2 = ax * ax + ay * ay + az * az;
     const double lin = -2.0 * fb - 4.0 * fc * q2, dg = fb + 2.0 * fc * q2;
     coef[q] = fa + q2 * (fb + fc * q2);
@@ -329,41 +302,26 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
                     const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
                     const double *qz, double *coef, long ldcc, hipStream_t st)
 {
-    const dim3 grid((unsigned)((nq_tile + 15) / 16));
     static const int nsamp = [] {
         const char *e = std::getenv("GPX_VAR_FIT_SAMPLES");  // 16 .. 128 strided training points per query
         const int v = e ? std::atoi(e) : VAR_FIT_SAMPLES_DEFAULT;
         return v < 16 ? 16 : (v > VAR_FIT_SAMPLES ? VAR_FIT_SAMPLES : v);
     }();
     // Small models (the small-model variance kernel's range): 32 samples.  The fit kernel's time is proportional to the
-    // samples and independent of N -- 0.74 ms for 2^21 queries at 64 samples, which is 7 % of the variance stage at N = 724
-    // but a quarter of it at N = 277 (profiles/r04_c5_kernel_stats.txt) -- while the accuracy is not (see gpx_internal.hpp:
-    // 3.6 / 3.7e-6 and 1.5 / 1.2e-6 at 32 / 64 samples).
+    // samples and independent of N -- 0.19 ms for 2^21 queries at 32 samples, 8 % of the variance stage at N = 277 -- while
+    // the accuracy is not (see gpx_internal.hpp: 3.6 / 3.7e-6 and 1.5 / 1.2e-6 at 32 / 64 samples).
     const int ns = n <= VARCOLS_MAX_N ? std::min(nsamp, 32) : nsamp;
     const int stride = (n + ns - 1) / ns;
     Cov<double> c = lower_cov<double>(h);
-    const int nper = (ns + 15) / 16;  // samples per lane
-#define GPX_FIT_LAUNCH(R32_, NPER_)                                                                                          \
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<R32_, KID, NPER_>), grid, dim3(256), 0, st, c, n, stride, px, py, \
-                                              pz, cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc))
+    const int ns16 = (ns + 15) / 16 * 16;  // (the sample counts are multiples of 16: what the 16-lane form of rounds 2-3 visited)
+    const dim3 g1((unsigned)((nq_tile + 255) / 256));
     if (op64) {
-        if (nper <= 2) {
-            GPX_FIT_LAUNCH(false, 2);
-        } else if (nper <= 4) {
-            GPX_FIT_LAUNCH(false, 4);
-        } else {
-            GPX_FIT_LAUNCH(false, 8);
-        }
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
+                                                  cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     } else {
-        if (nper <= 2) {
-            GPX_FIT_LAUNCH(true, 2);
-        } else if (nper <= 4) {
-            GPX_FIT_LAUNCH(true, 4);
-        } else {
-            GPX_FIT_LAUNCH(true, 8);
-        }
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
+                                                  cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     }
-#undef GPX_FIT_LAUNCH
 }
 
 // ---- the kernel operand of one variance batch ---------------------------------------------------------------------
