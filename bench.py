@@ -356,6 +356,118 @@ def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
     return out
 
 
+C5_OBJECTS = ["bowlA", "bowlB", "containerA", "containerB", "jug", "kettle", "pot", "mugD"]  # scripts/perform.sh of the reference
+
+
+class _DeviceBackend:
+    """libgpx on this rank's GPU behind the backend protocol of sharding.sharded_grid_step / objects_per_rank_step."""
+
+    def __init__(self, torch, gpx, sharding, dev, local_rank, kern, data, prec):
+        self.torch, self.gpx, self.sharding, self.dev, self.local_rank = torch, gpx, sharding, dev, local_rank
+        self.kern, self.data, self.prec = kern, data, prec
+        self.q = self.f = self.v = None
+
+    def lattice(self, g, lo, hi, scale=1.01):
+        """Lattice points [lo, hi) of the g^3 grid (x slowest, z fastest) resident in HBM, plus their output arrays."""
+        torch = self.torch
+        t = torch.linspace(-scale, scale, g, dtype=torch.float64, device=self.dev)
+        idx = torch.arange(lo, hi, device=self.dev, dtype=torch.int64)
+        self.q = (t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous())
+        del idx
+        self.f = torch.empty(hi - lo, dtype=torch.float64, device=self.dev)
+        self.v = torch.empty(hi - lo, dtype=torch.float64, device=self.dev)
+        self.range = (g, lo, hi)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def train(self):
+        return self.gpx.Model(self.kern, *self.data, precision=self.prec, prepare_variance=True, device=self.local_rank)
+
+    def shell(self):
+        return self.gpx.Model.shell(self.kern, len(self.data[0]), precision=self.prec, device=self.local_rank)
+
+    def blobs(self, m):
+        return [self.sharding.device_blob_as_tensor(self.torch, *m.state_blob(part), self.dev) for part in (0, 1)]
+
+    def commit(self, m):
+        m.commit(with_variance=True)
+
+    def evaluate(self, m, nq=None):
+        nq = int(self.f.numel()) if nq is None else nq
+        m.evaluate_device(nq, self.q[0].data_ptr(), self.q[1].data_ptr(), self.q[2].data_ptr(), self.f.data_ptr(), self.v.data_ptr())
+        m.sync()
+
+    def predict(self, m, g, x_lo, x_hi):
+        if self.range != (g, x_lo * g * g, x_hi * g * g):
+            raise RuntimeError("backend lattice %s was prepared for another slab than planes [%d, %d)" % (self.range, x_lo, x_hi))
+        self.evaluate(m)
+        f, v = self.f, self.v
+        return int(f.numel()), float(f.sum().item()), float(v.sum().item()), float(v.min().item()), float(v.max().item())
+
+    def close(self, m):
+        m.close()
+
+
+def multi_gpu_configs(torch, gpx, ds, sharding, dist, rank, world, dev, local_rank, grid4=256, grid5=128):
+    """BASELINE configs 4 and 5 in their multi-GPU form, run by EVERY rank after the timed region (never part of `value`):
+      C4_shard    -- N = 16384 thin plate R = 4, fp32 mode, the real 256^3 lattice cut into x-slabs by
+                     sharding.grid_x_slab; once with the state broadcast over RCCL, once with every rank rebuilding the model;
+      C5_per_rank -- the eight PCD objects, object o on rank o mod world (one per GPU at world 8), Gaussian(1,1), fp32 mode,
+                     128^3 lattice each, no data-path collective.
+    The rank logic is sharding.sharded_grid_step / objects_per_rank_step (the world-2 gloo tests run the same functions)."""
+    out = {}
+    clock = time.perf_counter
+    try:
+        n = N_TRAIN
+        be = _DeviceBackend(torch, gpx, sharding, dev, local_rank, gpx.make_kernel("thinplate", 4.0), ds.fibonacci_training_set(n), gpx.F32)
+        x_lo, x_hi, lo, hi = sharding.grid_x_slab(grid4, rank, world)
+        be.lattice(grid4, lo, hi)
+        m = be.train()  # warm-up: code objects, the fp64 training temporaries and the pool of this shape
+        if hi > lo:
+            be.evaluate(m, min(hi - lo, 8192))
+        be.close(m)
+        rec = {"workload": "C4: N=%d thin-plate R=4 fp32 mode, ONE model, the %d^3 lattice (%d queries) in x-slabs over %d rank(s)"
+                           % (n, grid4, grid4 ** 3, world)}
+        for state in ("broadcast", "recompute"):
+            rec[state] = sharding.sharded_grid_step(dist, torch, rank, world, grid4, state, be, dev, clock)
+        out["C4_shard"] = rec
+        del be
+        gpx.trim()
+        torch.cuda.empty_cache()
+    except Exception as e:
+        if world > 1:
+            raise  # a rank that left the collective sequence would hang the others: fail the job loudly instead
+        out["C4_shard"] = {"error": str(e)}
+    try:
+        pcd_dir = os.path.join(ROOT, "tests", "golden", "pcd")
+        kern = gpx.make_kernel("gaussian", 1.0, 1.0)
+        mine = sharding.objects_of_rank(len(C5_OBJECTS), rank, world)
+        sets = {o: gpx.node_training_set(gpx.pcd_read(os.path.join(pcd_dir, C5_OBJECTS[o] + ".pcd"))) for o in mine}
+        be = _DeviceBackend(torch, gpx, sharding, dev, local_rank, kern, None, gpx.F32)
+        be.lattice(grid5, 0, grid5 ** 3)
+
+        def run_object(o):
+            be.data = sets[o]
+            m = be.train()
+            be.evaluate(m)
+            m.close()
+            return len(sets[o][0]), int(be.f.numel()), float(be.f.sum().item()), float(be.v.sum().item())
+
+        sharding.objects_per_rank_step(dist, torch, rank, world, len(C5_OBJECTS), run_object, be, dev, clock)  # warm-up
+        rec = sharding.objects_per_rank_step(dist, torch, rank, world, len(C5_OBJECTS), run_object, be, dev, clock)
+        for o in rec["objects"]:
+            o["name"] = C5_OBJECTS[o["object"]]
+        rec["workload"] = ("C5: %d independent objects (%s), Gaussian(1,1), fp32 mode, %d^3 lattice each; object o on rank o mod %d"
+                           % (len(C5_OBJECTS), ", ".join(C5_OBJECTS), grid5, world))
+        out["C5_per_rank"] = rec
+    except Exception as e:
+        if world > 1:
+            raise
+        out["C5_per_rank"] = {"error": str(e)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -387,6 +499,7 @@ def main():
     if world > 1 or os.environ.get("GPX_BENCH_FORCE_DIST") == "1":  # the env switch rehearses the RCCL path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # only missing in the one-process rehearsal (GPX_BENCH_FORCE_DIST=1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     prec = {"f32": gpx.F32, "f64": gpx.F64, "mixed": gpx.MIXED, "f32split": gpx.F32_SPLIT}[args.precision]
@@ -477,6 +590,15 @@ def main():
         shard_rec["state_bytes"] = int(sum(model[0].state_blob(part)[1] for part in ((0, 1) if want_v else (0,))))
     total_q = nq if shard else nq * world
     value = total_q / (elapsed / args.steps)
+
+    mg = None
+    if dist is not None and not shard and not args.no_configs and args.precision == "f32" and n_train == N_TRAIN:
+        # BASELINE configs 4 and 5 in their multi-GPU form: collective legs, every rank takes part (after the timed region)
+        if model[0] is not None:
+            model[0].close()
+            model[0] = None
+        gpx.trim()
+        mg = multi_gpu_configs(torch, gpx, ds, sharding, dist, rank, world, dev, local_rank)
 
     if rank == 0:
         st = {k: float(np.mean([s[k] for s in stats_acc])) for k in stats_acc[0]}
@@ -723,6 +845,8 @@ def main():
                 out["roofline_small"] = small_model_roofline(torch, gpx, ds, dev, local_rank)
             except Exception as e:
                 out["roofline_small"] = {"error": str(e)}
+        if mg:
+            out.setdefault("configs", {}).update(mg)
         if world == 1:
             out["eigen_on_box"] = eigen_on_box()
         if world == 1 and not args.no_cpu_baseline:

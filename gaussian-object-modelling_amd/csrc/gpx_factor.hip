@@ -14,6 +14,7 @@
 //   tri_solve  : L y = b and L^T x = D^-1 y in one launch each (a workgroup per block row, results handed on
 //                through self-validating entries); fwd / bwd step kernels: the same, one launch per block step.
 #include "gpx_internal.hpp"
+#include "gpx_blk.hpp"
 
 // phase timing of diag_ldl_kernel for scripts/diag_bench.hip (which defines GPX_STAMP); nothing in the library build
 #ifndef GPX_STAMP
@@ -27,23 +28,7 @@ namespace gpx {
 // The 4-wave instantiation (fp32) is the one that fits on a CU BESIDE a workgroup of the trailing-update GEMM
 // (<= 256 VGPRs per SIMD, 68 of the 160 KB of LDS): the 8-wave one needs a whole CU and starves behind a running GEMM.
 constexpr int DIAG_THREADS = 512, DIAG_THREADS_NARROW = 256;
-constexpr int NB = 32;    // sub-block order inside the 128 x 128 diagonal block
-constexpr int PLD = NB + 1;
 
-// value of `v` in lane `src` (wave-uniform, here a compile-time constant after unrolling): v_readlane_b32 puts
-// the result in a SCALAR register, so the 1000 broadcasts of step A cost no vector registers
-// (with __shfl = ds_bpermute the scheduler kept hundreds in flight and spilled 1.3 KB per lane)
-__device__ __forceinline__ float bcast_lane(float v, int src)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ __forceinline__ double bcast_lane(double v, int src)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), src);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 // One 128 x 128 diagonal block: LDL^T without pivoting + the inverse of its unit-lower L, blocked by 32.
 //
@@ -65,22 +50,6 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
 // on the second wave + substitution: 90 / 159 us; assembly on MFMA: see DESIGN.md section 4.  A fully
 // register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
 
-// 1 / x to within an ulp or two by Newton steps on the hardware estimate: the IEEE division sequence (12 fp32 /
-// ~25 fp64 instructions) sat on the dependency chain of every pivot column.  Zero, infinite or NaN pivots give a
-// non-finite result, which the caller has already flagged.
-__device__ __forceinline__ float fast_rcp(float x)
-{
-    float y = __builtin_amdgcn_rcpf(x);
-    return fmaf(fmaf(-x, y, 1.0f), y, y);
-}
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return fma(fma(-x, y, 1.0), y, y);
-}
-__device__ __forceinline__ float pivot_huge(float) { return 3.0e38f; }
-__device__ __forceinline__ double pivot_huge(double) { return 1e300; }
 
 // Phase B of diag_ldl: a row of W L11^T = A21 is shared by G adjacent lanes, lane q of the group owning the columns
 // q + G m.  Step C_ takes w_C from its owner by a DPP quad permute and eliminates it from the columns right of it
@@ -161,93 +130,6 @@ __device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
     }
 }
 
-// 32 x 32 x 32 block product of two LDS operands (leading dimension PLD) by one wave on the 16x16x4 MFMA:
-// four 16 x 16 accumulator tiles.  A operand: lane supplies A[i = lane & 15][k = lane >> 4]; B: B[k][j = lane & 15].
-template <typename T>
-struct BlkMma;
-template <>
-struct BlkMma<float> {
-    typedef float acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
-template <>
-struct BlkMma<double> {
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <typename T>
-struct BlkAcc {
-    typename BlkMma<T>::acc_t t[2][2];
-    __device__ __forceinline__ void zero()
-    {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                t[i][j] = typename BlkMma<T>::acc_t{T(0), T(0), T(0), T(0)};
-    }
-    // += Ab (32 x 32) * Bb (32 x 32)
-    __device__ __forceinline__ void mac(const T *Ab, const T *Bb, int lane)
-    {
-        const int i = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) {
-            const int k = 4 * kk + kq;
-            const T a0 = Ab[i * PLD + k], a1 = Ab[(16 + i) * PLD + k];
-            const T b0 = Bb[k * PLD + i], b1 = Bb[k * PLD + 16 + i];
-            t[0][0] = BlkMma<T>::mma(a0, b0, t[0][0]);
-            t[0][1] = BlkMma<T>::mma(a0, b1, t[0][1]);
-            t[1][0] = BlkMma<T>::mma(a1, b0, t[1][0]);
-            t[1][1] = BlkMma<T>::mma(a1, b1, t[1][1]);
-        }
-    }
-    // -= / += Ab (32 x 32) * Bb^T  (Bb row-major [j][k])
-    __device__ __forceinline__ void msub_nt(const T *Ab, const T *Bb, int lane) { mac_nt<true>(Ab, Bb, lane); }
-    template <bool NEG>
-    __device__ __forceinline__ void mac_nt(const T *Ab, const T *Bb, int lane)
-    {
-        const int i = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) {
-            const int k = 4 * kk + kq;
-            const T a0 = NEG ? -Ab[i * PLD + k] : Ab[i * PLD + k], a1 = NEG ? -Ab[(16 + i) * PLD + k] : Ab[(16 + i) * PLD + k];
-            const T b0 = Bb[i * PLD + k], b1 = Bb[(16 + i) * PLD + k];
-            t[0][0] = BlkMma<T>::mma(a0, b0, t[0][0]);
-            t[0][1] = BlkMma<T>::mma(a0, b1, t[0][1]);
-            t[1][0] = BlkMma<T>::mma(a1, b0, t[1][0]);
-            t[1][1] = BlkMma<T>::mma(a1, b1, t[1][1]);
-        }
-    }
-    __device__ __forceinline__ void load(const T *g, long ldg, int lane)
-    {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    t[i][j][r] = g[(size_t)(16 * i + BlkMma<T>::crow(lane, r)) * ldg + 16 * j + (lane & 15)];
-    }
-    // sign * block -> LDS block (ld PLD, may be null) and / or global (ld ldg, may be null)
-    __device__ __forceinline__ void store(T sign, T *lds, T *g, long ldg, int lane) const
-    {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + BlkMma<T>::crow(lane, r), col = 16 * j + (lane & 15);
-                    const T v = sign * t[i][j][r];
-                    if (lds)
-                        lds[row * PLD + col] = v;
-                    if (g)
-                        g[(size_t)row * ldg + col] = v;
-                }
-    }
-};
 
 template <typename T, int DT>
 __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
@@ -523,13 +405,6 @@ __global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long
 // The inverse of the 128 x 128 L is assembled LEFT-looking, block row by block row, X_i: = -Xd_i (sum_k<i L_ik X_k:),
 // by waves that are idle during the panel steps; only the last block row needs Xd_3 and costs one product per block
 // after the last sub-block (was: last inverse 4.2 us + three product stages 3.4 us).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// workgroup barrier that waits for this wave's LDS traffic only (no vmcnt wait: see above)
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // trailing block (bi, bj), 1 <= bj <= bi <= 3, held in slot e of the k-th trailing wave:
 //   6 waves: one block each, (1,1) (2,1) (3,1) (2,2) (3,2) (3,3);  2 waves: the first the diagonal blocks, the second the others
@@ -547,117 +422,6 @@ __device__ __forceinline__ void own_block(int k, int e, int &bi, int &bj)
     }
 }
 
-// Sub-block step of diag_ldlm_kernel, fp32: the 32 x 32 block Dn (lower triangle valid) is factorised in the accumulator of
-// v_mfma_f32_32x32x2_f32 by one wave; L11 (strictly lower) -> Lx, L11^-1 -> Xdb, D -> dvec (lane = row).
-__device__ __forceinline__ void subblock_ldl(const float *Dn, float *Lx, float *Xdb, int lane, float &dvec)
-{
-    typedef float T;
-    const int half = lane >> 5, col = lane & 31;
-    f32x16 M, X;
-    {
-        // symmetric from the lower triangle: element (row, col) and its mirror image, two base addresses and immediate offsets
-        const T *b1 = Dn + 4 * half * PLD + col, *b2 = Dn + col * PLD + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = 8 * (r >> 2) + (r & 3), row = o + 4 * half;
-            const T v1 = b1[o * PLD], v2 = b2[o];
-            M[r] = row > col ? v1 : v2;
-            X[r] = row == col ? 1.0f : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;  // row j: register rj of wave half hj
-        const T rowj = M[rj];
-        const T dj = bcast_lane(rowj, j + 32 * hj);
-        const T lj = rowj * fast_rcp(dj);
-        const bool act = half == hj && col > j;
-        const T a = act ? -lj : 0.0f;
-        if (lane == j)
-            dvec = dj;
-        M = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rowj, M, 0, 0, 0);
-        X = __builtin_amdgcn_mfma_f32_32x32x2f32(a, X[rj], X, 0, 0, 0);
-        if (act)
-            Lx[col * PLD + j] = lj;  // L11[col][j]
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        Xdb[(8 * (r >> 2) + 4 * half + (r & 3)) * PLD + col] = X[r];  // exact zeros above, ones on the diagonal
-}
-
-// fp64: no 32 x 32 form; the block is three 16 x 16 tiles of v_mfma_f64_16x16x4_f64 -- T00, T01 (rows 0-15 of the right
-// half: the mirror image of the lower-left tile, which is never needed because the steps read ROWS) and T11 -- and its
-// inverse three more (X00, X10, X11).  Element (row 4 r + g, col c) of a tile is register r of lane 16 g + c, so row j is
-// register j / 4 of lane group j % 4: again the B operand as it stands (k = lane group) and, scaled, the A operand.
-// Steps 0-15: 3 + 2 MFMAs, steps 16-31: 1 + 2.
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, double *Xdb, int lane, double &dvec)
-{
-    typedef double T;
-    const int g = lane >> 4, c = lane & 15;
-    f64x4 T00, T01, T11, X00, X10, X11;
-    {
-        const T *b1 = Dn + g * PLD + c, *b2 = Dn + c * PLD + g;  // (row 4 r + g, col c) and its mirror image
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * r + g;
-            const T lo = b1[4 * r * PLD], up = b2[4 * r];
-            const T lo11 = b1[(16 + 4 * r) * PLD + 16], up11 = b2[16 * PLD + 16 + 4 * r];
-            T00[r] = row > c ? lo : up;
-            T01[r] = b2[16 * PLD + 4 * r];           // (row, 16 + c) = mirror of (16 + c, row)
-            T11[r] = row > c ? lo11 : up11;
-            X00[r] = row == c ? 1.0 : 0.0;
-            X10[r] = 0.0;
-            X11[r] = row == c ? 1.0 : 0.0;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = j >> 2, gj = j & 3;
-        const T row0 = T00[r], row1 = T01[r];
-        const T dj = bcast_lane(row0, 16 * gj + j);
-        const T rinv = fast_rcp(dj);
-        const T l0 = row0 * rinv, l1 = row1 * rinv;
-        const bool ing = g == gj, act = ing && c > j;
-        const T a0 = act ? -l0 : 0.0, a1 = ing ? -l1 : 0.0;
-        if (lane == j)
-            dvec = dj;
-        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row0, T00, 0, 0, 0);
-        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row1, T01, 0, 0, 0);
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-        const T xr = X00[r];
-        X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xr, X00, 0, 0, 0);
-        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xr, X10, 0, 0, 0);
-        if (act)
-            Lx[c * PLD + j] = l0;
-        if (ing)
-            Lx[(16 + c) * PLD + j] = l1;
-    }
-#pragma unroll
-    for (int j = 16; j < NB; ++j) {
-        const int jj = j - 16, r = jj >> 2, gj = jj & 3;
-        const T row1 = T11[r];
-        const T dj = bcast_lane(row1, 16 * gj + jj);
-        const T l1 = row1 * fast_rcp(dj);
-        const bool act = g == gj && c > jj;
-        const T a1 = act ? -l1 : 0.0;
-        if (lane == j)
-            dvec = dj;
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X10[r], X10, 0, 0, 0);
-        X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X11[r], X11, 0, 0, 0);
-        if (act)
-            Lx[(16 + c) * PLD + j] = l1;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * r + g;
-        Xdb[row * PLD + c] = X00[r];
-        Xdb[row * PLD + 16 + c] = 0.0;
-        Xdb[(16 + row) * PLD + c] = X10[r];
-        Xdb[(16 + row) * PLD + 16 + c] = X11[r];
-    }
-}
 
 template <typename T, int DT>
 __global__ __launch_bounds__(DT, 2) void diag_ldlm_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,

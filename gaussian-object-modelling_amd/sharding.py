@@ -97,3 +97,132 @@ def shard_record(state, per_rank):
             "t_train_other_ranks_ms": ms(max([r[0] for r in others], default=0.0)) if state == "recompute" else 0.0,
             "idle_max_ms": ms(idle), "t_predict_max_ms": ms(max(r[3] for r in per_rank)),
             "t_step_max_ms": ms(max(sum(r) for r in per_rank))}
+
+
+# ------------------------------------------------------------------ BASELINE configs 4 and 5 in their multi-GPU form
+# The two drivers below hold ALL of the rank logic (who trains, what travels, which x-planes / which objects a rank
+# owns, how the phase times are reduced); the compute sits behind a small duck-typed backend, so that bench.py runs
+# them on libgpx models over RCCL and tests/test_multirank_gloo.py runs the SAME functions on the CPU oracle over gloo.
+
+def grid_x_slab(g, rank, world):
+    """Rank's share of the g^3 lattice (x slowest, z fastest: src/gp_node.cpp:1025-1036) as whole x-planes:
+    (x_lo, x_hi, idx_lo, idx_hi) -- planes [x_lo, x_hi), i.e. lattice indices [x_lo g^2, x_hi g^2).  Remainder planes
+    go to the low ranks; a rank beyond the g-th plane gets an empty slab."""
+    x_lo, x_hi = slab_range(g, rank, world)
+    return x_lo, x_hi, x_lo * g * g, x_hi * g * g
+
+
+def objects_of_rank(n_objects, rank, world):
+    """Independent models (BASELINE config 5): object o is trained and evaluated by rank o mod world -- one object per
+    rank when world == n_objects, round-robin queues below that, idle ranks above it."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return list(range(rank, int(n_objects), world))
+
+
+def _gather_rows(dist, torch, row, world, device):
+    mine = torch.tensor([float(v) for v in row], dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        return [mine.tolist()]
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    return [r.tolist() for r in rows]
+
+
+def _fence(dist, be):
+    be.sync()
+    if dist is not None:
+        dist.barrier()
+    be.sync()
+
+
+def sharded_grid_step(dist, torch, rank, world, g, state, be, device, clock):
+    """ONE model, its g^3 query lattice cut into x-slabs (BASELINE config 4).  state == "broadcast": rank 0
+    trains, the others allocate a shell, every state blob goes through ONE dist.broadcast, the receivers commit.
+    state == "recompute": every rank trains the same model itself -- no collective on the data path.
+    Backend: be.train() / be.shell() -> model; be.blobs(m) -> list of uint8 tensors (in place views of the state);
+    be.commit(m); be.predict(m, g, x_lo, x_hi) -> (n_queries, sum f, sum v, min v, max v) of the rank's planes;
+    be.close(m); be.sync().  Returns the record of the step (same on every rank)."""
+    if state not in ("broadcast", "recompute"):
+        raise ValueError("state must be 'broadcast' or 'recompute'")
+    x_lo, x_hi, lo, hi = grid_x_slab(g, rank, world)
+    _fence(dist, be)
+    t0 = clock()
+    if state == "broadcast":
+        m = be.train() if rank == 0 else be.shell()
+        be.sync()
+        t1 = clock()
+        bufs = be.blobs(m)
+        if dist is not None:
+            broadcast_state(dist, bufs, src=0)
+        be.sync()
+        t2 = clock()
+        if rank != 0:
+            be.commit(m)
+            be.sync()
+        t3 = clock()
+        nbytes = int(sum(int(b.numel()) * int(b.element_size()) for b in bufs))
+    else:
+        m = be.train()
+        be.sync()
+        t1 = t2 = t3 = clock()
+        nbytes = 0
+    nq, sf, sv, vmin, vmax = be.predict(m, g, x_lo, x_hi) if x_hi > x_lo else (0, 0.0, 0.0, float("inf"), float("-inf"))
+    be.sync()
+    t4 = clock()
+    be.close(m)
+    _fence(dist, be)
+    t5 = clock()
+    rows = _gather_rows(dist, torch, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t0, x_lo, x_hi, nq, sf, sv,
+                                      min(vmin, 1e300), max(vmax, -1e300)), world, device)
+    rec = shard_record(state, [tuple(r[:4]) for r in rows])
+    wall = max(r[4] for r in rows)
+    rec.update({"grid": g, "n_query": g ** 3, "world": world, "state_bytes": nbytes, "ms_per_step": 1e3 * wall,
+                "value": g ** 3 / wall, "unit": "query-points/s (whole grid / max-over-ranks wall time, barrier to barrier)",
+                "slabs": [{"rank": r, "x_planes": [int(rows[r][5]), int(rows[r][6])], "n_query": int(rows[r][7]),
+                           "t_predict_ms": 1e3 * rows[r][3]} for r in range(world)],
+                "sum_f": sum(r[8] for r in rows), "sum_v": sum(r[9] for r in rows),
+                "v_min": min(r[10] for r in rows), "v_max": max(r[11] for r in rows)})
+    if sum(s["n_query"] for s in rec["slabs"]) != g ** 3:
+        raise RuntimeError("slabs do not tile the lattice")
+    return rec
+
+
+def objects_per_rank_step(dist, torch, rank, world, n_objects, run_object, be, device, clock):
+    """Independent models, one per GPU (BASELINE config 5): rank r trains and evaluates the objects of
+    objects_of_rank(n_objects, r, world), one after the other; no data-path collective.  run_object(o) -> (n_train,
+    n_query, sum f, sum v) after the object's results are complete.  Returns the record (same on every rank): wall time
+    = barrier to barrier, value = all queries of all objects / that time."""
+    mine = objects_of_rank(n_objects, rank, world)
+    _fence(dist, be)
+    t0 = clock()
+    done = []
+    for o in mine:
+        ta = clock()
+        n_train, nq, sf, sv = run_object(o)
+        done.append((o, n_train, nq, sf, sv, clock() - ta))
+    be.sync()
+    t_mine = clock() - t0
+    _fence(dist, be)
+    wall = clock() - t0
+    # fixed-width rows: per object slot (o, n_train, nq, sum f, sum v, seconds), padded with -1
+    slots = (n_objects + world - 1) // world
+    row = [t_mine, wall]
+    for s in range(slots):
+        row += list(done[s]) if s < len(done) else [-1, 0, 0, 0.0, 0.0, 0.0]
+    rows = _gather_rows(dist, torch, row, world, device)
+    objs = {}
+    for r, rw in enumerate(rows):
+        for s in range(slots):
+            o, n_train, nq, sf, sv, sec = rw[2 + 6 * s: 8 + 6 * s]
+            if o >= 0:
+                if int(o) in objs:
+                    raise RuntimeError("object %d ran on two ranks" % int(o))
+                objs[int(o)] = {"rank": r, "n_train": int(n_train), "n_query": int(nq), "sum_f": sf, "sum_v": sv, "ms": 1e3 * sec}
+    if sorted(objs) != list(range(n_objects)):
+        raise RuntimeError("objects %s were not all run" % sorted(objs))
+    wall = max(rw[1] for rw in rows)
+    total_q = sum(o["n_query"] for o in objs.values())
+    return {"world": world, "n_objects": n_objects, "ms_per_step": 1e3 * wall, "value": total_q / wall,
+            "unit": "query-points/s (all objects / max-over-ranks wall time, barrier to barrier)", "n_query": total_q,
+            "t_rank_ms": [1e3 * rw[0] for rw in rows], "objects": [dict(objs[o], object=o) for o in range(n_objects)]}

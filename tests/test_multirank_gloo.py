@@ -222,3 +222,136 @@ def test_shard_record_arithmetic():
     assert abs(rec["idle_max_ms"] - 43) < 1e-9 and abs(rec["t_predict_max_ms"] - 510) < 1e-9
     with pytest.raises(ValueError):
         sh.shard_record("gossip", [])
+
+
+class _OracleBackend:
+    """The CPU oracle behind the backend protocol of sharding.sharded_grid_step / objects_per_rank_step (bench.py puts
+    libgpx models on the GPU behind the same protocol).  The "state" that travels is the training data + alpha as one
+    uint8 tensor; a shell holds zeros until the broadcast filled them, and commit() rebuilds the model from the bytes."""
+
+    def __init__(self, orc, ds, torch, kern, data):
+        self.orc, self.ds, self.torch, self.kern, self.data = orc, ds, torch, kern, data
+        self.n = len(data[0])
+        self.trained = 0
+
+    def sync(self):
+        pass
+
+    def train(self):
+        self.trained += 1
+        m = {"model": self.orc.Model(self.kern, *self.data)}
+        m["blob"] = self.torch.from_numpy(np.concatenate(list(self.data) + [m["model"].alpha]).view(np.uint8).copy())
+        return m
+
+    def shell(self):
+        return {"model": None, "blob": self.torch.zeros(8 * 6 * self.n, dtype=self.torch.uint8)}
+
+    def blobs(self, m):
+        return [m["blob"]]
+
+    def commit(self, m):
+        a = m["blob"].numpy().view(np.float64).reshape(6, self.n)
+        m["model"] = self.orc.Model(self.kern, a[0], a[1], a[2], a[3], a[4])
+        assert np.array_equal(m["model"].alpha, a[5])  # same arithmetic on the same bytes
+
+    def predict(self, m, g, x_lo, x_hi):
+        qx, qy, qz = self.ds.query_grid(g)
+        lo, hi = x_lo * g * g, x_hi * g * g
+        out = m["model"].evaluate(qx[lo:hi], qy[lo:hi], qz[lo:hi], want_v=True)
+        return hi - lo, float(out["f"].sum()), float(out["v"].sum()), float(out["v"].min()), float(out["v"].max())
+
+    def close(self, m):
+        m.clear()
+
+
+def _configs_worker(rank, world, port, q):
+    """BASELINE configs 4 and 5 in their multi-GPU form: the rank logic bench.py runs on the GPUs (sharding.sharded_grid_step
+    for both ways of getting the state, sharding.objects_per_rank_step), here over gloo with the oracle as the compute."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import time
+    import torch
+    import torch.distributed as dist
+    import gp_oracle as orc
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    ds = importlib.import_module("gaussian-object-modelling_amd.datasets")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        g, n = 7, 70  # 7 x-planes over 2 ranks: 4 + 3
+        kern = orc.make_kernel("thinplate", 4.0)
+        data = ds.fibonacci_training_set(n)
+        be = _OracleBackend(orc, ds, torch, kern, data)
+        recs = {}
+        for state in ("broadcast", "recompute"):
+            before = be.trained
+            recs[state] = sh.sharded_grid_step(dist, torch, rank, world, g, state, be, "cpu", time.perf_counter)
+            recs[state]["trained_here"] = be.trained - before
+        # five independent objects over two ranks: rank 0 gets 0, 2, 4 and rank 1 gets 1, 3
+        sizes = [40, 55, 33, 61, 48]
+        qx, qy, qz = ds.query_grid(5)
+
+        def run_object(o):
+            m = orc.Model(orc.make_kernel("gaussian", 1.0, 1.0), *ds.fibonacci_training_set(sizes[o], seed=100 + o))
+            out = m.evaluate(qx, qy, qz, want_v=True)
+            return sizes[o], len(qx), float(out["f"].sum()), float(out["v"].sum())
+
+        c5 = sh.objects_per_rank_step(dist, torch, rank, world, len(sizes), run_object, be, "cpu", time.perf_counter)
+        trained = torch.tensor([recs["broadcast"]["trained_here"], recs["recompute"]["trained_here"]], dtype=torch.float64)
+        allt = [torch.zeros_like(trained) for _ in range(world)]
+        dist.all_gather(allt, trained)
+        if rank == 0:
+            whole = orc.Model(kern, *data).evaluate(*ds.query_grid(g), want_v=True)
+            ref5 = [run_object(o) for o in range(len(sizes))]
+            q.put((recs, c5, [t.tolist() for t in allt], float(whole["f"].sum()), float(whole["v"].sum()), ref5))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_baseline_configs_4_and_5_rank_logic_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29200 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_configs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    recs, c5, trained, sum_f, sum_v, ref5 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # C4: who trained -- broadcast: rank 0 only; recompute: both
+    assert trained == [[1.0, 1.0], [0.0, 1.0]]
+    for state in ("broadcast", "recompute"):
+        r = recs[state]
+        assert [s["x_planes"] for s in r["slabs"]] == [[0, 4], [4, 7]] and [s["n_query"] for s in r["slabs"]] == [4 * 49, 3 * 49]
+        assert r["n_query"] == 343 and r["world"] == 2 and r["state"] == state
+        assert abs(r["sum_f"] - sum_f) <= 1e-12 * abs(sum_f) + 1e-12 and abs(r["sum_v"] - sum_v) <= 1e-12 * abs(sum_v)
+        assert r["ms_per_step"] > 0 and r["value"] > 0 and r["t_predict_max_ms"] > 0
+    assert recs["broadcast"]["state_bytes"] == 8 * 6 * 70 and recs["broadcast"]["t_commit_ms"] > 0
+    assert recs["recompute"]["state_bytes"] == 0 and recs["recompute"]["t_bcast_ms"] == 0.0
+    assert recs["recompute"]["t_train_other_ranks_ms"] > 0
+    # C5: object o on rank o mod 2, every object exactly once, results those of a single process
+    assert [o["rank"] for o in c5["objects"]] == [0, 1, 0, 1, 0]
+    assert [o["n_train"] for o in c5["objects"]] == [40, 55, 33, 61, 48]
+    for o, ref in zip(c5["objects"], ref5):
+        assert o["sum_f"] == ref[2] and o["sum_v"] == ref[3] and o["n_query"] == 125
+    assert c5["n_query"] == 5 * 125 and len(c5["t_rank_ms"]) == 2 and c5["ms_per_step"] >= max(c5["t_rank_ms"]) * 0.999
+
+
+def test_grid_x_slab_and_object_assignment():
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    for g, world in ((256, 1), (256, 2), (256, 4), (256, 8), (7, 3), (5, 8)):
+        slabs = [sh.grid_x_slab(g, r, world) for r in range(world)]
+        assert slabs[0][0] == 0 and slabs[-1][1] == g and slabs[0][2] == 0 and slabs[-1][3] == g ** 3
+        for a, b in zip(slabs, slabs[1:]):
+            assert a[1] == b[0] and a[3] == b[2]  # contiguous planes, contiguous lattice indices
+        assert all(s[3] - s[2] == (s[1] - s[0]) * g * g for s in slabs)
+    assert sh.grid_x_slab(256, 3, 8) == (96, 128, 96 * 65536, 128 * 65536)
+    for n_obj, world in ((8, 8), (8, 4), (8, 2), (8, 1), (8, 3), (3, 8)):
+        got = [sh.objects_of_rank(n_obj, r, world) for r in range(world)]
+        assert sorted(o for l in got for o in l) == list(range(n_obj))
+        assert max(len(l) for l in got) - min(len(l) for l in got) <= 1
+    assert sh.objects_of_rank(8, 5, 8) == [5] and sh.objects_of_rank(8, 1, 4) == [1, 5]
+    with pytest.raises(ValueError):
+        sh.objects_of_rank(8, 8, 8)
