@@ -110,11 +110,72 @@ void stream_release(int device, hipStream_t s)
     }
     (void)hipStreamDestroy(s);
 }
+
+// Pinned host blocks for the staging of a small model's create (one host-to-device and one device-to-host copy per
+// model): hipHostMalloc / hipHostFree cost more than the device work of such a create, so the blocks are recycled.
+static std::mutex g_pin_mtx;
+static std::vector<std::pair<void *, size_t>> g_pin_pool;
+constexpr size_t PIN_POOL_MAX = 64;
+static std::vector<std::pair<void *, size_t>> g_pin_live;
+
+hipError_t pinned_acquire(size_t bytes, void **p)
+{
+    const size_t want = (bytes + 65535) / 65536 * 65536;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mtx);
+        for (size_t i = 0; i < g_pin_pool.size(); ++i)
+            if (g_pin_pool[i].second >= want) {
+                *p = g_pin_pool[i].first;
+                g_pin_live.push_back(g_pin_pool[i]);
+                g_pin_pool.erase(g_pin_pool.begin() + i);
+                return hipSuccess;
+            }
+    }
+    const hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pin_mtx);
+        g_pin_live.push_back({*p, want});
+    }
+    return e;
+}
+
+void pinned_release(void *p)
+{
+    if (!p)
+        return;
+    std::pair<void *, size_t> blk{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mtx);
+        for (size_t i = 0; i < g_pin_live.size(); ++i)
+            if (g_pin_live[i].first == p) {
+                blk = g_pin_live[i];
+                g_pin_live.erase(g_pin_live.begin() + i);
+                break;
+            }
+        if (blk.first && g_pin_pool.size() < PIN_POOL_MAX) {
+            g_pin_pool.push_back(blk);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+static void pinned_trim()
+{
+    std::vector<std::pair<void *, size_t>> v;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mtx);
+        v.swap(g_pin_pool);
+    }
+    for (auto &b : v)
+        (void)hipHostFree(b.first);
+}
 }  // namespace gpxh
 
 extern "C" void gpx_trim(void)
 {
     gpxh::pool().trim();
+    gpxh::pinned_trim();
     int prev = -1;
     (void)hipGetDevice(&prev);
     {

@@ -3,6 +3,7 @@
 // substitution with fp64 matrix-free residual refinement (:163), normals (:166-181), the inverse factor X = L^-1 by
 // recursive doubling, the rank-n append of update() and the MIXED-precision demotion.
 #include "gpx_model.hpp"
+#include "gpx_small.hpp"
 
 namespace gpxh {
 
@@ -727,6 +728,202 @@ static int demote_to_f32(gpx_model *m)
     return GPX_OK;
 }
 
+// ---- create of a small model in three launches (gpx_small.hip) ---------------------------------------------------
+// Taken for a fresh create (no rank-n append) of a model that trains in fp64 and has at most SMALL_CREATE_MAX_NP padded
+// rows -- every model of the reference's own sizes in every precision mode (F32 / F32_SPLIT models of this size train in
+// fp64, set_training_precision).  GPX_SMALL_CREATE=0 keeps the general chain (its tested twin).
+static bool small_create_eligible(const gpx_model *m, const kept_factor *keep)
+{
+    if (keep || m->prec != GPX_PREC_F64 || m->npad > SMALL_CREATE_MAX_NP)
+        return false;
+    if (const char *e = std::getenv("GPX_SMALL_CREATE"))
+        return std::atoi(e) != 0;
+    return true;
+}
+
+// *fell_back = true: a wait inside the launches gave up (the GPU was too busy to hold the whole grid); nothing of the
+// model is valid and the caller runs the general chain.  Otherwise the model is complete -- points, factor, inverse
+// factor, alpha, row corrections, and for the fp32 modes the rounded state -- exactly as build_model leaves it.
+static int build_model_small(gpx_model *m, bool *fell_back)
+{
+    *fell_back = false;
+    const int n = m->n, np = m->npad;
+    small_create_init();
+    std::vector<double> diag(n);
+    for (int i = 0; i < n; ++i)
+        diag[i] = m->cov.k0 + (m->has_s2 ? m->hs2[i] : 0.0);
+    eigen_pivot_order(diag, m->perm);
+    if (!m->dvecs) {
+        int rc = alloc_model(m);
+        if (rc)
+            return rc;
+        HIPCHK(big_alloc(&m->Kmat, sizeof(double) * (size_t)np * np));
+        HIPCHK(big_alloc(&m->linv, sizeof(double) * (size_t)m->nblk * TILE * TILE));
+        HIPCHK(big_alloc(&m->Wp, sizeof(double) * (size_t)np * WIDE_PANEL));
+    }
+    if (!m->X)
+        HIPCHK(big_alloc(&m->X, sizeof(double) * (size_t)np * np));
+    const SmallWs lay = small_ws_layout(np);
+    DevGuard gws(nullptr, true), gnb(nullptr, true), gnX(nullptr, true);
+    HIPCHK(big_alloc(&gws.p, lay.bytes));
+    char *ws = (char *)gws.p;
+    size_t nblob_bytes = 0;
+    if (m->train64) {  // the fp32 state the model ends up in (demote_to_f32), filled by the third launch
+        int rc = alloc_blob0(m, 4, &gnb.p, &nblob_bytes);
+        if (rc)
+            return rc;
+        HIPCHK(big_alloc(&gnX.p, sizeof(float) * (size_t)np * np));
+    }
+    // host block: [5][np] staging | SmallResult | D[np]
+    const size_t res_bytes = lay.res_d + sizeof(double) * (size_t)np - lay.res;
+    const size_t host_bytes = sizeof(double) * 5 * (size_t)np + res_bytes;
+    void *hp = nullptr;
+    HIPCHK(pinned_acquire(host_bytes, &hp));
+    struct PinGuard {
+        void *p;
+        ~PinGuard() { pinned_release(p); }
+    } pin_guard{hp};
+    double *st = (double *)hp;
+    std::memset(st, 0, sizeof(double) * 5 * (size_t)np);
+    double c[3] = {0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        const int i = m->perm[k];
+        st[k] = m->hx[i];
+        st[np + k] = m->hy[i];
+        st[2 * (size_t)np + k] = m->hz[i];
+        st[3 * (size_t)np + k] = m->hlabel[i];
+        st[4 * (size_t)np + k] = m->has_s2 ? m->hs2[i] : 0.0;
+        c[0] += st[k], c[1] += st[np + k], c[2] += st[2 * (size_t)np + k];
+    }
+    for (int d = 0; d < 3; ++d)
+        m->cen[d] = c[d] / n;
+    double ymax = 0.0;
+    for (int i = 0; i < n; ++i)
+        ymax = std::max(ymax, std::fabs(m->hlabel[i]));
+    SmallArgs a;
+    a.stage = (const double *)(ws + lay.stage);
+    a.n = n, a.np = np, a.nbt = np / SMALL_TILE, a.nb = (n + SMALL_TILE - 1) / SMALL_TILE;
+    a.ntiles = a.nbt * (a.nbt + 1) / 2;
+    a.cov = lower_cov<double>(m->cov);
+    for (int d = 0; d < 3; ++d)
+        a.cen[d] = m->cen[d];
+    a.want_corr = m->var_fit_opt ? 1 : 0;
+    a.op64 = m->op64 ? 1 : 0;
+    a.ir_adaptive = m->opt.ir_steps < 0 ? 1 : 0;
+    a.ir_max = a.ir_adaptive ? 4 : m->opt.ir_steps;
+    a.ir_tol = 1e-9 * std::max(ymax, 1e-300);
+    if (const char *we = std::getenv("GPX_VAR_FIT_WDELTA"))
+        a.wd_override = std::max(0.0, std::atof(we));
+    a.epoch = small_create_epoch();
+    if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
+        a.spin_limit = std::max(1, std::atoi(sl));
+    a.abort_idx = 2 * a.ntiles, a.bar_idx = 2 * a.ntiles + 1;
+    a.K = (double *)m->Kmat, a.X = (double *)m->X, a.linv = (double *)m->linv;
+    a.d = (double *)m->t_d, a.dinv = (double *)m->t_dinv;
+    a.d_x = m->d_x, a.d_y = m->d_y, a.d_z = m->d_z;
+    a.t_x = (double *)m->t_x, a.t_y = (double *)m->t_y, a.t_z = (double *)m->t_z;
+    a.d_lab = m->d_lab, a.d_s2 = m->d_s2, a.t_s2 = (double *)m->t_s2;
+    a.d_alpha = m->d_alpha, a.t_alpha = (double *)m->t_alpha, a.d_r = m->d_r;
+    a.d_corr = m->d_corr, a.d_dinv64 = m->d_dinv64, a.d_meta = m->d_meta, a.info = m->d_info;
+    a.blob0 = (const double *)m->blob0, a.nblob = gnb.p, a.nX = (float *)gnX.p;
+    a.XT = (double *)(ws + lay.xt);
+    a.flags = (unsigned long long *)(ws + lay.flags);
+    a.tmax = (double *)(ws + lay.tmax), a.rmaxv = (double *)(ws + lay.rmaxv), a.u = (double *)(ws + lay.u);
+    a.tij = (int *)(ws + lay.tij), a.negcnt = (int *)(ws + lay.negcnt), a.badrow = (int *)(ws + lay.badrow);
+    a.res = (SmallResult *)(ws + lay.res), a.res_d = (double *)(ws + lay.res_d);
+    hipStream_t s = m->stream;
+    HIPCHK(hipMemcpyAsync(ws + lay.stage, st, sizeof(double) * 5 * (size_t)np, hipMemcpyHostToDevice, s));
+    (void)hipEventRecord(m->ev[EV_T0], s);
+    (void)hipEventRecord(m->ev[EV_KBUILD], s);
+    launch_small_create(m->kern.id, a, m->train64, s, m->ev[EV_FACTOR], m->ev[EV_SOLVE]);
+    (void)hipEventRecord(m->ev[EV_NORMALS], s);
+    char *hres = (char *)hp + sizeof(double) * 5 * (size_t)np;
+    HIPCHK(hipMemcpyAsync(hres, ws + lay.res, res_bytes, hipMemcpyDeviceToHost, s));
+    {
+        const hipError_t se = hipStreamSynchronize(s);
+        if (se != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            return fail(GPX_E_HIP, std::string("small-model create: ") + hipGetErrorString(se));
+        }
+        HIPCHK(hipGetLastError());
+    }
+    const SmallResult *res = (const SmallResult *)hres;
+    const double *hd = (const double *)(hres + (lay.res_d - lay.res));
+    if (res->info[5] != 0) {
+        *fell_back = true;
+        return GPX_OK;  // (the guards hand the workspace and the unused fp32 state back)
+    }
+    float ms;
+    m->stats = gpx_stats{};
+    // kernel matrix, LDL^T and inverse factor are ONE launch here: its time is reported as the factorisation's
+    if (hipEventElapsedTime(&ms, m->ev[EV_KBUILD], m->ev[EV_FACTOR]) == hipSuccess)
+        m->stats.t_factor_ms = ms;
+    if (hipEventElapsedTime(&ms, m->ev[EV_FACTOR], m->ev[EV_SOLVE]) == hipSuccess)
+        m->stats.t_solve_ms = ms;
+    if (m->train64 && hipEventElapsedTime(&ms, m->ev[EV_SOLVE], m->ev[EV_NORMALS]) == hipSuccess)
+        m->stats.t_inverse_ms = ms;  // (the rounding of the state)
+    m->gemm_ev_used_factor = 0;
+    m->stats.n = n;
+    m->stats.n_padded = np;
+    m->stats.n_negative_pivots = res->info[1];
+    m->stats.ir_steps_done = res->ir_done;
+    m->stats.alpha_residual = res->rmax;
+    if (res->info[0] != 0)
+        return fail(GPX_E_SINGULAR, "LDL^T: zero or non-finite pivot at internal row " + std::to_string(res->info[0] - 1));
+    {  // Model::R (gp_regressor.hpp:135): the device found the arg-max pair, the distance is fp64 from the caller's points
+        const int p = res->info[2], q = res->info[3];
+        if (p >= 0 && p < n && q >= 0 && q < n) {
+            const int ia = m->perm[p], ib = m->perm[q];
+            const double dx = m->hx[ia] - m->hx[ib], dy = m->hy[ia] - m->hy[ib], dz = m->hz[ia] - m->hz[ib];
+            m->R = std::sqrt(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    m->ready = true;
+    m->has_inverse = true;
+    m->var_fit = m->var_fit_opt;
+    m->promoted = false;
+    if (m->train64 && m->stats.n_negative_pivots > 0 && !std::getenv("GPX_NO_PROMOTE")) {
+        m->train64 = false;  // an indefinite kernel matrix keeps its fp64 state (see build_model)
+        m->var_fit = false;
+        m->promoted = true;
+    } else if (m->train64 && m->stats.n_negative_pivots > 0) {
+        // GPX_NO_PROMOTE (tests): the third launch skipped the rounding of an indefinite model -- do it now
+        int rc = demote_to_f32(m);
+        return rc ? rc : pack_split(m);
+    }
+    if (m->train64) {  // adopt the fp32 state the third launch has filled (what demote_to_f32 does for the chain)
+        m->hD.assign(hd, hd + n);
+        big_free(m->blob0);
+        big_free(m->X);
+        big_free(m->Kmat);
+        big_free(m->linv);
+        big_free(m->Wp);
+        big_free(m->tvecs);
+        m->Kmat = m->linv = m->Wp = m->tvecs = nullptr;
+        m->t_s2 = m->t_d = m->t_b = m->t_yv = m->t_xs = m->t_alpha = nullptr;
+        m->blob0 = gnb.release();
+        m->blob0_bytes = nblob_bytes;
+        m->X = gnX.release();
+        m->prec = GPX_PREC_F32;
+        m->esz = 4;
+        carve_blob0(m);
+    }
+    if (m->opt.with_normals) {  // create<true> (gp_regressor.hpp:166-181): the gradient kernel at the training points
+        size_t need = predict_ws_doubles(n, np, true) * sizeof(double);
+        int rc = ensure(m, (void **)&m->ws_pred, &m->ws_pred_doubles, need);
+        if (rc)
+            return rc;
+        if (!m->d_normals)
+            HIPCHK(hipMalloc((void **)&m->d_normals, sizeof(double) * 3 * (size_t)n));
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, n, m->d_x, m->d_y, m->d_z, m->d_f,
+                       m->d_normals, m->ws_pred, s);
+        launch_normalize_rows3(n, m->d_normals, s);
+        HIPCHK(hipStreamSynchronize(s));
+        m->has_normals = true;
+    }
+    return m->prec == GPX_PREC_F32 ? pack_split(m) : GPX_OK;
+}
+
 // ---- create: everything after the host arrays are in place ---------------------------------------
 int build_model(gpx_model *m, kept_factor *keep)
 {
@@ -734,6 +931,7 @@ int build_model(gpx_model *m, kept_factor *keep)
     const size_t e = m->esz;
     HIPCHK(hipSetDevice(m->device));
     factor_init(m->prec);
+    int64_t small_fallbacks = 0;
     // Eigen's pivot order from the original diagonal k(0) + sigma2_i
     std::vector<double> diag(n);
     for (int i = 0; i < n; ++i)
@@ -749,6 +947,13 @@ int build_model(gpx_model *m, kept_factor *keep)
         st[3 * (size_t)np + k] = m->hlabel[i];
         st[4 * (size_t)np + k] = m->has_s2 ? m->hs2[i] : 0.0;
     }
+    if (small_create_eligible(m, keep)) {
+        bool fell_back = false;
+        const int rc = build_model_small(m, &fell_back);
+        if (!fell_back)
+            return rc;
+        small_fallbacks = 1;  // a wait of the dataflow launches gave up: the general chain below redoes the create
+    }
     if (!m->dvecs) {
         int rc = alloc_model(m);
         if (rc)
@@ -756,6 +961,8 @@ int build_model(gpx_model *m, kept_factor *keep)
         HIPCHK(big_alloc(&m->Kmat, e * (size_t)np * np));
         HIPCHK(big_alloc(&m->linv, e * (size_t)m->nblk * TILE * TILE));
         HIPCHK(big_alloc(&m->Wp, e * (size_t)np * WIDE_PANEL));
+    }
+    if (!m->d_tmax) {
         const int nt = np / TILE, ntiles = nt * (nt + 1) / 2;
         HIPCHK(hipMalloc((void **)&m->d_tmax, sizeof(float) * ntiles));
         HIPCHK(hipMalloc((void **)&m->d_tij, sizeof(int) * 2 * ntiles));
@@ -913,7 +1120,7 @@ int build_model(gpx_model *m, kept_factor *keep)
     m->stats.n_negative_pivots = info[1] + (keep ? keep->n_neg : 0);
     m->stats.ir_steps_done = ir;
     m->stats.alpha_residual = rmax;
-    m->stats.solve_fallbacks = solve_fallbacks;
+    m->stats.solve_fallbacks = solve_fallbacks + small_fallbacks;
     if (info[5] != 0)  // cannot happen: the step kernels never raise it
         return fail(GPX_E_HIP, "block substitution: give-up flag set after the launch-per-step fallback");
     if (info[0] != 0)

@@ -151,6 +151,8 @@ namespace gpxh {
 // go back (synchronised) to, a per-device pool of non-blocking streams; gpx_trim() destroys the pooled ones.
 hipError_t stream_acquire(int device, hipStream_t *s);  // the current device must be `device`
 void stream_release(int device, hipStream_t s);
+hipError_t pinned_acquire(size_t bytes, void **p);  // recycled pinned host blocks (gpx_api.hip)
+void pinned_release(void *p);
 hipError_t big_alloc(void **p, size_t bytes);  // BigPool of gpx_host.hpp over the HIP backend
 void big_free(void *p);
 // releases a device allocation when the scope is left on an error path (HIPCHK returns early); release() hands it on

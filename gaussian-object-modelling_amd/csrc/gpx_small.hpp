@@ -1,0 +1,79 @@
+// gpx_small.hpp -- interface of the three-launch create of small models (gpx_small.hip; host side: build_model_small in
+// gpx_build.hip).
+#pragma once
+#include "gpx_internal.hpp"
+
+namespace gpx {
+
+constexpr int SMALL_TILE = 64;          // tile edge of the dataflow factorisation
+constexpr int SMALL_CREATE_MAX_NP = 1024;  // padded rows up to which create() takes this path (fp64 training only)
+
+// what the host reads back after the launches (one copy)
+struct SmallResult {
+    int info[8];   // as gpx_model::d_info: [0] first bad pivot (1-based), [1] negative pivots, [2..3] arg-max pair of the
+                   // squared distance (internal indices), [5] a wait gave up (the results are void)
+    double rmax;   // max |y - K alpha| of the last residual
+    double d2max;  // largest squared training distance
+    int ir_done;
+    int pad;
+};
+
+struct SmallArgs {
+    // ---- input ----
+    const double *stage = nullptr;  // [5][np]: x y z label sigma2 in internal (pivot) order, zero padded
+    int n = 0, np = 0, nbt = 0 /* np / 64 */, nb = 0 /* tile rows that hold training points */, ntiles = 0;
+    Cov<double> cov{};
+    double cen[3] = {0, 0, 0};
+    int want_corr = 0, op64 = 0, ir_max = 4, ir_adaptive = 1;
+    double ir_tol = 0, wd_override = -1.0;
+    unsigned long long epoch = 0;
+    int spin_limit = 1 << 20, abort_idx = 0, bar_idx = 0;
+    // ---- model state written by the launches ----
+    double *K = nullptr, *X = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;
+    double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *t_x = nullptr, *t_y = nullptr, *t_z = nullptr;
+    double *d_lab = nullptr, *d_s2 = nullptr, *t_s2 = nullptr, *d_alpha = nullptr, *t_alpha = nullptr, *d_r = nullptr;
+    double *d_corr = nullptr, *d_dinv64 = nullptr, *d_meta = nullptr;
+    int *info = nullptr;
+    const double *blob0 = nullptr;  // demotion: source (fp64 layout) and the fp32 state it fills
+    void *nblob = nullptr;
+    float *nX = nullptr;
+    // ---- workspace ----
+    double *XT = nullptr;              // transposed copy of X (read on and above its diagonal)
+    unsigned long long *flags = nullptr;  // [ntiles] factor tiles, [ntiles] inverse tiles, abort, barrier counter
+    double *tmax = nullptr, *rmaxv = nullptr, *u = nullptr, *res_d = nullptr;
+    int *tij = nullptr, *negcnt = nullptr, *badrow = nullptr;
+    SmallResult *res = nullptr;
+};
+
+// byte offsets of the workspace block for a padded order np (one big_alloc per model; layout below)
+struct SmallWs {
+    size_t stage, xt, flags, tmax, rmaxv, u, tij, negcnt, badrow, res, res_d, bytes;
+};
+inline SmallWs small_ws_layout(int np)
+{
+    const size_t nbt = (size_t)np / SMALL_TILE, nt = nbt * (nbt + 1) / 2;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    SmallWs w{};
+    size_t o = 0;
+    w.stage = o, o += al(sizeof(double) * 5 * np);
+    w.xt = o, o += al(sizeof(double) * (size_t)np * np);
+    w.flags = o, o += al(sizeof(unsigned long long) * (2 * nt + 2));
+    w.tmax = o, o += al(sizeof(double) * nt);
+    w.rmaxv = o, o += al(sizeof(double) * 8);
+    w.u = o, o += al(sizeof(double) * np);
+    w.tij = o, o += al(sizeof(int) * 2 * nt);
+    w.negcnt = o, o += al(sizeof(int) * nbt);
+    w.badrow = o, o += al(sizeof(int) * nbt);
+    w.res = o, o += al(sizeof(SmallResult));   // res and res_d are adjacent: one device-to-host copy
+    w.res_d = o, o += al(sizeof(double) * np);
+    w.bytes = o;
+    return w;
+}
+
+void small_create_init();                  // per-device kernel attributes
+unsigned long long small_create_epoch();   // a value no earlier create of this process has used (flags are never cleared)
+// factor (+ record ev_factor), alpha (+ record ev_solve) and, when demote, the fp32 state; asynchronous on st
+void launch_small_create(int kernel_id, const SmallArgs &a, bool demote, hipStream_t st, hipEvent_t ev_factor,
+                         hipEvent_t ev_solve);
+
+}  // namespace gpx
