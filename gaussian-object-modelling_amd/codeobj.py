@@ -1,0 +1,222 @@
+"""Reads the AMDGPU code-object metadata (msgpack note NT_AMDGPU_METADATA) of every gfx950 kernel inside a host
+shared library built by hipcc: the .hip_fatbin section is a sequence of clang offload bundles, each holding one
+device ELF per target.  Used by the CPU-side checks on register spills / scratch (tests/test_codeobj.py) and by
+scripts/kernel_resources.py."""
+import struct
+import subprocess
+
+import msgpack
+
+OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _fatbin(path, tmp):
+    out = str(tmp) + "/fat.bin"
+    subprocess.run([OBJCOPY, "--dump-section", ".hip_fatbin=" + out, path], check=True)
+    return open(out, "rb").read()
+
+
+def _device_elfs(fat):
+    pos = fat.find(MAGIC)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", fat, pos + 24)[0]
+        off = pos + 32
+        for _ in range(n):
+            eo, es, tl = struct.unpack_from("<QQQ", fat, off)
+            triple = fat[off + 24:off + 24 + tl].decode()
+            off += 24 + tl
+            if "gfx950" in triple and es > 0:
+                yield fat[pos + eo:pos + eo + es]
+        pos = fat.find(MAGIC, pos + 24)
+
+
+def _notes(elf):
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2
+    shoff = struct.unpack_from("<Q", elf, 0x28)[0]
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    for i in range(shnum):
+        sh = elf[shoff + i * shentsize:shoff + (i + 1) * shentsize]
+        stype = struct.unpack_from("<I", sh, 4)[0]
+        if stype != 7:  # SHT_NOTE
+            continue
+        o, sz = struct.unpack_from("<QQ", sh, 0x18)
+        p, end = o, o + sz
+        while p + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+            p += 12
+            name = elf[p:p + namesz]
+            p += (namesz + 3) & ~3
+            desc = elf[p:p + descsz]
+            p += (descsz + 3) & ~3
+            if ntype == 32 and name.startswith(b"AMDGPU"):
+                yield msgpack.unpackb(desc, raw=False, strict_map_key=False)
+
+
+def kernels(lib_path, tmp_dir):
+    """[{name, vgpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size,
+    group_segment_fixed_size, max_flat_workgroup_size}, ...] for every gfx950 kernel in lib_path."""
+    out = []
+    for elf in _device_elfs(_fatbin(lib_path, tmp_dir)):
+        for md in _notes(elf):
+            for k in md.get("amdhsa.kernels", []):
+                out.append({"name": k[".name"], "vgpr_count": k.get(".vgpr_count", 0), "agpr_count": k.get(".agpr_count", 0),
+                            "sgpr_count": k.get(".sgpr_count", 0), "vgpr_spill_count": k.get(".vgpr_spill_count", 0),
+                            "sgpr_spill_count": k.get(".sgpr_spill_count", 0),
+                            "private_segment_fixed_size": k.get(".private_segment_fixed_size", 0),
+                            "group_segment_fixed_size": k.get(".group_segment_fixed_size", 0),
+                            "max_flat_workgroup_size": k.get(".max_flat_workgroup_size", 0)})
+    return out
+
+
+def disassemble(lib_path, tmp_dir, name_part):
+    """{kernel symbol: [instruction text, ...]} for the gfx950 kernels of lib_path whose symbol contains name_part
+    (llvm-objdump -d of the device ELFs; branch targets keep their '<symbol+0xoffset>' form)."""
+    out = {}
+    for n, elf in enumerate(_device_elfs(_fatbin(lib_path, tmp_dir))):
+        path = "%s/dev%d.elf" % (tmp_dir, n)
+        open(path, "wb").write(elf)
+        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", path], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in txt.splitlines():
+            if line.endswith(">:") and "<" in line:
+                sym = line[line.index("<") + 1:-2]
+                cur = sym if name_part in sym else None
+                if cur:
+                    out[cur] = []
+            elif cur and line.strip():
+                out[cur].append(line.strip())
+    return out
+
+
+# ---- guards on the kernels whose MFMAs are inline asm -----------------------------------------------------------------
+# hipcc neither sees the latency of an asm MFMA nor pads the hazards around it, so the correctness of these kernels rests
+# on what the compiler put BETWEEN them -- checked here on the disassembly of the built library.  __graft_entry__.build()
+# runs check_library() on every build (a toolchain that reorders around the asm MFMAs fails the build, not a later test);
+# tests/test_codeobj.py runs the same functions one by one.
+def guard_one_wave_main_loops(lib_path, tmp_dir):
+    """The main loops of gpx_vargemm.hip issue their MFMAs from inline asm, which hipcc's hazard recogniser and register
+    allocator cannot see into: an accumulator copy (v_accvgpr_*) or a spill next to them would read a result that is
+    still in flight (one build of the [k][n] kernel carried 64 such moves per trip until an early-return path was removed).
+    Every backward branch of these kernels whose body holds >= 128 MFMAs must hold only MFMAs, buffer loads, waits and
+    scalar / address arithmetic."""
+    dis = disassemble(lib_path, tmp_dir, "w1_")
+    assert len(dis) == 10, sorted(dis)  # var_w1_kernel<true|false, 8|6|4|2>, var_w1_f64_kernel, w1_f64_nn_kernel
+    for sym, lines in dis.items():
+        # 'mnemonic operands   // ADDRESS: ENCODING [<symbol+0xOFFSET>]'
+        ins = [(int(l.split("//")[1].split(":")[0], 16), l.split("//")[0].strip(), l) for l in lines if "//" in l]
+        first = ins[0][0]
+        spans = []  # backward branches whose body holds the MFMAs; the innermost one is the main loop (the paired launch wraps it)
+        for a, text, raw in ins:
+            if not text.startswith("s_cbranch") or "+0x" not in raw:
+                continue
+            target = first + int(raw[raw.rindex("+0x") + 3:raw.rindex(">")], 16)
+            if target < a and sum(t.startswith("v_mfma") for b, t, _ in ins if target <= b <= a) >= 128:
+                spans.append((a - target, target, a))
+        assert spans, sym
+        _, lo, hi = min(spans)
+        body = [t for b, t, _ in ins if lo <= b <= hi]
+        bad = [t for t in body if t.startswith(("v_accvgpr", "scratch_", "v_mov_b", "ds_"))]
+        assert not bad, (sym, bad[:5])
+
+
+def guard_one_wave_accumulators(lib_path, tmp_dir):
+    """Round 4 put the diagonal block of the one-wave tiles behind branches (zero fragments skipped).  At a merge hipcc may
+    rename accumulators -- v_accvgpr_read / _mov / spills right behind asm MFMAs it cannot see into, i.e. reads of results
+    still in flight (the first fp64 form did: 1e-6 errors at N = 4096).  From the first to the last accumulating MFMA of
+    var_w1_kernel<with the fit, 8 fragments> and var_w1_f64_kernel nothing may read or move an accumulator register."""
+    dis = disassemble(lib_path, tmp_dir, "var_w1_")
+    seen = 0
+    for sym, lines in dis.items():
+        if "var_w1_f64_kernel" in sym:
+            mf, expect = "v_mfma_f64_16x16x4_f64 a", 128 + 2 * 576   # main loop + the diagonal pairs, ascending and descending
+        elif "var_w1_kernelILb1ELi8" in sym:
+            mf, expect = "v_mfma_f32_16x16x4_f32 a", 512 + 2 * 512   # main loop + one rolled pair of diagonal chunks per direction
+        else:
+            continue
+        seen += 1
+        text = [l.split("//")[0].strip() for l in lines]
+        idx = [i for i, t in enumerate(text) if t.startswith(mf)]
+        assert len(idx) == expect, (sym, len(idx))
+        bad = [t for t in text[idx[0]:idx[-1]] if t.startswith(("v_accvgpr_read", "v_accvgpr_mov", "scratch_"))]
+        assert not bad, (sym, bad[:5])
+    assert seen == 2
+
+
+def guard_small_model_accumulator_reads(lib_path, tmp_dir):
+    """The fp32 MFMAs of gpx_varcols_kernel.hpp are inline asm: hipcc neither sees their latency nor pads the hazards around
+    them.  The epilogue of a row fragment reads its accumulators (v_accvgpr_read) from compiler-generated code placed behind
+    later MFMAs; a read scheduled right behind the fragment's own last MFMA would fetch a result still in the pipe.  Every
+    v_accvgpr_read of the kernels must therefore lie at least 4 MFMAs (128 cycles; the result is written after 8 passes = 32)
+    or an explicit run of wait states behind the last MFMA that wrote the register."""
+    import re
+    dis = disassemble(lib_path, tmp_dir, "var_cols_kernel")
+    assert len(dis) == 4, sorted(dis)
+    for sym, lines in dis.items():
+        last_write = {}  # accumulator register -> index (in MFMAs) of the last MFMA that wrote it
+        nops_since = {}  # accumulator register -> wait states (s_nop) seen since that MFMA
+        n_mfma = reads = 0
+        for l in lines:
+            text = l.split("//")[0].strip()
+            if text.startswith("v_mfma_f32"):
+                m = re.match(r"v_mfma_f32\S*\s+a\[(\d+):(\d+)\]", text)
+                assert m, text
+                for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                    last_write[r] = n_mfma
+                    nops_since[r] = 0
+                n_mfma += 1
+            elif text.startswith("s_nop"):
+                w = int(text.split()[1]) + 1
+                for r in nops_since:
+                    nops_since[r] += w
+            elif text.startswith("v_accvgpr_read"):
+                r = int(re.search(r"\ba(\d+)\b", text).group(1))
+                if r in last_write:  # (registers the compiler parks values in are never MFMA destinations)
+                    reads += 1
+                    assert n_mfma - last_write[r] >= 4 or nops_since[r] >= 16, (sym, text, n_mfma - last_write[r], nops_since[r])
+        assert n_mfma >= 500 and reads >= 96, (sym, n_mfma, reads)
+
+
+def guard_split_contraction_staging(lib_path, tmp_dir):
+    """gpx_vsplit.hip: the k-tiles of the F32_SPLIT contraction arrive by LDS-DMA (global_load_lds_dwordx4), 8 per wave and
+    tile, with no ds_write in the main loop; two workgroups must fit a CU (<= 256 registers, 64 KiB of LDS each).  An
+    LDS-DMA write becomes visible to the other waves' ds_reads only through the issuing wave's `s_waitcnt vmcnt(0)` before
+    the barrier -- hipcc left that wait out of one of the loop's two barriers until it was written into the source, so every
+    s_barrier of the main loop must have one in the instructions in front of it."""
+    ks = [k for k in kernels(lib_path, tmp_dir) if "vsplit_gemm_kernel" in k["name"]]
+    assert len(ks) == 1
+    assert ks[0]["vgpr_count"] + ks[0]["agpr_count"] <= 256, ks[0]
+    dis = disassemble(lib_path, tmp_dir, "vsplit_gemm_kernel")
+    assert len(dis) == 1, sorted(dis)
+    lines = next(iter(dis.values()))
+    ins = [(int(l.split("//")[1].split(":")[0], 16), l.split("//")[0].strip(), l) for l in lines if "//" in l]
+    first = ins[0][0]
+    spans = []
+    for a, text, raw in ins:
+        if text.startswith("s_cbranch") and "+0x" in raw:
+            target = first + int(raw[raw.rindex("+0x") + 3:raw.rindex(">")], 16)
+            if target < a and sum(t.startswith("v_mfma") for b, t, _ in ins if target <= b <= a) >= 96:
+                spans.append((a - target, target, a))
+    assert spans
+    _, lo, hi = min(spans)
+    body = [t for b, t, _ in ins if lo <= b <= hi]
+    assert sum(t.startswith("v_mfma_f32_16x16x32_f16") for t in body) == 96   # 2 k-tiles x 16 fragment pairs x 3 products
+    assert sum(t.startswith("global_load_lds_dwordx4") for t in body) == 16  # 2 k-tiles x 2 operands x 4 pieces per wave
+    assert sum(t.startswith("ds_read_b128") for t in body) == 32
+    assert not [t for t in body if t.startswith(("ds_write", "scratch_", "global_load_dword", "buffer_load"))]
+    barriers = [i for i, t in enumerate(body) if t.startswith("s_barrier")]
+    assert len(barriers) == 2
+    for i in barriers:
+        assert any("vmcnt(0)" in t for t in body[max(0, i - 3):i]), body[max(0, i - 3):i + 1]
+
+
+
+def check_library(lib_path):
+    """Every guard above on lib_path; raises AssertionError naming the kernel and the offending instructions."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        guard_one_wave_main_loops(lib_path, td)
+        guard_one_wave_accumulators(lib_path, td)
+        guard_small_model_accumulator_reads(lib_path, td)
+        guard_split_contraction_staging(lib_path, td)

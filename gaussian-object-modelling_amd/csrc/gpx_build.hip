@@ -774,9 +774,9 @@ static int build_model_small(gpx_model *m, bool *fell_back)
             return rc;
         HIPCHK(big_alloc(&gnX.p, sizeof(float) * (size_t)np * np));
     }
-    // host block: [5][np] staging | SmallResult | D[np]
+    // host block: [5][np] staging + argument block (as in the workspace) | SmallResult | D[np]
     const size_t res_bytes = lay.res_d + sizeof(double) * (size_t)np - lay.res;
-    const size_t host_bytes = sizeof(double) * 5 * (size_t)np + res_bytes;
+    const size_t host_bytes = lay.stage_bytes + res_bytes;
     void *hp = nullptr;
     HIPCHK(pinned_acquire(host_bytes, &hp));
     struct PinGuard {
@@ -817,7 +817,8 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     a.epoch = small_create_epoch();
     if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
         a.spin_limit = std::max(1, std::atoi(sl));
-    a.abort_idx = 2 * a.ntiles, a.bar_idx = 2 * a.ntiles + 1;
+    a.abort_idx = 2 * a.ntiles, a.bar_idx = 2 * a.ntiles + 1, a.pre_idx = 2 * a.ntiles + 2;
+    a.dbg = (unsigned long long *)(ws + lay.dbg);
     a.K = (double *)m->Kmat, a.X = (double *)m->X, a.linv = (double *)m->linv;
     a.d = (double *)m->t_d, a.dinv = (double *)m->t_dinv;
     a.d_x = m->d_x, a.d_y = m->d_y, a.d_z = m->d_z;
@@ -832,12 +833,16 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     a.tij = (int *)(ws + lay.tij), a.negcnt = (int *)(ws + lay.negcnt), a.badrow = (int *)(ws + lay.badrow);
     a.res = (SmallResult *)(ws + lay.res), a.res_d = (double *)(ws + lay.res_d);
     hipStream_t s = m->stream;
-    HIPCHK(hipMemcpyAsync(ws + lay.stage, st, sizeof(double) * 5 * (size_t)np, hipMemcpyHostToDevice, s));
+    std::memcpy((char *)hp + (lay.args - lay.stage), &a, sizeof(a));
+    HIPCHK(hipMemcpyAsync(ws + lay.stage, st, lay.stage_bytes, hipMemcpyHostToDevice, s));
+#ifdef SM_TIMING
+    (void)hipMemsetAsync(ws + lay.dbg, 0, sizeof(unsigned long long) * (size_t)a.ntiles * SMALL_DBG_STAMPS, s);
+#endif
     (void)hipEventRecord(m->ev[EV_T0], s);
     (void)hipEventRecord(m->ev[EV_KBUILD], s);
-    launch_small_create(m->kern.id, a, m->train64, s, m->ev[EV_FACTOR], m->ev[EV_SOLVE]);
+    launch_small_create(m->kern.id, a, (const SmallArgs *)(ws + lay.args), m->train64, s, m->ev[EV_FACTOR], m->ev[EV_SOLVE]);
     (void)hipEventRecord(m->ev[EV_NORMALS], s);
-    char *hres = (char *)hp + sizeof(double) * 5 * (size_t)np;
+    char *hres = (char *)hp + lay.stage_bytes;
     HIPCHK(hipMemcpyAsync(hres, ws + lay.res, res_bytes, hipMemcpyDeviceToHost, s));
     {
         const hipError_t se = hipStreamSynchronize(s);
@@ -849,6 +854,21 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     }
     const SmallResult *res = (const SmallResult *)hres;
     const double *hd = (const double *)(hres + (lay.res_d - lay.res));
+#ifdef SM_TIMING
+    if (const char *dump = std::getenv("GPX_SMALL_TIMING_DUMP")) {  // developer build: the stamps of every workgroup
+        std::vector<unsigned long long> hs((size_t)a.ntiles * SMALL_DBG_STAMPS);
+        (void)hipMemcpy(hs.data(), ws + lay.dbg, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (FILE *fp = std::fopen(dump, "w")) {
+            for (int t = 0; t < a.ntiles; ++t) {
+                std::fprintf(fp, "%d", t);
+                for (int k = 0; k < 24; ++k)
+                    std::fprintf(fp, " %llu", hs[(size_t)t * SMALL_DBG_STAMPS + k]);
+                std::fprintf(fp, "\n");
+            }
+            std::fclose(fp);
+        }
+    }
+#endif
     if (res->info[5] != 0) {
         *fell_back = true;
         return GPX_OK;  // (the guards hand the workspace and the unused fp32 state back)

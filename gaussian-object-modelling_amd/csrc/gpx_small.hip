@@ -34,9 +34,31 @@ constexpr int SBLK = NB * PLD;       // one 32 x 32 block in LDS (doubles)
 constexpr int SM_THREADS = 256;
 constexpr int SM_LDS_DOUBLES = 12 * SBLK + 2 * ST + 4 * ST + 3 * ST;
 typedef unsigned long long u64;
+#ifdef SM_TIMING
+#define SM_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0)                                                                         \
+            a.dbg[(size_t)blockIdx.x * SMALL_DBG_STAMPS + (k)] = wall_clock64();                      \
+    } while (0)
+#else
+#define SM_STAMP(k)
+#endif
 
 __device__ __forceinline__ u64 ld_flag(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_flag(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Data that travels between workgroups INSIDE a launch is stored and loaded at agent scope (sc1: written through to /
+// read from the memory side, the point where the XCDs' L2s meet): the tiles and vectors validate themselves behind a flag
+// or a barrier without any L2 write-back or invalidation -- so everything else (the points, X and X^T in the second
+// launch) stays cached.  Same idea as tri_solve_kernel's entries (gpx_factor.hip).
+__device__ __forceinline__ double ld_cg(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_cg(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<u64 *>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // thread 0 of the workgroup: wait until *f == want (false: the abort flag went up, or the spin limit ran out and this
 // call raised it)
@@ -53,14 +75,13 @@ __device__ bool poll_flag(const u64 *f, u64 want, u64 *abortf, int limit)
     return false;
 }
 
-// all threads: wait for one or two tile flags, then make the tiles behind them visible to this workgroup
+// all threads: wait for one or two tile flags (the tiles behind them are then read with ld_cg)
 __device__ __forceinline__ bool wait_tiles(const u64 *f1, const u64 *f2, const SmallArgs &a, int *s_ok)
 {
     if (threadIdx.x == 0) {
         bool ok = poll_flag(f1, a.epoch, a.flags + a.abort_idx, a.spin_limit);
         if (ok && f2)
             ok = poll_flag(f2, a.epoch, a.flags + a.abort_idx, a.spin_limit);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *s_ok = ok ? 1 : 0;
     }
     __syncthreads();
@@ -69,15 +90,13 @@ __device__ __forceinline__ bool wait_tiles(const u64 *f1, const u64 *f2, const S
     return ok;
 }
 
-// all threads: everything this workgroup has stored so far becomes visible device-wide, then the flag goes up
+// all threads: the tile this workgroup has just stored (st_cg) is complete, then the flag goes up
 __device__ __forceinline__ void publish_tile(u64 *f, u64 v)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // L2 write-back: the consumers may sit on another XCD
+    if (threadIdx.x == 0)
         st_flag(f, v);
-    }
 }
 
 __device__ __forceinline__ int tidx(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -91,7 +110,7 @@ __device__ __forceinline__ void stage_tile(double *buf, const double *g, long ld
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-        v[e] = g[(size_t)r * ld + c];
+        v[e] = ld_cg(g + (size_t)r * ld + c);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -99,6 +118,41 @@ __device__ __forceinline__ void stage_tile(double *buf, const double *g, long ld
         const double s = colscale ? colscale[c] : 1.0;
         buf[((r >> 5) * 2 + (c >> 5)) * SBLK + (r & 31) * PLD + (c & 31)] = v[e] * s;
     }
+}
+
+// sign * (32 x 32 accumulator block) -> LDS block (may be null) and / or global with write-through stores (may be null)
+__device__ __forceinline__ void store_blk_cg(const BlkAcc<double> &b, double sign, double *lds, double *g, long ldg, int lane)
+{
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i2 + BlkMma<double>::crow(lane, r), col = 16 * j2 + (lane & 15);
+                const double v = sign * b.t[i2][j2][r];
+                if (lds)
+                    lds[row * PLD + col] = v;
+                if (g)
+                    st_cg(g + (size_t)row * ldg + col, v);
+            }
+}
+
+// one 16 x 16 tile of a product of two 32 x 32 LDS blocks (K = 32) on one wave: rows 16 i2.. of A, columns 16 j2.. of the
+// result; NT: B is [n][k] (A B^T), else [k][n].  The four waves of the workgroup share a 32 x 32 product this way.
+typedef BlkMma<double>::acc_t acc16_t;
+template <bool NT, bool NEG>
+__device__ __forceinline__ acc16_t mma16(const double *Ab, const double *Bb, int i2, int j2, int lane, acc16_t t)
+{
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const int k = 4 * kk + kq;
+        const double av = Ab[(16 * i2 + i) * PLD + k];
+        const double bv = NT ? Bb[(16 * j2 + i) * PLD + k] : Bb[k * PLD + 16 * j2 + i];
+        t = BlkMma<double>::mma(NEG ? -av : av, bv, t);
+    }
+    return t;
 }
 
 __device__ __forceinline__ double lds_tile(const double *buf, int r, int c)
@@ -154,8 +208,9 @@ __device__ void scatter_rows(const SmallArgs &a, int i)
 }  // namespace
 
 template <int KID>
-__global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a)
+__global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(const SmallArgs *__restrict__ ap)
 {
+    const SmallArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *bufA = sm, *bufB = sm + 4 * SBLK, *bufC = sm + 8 * SBLK;
     double *dvec = sm + 12 * SBLK;   // [64] D of the diagonal tile | scale vector of a staged operand
@@ -174,7 +229,7 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
         ++j;
     }
     const int i = j + rem;
-    u64 *Ff = a.flags, *Xf = a.flags + a.ntiles;
+    u64 *Ff = a.flags, *Xf = a.flags + a.ntiles, *Pf = a.flags + a.pre_idx;  // factor tiles, inverse tiles, handed-over sums (per row)
     if (blockIdx.x == 0 && tid < 16) {
         // state of the second launch: barrier counter, residual maxima (stream order: it starts after this grid has ended)
         if (tid == 0)
@@ -254,11 +309,19 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
         }
     }
     // ---- A_ij -= sum_k (L_ik D_k) L_jk^T as the tiles of the earlier columns appear ----
-    for (int k = 0; k < j; ++k) {
+    // The chain of the factorisation is diagonal tile j -> panel tile (j+1, j) -> diagonal tile j+1.  The diagonal tile
+    // takes the middle link itself: tile (j+1, j) hands over its finished sums A_{j+1,j} BEFORE diagonal tile j is done
+    // (through the unused tile (j, j+1) above the diagonal), and diagonal tile j+1, which has staged them while it waited,
+    // forms W = A Xd_j^T, L = W D_j^-1 and its own last update as soon as Xd_j appears -- one publish, one poll and one
+    // round trip to memory less per 64 columns on the critical path; the panel tile does the same product again for
+    // everybody else.
+    const int kend = i == j ? j - 1 : j;  // (the diagonal tile's last step is the one described above)
+    SM_STAMP(0);
+    for (int k = 0; k < kend; ++k) {
         if (!wait_tiles(Ff + tidx(i, k), i != j ? Ff + tidx(j, k) : nullptr, a, &s_ok))
             return;
         if (tid < ST)
-            dvec[tid] = a.d[ST * k + tid];
+            dvec[tid] = ld_cg(a.d + ST * k + tid);
         __syncthreads();
         stage_tile(bufA, a.K + (size_t)(ST * i) * np + ST * k, np, dvec);
         stage_tile(bufB, a.K + (size_t)(ST * j) * np + ST * k, np, nullptr);
@@ -268,6 +331,50 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
             acc.template mac_nt<true>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
         __syncthreads();
     }
+    SM_STAMP(1);
+    if (i == j && j >= 1) {
+        const int k = j - 1;
+        if (!wait_tiles(Pf + i, nullptr, a, &s_ok))
+            return;
+        stage_tile(bufA, a.K + (size_t)(ST * k) * np + ST * i, np, nullptr);  // A_{i,k}, parked above the diagonal
+        SM_STAMP(2);
+        if (!wait_tiles(Ff + tidx(k, k), nullptr, a, &s_ok))
+            return;
+        SM_STAMP(3);
+        if (tid < ST)
+            dvec[tid] = ld_cg(a.dinv + ST * k + tid);
+        stage_tile(bufB, a.X + (size_t)(ST * k) * np + ST * k, np, nullptr);
+        __syncthreads();
+        SM_STAMP(4);
+        BlkAcc<double> w;
+        w.zero();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            w.template mac_nt<false>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
+        __syncthreads();  // every wave has read A before L takes its place
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i2 + BlkMma<double>::crow(lane, r), col = 16 * j2 + (lane & 15);
+                    const double wv = w.t[i2][j2][r];
+                    bufC[(qi * 2 + qj) * SBLK + row * PLD + col] = wv;
+                    bufA[(qi * 2 + qj) * SBLK + row * PLD + col] = wv * dvec[32 * qj + col];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            acc.template mac_nt<true>(bufC + (qi * 2 + h) * SBLK, bufA + (qj * 2 + h) * SBLK, lane);
+        __syncthreads();
+        SM_STAMP(5);
+    }
+    if (i == j + 1) {
+        // hand the finished sums to the diagonal tile of this row (see above)
+        store_blk_cg(acc, 1.0, nullptr, a.K + (size_t)(ST * j + 32 * qi) * np + ST * i + 32 * qj, np, lane);
+        publish_tile(Pf + i, a.epoch);
+    }
     double *Ktile = a.K + (size_t)(ST * i) * np + ST * j;
     double *Xtile = a.X + (size_t)(ST * i) * np + ST * j;
     const bool same128 = (i >> 1) == (j >> 1);
@@ -276,12 +383,17 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
         // ---- diagonal tile: LDL^T of the 64 x 64 block and the inverse of its L (gp_regressor.hpp:161-162) ----
         acc.store(1.0, bufC + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
         __syncthreads();
+        SM_STAMP(6);
         double *Lx0 = bufA, *W21 = bufA + SBLK, *L21 = bufA + 2 * SBLK, *Lx1 = bufA + 3 * SBLK;
         double *Xd0 = bufB, *T0 = bufB + SBLK, *X10 = bufB + 2 * SBLK, *Xd1 = bufB + 3 * SBLK;
+        double *A21 = bufC + 2 * SBLK, *A22 = bufC + 3 * SBLK;
+        // The two 32 x 32 sub-blocks are factorised (and their L inverted) by wave 0, one rank-1 MFMA update per column
+        // (gpx_blk.hpp: 6.9 us each in fp64); the products between them are shared by the four waves, a 16 x 16 tile each.
+        const int i2 = wave >> 1, j2 = wave & 1;
+        const int trow = 16 * i2 + (lane >> 4), tcol = 16 * j2 + (lane & 15);  // element r of the lane's tile: row trow + 4 r
+        double dv = 1.0;
+        unsigned long long mneg = 0, mbad = 0;
         if (wave == 0) {
-            auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
-            double dv = 1.0;
-            unsigned long long mneg = 0, mbad = 0;
             subblock_ldl(bufC, Lx0, Xd0, lane, dv);
             if (lane < NB) {
                 dvec[lane] = dv;
@@ -289,42 +401,43 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
             }
             mneg = __ballot(lane < NB && dv < 0.0);
             mbad = __ballot(lane < NB && (!(fabs(dv) > 0.0) || !(fabs(dv) < pivot_huge(0.0))));
-            wave_sync();
-            BlkAcc<double> w;
-            w.zero();
-            w.template mac_nt<false>(bufC + 2 * SBLK, Xd0, lane);  // W21 = A21 X11^T
+        }
+        __syncthreads();
+        SM_STAMP(16);
+        {   // W21 = A21 X11^T, L21 = W21 D^-1
+            acc16_t t = {0.0, 0.0, 0.0, 0.0};
+            t = mma16<true, false>(A21, Xd0, i2, j2, lane, t);
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
+            for (int r = 0; r < 4; ++r) {
+                W21[(trow + 4 * r) * PLD + tcol] = t[r];
+                L21[(trow + 4 * r) * PLD + tcol] = t[r] * dinvv[tcol];
+            }
+        }
+        __syncthreads();
+        SM_STAMP(17);
+        {   // A22 -= W21 L21^T ; T0 = L21 Xd0 (for X10, off the chain of the second sub-block)
+            acc16_t c, t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int j2 = 0; j2 < 2; ++j2)
+            for (int r = 0; r < 4; ++r)
+                c[r] = A22[(trow + 4 * r) * PLD + tcol];
+            c = mma16<true, true>(W21, L21, i2, j2, lane, c);
+            t = mma16<false, false>(L21, Xd0, i2, j2, lane, t);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i2 + BlkMma<double>::crow(lane, r), col = 16 * j2 + (lane & 15);
-                        const double wv = w.t[i2][j2][r];
-                        W21[row * PLD + col] = wv;
-                        L21[row * PLD + col] = wv * dinvv[col];
-                    }
-            wave_sync();
-            BlkAcc<double> c22;
-            c22.load(bufC + 3 * SBLK, PLD, lane);
-            c22.template mac_nt<true>(W21, L21, lane);  // A22 -= W21 L21^T
-            c22.store(1.0, bufC + 3 * SBLK, (double *)nullptr, 0, lane);
-            wave_sync();
-            subblock_ldl(bufC + 3 * SBLK, Lx1, Xd1, lane, dv);
+            for (int r = 0; r < 4; ++r) {
+                A22[(trow + 4 * r) * PLD + tcol] = c[r];
+                T0[(trow + 4 * r) * PLD + tcol] = t[r];
+            }
+        }
+        __syncthreads();
+        SM_STAMP(18);
+        if (wave == 0) {
+            subblock_ldl(A22, Lx1, Xd1, lane, dv);
             if (lane < NB) {
                 dvec[NB + lane] = dv;
                 dinvv[NB + lane] = 1.0 / dv;
             }
             const unsigned long long mneg1 = __ballot(lane < NB && dv < 0.0);
             const unsigned long long mbad1 = __ballot(lane < NB && (!(fabs(dv) > 0.0) || !(fabs(dv) < pivot_huge(0.0))));
-            wave_sync();
-            w.zero();
-            w.mac(L21, Xd0, lane);  // X10 = -Xd1 (L21 Xd0)
-            w.store(1.0, T0, (double *)nullptr, 0, lane);
-            wave_sync();
-            w.zero();
-            w.mac(Xd1, T0, lane);
-            w.store(-1.0, X10, (double *)nullptr, 0, lane);
             if (lane == 0) {
                 a.negcnt[i] = __builtin_popcountll(mneg) + __builtin_popcountll(mneg1);
                 int bad = 0;
@@ -336,6 +449,17 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
             }
         }
         __syncthreads();
+        SM_STAMP(19);
+        {   // X10 = -Xd1 (L21 Xd0)
+            acc16_t t = {0.0, 0.0, 0.0, 0.0};
+            t = mma16<false, true>(Xd1, T0, i2, j2, lane, t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X10[(trow + 4 * r) * PLD + tcol] = t[r];
+        }
+        __syncthreads();
+        SM_STAMP(7);
+        // what the tiles below wait for first: Xd (to the tile of X), L, D, 1/D; then the flag; the rest afterwards
         for (int e = 0; e < 16; ++e) {
             const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
             double lv, xv;
@@ -353,8 +477,22 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
                 xv = c < NB ? Xd0[r * PLD + c] : 0.0;
             else
                 xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
-            Ktile[(size_t)r * np + c] = lv;
-            Xtile[(size_t)r * np + c] = xv;
+            st_cg(Ktile + (size_t)r * np + c, lv);
+            st_cg(Xtile + (size_t)r * np + c, xv);
+        }
+        if (tid < ST) {
+            st_cg(a.d + ST * i + tid, dvec[tid]);
+            st_cg(a.dinv + ST * i + tid, dinvv[tid]);
+        }
+        publish_tile(Ff + tidx(i, i), a.epoch);
+        SM_STAMP(8);
+        for (int e = 0; e < 16; ++e) {
+            const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
+            double xv;
+            if (r < NB)
+                xv = c < NB ? Xd0[r * PLD + c] : 0.0;
+            else
+                xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
             lb[(size_t)r * TILE + c] = xv;
             if (!(i & 1))
                 lb[(size_t)r * TILE + ST + c] = 0.0;  // upper-right quadrant of the 128 x 128 inverse block
@@ -368,20 +506,16 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
                 xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
             a.XT[(size_t)(ST * i + c) * np + ST * i + r] = xv;
         }
-        if (tid < ST) {
-            a.d[ST * i + tid] = dvec[tid];
-            a.dinv[ST * i + tid] = dinvv[tid];
-        }
-        publish_tile(Ff + tidx(i, i), a.epoch);
-        if (tid == 0)
-            st_flag(Xf + tidx(i, i), a.epoch);
+        SM_STAMP(9);
         return;
     }
     // ---- tile below the diagonal: L_ij = (A_ij Xd_j^T) D_j^-1 (the panel solve as a product with the inverse block) ----
+    SM_STAMP(10);
     if (!wait_tiles(Ff + tidx(j, j), nullptr, a, &s_ok))
         return;
+    SM_STAMP(11);
     if (tid < ST)
-        dvec[tid] = a.dinv[ST * j + tid];
+        dvec[tid] = ld_cg(a.dinv + ST * j + tid);
     acc.store(1.0, bufA + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
     stage_tile(bufB, a.X + (size_t)(ST * j) * np + ST * j, np, nullptr);
     __syncthreads();
@@ -398,8 +532,9 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     w.t[i2][j2][r] *= dvec[32 * qj + 16 * j2 + (lane & 15)];
-        w.store(1.0, bufC + (qi * 2 + qj) * SBLK, Ktile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
+        store_blk_cg(w, 1.0, bufC + (qi * 2 + qj) * SBLK, Ktile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
     }
+    SM_STAMP(12);
     publish_tile(Ff + tidx(i, j), a.epoch);  // (its barrier also orders the LDS stores of L before the products below)
     // ---- the tile of the inverse factor: X_ij = -Xd_i sum_{k = j}^{i-1} L_ik X_kj ----
     acc.zero();
@@ -416,8 +551,10 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
         for (int h = 0; h < 2; ++h)
             acc.mac(bufA + (qi * 2 + h) * SBLK, bufB + (h * 2 + qj) * SBLK, lane);
     }
+    SM_STAMP(13);
     if (!wait_tiles(Ff + tidx(i, i), nullptr, a, &s_ok))
         return;
+    SM_STAMP(14);
     stage_tile(bufA, a.X + (size_t)(ST * i) * np + ST * i, np, nullptr);
     acc.store(1.0, bufC + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
     __syncthreads();
@@ -427,7 +564,7 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             x.mac(bufA + (qi * 2 + h) * SBLK, bufC + (h * 2 + qj) * SBLK, lane);
-        x.store(-1.0, bufB + (qi * 2 + qj) * SBLK, Xtile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
+        store_blk_cg(x, -1.0, bufB + (qi * 2 + qj) * SBLK, Xtile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
         if (same128)
             x.store(-1.0, (double *)nullptr, lb + (size_t)(32 * qi) * TILE + 32 * qj, TILE, lane);
     }
@@ -439,17 +576,18 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(SmallArgs a
         a.K[(size_t)(ST * j + c) * np + ST * i + r] = 0.0;
     }
     publish_tile(Xf + tidx(i, j), a.epoch);
+    SM_STAMP(15);
 }
 
 // ---- alpha, refinement, row corrections ----------------------------------------------------------------------------
 namespace {
-// grid barrier number `index` (1, 2, ...) of a launch of gridDim.x workgroups
+// grid barrier number `index` (1, 2, ...) of a launch of gridDim.x workgroups.  The vectors that cross it are written
+// with st_cg and read with ld_cg, so it needs no cache maintenance: X and X^T stay in the L2 from phase to phase.
 __device__ __forceinline__ bool grid_barrier(const SmallArgs &a, int index, int *s_ok)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         u64 *cnt = a.flags + a.bar_idx, *abortf = a.flags + a.abort_idx;
         __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u64 target = (u64)gridDim.x * (u64)index;
@@ -465,7 +603,6 @@ __device__ __forceinline__ bool grid_barrier(const SmallArgs &a, int index, int 
         }
         if (!ok)
             st_flag(abortf, a.epoch);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *s_ok = ok ? 1 : 0;
     }
     __syncthreads();
@@ -484,31 +621,38 @@ __device__ __forceinline__ double wave_sum(double s)
 }  // namespace
 
 template <int KID>
-__global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(SmallArgs a)
+__global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs *__restrict__ ap)
 {
+    const SmallArgs &a = *ap;
     __shared__ int s_ok;
+    __shared__ double vec[SMALL_CREATE_MAX_NP];  // the vector the current phase multiplies with
     const int tid = threadIdx.x, lane = tid & 63;
     const int gw = (int)blockIdx.x * 4 + (tid >> 6), nw = (int)gridDim.x * 4;
     const int np = a.np, n = a.n, nrows = a.nb * ST;
     const bool aborted = ld_flag(a.flags + a.abort_idx) == a.epoch;  // the factorisation gave up: nothing here is valid
     int bar = 0, ir = 0;
     double rmax_last = 0.0;
+    auto stage_vec = [&](const double *src, int len) {
+        for (int k = tid; k < len; k += SM_THREADS)
+            vec[k] = ld_cg(src + k);
+        __syncthreads();
+    };
     if (!aborted) {
         for (int it = 0;; ++it) {
-            const double *rhs = it == 0 ? a.d_lab : a.d_r;
             // ---- t = X rhs, u = D^-1 t (L y = b and the scaling of LDLT::solve, gp_regressor.hpp:163) ----
+            stage_vec(it == 0 ? a.d_lab : a.d_r, np);
             for (int r = gw; r < np; r += nw) {
                 double s = 0.0;
                 if (r < nrows) {
                     const double *row = a.X + (size_t)r * np;
                     for (int c = lane; c <= r; c += 64)
-                        s += row[c] * rhs[c];
+                        s = fma(row[c], vec[c], s);
                     s = wave_sum(s);
                 } else {
-                    s = rhs[r];
+                    s = vec[r];
                 }
                 if (lane == 0)
-                    a.u[r] = s * a.dinv[r];
+                    st_cg(a.u + r, s * a.dinv[r]);
                 if (it == 0 && a.want_corr) {
                     // row-correction vectors of the variance fit: out[c][r] = sum_{l < n} X[r][l] b_c(p'_l) (gpx_internal.hpp)
                     double sc[VAR_NCORR];
@@ -552,22 +696,24 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(SmallArgs a)
             if (!grid_barrier(a, ++bar, &s_ok))
                 break;
             // ---- alpha += X^T u (L^T x = y) ----
+            stage_vec(a.u, np);
             for (int c = gw; c < np; c += nw) {
                 double s = 0.0;
                 if (c < nrows) {
                     const double *row = a.XT + (size_t)c * np;
                     for (int r = c + lane; r < nrows; r += 64)
-                        s += row[r] * a.u[r];
+                        s = fma(row[r], vec[r], s);
                     s = wave_sum(s);
                 } else {
-                    s = a.u[c];
+                    s = vec[c];
                 }
                 if (lane == 0)
-                    a.d_alpha[c] = (it == 0 ? 0.0 : a.d_alpha[c]) + s;
+                    st_cg(a.d_alpha + c, (it == 0 ? 0.0 : ld_cg(a.d_alpha + c)) + s);
             }
             if (!grid_barrier(a, ++bar, &s_ok))
                 break;
             // ---- r = y - K alpha in fp64, matrix-free from the fp64 points ----
+            stage_vec(a.d_alpha, np);
             {
                 const Cov<double> cov = a.cov;
                 double wmax = 0.0;
@@ -579,13 +725,13 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(SmallArgs a)
                         for (int c = lane; c < n; c += 64) {
                             const double dx = px - a.d_x[c], dy = py - a.d_y[c], dz = pz - a.d_z[c];
                             const double d2 = dx * dx + dy * dy + dz * dz;
-                            s = fma(cov_k<double, KID, MathFast>(cov, d2 + 1e-300), a.d_alpha[c], s);
+                            s = fma(cov_k<double, KID, MathFast>(cov, d2 + 1e-300), vec[c], s);
                         }
                         s = wave_sum(s);
-                        res = a.d_lab[r] - s - a.d_s2[r] * a.d_alpha[r];
+                        res = a.d_lab[r] - s - a.d_s2[r] * vec[r];
                     }
                     if (lane == 0)
-                        a.d_r[r] = res;
+                        st_cg(a.d_r + r, res);
                     wmax = fmax(wmax, fabs(res));
                 }
                 if (lane == 0 && wmax > 0.0)
@@ -604,7 +750,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(SmallArgs a)
     // ---- the rest of the state and the result block (every workgroup has passed the same barriers) ----
     for (int r = (int)blockIdx.x * SM_THREADS + tid; r < np; r += (int)gridDim.x * SM_THREADS) {
         a.d_dinv64[r] = a.dinv[r];
-        a.t_alpha[r] = a.d_alpha[r];
+        a.t_alpha[r] = ld_cg(a.d_alpha + r);
         a.res_d[r] = a.d[r];
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -647,8 +793,9 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(SmallArgs a)
 }
 
 // ---- the fp32 state of a model that trained in fp64 (MIXED-style demotion), one launch ------------------------------
-__global__ __launch_bounds__(SM_THREADS) void small_demote_kernel(SmallArgs a)
+__global__ __launch_bounds__(SM_THREADS) void small_demote_kernel(const SmallArgs *__restrict__ ap)
 {
+    const SmallArgs &a = *ap;
     const SmallResult *res = a.res;
     // an indefinite kernel matrix keeps its fp64 state (build_model): nothing to round
     if (res->info[0] != 0 || res->info[1] != 0 || res->info[5] != 0)
@@ -692,19 +839,19 @@ u64 small_create_epoch()
     return 0x5a17c0de00000000ull | (ctr.fetch_add(1) & 0xffffffffull);
 }
 
-void launch_small_create(int kernel_id, const SmallArgs &a, bool demote, hipStream_t st, hipEvent_t ev_factor,
-                         hipEvent_t ev_solve)
+void launch_small_create(int kernel_id, const SmallArgs &a, const SmallArgs *d_args, bool demote, hipStream_t st,
+                         hipEvent_t ev_factor, hipEvent_t ev_solve)
 {
     const size_t lds = SM_LDS_DOUBLES * sizeof(double);
-    GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_factor_kernel<KID>), dim3(a.ntiles), dim3(SM_THREADS), lds, st, a));
+    GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_factor_kernel<KID>), dim3(a.ntiles), dim3(SM_THREADS), lds, st, d_args));
     if (ev_factor)
         (void)hipEventRecord(ev_factor, st);
     const int g = std::max(16, std::min(128, a.np / 8));
-    GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_alpha_kernel<KID>), dim3(g), dim3(SM_THREADS), 0, st, a));
+    GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_alpha_kernel<KID>), dim3(g), dim3(SM_THREADS), 0, st, d_args));
     if (ev_solve)
         (void)hipEventRecord(ev_solve, st);
     if (demote)
-        hipLaunchKernelGGL(small_demote_kernel, dim3(std::max(8, a.np * a.np / (SM_THREADS * 16))), dim3(SM_THREADS), 0, st, a);
+        hipLaunchKernelGGL(small_demote_kernel, dim3(std::max(8, a.np * a.np / (SM_THREADS * 16))), dim3(SM_THREADS), 0, st, d_args);
 }
 
 }  // namespace gpx

@@ -27,7 +27,7 @@ struct SmallArgs {
     int want_corr = 0, op64 = 0, ir_max = 4, ir_adaptive = 1;
     double ir_tol = 0, wd_override = -1.0;
     unsigned long long epoch = 0;
-    int spin_limit = 1 << 20, abort_idx = 0, bar_idx = 0;
+    int spin_limit = 1 << 20, abort_idx = 0, bar_idx = 0, pre_idx = 0;
     // ---- model state written by the launches ----
     double *K = nullptr, *X = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;
     double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *t_x = nullptr, *t_y = nullptr, *t_z = nullptr;
@@ -39,15 +39,17 @@ struct SmallArgs {
     float *nX = nullptr;
     // ---- workspace ----
     double *XT = nullptr;              // transposed copy of X (read on and above its diagonal)
-    unsigned long long *flags = nullptr;  // [ntiles] factor tiles, [ntiles] inverse tiles, abort, barrier counter
+    unsigned long long *flags = nullptr;  // [ntiles] factor tiles, [ntiles] inverse tiles, abort, barrier counter, [nbt] handed-over sums
     double *tmax = nullptr, *rmaxv = nullptr, *u = nullptr, *res_d = nullptr;
     int *tij = nullptr, *negcnt = nullptr, *badrow = nullptr;
     SmallResult *res = nullptr;
+    unsigned long long *dbg = nullptr;  // make EXTRA=-DSM_TIMING: [ntiles][SMALL_DBG_STAMPS] wall-clock stamps (100 MHz) per workgroup
 };
+constexpr int SMALL_DBG_STAMPS = 64;
 
 // byte offsets of the workspace block for a padded order np (one big_alloc per model; layout below)
 struct SmallWs {
-    size_t stage, xt, flags, tmax, rmaxv, u, tij, negcnt, badrow, res, res_d, bytes;
+    size_t stage, args, stage_bytes /* staging + argument block: one host-to-device copy */, xt, flags, tmax, rmaxv, u, tij, negcnt, badrow, res, res_d, dbg, bytes;
 };
 inline SmallWs small_ws_layout(int np)
 {
@@ -56,8 +58,10 @@ inline SmallWs small_ws_layout(int np)
     SmallWs w{};
     size_t o = 0;
     w.stage = o, o += al(sizeof(double) * 5 * np);
+    w.args = o, o += al(sizeof(SmallArgs));
+    w.stage_bytes = o - w.stage;
     w.xt = o, o += al(sizeof(double) * (size_t)np * np);
-    w.flags = o, o += al(sizeof(unsigned long long) * (2 * nt + 2));
+    w.flags = o, o += al(sizeof(unsigned long long) * (2 * nt + 2 + nbt));
     w.tmax = o, o += al(sizeof(double) * nt);
     w.rmaxv = o, o += al(sizeof(double) * 8);
     w.u = o, o += al(sizeof(double) * np);
@@ -66,6 +70,7 @@ inline SmallWs small_ws_layout(int np)
     w.badrow = o, o += al(sizeof(int) * nbt);
     w.res = o, o += al(sizeof(SmallResult));   // res and res_d are adjacent: one device-to-host copy
     w.res_d = o, o += al(sizeof(double) * np);
+    w.dbg = o, o += al(sizeof(unsigned long long) * nt * 64);
     w.bytes = o;
     return w;
 }
@@ -73,7 +78,9 @@ inline SmallWs small_ws_layout(int np)
 void small_create_init();                  // per-device kernel attributes
 unsigned long long small_create_epoch();   // a value no earlier create of this process has used (flags are never cleared)
 // factor (+ record ev_factor), alpha (+ record ev_solve) and, when demote, the fp32 state; asynchronous on st
-void launch_small_create(int kernel_id, const SmallArgs &a, bool demote, hipStream_t st, hipEvent_t ev_factor,
-                         hipEvent_t ev_solve);
+// d_args: the device copy of `a` (the launches read their ~60 arguments from memory: passed by value they cost 95 spilled
+// scalar registers)
+void launch_small_create(int kernel_id, const SmallArgs &a, const SmallArgs *d_args, bool demote, hipStream_t st,
+                         hipEvent_t ev_factor, hipEvent_t ev_solve);
 
 }  // namespace gpx

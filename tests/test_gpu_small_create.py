@@ -1,0 +1,108 @@
+"""GPU suite: GPRegressor::create for the reference's own model sizes in three launches (csrc/gpx_small.hip) -- against the
+oracle, against its twin (the general launch chain, GPX_SMALL_CREATE=0) and through its give-up path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import nerr, verr_v
+
+pytestmark = pytest.mark.gpu
+
+
+def _twin(gpu, kern, data, prec, small, **kw):
+    old = os.environ.get("GPX_SMALL_CREATE")
+    os.environ["GPX_SMALL_CREATE"] = "1" if small else "0"
+    try:
+        return gpu.Model(kern, *data, precision=prec, **kw)
+    finally:
+        if old is None:
+            del os.environ["GPX_SMALL_CREATE"]
+        else:
+            os.environ["GPX_SMALL_CREATE"] = old
+
+
+@pytest.mark.parametrize("n", [17, 63, 64, 65, 129, 277, 320, 321, 513, 724, 1024])
+def test_three_launch_create_matches_the_chain_and_the_oracle(gpu, orc, ds, n):
+    """Every tile-count edge of the 64 x 64 dataflow (one partial tile, exactly one tile, the 128 / 256 padding edges, the
+    largest size), six kernels incl. the indefinite ThinPlate(2.0), fp64 and fp32 mode: alpha, D, pivots, R, f, v, grad."""
+    data = ds.fibonacci_training_set(n)
+    qx, qy, qz = ds.query_grid(6, scale=1.3)
+    for kn, par in (("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0)), ("matern32", (1.0, 1.0)), ("matern52", (1.0, 1.0)),
+                    ("thinplate", (4.0,)), ("thinplate", (2.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), *data)
+        ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+        oD = np.diag(om.ldlt()[0]).copy()  # Eigen's vectorD (uniform sigma2: no transpositions)
+        for prec, tol, tol_tw in ((gpu.F64, 1e-10, 1e-10), (gpu.F32, 1e-5, 2e-7)):
+            ms = _twin(gpu, gpu.make_kernel(kn, *par), data, prec, True, prepare_variance=True)
+            mc = _twin(gpu, gpu.make_kernel(kn, *par), data, prec, False, prepare_variance=True)
+            ss, sc = ms.stats, mc.stats
+            assert ss["solve_fallbacks"] == 0 and ss["t_kbuild_ms"] == 0.0 and sc["t_kbuild_ms"] > 0.0  # each took its own path
+            assert ss["n_negative_pivots"] == sc["n_negative_pivots"] == int(np.sum(oD < 0))
+            assert abs(ms.R - om.R) <= 1e-14 * om.R and abs(ms.R - mc.R) <= 1e-14 * om.R  # (float arg-max of the chain: a tie may pick another pair)
+            assert nerr(ms.alpha, om.alpha) < 1e-9 and nerr(ms.alpha, mc.alpha) < 1e-10
+            assert nerr(ms.D, oD) < 1e-10 and nerr(ms.D, mc.D) < 1e-11
+            assert np.array_equal(ms.perm, mc.perm)
+            a, b = (m.evaluate(qx, qy, qz, want_v=True, want_grad=True) for m in (ms, mc))
+            for key in ("f", "grad"):
+                assert nerr(a[key], ref[key]) < 1e-9 and nerr(a[key], b[key]) < 1e-10
+            assert verr_v(a["v"], ref["v"]) < tol, (n, kn, par, prec)
+            assert verr_v(a["v"], b["v"]) < tol_tw, (n, kn, par, prec)  # same state up to the rounding of the factorisation order
+            ms.close(), mc.close()
+
+
+def test_three_launch_create_with_normals_and_noise_order(gpu, orc, ds, golden):
+    """create<true> (gp_regressor.hpp:166-181) and Eigen's pivot order for a non-uniform sigma2 on the node's own cloud."""
+    x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
+    s2 = s2 * (1.0 + 0.5 * np.cos(np.arange(len(s2))))
+    kern = ("matern52", (1.0, 1.0))
+    om = orc.Model(orc.make_kernel(kern[0], *kern[1]), x, y, z, lab, s2, with_normals=True)
+    for prec in (gpu.F64, gpu.F32, gpu.MIXED, gpu.F32_SPLIT):
+        gm = gpu.Model(gpu.make_kernel(kern[0], *kern[1]), x, y, z, lab, s2, precision=prec, with_normals=True, prepare_variance=True)
+        assert gm.stats["t_kbuild_ms"] == 0.0  # the three-launch path
+        assert nerr(gm.alpha, om.alpha) < 1e-9 and nerr(gm.normals, om.normals) < 1e-9
+        assert not np.array_equal(gm.perm, np.arange(len(x)))  # the order is Eigen's, not the caller's
+        qx, qy, qz = ds.query_grid(5)
+        out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
+        assert nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < (1e-10 if prec == gpu.F64 else 1e-5)
+        gm.close()
+
+
+def test_a_wait_that_gives_up_falls_back_to_the_chain(gpu, orc, ds):
+    """Every wait of the dataflow launches has a spin limit; with the limit forced to one poll some workgroup gives up, the
+    host sees the flag, and the create is redone by the general chain: same model, gpx_stats.solve_fallbacks = 1."""
+    data = ds.fibonacci_training_set(300)
+    kern = gpu.make_kernel("matern52", 1.0, 1.0)
+    om = orc.Model(orc.make_kernel("matern52", 1.0, 1.0), *data)
+    os.environ["GPX_SMALL_SPIN_LIMIT"] = "1"
+    try:
+        for prec in (gpu.F64, gpu.F32):
+            gm = gpu.Model(kern, *data, precision=prec, prepare_variance=True)
+            st = gm.stats
+            assert st["solve_fallbacks"] == 1 and st["t_kbuild_ms"] > 0.0
+            assert nerr(gm.alpha, om.alpha) < 1e-9
+            qx, qy, qz = ds.query_grid(5)
+            out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
+            assert nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < (1e-10 if prec == gpu.F64 else 1e-5)
+            gm.close()
+    finally:
+        del os.environ["GPX_SMALL_SPIN_LIMIT"]
+    gm = gpu.Model(kern, *data, precision=gpu.F64)
+    assert gm.stats["solve_fallbacks"] == 0
+    gm.close()
+
+
+def test_three_launch_create_then_update(gpu, orc, ds):
+    """What follows a create keeps working on a model built by the three launches: the rank-n append of update() on its factor
+    and inverse factor (the state blobs of such a model: test_shell_broadcast_commit_roundtrip, N = 300)."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(420)
+    kern = gpu.make_kernel("gaussian", 1.0, 1.0)
+    k = 300
+    gm = gpu.Model(kern, x[:k], y[:k], z[:k], lab[:k], s2[:k], precision=gpu.F64, prepare_variance=True)
+    assert gm.stats["t_kbuild_ms"] == 0.0
+    gm.update(x[k:], y[k:], z[k:], lab[k:], s2[k:])
+    om = orc.Model(orc.make_kernel("gaussian", 1.0, 1.0), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(5)
+    out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
+    assert nerr(gm.alpha, om.alpha) < 1e-9 and nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < 1e-9
+    gm.close()
