@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -19,6 +20,7 @@ int main(int argc, char **argv)
 {
     if (argc < 2)
         return 2;
+    const bool json = argc > 2 && std::strcmp(argv[2], "--json") == 0;  // one JSON line on stdout (bench.py: configs.C1_node)
     long npts = gpx_pcd_read(argv[1], nullptr, 0);
     if (npts <= 0)
         return 3;
@@ -34,10 +36,14 @@ int main(int argc, char **argv)
     Model::Ptr obj_gp;
     auto t0 = Clock::now();
     reg_->create<false>(data_gp, obj_gp);
-    std::printf("create N=%zu: %.2f ms (first call: includes device initialisation)\n", n, ms_since(t0));
+    const double t_create_first = ms_since(t0);
     t0 = Clock::now();
     reg_->create<false>(data_gp, obj_gp);
-    std::printf("create N=%zu again: %.2f ms\n", n, ms_since(t0));
+    const double t_create = ms_since(t0);
+    if (!json) {
+        std::printf("create N=%zu: %.2f ms (first call: includes device initialisation)\n", n, t_create_first);
+        std::printf("create N=%zu again: %.2f ms\n", n, t_create);
+    }
     const double scale = 1.01, pass = 0.07;  // src/gp_node.cpp:635, sample_res default
     std::mutex mtx;
     size_t kept = 0, count = 0;
@@ -69,8 +75,9 @@ int main(int argc, char **argv)
             t.join();
     }
     const double t_node = ms_since(t0);
-    std::printf("node pattern: %zu single-point evaluate(f,v) calls, one thread each: %.1f ms = %.1f us per call; %zu points with |f| <= 0.01 (mean v %.6f)\n",
-                count, t_node, t_node * 1e3 / count, kept, kept ? sum_v / kept : 0.0);
+    if (!json)
+        std::printf("node pattern: %zu single-point evaluate(f,v) calls, one thread each: %.1f ms = %.1f us per call; %zu points with |f| <= 0.01 (mean v %.6f)\n",
+                    count, t_node, t_node * 1e3 / count, kept, kept ? sum_v / kept : 0.0);
     // thread creation alone, for scale
     t0 = Clock::now();
     for (int s = 0; s < 29; ++s) {
@@ -80,7 +87,9 @@ int main(int argc, char **argv)
         for (auto &t : threads)
             t.join();
     }
-    std::printf("  (creating and joining the same %d empty threads: %.1f ms)\n", 29 * 841, ms_since(t0));
+    const double t_threads = ms_since(t0);
+    if (!json)
+        std::printf("  (creating and joining the same %d empty threads: %.1f ms)\n", 29 * 841, t_threads);
     // the batched forms
     Data::Ptr all = std::make_shared<Data>();
     for (double x = -scale; x <= scale; x += pass)
@@ -91,11 +100,21 @@ int main(int argc, char **argv)
     reg_->evaluate(obj_gp, all, f, v);
     t0 = Clock::now();
     reg_->evaluate(obj_gp, all, f, v);
-    std::printf("one evaluate(f,v) call over all %zu points: %.2f ms\n", f.size(), ms_since(t0));
+    const double t_batched = ms_since(t0);
+    if (!json)
+        std::printf("one evaluate(f,v) call over all %zu points: %.2f ms\n", f.size(), t_batched);
     std::vector<size_t> idx;
     reg_->sampleSurface(obj_gp, all, 0.01, idx, f, v);
     t0 = Clock::now();
     reg_->sampleSurface(obj_gp, all, 0.01, idx, f, v);
-    std::printf("one sampleSurface call (variance only for the %zu survivors): %.2f ms\n", idx.size(), ms_since(t0));
+    const double t_surface = ms_since(t0);
+    if (!json)
+        std::printf("one sampleSurface call (variance only for the %zu survivors): %.2f ms\n", idx.size(), t_surface);
+    else
+        std::printf("{\"n_train\": %zu, \"create_ms\": %.4f, \"calls\": %zu, \"node_ms\": %.3f, \"us_per_call\": %.3f, "
+                    "\"threads_only_ms\": %.3f, \"batched_evaluate_ms\": %.4f, \"sample_surface_ms\": %.4f, \"survivors\": %zu, "
+                    "\"kept_by_node_loop\": %zu, \"mean_v_kept\": %.9g}\n",
+                    n, t_create, count, t_node, t_node * 1e3 / count, t_threads, t_batched, t_surface, idx.size(), kept,
+                    kept ? sum_v / kept : 0.0);
     return idx.size() == kept ? 0 : 1;
 }

@@ -1,5 +1,5 @@
 """Per-kernel totals and the serial chain of one create() from a rocprofv3 --kernel-trace CSV: the LAST create in the
-trace is cut at its kbuild launch; for every kernel name: calls, total, average; plus busy / idle time of the window."""
+trace is cut at its kbuild launch (small models: at the small_factor_kernel launch); for every kernel name: calls, total, average; plus busy / idle time of the window."""
 import csv, glob, os, sys
 src = sys.argv[1]
 f = max(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
@@ -7,7 +7,7 @@ rows = [r for r in csv.DictReader(open(f))]
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-starts = [i for i, r in enumerate(rows) if "kbuild_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "kbuild_kernel" in r["Kernel_Name"] or "small_factor_kernel" in r["Kernel_Name"]]
 i0 = starts[-1]
 win = rows[i0:]
 t0, t1 = win[0]["s"], max(r["e"] for r in win)
