@@ -322,10 +322,8 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     // ... and form that operand, k - fit, in fp64 from the fp64 points, rounding once -- for the thin plate, whose
     // values are all of the size of k(0) = R^3 while the variance is ~k(0)/60 at N = 16384: forming k and the fit
     // separately in fp32 costs 8e-6 of max|v| there, against 4e-7 for Matern-5/2 (profiles/r03_fit_variants_*.txt), and the
-    // exponential kernels would pay ~40 % more operand time for the fp64 exp.  GPX_VAR_OP64=0 / 1 forces either.
+    // exponential kernels would pay ~40 % more operand time for the fp64 exp.
     m->op64 = kernel->id == GPX_KERNEL_THINPLATE;
-    if (const char *vo = std::getenv("GPX_VAR_OP64"))
-        m->op64 = std::atoi(vo) != 0;
     m->var_fit_opt = m->var_fit;
     if (gpxh::stream_acquire(m->device, &m->stream) != hipSuccess) {
         delete m;

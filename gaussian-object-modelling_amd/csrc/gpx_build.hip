@@ -812,8 +812,6 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     a.ir_adaptive = m->opt.ir_steps < 0 ? 1 : 0;
     a.ir_max = a.ir_adaptive ? 4 : m->opt.ir_steps;
     a.ir_tol = 1e-9 * std::max(ymax, 1e-300);
-    if (const char *we = std::getenv("GPX_VAR_FIT_WDELTA"))
-        a.wd_override = std::max(0.0, std::atof(we));
     a.epoch = small_create_epoch();
     if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
         a.spin_limit = std::max(1, std::atoi(sl));
@@ -1155,9 +1153,7 @@ int build_model(gpx_model *m, kept_factor *keep)
         }
     }
     {  // weight offset of the variance fit (gpx_internal.hpp), from the extent of the cloud; travels in the meta block
-        double wd = m->R * m->R / VAR_FIT_WDELTA_DIV;
-        if (const char *we = std::getenv("GPX_VAR_FIT_WDELTA"))
-            wd = std::atof(we);
+        const double wd = m->R * m->R / VAR_FIT_WDELTA_DIV;
         HIPCHK(hipMemcpy(m->d_meta + 4, &wd, sizeof(double), hipMemcpyHostToDevice));
     }
     m->ready = true;

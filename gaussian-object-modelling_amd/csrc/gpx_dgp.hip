@@ -595,24 +595,32 @@ extern "C" int gpx_dgp_loglik_gradient(const gpx_dgp *cg, double *grad2)
         return rc;
     const int nt32 = np_rows / 32;
     const size_t n_part = (size_t)2 * np_rows + (size_t)nt32 * nt32;
-    double *dK = nullptr, *Z = nullptr, *part = nullptr;
-    auto release = [&] {
-        for (double *p : {dK, Z, part})
-            if (p)
-                (void)hipFree(p);
-    };
+    // workspace from the pool (an optimise call comes here up to max_iter times); alpha in row order is uploaded from the host
+    // copy the likelihood terms below use -- not read from the substitution's scratch, which any later solve may overwrite
+    DevGuard gdK(nullptr, true), gZ(nullptr, true), gpart(nullptr, true);
     hipError_t he;
-    if ((he = hipMalloc((void **)&dK, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
-        (he = hipMalloc((void **)&Z, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
-        (he = hipMalloc((void **)&part, sizeof(double) * n_part)) != hipSuccess) {
-        release();
+    if ((he = big_alloc(&gdK.p, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
+        (he = big_alloc(&gZ.p, sizeof(double) * (size_t)np_rows * np)) != hipSuccess ||
+        (he = big_alloc(&gpart.p, sizeof(double) * (n_part + (size_t)np_rows))) != hipSuccess) {
         (void)hipGetLastError();
         return fail(he == hipErrorOutOfMemory ? GPX_E_OOM : GPX_E_HIP, std::string("gpx_dgp_loglik_gradient: ") + hipGetErrorString(he));
+    }
+    double *dK = (double *)gdK.p, *Z = (double *)gZ.p, *part = (double *)gpart.p, *d_arows = part + n_part;
+    auto release = [&] {
+        (void)hipStreamSynchronize(s);  // nothing may still use the buffers when the guards park them
+    };
+    {
+        std::vector<double> ar((size_t)np_rows, 0.0);
+        for (int i = 0; i < n4; ++i)
+            ar[i] = g->h_alpha_rows[i];
+        he = hipMemcpy(d_arows, ar.data(), sizeof(double) * (size_t)np_rows, hipMemcpyHostToDevice);
+        if (he != hipSuccess)
+            return fail(GPX_E_HIP, std::string("gpx_dgp_loglik_gradient: ") + hipGetErrorString(he));
     }
     double *p_quad = part, *p_trk = part + np_rows, *p_tr = part + 2 * (size_t)np_rows;
     hipLaunchKernelGGL(gpx::dgp_dk_kernel, dim3(np_rows / TILE, np_rows / TILE), dim3(256), 0, s, g->cov, np, g->d_row, g->d_x,
                        g->d_y, g->d_z, dK);
-    hipLaunchKernelGGL(gpx::dgp_quad_rows_kernel, dim3(n4), dim3(256), 0, s, n4, np, dK, (const double *)m->t_xs, p_quad);
+    hipLaunchKernelGGL(gpx::dgp_quad_rows_kernel, dim3(n4), dim3(256), 0, s, n4, np, dK, (const double *)d_arows, p_quad);
     hipLaunchKernelGGL(gpx::dgp_trkinv_rows_kernel, dim3(n4), dim3(256), 0, s, np, (const double *)m->X,
                        (const double *)m->t_dinv, p_trk);
     GemmArgs a;  // Z[a][m] = sum_b dK[a][b] X[m][b]
@@ -688,6 +696,13 @@ extern "C" int gpx_dgp_optimise(gpx_dgp *g, const gpx_rprop *desc, gpx_rprop_res
     gpx_rprop_default(&d);
     if (desc)
         d = *desc;
+    {
+        auto pos = [](double v) { return std::isfinite(v) && v > 0.0; };
+        if (!pos(d.delta0) || !pos(d.delta_min) || !pos(d.delta_max) || !pos(d.eta_minus) || !pos(d.eta_plus) ||
+            d.eta_minus > 1.0 || d.eta_plus < 1.0 || d.delta_min > d.delta_max || !std::isfinite(d.eps_stop) || d.eps_stop < 0.0)
+            return fail(GPX_E_BAD_ARG, "gpx_dgp_optimise: step sizes must be finite and positive, delta_min <= delta_max, "
+                                       "eta_minus <= 1 <= eta_plus, eps_stop >= 0");
+    }
     auto sign = [](double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); };
     auto kernel_of = [](const double *p) {
         gpx_kernel k{};
@@ -721,8 +736,13 @@ extern "C" int gpx_dgp_optimise(gpx_dgp *g, const gpx_rprop *desc, gpx_rprop_res
         grad_old[0] = grad[0], grad_old[1] = grad[1];
         if (std::sqrt(grad[0] * grad[0] + grad[1] * grad[1]) < d.eps_stop)
             break;
-        if ((rc = dgp_refit(g, kernel_of(params))))
+        if ((rc = dgp_refit(g, kernel_of(params)))) {
+            // parameters whose covariance does not factorise (or does not fit): the search ends HERE, as documented -- the
+            // model is unchanged by the failed refit (dgp_refit), the result is the best point met, the call succeeds
+            if (rc == GPX_E_SINGULAR || rc == GPX_E_OOM)
+                rc = GPX_OK;
             break;
+        }
         at_best = false;
         ++done;
         if (g->loglik > best) {

@@ -55,7 +55,10 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     }
     const bool cols_gen = use_cols && var_cols_gen(vc);
     const size_t nq_tiles = ((nq + TILE - 1) / TILE) * TILE;
-    const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, (size_t)1 << 21) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
+    // (an explicitly set gpx_options.query_batch bounds the batch -- and with it the 136 bytes per query of ws_coef -- on
+    // every path; the default of the small-model kernel is the whole call in slices of 2^21 queries)
+    const size_t cols_cap = m->opt.query_batch > 0 ? (size_t)m->qbatch : (size_t)1 << 21;
+    const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, cols_cap) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
     if (v) {
         int rc;
         const size_t qb = qbatch;

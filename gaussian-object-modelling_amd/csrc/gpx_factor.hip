@@ -8,15 +8,14 @@
 //                every panel solve and every block substitution into matrix products.  Round 2 (diag_ldlm_kernel):
 //                the 32 x 32 sub-block is factorised AND inverted by rank-1 MFMA updates of accumulators that hold it,
 //                the rows below by one product with that inverse, the trailing blocks stay in registers, the 128 x 128
-//                inverse is assembled left-looking in the shadow of the panel steps.  Round 1 (diag_ldl_kernel, kept
-//                for A/B runs): sub-block in the registers of one wave by v_readlane + FMA, substitution, recursive
-//                doubling at the end.  identity_blocks: the same result for blocks that lie in the padding.
+//                inverse is assembled left-looking in the shadow of the panel steps.  identity_blocks: the same result
+//                for blocks that lie in the padding.
 //   tri_solve  : L y = b and L^T x = D^-1 y in one launch each (a workgroup per block row, results handed on
 //                through self-validating entries); fwd / bwd step kernels: the same, one launch per block step.
 #include "gpx_internal.hpp"
 #include "gpx_blk.hpp"
 
-// phase timing of diag_ldl_kernel for scripts/diag_bench.hip (which defines GPX_STAMP); nothing in the library build
+// phase timing of diag_ldlm_kernel for scripts/diag_bench.hip (which defines GPX_STAMP); nothing in the library build
 #ifndef GPX_STAMP
 #define GPX_STAMP(i)
 #endif
@@ -30,362 +29,10 @@ namespace gpx {
 constexpr int DIAG_THREADS = 512, DIAG_THREADS_NARROW = 256;
 
 
-// One 128 x 128 diagonal block: LDL^T without pivoting + the inverse of its unit-lower L, blocked by 32.
-//
-//   per 32-column panel  A) the 32 x 32 diagonal sub-block is factorised by wave 0 with the rows in registers
-//                           (static indices; pivot rows / columns travel by v_readlane, no barrier); in the same
-//                           interval wave 1 inverts the PREVIOUS sub-block's L the same way, so the inverses --
-//                           needed only by the assembly at the end -- are off the critical path,
-//                        B) the rows below: W L11^T = A21 by forward substitution, the row in the registers of
-//                           4 (fp64: 2) adjacent lanes, pivots by DPP, L11 from LDS; L21 = W D^-1,
-//                        C) the trailing update A22 -= W L21^T on the (L2-resident) global block, panel
-//                           operands in LDS.
-//   then the 128 x 128 inverse X of L is assembled from the four 32 x 32 inverses Xd and the six L blocks (all
-//   kept in LDS) by recursive doubling, every 32 x 32 x 32 product on MFMA (one wave per output block):
-//        X10 = -Xd1 (L10 Xd0),  X32 = -Xd3 (L32 Xd2)                        [first product beside the last inverse]
-//        T   = L_BA X_A   (64 x 64: L20 L21 / L30 L31  times  Xd0 0 / X10 Xd1)
-//        X_BA = -X_B T    (X_B = Xd2 0 / X32 Xd3).
-// History: unblocked LDS kernel 348 us, 177 us with 1024 threads; blocked by 32 with the sub-block factorised AND
-// inverted by one wave, B as W = A21 X11^T and the assembly as scalar loops: 105 us (fp32) / 190 us (fp64); inverse
-// on the second wave + substitution: 90 / 159 us; assembly on MFMA: see DESIGN.md section 4.  A fully
-// register-resident 128-wide variant was tried too: hipcc needs 4.5 min for it and spills 2.8 KB per lane.
-
-
-// Phase B of diag_ldl: a row of W L11^T = A21 is shared by G adjacent lanes, lane q of the group owning the columns
-// q + G m.  Step C_ takes w_C from its owner by a DPP quad permute and eliminates it from the columns right of it
-// (L11 is stored with zeros on and above the diagonal, so "right of it" needs no per-lane test); the lane's slice
-// of column C_ + 1 of L11 is fetched one step ahead -- left to itself the compiler issued every LDS read just
-// before its FMA and waited for it.
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// position of row l of L11 inside a column of Lt: the M rows of one lane slot are contiguous
-template <int G>
-__device__ __forceinline__ int lt_slot(int l)
-{
-    return (l % G) * (NB / G) + l / G;
-}
-template <typename T, int G, int C_>
-struct SubstStep {
-    static constexpr int M = NB / G;
-    static __device__ __forceinline__ void run(T (&a)[M], T (&lc)[M], T (&ln)[M], const T *ltq)
-    {
-        if constexpr (C_ < NB - 1) {
-            constexpr int MO = C_ / G, QO = C_ % G;        // owner of column C_: slot MO of lane QO
-            constexpr int MN = (C_ + 1) / G;               // first slot column C_ + 1 still needs
-            constexpr int EPV = 16 / sizeof(T);            // elements per 16-byte LDS read
-            constexpr int M0 = MN / EPV * EPV;
-#pragma unroll
-            for (int m = M0; m < M; ++m)
-                ln[m] = ltq[(C_ + 1) * NB + m];
-            constexpr int CTRL = G == 4 ? QO * 0x55 : (QO | (QO << 2) | ((2 + QO) << 4) | ((2 + QO) << 6));
-            const T w = dpp_quad<CTRL>(a[MO]);
-#pragma unroll
-            for (int m = MO; m < M; ++m)
-                a[m] -= w * lc[m];
-            __builtin_amdgcn_sched_group_barrier(0x100, (M - M0) / EPV, 0);  // DS reads of the next column first
-            __builtin_amdgcn_sched_group_barrier(0x002, M - MO + 1, 0);      // then this column's DPP move and FMAs
-            SubstStep<T, G, C_ + 1>::run(a, ln, lc, ltq);
-        }
-    }
-};
-
-// unit-lower inverse of a 32 x 32 L held as r[c] = L[l][c] in lane l:  X[l][j] = -( L[l][j] + sum_{j<k<l} X[l][k] L[k][j] )
-// (reading column j of L from Lt as uniform LDS reads instead of v_readlane was measured slower: 5.2 vs 4.2 us)
-template <typename T>
-__device__ __forceinline__ void sub_inverse(const T (&r)[NB], T (&x)[NB], int l)
-{
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-        x[c] = T(0);
-#pragma unroll
-    for (int j = NB - 2; j >= 0; --j) {
-        T s0 = T(0), s1 = T(0);
-        // L is known up front, so nothing orders its 496 broadcasts: the compiler emitted all of them first and
-        // spilled the SGPRs to VGPR lanes (writelane + readlane each).  The empty asm ties column j to the result of
-        // the previous step.
-        T rj = r[j];
-        if (j < NB - 2)
-            asm("" : "+v"(rj) : "v"(x[j + 1]));
-#pragma unroll
-        for (int k = j + 1; k < NB; ++k) {
-            const T lkj = bcast_lane(rj, k);  // L[k][j]
-            // x[k] is still 0 for k >= l (set below only when l > k), so no select is needed
-            if (k & 1)
-                s1 += x[k] * lkj;
-            else
-                s0 += x[k] * lkj;
-        }
-        x[j] = (l > j) ? -(r[j] + s0 + s1) : T(0);
-    }
-}
-
-
-template <typename T, int DT>
-__global__ __launch_bounds__(DT, 2) void diag_ldl_kernel(T *__restrict__ A, long lda, T *__restrict__ linv,
-                                                      T *__restrict__ d, T *__restrict__ dinv,
-                                                      int *__restrict__ info, int blk)
-{
-    constexpr int BLK = NB * PLD;                  // one 32 x 32 LDS block
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *Pa = reinterpret_cast<T *>(smem_raw);       // [TILE][PLD]  panel: A entries, then W = L D
-    T *Lt = Pa + TILE * PLD;                       // [2][NB][NB]  L11 of the current / previous panel: [column][lt_slot(row)]
-    T *Di = Lt + 2 * NB * NB;                      // [TILE]       1 / D
-    T *Ls = Di + TILE;                             // [6][NB][PLD] L blocks (1,0) (2,0) (3,0) | (2,1) (3,1) | (3,2)
-    T *Xd = Ls + 6 * BLK;                          // [4][NB][PLD] inverses of the diagonal sub-blocks
-    // the inverse assembly re-uses Pa | Lt | Di (6400 elements) as six blocks R0 .. R5
-    T *R = Pa;
-    static_assert(6 * BLK <= TILE * PLD + 2 * NB * NB + TILE, "assembly blocks must fit the panel region");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    T *Xg = linv + (size_t)blk * TILE * TILE;
-    constexpr int BG = DT / 128;                 // lanes that share a row in phase B
-    constexpr int NCW = DT / 64 - 2;             // waves that carry the trailing update (all but the two of step A)
-    constexpr int MAXB = (6 + NCW - 1) / NCW;    // 32 x 32 blocks per such wave (panel 0 has six)
-    BlkAcc<T> cacc[MAXB];
-
-    GPX_STAMP(0);
-    for (int jb = 0; jb < 4; ++jb) {
-        const int c0 = NB * jb;
-        const int nrows = TILE - c0;
-        GPX_STAMP(1 + 4 * jb);
-        // ---- A: wave 0 factorises sub-block jb, wave 1 inverts L of sub-block jb - 1; lane l (and its twin
-        //         l + 32) owns row l ----
-        if (wave == 0) {
-            // l is made opaque once per panel: left loop-invariant, hipcc computes the ~150 lane masks (l == j, l > j,
-            // c < l ...) of all 32 columns at kernel entry, keeps them alive across the four panels and spills
-            // 185-210 SGPRs to VGPR lanes; recomputing a mask next to its use is one v_cmp
-            int l = lane & 31;
-            asm volatile("" : "+v"(l));
-            T r[NB];
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                r[c] = A[(size_t)(c0 + l) * lda + c0 + c];  // straight from global: no staging, no barrier
-            T dmine = T(1);
-            int nneg = 0;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const T dj = bcast_lane(r[j], j);
-                if (!(fabs(dj) > T(0)) || !(fabs(dj) < pivot_huge(T(0))))
-                    bad = true;
-                if (dj < T(0))
-                    ++nneg;
-                if (l == j)
-                    dmine = dj;
-                const T lij = r[j] * fast_rcp(dj);
-#pragma unroll
-                for (int k = j + 1; k < NB; ++k) {
-                    const T akj = bcast_lane(r[j], k);  // a_kj (still un-scaled in lane k)
-                    r[k] -= lij * akj;
-                }
-                if (l > j)
-                    r[j] = lij;
-            }
-            if (lane < NB) {
-                T *lt = Lt + (jb & 1) * NB * NB;
-#pragma unroll
-                for (int c = 0; c < NB; ++c) {
-                    lt[c * NB + lt_slot<BG>(l)] = c < l ? r[c] : T(0);  // L11[l][c], zero on / above the diagonal
-                    if (c < l)
-                        A[(size_t)(c0 + l) * lda + c0 + c] = r[c];
-                }
-                A[(size_t)(c0 + l) * lda + c0 + l] = dmine;
-                Di[c0 + l] = T(1) / dmine;
-                d[blk * TILE + c0 + l] = dmine;
-                dinv[blk * TILE + c0 + l] = T(1) / dmine;
-                if (l == 0) {
-                    if (bad)
-                        atomicCAS(&info[0], 0, blk * TILE + c0 + 1);
-                    if (nneg)
-                        atomicAdd(&info[1], nneg);
-                }
-            }
-        } else if (wave == 1 && jb > 0) {
-            int l = lane & 31;
-            asm volatile("" : "+v"(l));
-            const T *lt = Lt + ((jb - 1) & 1) * NB * NB;
-            T r[NB], x[NB];
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                r[c] = lt[c * NB + lt_slot<BG>(l)];
-            sub_inverse(r, x, l);
-            if (lane < NB) {
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                    Xd[((jb - 1) * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
-            }
-        }
-        if (wave >= 2 || (wave == 1 && jb == 0)) {
-            // the panel rows below the sub-block -> Pa (they are needed from phase B on)
-            const int first = jb == 0 ? 64 : 128;
-            for (int idx = tid - first; idx < (nrows - NB) * NB; idx += DT - first) {
-                const int r_ = idx >> 5, c_ = idx & 31;
-                Pa[(c0 + NB + r_) * PLD + c_] = A[(size_t)(c0 + NB + r_) * lda + c0 + c_];
-            }
-        }
-        if (wave >= 2) {
-            // the trailing blocks this wave will update in C, in accumulator layout (final since the last barrier)
-#pragma unroll
-            for (int e = 0; e < MAXB; ++e) {
-                const int t = (wave - 2) + NCW * e;
-                if (t < (3 - jb) * (4 - jb) / 2) {
-                    const int bi = t < 1 ? 0 : (t < 3 ? 1 : 2), bj = t - bi * (bi + 1) / 2;
-                    cacc[e].load(A + (size_t)(c0 + NB + NB * bi) * lda + c0 + NB + NB * bj, lda, lane);
-                }
-            }
-            // idle otherwise: the parts of X known by now -- zeros right of the diagonal block in block row jb and
-            // the diagonal block jb - 2 (inverted during the previous interval)
-            for (int idx = tid - 128; idx < NB * (TILE - c0 - NB); idx += DT - 128) {
-                const int w_ = TILE - c0 - NB, r_ = idx / w_, c_ = idx - r_ * w_;
-                Xg[(size_t)(c0 + r_) * TILE + c0 + NB + c_] = T(0);
-            }
-            if (jb >= 2)
-                for (int idx = tid - 128; idx < NB * NB; idx += DT - 128) {
-                    const int b = jb - 2, r_ = idx >> 5, c_ = idx & 31;
-                    Xg[(size_t)(b * NB + r_) * TILE + b * NB + c_] = Xd[(b * NB + r_) * PLD + c_];
-                }
-        }
-        __syncthreads();
-        GPX_STAMP(2 + 4 * jb);
-        const int nb_rows = nrows - NB;  // rows below the diagonal sub-block
-        if (nb_rows > 0) {
-            T *Lsp = Ls + (jb == 0 ? 0 : (jb == 1 ? 3 : 5)) * BLK;  // L blocks (jb+1 .., jb), rows from c0 + NB
-            // ---- B: row i of W solves W L11^T = A21:  w_c = a_ic - sum_{k<c} w_k L11[c][k]; BG lanes per row ----
-            if (tid < nb_rows * BG) {
-                constexpr int M = NB / BG;
-                const int row = tid / BG, q = tid % BG;
-                const int i_ = c0 + NB + row;
-                const T *ltq = Lt + (jb & 1) * NB * NB + q * M;
-                T a[M], lc[M], ln[M];
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    a[m] = Pa[i_ * PLD + q + BG * m];
-                    lc[m] = ltq[m];
-                }
-                SubstStep<T, BG, 0>::run(a, lc, ln, ltq);
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    Pa[i_ * PLD + q + BG * m] = a[m];
-                    Lsp[row * PLD + q + BG * m] = a[m] * Di[c0 + q + BG * m];
-                }
-            }
-            __syncthreads();
-            GPX_STAMP(3 + 4 * jb);
-            if (wave < 2)
-                for (int idx = tid; idx < nb_rows * NB; idx += 128) {
-                    const int r_ = idx >> 5, c_ = idx & 31;
-                    A[(size_t)(c0 + NB + r_) * lda + c0 + c_] = Lsp[r_ * PLD + c_];
-                }
-            // ---- C: trailing update A22 -= W L21^T, one 32 x 32 block per wave on MFMA (lower blocks; a diagonal
-            //         block is updated whole, its upper half is never read).  The blocks were fetched during A. ----
-            if (wave >= 2) {
-                const int r0 = c0 + NB;
-#pragma unroll
-                for (int e = 0; e < MAXB; ++e) {
-                    const int t = (wave - 2) + NCW * e;
-                    if (t < (3 - jb) * (4 - jb) / 2) {
-                        const int bi = t < 1 ? 0 : (t < 3 ? 1 : 2), bj = t - bi * (bi + 1) / 2;
-                        cacc[e].msub_nt(Pa + (r0 + NB * bi) * PLD, Lsp + NB * bj * PLD, lane);
-                        cacc[e].store(T(1), (T *)nullptr, A + (size_t)(r0 + NB * bi) * lda + r0 + NB * bj, lda, lane);
-                    }
-                }
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        GPX_STAMP(4 + 4 * jb);
-    }
-
-    // ---- inverse of the 128 x 128 unit-lower L ----
-    const T *L10 = Ls, *L20 = Ls + BLK, *L30 = Ls + 2 * BLK, *L21 = Ls + 3 * BLK, *L31 = Ls + 4 * BLK, *L32 = Ls + 5 * BLK;
-    const T *Xd0 = Xd, *Xd1 = Xd + BLK, *Xd2 = Xd + 2 * BLK, *Xd3 = Xd + 3 * BLK;
-    T *R0 = R, *R1 = R + BLK, *R2 = R + 2 * BLK, *R3 = R + 3 * BLK, *R4 = R + 4 * BLK, *R5 = R + 5 * BLK;
-    BlkAcc<T> &acc = cacc[0];
-    // E: wave 1 inverts the last sub-block (reads the second half of Lt = part of R3 .. R5, which stay untouched
-    //    until phase G); waves 2, 3: R0 = L10 Xd0, R1 = L32 Xd2; the rest writes what is already known of X
-    if (wave == 1) {
-        int l = lane & 31;
-        asm volatile("" : "+v"(l));
-        const T *lt = Lt + NB * NB;
-        T r[NB], x[NB];
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-            r[c] = lt[c * NB + lt_slot<BG>(l)];
-        sub_inverse(r, x, l);
-        if (lane < NB) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-                Xd[(3 * NB + l) * PLD + c] = c < l ? x[c] : (c == l ? T(1) : T(0));
-        }
-    } else if (wave == 2 || wave == 3) {
-        acc.zero();
-        acc.mac(wave == 2 ? L10 : L32, wave == 2 ? Xd0 : Xd2, lane);
-        acc.store(T(1), wave == 2 ? R0 : R1, (T *)nullptr, 0, lane);
-    } else {
-        // diagonal block 2 of X (blocks 0, 1 and the zeros went out during the panel intervals)
-        const int ft = wave == 0 ? lane : 64 + (tid - 256);
-        constexpr int NF = 64 + (DT > 256 ? DT - 256 : 0);
-        for (int idx = ft; idx < NB * NB; idx += NF)
-            Xg[(size_t)(2 * NB + (idx >> 5)) * TILE + 2 * NB + (idx & 31)] = Xd2[(idx >> 5) * PLD + (idx & 31)];
-    }
-    __syncthreads();
-    GPX_STAMP(20);
-    // F: X10 = -Xd1 R0 -> R2, X32 = -Xd3 R1 -> R3 (needs the second half of Lt no more); diagonal block 3
-    if (wave < 2) {
-        acc.zero();
-        acc.mac(wave == 0 ? Xd1 : Xd3, wave == 0 ? R0 : R1, lane);
-        acc.store(T(-1), wave == 0 ? R2 : R3, wave == 0 ? Xg + (size_t)NB * TILE : Xg + (size_t)3 * NB * TILE + 2 * NB, TILE,
-                  lane);
-    } else {
-        for (int idx = tid - 128; idx < NB * NB; idx += DT - 128)
-            Xg[(size_t)(3 * NB + (idx >> 5)) * TILE + 3 * NB + (idx & 31)] = Xd3[(idx >> 5) * PLD + (idx & 31)];
-    }
-    __syncthreads();
-    GPX_STAMP(21);
-    // G: T = L_BA X_A: T20 = L20 Xd0 + L21 X10 -> R0, T30 = L30 Xd0 + L31 X10 -> R1, T21 = L21 Xd1 -> R4, T31 = L31 Xd1 -> R5
-    if (wave < 4) {
-        acc.zero();
-        if (wave < 2) {
-            acc.mac(wave == 0 ? L20 : L30, Xd0, lane);
-            acc.mac(wave == 0 ? L21 : L31, R2, lane);
-        } else {
-            acc.mac(wave == 2 ? L21 : L31, Xd1, lane);
-        }
-        // R0, R1 were last read in F; R4 / R5 overlap Lt and Di, dead since E / the last panel
-        acc.store(T(1), wave == 0 ? R0 : (wave == 1 ? R1 : (wave == 2 ? R4 : R5)), (T *)nullptr, 0, lane);
-    }
-    __syncthreads();
-    GPX_STAMP(22);
-    // H: X_BA = -X_B T: X20 = -Xd2 T20, X30 = -(X32 T20 + Xd3 T30), X21 = -Xd2 T21, X31 = -(X32 T21 + Xd3 T31)
-    if (wave < 4) {
-        const T *Tt = (wave & 1) ? R4 : R0, *Tb = (wave & 1) ? R5 : R1;  // column 0: waves 0, 2; column 1: waves 1, 3
-        acc.zero();
-        if (wave < 2) {
-            acc.mac(Xd2, Tt, lane);
-        } else {
-            acc.mac(R3, Tt, lane);
-            acc.mac(Xd3, Tb, lane);
-        }
-        acc.store(T(-1), (T *)nullptr, Xg + (size_t)(wave < 2 ? 2 : 3) * NB * TILE + (wave & 1) * NB, TILE, lane);
-    }
-    GPX_STAMP(23);
-    GPX_STAMP(24);
-}
-
 // ---- diagonal block on the matrix cores (round 2): diag_ldlm_kernel<float | double> ---------------------------------
-// Same contract as diag_ldl_kernel (LDL^T of a 128 x 128 block without pivoting + the unit-lower inverse of its L), which
-// it replaces in both precisions (GPX_DIAG_LEGACY=1 brings the old one back for A/B runs).  In fp32 -- fp64: subblock_ldl
-// below --
+// LDL^T of a 128 x 128 block without pivoting + the unit-lower inverse of its L (the round-1 kernel it replaced -- sub-block by
+// v_readlane + FMA, inverse on a second wave: fp32 38 us, fp64 55 -- was deleted in round 5).  In fp32 -- fp64: subblock_ldl in
+// gpx_blk.hpp --
 // the 32 x 32 sub-block is no longer factorised by 1000 v_readlane + FMA pairs in one wave (5.1 us): it sits in the
 // accumulator of v_mfma_f32_32x32x2_f32 (column on the lane, rows in the 16 registers) and every elimination step is
 // ONE rank-1 MFMA:  M <- M - (u_j / d_j) u_j^T  with u_j = row j of M, which is one accumulator register of one wave
@@ -687,11 +334,6 @@ __global__ __launch_bounds__(DT, 2) void diag_ldlm_kernel(T *__restrict__ A, lon
     GPX_STAMP(24);
 }
 
-static size_t diag_shmem_bytes(size_t esz)
-{
-    return esz * (size_t)(TILE * PLD + 2 * NB * NB + TILE + 6 * NB * PLD + 4 * NB * PLD);  // Pa + Lt + Di + Ls + Xd
-}
-
 static size_t diagm_shmem_bytes(size_t esz)
 {
     return esz * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);  // Di + Ls[6] Xd[4] Dn Lx + panel rows 32 .. 127
@@ -702,40 +344,16 @@ static void diagm_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *
     hipLaunchKernelGGL((diag_ldlm_kernel<T, DT>), dim3(1), dim3(DT), diagm_shmem_bytes(sizeof(T)), st, (T *)Ablk, lda, (T *)linv,
                        (T *)d, (T *)dinv, info, blk);
 }
-// GPX_DIAG_LEGACY=1: the round-1 kernels (sub-block by v_readlane + FMA, inverse on a second wave), for A/B timing
-static bool diag_legacy()
-{
-    static const bool v = [] {
-        const char *e = std::getenv("GPX_DIAG_LEGACY");
-        return e && std::atoi(e) != 0;
-    }();
-    return v;
-}
-
-template <typename T, int DT>
-static void diag_t(void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk, hipStream_t st)
-{
-    const size_t shmem = diag_shmem_bytes(sizeof(T));
-    hipLaunchKernelGGL((diag_ldl_kernel<T, DT>), dim3(1), dim3(DT), shmem, st, (T *)Ablk, lda, (T *)linv, (T *)d, (T *)dinv,
-                       info, blk);
-}
-
 void factor_init(int prec)
 {
     static PerDeviceOnce once64, once32;  // per device, see gpx_internal.hpp
     if (prec == GPX_PREC_F64) {
         once64.run([] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<double, DIAG_THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(double)));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<double, DIAG_THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)diagm_shmem_bytes(sizeof(double)));
         });
     } else {
         once32.run([] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldl_kernel<float, DIAG_THREADS_NARROW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_shmem_bytes(sizeof(float)));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<float, DIAG_THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)diagm_shmem_bytes(sizeof(float)));
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&diag_ldlm_kernel<float, DIAG_THREADS_NARROW>),
@@ -748,14 +366,8 @@ void factor_init(int prec)
 void launch_diag_ldl(int prec, void *Ablk, long lda, void *linv, void *d, void *dinv, int *info, int blk,
                      hipStream_t st, bool narrow)
 {
-    if (prec == GPX_PREC_F64 && diag_legacy())
-        diag_t<double, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
-    else if (prec == GPX_PREC_F64)
+    if (prec == GPX_PREC_F64)
         diagm_t<double, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
-    else if (diag_legacy() && narrow)
-        diag_t<float, DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
-    else if (diag_legacy())
-        diag_t<float, DIAG_THREADS>(Ablk, lda, linv, d, dinv, info, blk, st);
     else if (narrow)
         diagm_t<float, DIAG_THREADS_NARROW>(Ablk, lda, linv, d, dinv, info, blk, st);
     else

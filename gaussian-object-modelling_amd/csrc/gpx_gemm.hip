@@ -662,11 +662,7 @@ void launch_gemm(int prec, const GemmArgs &g, hipStream_t st)
         return;
     }
     if (prec == GPX_PREC_F64) {
-        static const int w1_nn = [] {
-            const char *e = std::getenv("GPX_W1_NN");
-            return e ? std::atoi(e) : 1;
-        }();
-        if (w1_nn && w1_f64_nn_fits(g)) {
+        if (w1_f64_nn_fits(g)) {
             launch_w1_f64_nn(g, st);
             return;
         }

@@ -92,8 +92,7 @@ void launch_reduce_tilemax(int ntiles, const float *tile_max_d2, const int *tile
 constexpr int VAR_FIT_SAMPLES = 128;
 constexpr int VAR_FIT_SAMPLES_DEFAULT = 64;  // GPX_VAR_FIT_SAMPLES (16 .. 128)
 // weights 1 / (s + delta) of the least squares, delta = R_max^2 / VAR_FIT_WDELTA_DIV with R_max = Model::R, the largest
-// pairwise training distance (0.05 for the node's unit-ball clouds with their exterior sphere of radius 2);
-// GPX_VAR_FIT_WDELTA overrides delta itself, <= 0: uniform weights
+// pairwise training distance (0.05 for the node's unit-ball clouds with their exterior sphere of radius 2)
 constexpr double VAR_FIT_WDELTA_DIV = 320.0;
 // coef (doubles, [VAR_NCOEF][ldcc]) for the queries [0, nq_tile) of a batch (zero from nq_valid on): rows 0..13 the
 // query-side coefficients of the 14 basis functions, rows 14..16 a_q, b_q, c_q.
@@ -213,7 +212,7 @@ void launch_var_w1_f64(const GemmArgs &g, hipStream_t st);
 // launch against 7.6 GB with the padded stride, paired launch; profiles/r03_w1_traffic.txt)
 constexpr int KQP_LDPAD = 32;
 // fp64 C = alpha A B (B in [k][n] form, EPI_STORE, beta = 0) with K >= W1_NN_MIN_K goes to the one-wave kernel as well
-// (the three largest levels of the inverse-factor assembly carry 98 % of its flops); GPX_W1_NN=0 keeps the LDS tiles
+// (the three largest levels of the inverse-factor assembly carry 98 % of its flops)
 constexpr int W1_NN_MIN_K = 1024;
 bool w1_f64_nn_fits(const GemmArgs &g);
 void launch_w1_f64_nn(const GemmArgs &g, hipStream_t st);

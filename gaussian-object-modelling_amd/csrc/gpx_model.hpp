@@ -87,7 +87,7 @@ struct gpx_model {
     bool var_fit = false;  // the low-rank fit is taken out of the kernel operand of the variance GEMM (fp32 modes)
     bool var_fit_opt = false;  // ... as the options / environment asked for it (var_fit: after the promotion rule)
     bool promoted = false;     // indefinite kernel matrix: the model kept its fp64 state (build_model)
-    bool op64 = true;      // ... and that operand, k - fit, is formed in fp64 and rounded once (GPX_VAR_OP64=0: in fp32)
+    bool op64 = true;      // ... and that operand, k - fit, is formed in fp64 and rounded once (the thin plate), else in fp32
     // other fp64 vectors (npad each): label s2 r f, then one double for max|r|
     double *dvecs = nullptr;
     double *d_lab = nullptr, *d_s2 = nullptr, *d_r = nullptr, *d_f = nullptr, *d_rmax = nullptr, *d_normals = nullptr;

@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad
     int bi = 0, bj = 0;
     // Interior tiles -- strictly below the block diagonal and clear of the padding, all but ~2 / nt of them -- have no
     // diagonal entry, no identity padding and no index to carry through the loop: the maximum of d2 alone is tracked (one
-    // v_max per entry, one compare / select per row of four) and its column found afterwards from that one row.  The general body below costs
+    // v_max per entry, a handful of compares / selects per row of four for its column).  The general body below costs
     // 4 compare / select instructions per entry and a divergent branch per store for conditions that are uniformly false
     // here; with them the kernel is VALU-bound at 5.2 TB/s (104.7 us at N = 16384, profiles/r03_bench_kernel_stats.txt).
     const bool interior = tj < ti && (ti + 1) * TILE <= n;
     if (interior) {
-        int br = 0;  // the row pass in which the lane's running maximum was last raised
+        int br = 0, bc = 0;  // the row pass in which the lane's running maximum was last raised, and its column there
 #pragma unroll 4
         for (int r = 0; r < 16; ++r) {
             const int li = ty + 8 * r;
@@ -94,24 +94,18 @@ __global__ __launch_bounds__(256) void kbuild_kernel(Cov<T> cov, int n, int npad
                 out[c] = cov_k<T, KID>(cov, d2);
                 d2f[c] = (float)d2;
             }
-            const float m = fmaxf(fmaxf(d2f[0], d2f[1]), fmaxf(d2f[2], d2f[3]));
-            br = m > best ? r : br;
+            const float m01 = fmaxf(d2f[0], d2f[1]), m23 = fmaxf(d2f[2], d2f[3]);
+            const float m = fmaxf(m01, m23);
+            // the first of the four entries that reaches the row's maximum (what the general body's strict comparison keeps),
+            // from the values compared -- nothing is recomputed, so no second evaluation has to round the same way
+            const int cm = m01 >= m23 ? (d2f[0] >= d2f[1] ? 0 : 1) : (d2f[2] >= d2f[3] ? 2 : 3);
+            const bool up = m > best;
+            br = up ? r : br;
+            bc = up ? cm : bc;
             best = fmaxf(best, m);
             store4<T>(K + (size_t)(ti * TILE + li) * npad + gj0, out);
         }
-        // position of the lane's maximum: the first of the four entries of row pass br that reaches it (what the general
-        // body's strict comparison keeps)
-        {
-            const int li = ty + 8 * br;
-            const T ax = rx[li], ay = ry[li], az = rz[li];
-            bi = ti * TILE + li, bj = gj0 + 3;
-#pragma unroll
-            for (int c = 2; c >= 0; --c) {
-                const T dx = ax - cx[c], dy = ay - cy[c], dz = az - cz[c];
-                const T d2 = dx * dx + dy * dy + dz * dz;
-                bj = (float)d2 == best ? gj0 + c : bj;
-            }
-        }
+        bi = ti * TILE + ty + 8 * br, bj = gj0 + bc;
     } else {
 #pragma unroll 4
     for (int r = 0; r < 16; ++r) {

@@ -788,7 +788,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
         res->d2max = best;
         for (int k = 0; k < 8; ++k)
             a.info[k] = k == 5 ? 0 : res->info[k];  // (info[5] is the substitution's give-up flag of the general chain)
-        a.d_meta[4] = a.wd_override >= 0.0 ? a.wd_override : fmax(best, 0.0) / VAR_FIT_WDELTA_DIV;
+        a.d_meta[4] = fmax(best, 0.0) / VAR_FIT_WDELTA_DIV;
     }
 }
 

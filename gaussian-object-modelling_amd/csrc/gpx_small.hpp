@@ -25,7 +25,7 @@ struct SmallArgs {
     Cov<double> cov{};
     double cen[3] = {0, 0, 0};
     int want_corr = 0, op64 = 0, ir_max = 4, ir_adaptive = 1;
-    double ir_tol = 0, wd_override = -1.0;
+    double ir_tol = 0;
     unsigned long long epoch = 0;
     int spin_limit = 1 << 20, abort_idx = 0, bar_idx = 0, pre_idx = 0;
     // ---- model state written by the launches ----

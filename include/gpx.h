@@ -299,7 +299,10 @@ int gpx_dgp_loglik_gradient(const gpx_dgp *g, double *grad2);
  * setToDefault (:64-73).  gpx_dgp_optimise = Optimisation::find (:86-122) on a GPX_KERNEL_SE model: at most max_iter
  * steps in (log l, log sf), each one a gradient, a step, a refit (setLogHyper + compute()) and a likelihood; the model
  * ends on the best parameters met (:120).  res (may be NULL): those parameters, their likelihood (the model's own if no
- * step was applied) and the number of steps applied.  External exclusion against evaluate, as for gpx_dgp_add. */
+ * step was applied) and the number of steps applied.  A step onto parameters whose covariance does not factorise ends
+ * the search there: the call still returns GPX_OK with the model on the best parameters met.  A descriptor with a
+ * non-finite or non-positive step size, delta_min > delta_max, eta_minus > 1 or eta_plus < 1 is GPX_E_BAD_ARG.
+ * External exclusion against evaluate, as for gpx_dgp_add. */
 typedef struct {
     double delta0, delta_min, delta_max, eta_minus, eta_plus, eps_stop;
     uint64_t max_iter;

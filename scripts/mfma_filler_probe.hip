@@ -8,14 +8,24 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int IT = 128, NMF = 8;
 
-enum { F_FMA32 = 0, F_PKFMA32, F_EXP32, F_FMA64, F_CVT64, F_ACCREAD, F_DSREAD, F_SALU };
+enum { F_FMA32 = 0, F_PKFMA32, F_EXP32, F_FMA64, F_CVT64, F_ACCREAD, F_DSREAD, F_SALU, F_FMA32_IND, F_PKFMA32_IND, F_FMA64_IND };
+constexpr int KMAX = 12;
 
+// the *_IND kinds: filler k of a group works on ITS OWN register, so the K fillers behind one MFMA are independent of each
+// other (a register is touched again one MFMA later, >= 32 cycles: no dependency stall) -- the column the round-4 table lacked
 template <int KIND, int K>
-__device__ __forceinline__ void fillers(float &x, f2v &p, double &dd, f4v &acc0, unsigned lds_addr, int &sc)
+__device__ __forceinline__ void fillers(float &x, f2v &p, double &dd, f4v &acc0, unsigned lds_addr, int &sc, float (&xs)[KMAX],
+                                        f2v (&ps)[KMAX], double (&ds)[KMAX])
 {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (KIND == F_FMA32)
+        if (KIND == F_FMA32_IND)
+            asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(xs[k]));
+        else if (KIND == F_PKFMA32_IND)
+            asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(ps[k]));
+        else if (KIND == F_FMA64_IND)
+            asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(ds[k]));
+        else if (KIND == F_FMA32)
             asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x));
         else if (KIND == F_PKFMA32)
             asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p));
@@ -46,6 +56,12 @@ __global__ __launch_bounds__(256) void probe(float *out, long long *t)
     f2v p = {0.5f, 0.25f};
     double dd = 0.5;
     int sc = 0;
+    float xs[KMAX];
+    f2v ps[KMAX];
+    double ds[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        xs[k] = 0.5f + 1e-3f * k, ps[k] = f2v{0.5f, 0.25f + 1e-3f * k}, ds[k] = 0.5 + 1e-3 * k;
     const unsigned lds_addr = (unsigned)(size_t)(lds + lane);
     f4v acc[NMF];
 #pragma unroll
@@ -56,12 +72,15 @@ __global__ __launch_bounds__(256) void probe(float *out, long long *t)
 #pragma unroll
         for (int c = 0; c < NMF; ++c) {
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[c]) : "v"(a), "v"(b));
-            fillers<KIND, K>(x, p, dd, acc[(c + 4) % NMF], lds_addr, sc);
+            fillers<KIND, K>(x, p, dd, acc[(c + 4) % NMF], lds_addr, sc, xs, ps, ds);
         }
     }
     asm volatile("s_nop 15\n s_nop 15" ::: "memory");
     const long long c1 = clock64();
     float s = x + p.x + (float)dd + (float)sc;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        s += xs[k] + ps[k].x + (float)ds[k];
 #pragma unroll
     for (int c = 0; c < NMF; ++c)
         s += acc[c].x;
@@ -110,5 +129,9 @@ int main()
     run<F_ACCREAD>("v_accvgpr_read_b32", out, t);
     run<F_DSREAD>("ds_read_b32 + wait", out, t);
     run<F_SALU>("s_add_i32", out, t);
+    printf("independent fillers (filler k of every group on its own register)\n");
+    run<F_FMA32_IND>("v_fma_f32 indep.", out, t);
+    run<F_PKFMA32_IND>("v_pk_fma_f32 indep.", out, t);
+    run<F_FMA64_IND>("v_fma_f64 indep.", out, t);
     return 0;
 }

@@ -8,15 +8,10 @@ import pytest
 
 import codeobj
 
-# SGPRs parked in VGPR lanes (v_writelane / v_readlane, no memory traffic).  Every kernel is at 0 except the
-# diagonal-block kernel: it had 185-210 -- the ~150 lane masks of all 32 pivot columns hoisted to the kernel entry --
-# until the lane index was made opaque per panel; what is left (43-47 fp32, 97 fp64) are kernel arguments and
-# role masks that are parked at entry and fetched at phase boundaries, none inside the pivot recurrence.  Those are the
-# round-1 kernels (GPX_DIAG_LEGACY); the matrix-core kernel of round 2 has none in fp32 and 21 in fp64 (lane-group masks
-# of its 32 elimination steps).
-# (small_alpha_kernel: the second launch of the small-model create keeps ~20 pointers of its argument block live across its
-# three phases; two of them go to VGPR lanes)
-SGPR_SPILL_LIMIT = {"diag_ldl_kernelIf": 48, "diag_ldl_kernelId": 100, "diag_ldlm_kernelId": 24, "small_alpha_kernel": 4}
+# SGPR spills go to VGPR lanes (v_writelane / v_readlane), not to memory: tolerated where they sit outside the hot recurrences.
+# diag_ldlm_kernel<double>: 21 lane-group masks of its 32 elimination steps, parked at entry.  small_alpha_kernel (second launch
+# of the small-model create): ~20 pointers of its argument block live across its three phases, two of them go to VGPR lanes.
+SGPR_SPILL_LIMIT = {"diag_ldlm_kernelId": 24, "small_alpha_kernel": 4}
 
 
 @pytest.fixture(scope="module")

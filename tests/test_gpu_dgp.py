@@ -212,3 +212,19 @@ def test_rprop_optimiser_follows_the_reference_loop(gpu, orc):
                                 P[:, 0], P[:, 1], P[:, 2], t, nr)
         assert nerr(gg.alpha, best.alpha) < 1e-9
         gg.close()
+
+
+def test_rprop_descriptor_is_validated(gpu):
+    """gpx_dgp_optimise rejects step sizes that would send NaN or a growing step into exp(): non-finite or non-positive
+    delta / eta, delta_min > delta_max, eta_minus > 1, eta_plus < 1 -- GPX_E_BAD_ARG, the model untouched."""
+    P, t, nr = _cloud(40, 5)
+    gg = gpu.DerivativeGP(gpu.make_kernel("se", 0.9, 0.5), 0.05, P[:, 0], P[:, 1], P[:, 2], t, nr)
+    before = gg.loglik
+    for kw in ({"delta0": float("nan")}, {"delta0": -0.1}, {"eta_minus": 1.5}, {"eta_plus": 0.9}, {"delta_min": 1.0, "delta_max": 0.5},
+               {"delta_max": float("inf")}, {"eps_stop": -1.0}):
+        with pytest.raises(gpu.GpxError) as ei:
+            gg.optimise(**kw)
+        assert ei.value.code == gpu.E_BAD_ARG, kw
+    assert gg.loglik == before
+    assert gg.optimise(max_iter=2)["iterations"] <= 2
+    gg.close()

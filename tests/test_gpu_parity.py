@@ -802,45 +802,6 @@ def test_error_codes_on_device(gpu):
     assert ei.value.code == gpu.E_SINGULAR
 
 
-def test_round1_and_round2_diagonal_block_kernels_agree(gpu, ds, tmp_path, monkeypatch):
-    """The matrix-core diagonal-block kernel (diag_ldlm_kernel, default) against the round-1 VALU kernel kept behind
-    GPX_DIAG_LEGACY=1 (read once per process, hence the child): the same LDL^T up to the roundings of two different
-    elimination orders -- fp64 1e-11, fp32 1e-5 on alpha / D / variance, thin-plate included (ragged sizes: 6 and 19
-    diagonal blocks, the last one partly padding)."""
-    import subprocess, sys
-    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # F32 = the fp32 kernels at every size
-    child = (
-        "import sys, importlib, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "gpx = importlib.import_module('gaussian-object-modelling_amd.gpx')\n"
-        "ds = importlib.import_module('gaussian-object-modelling_amd.datasets')\n"
-        "out = {}\n"
-        "for n in (700, 2305):\n"
-        "    x, y, z, lab, s2 = ds.fibonacci_training_set(n)\n"
-        "    qx, qy, qz = ds.query_grid(5)\n"
-        "    for kn, par in (('matern52', (1.0, 1.0)), ('thinplate', (4.0,))):\n"
-        "        for prec in (gpx.F64, gpx.F32):\n"
-        "            gm = gpx.Model(gpx.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec)\n"
-        "            o = gm.evaluate(qx, qy, qz, want_v=True)\n"
-        "            key = '%%d/%%s/%%d/' %% (n, kn, prec)\n"
-        "            out[key + 'alpha'], out[key + 'D'], out[key + 'v'] = gm.alpha, gm.D, o['v']\n"
-        "            gm.close()\n"
-        "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for legacy in ("0", "1"):
-        path = str(tmp_path / ("diag%s.npz" % legacy))
-        env = dict(os.environ, GPX_DIAG_LEGACY=legacy)
-        r = subprocess.run([sys.executable, "-c", child, path], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[legacy] = np.load(path)
-    assert sorted(res["0"].files) == sorted(res["1"].files) and len(res["0"].files) == 24
-    for key in res["0"].files:
-        tol = 1e-11 if key.split("/")[2] == str(gpu.F64) else 1e-5
-        a, b = res["0"][key], res["1"][key]
-        scale = max(np.max(np.abs(b)), 64.0 if key.endswith("/v") and "thinplate" in key else 0.0)
-        assert np.max(np.abs(a - b)) / scale < tol, key
-
-
 def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
     """Models of up to 1024 points take the variance contraction of gpx_varcols_kernel.hpp (every row fragment resident in one
     wave, the triangle of X skipped per 16-row fragment, fp64 add-back inside the triangle, operand formed in the wave).
@@ -944,7 +905,7 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         "            gm.close()\n"
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_W1_NN", "GPX_VAR_TILE", "GPX_VAR_FIT", "GPX_VAR_DIAG_SKIP")}
+    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_VAR_TILE", "GPX_VAR_FIT", "GPX_VAR_DIAG_SKIP")}
     for tile, fit in (("6", "1"), ("3", "1"), ("6", "0"), ("3", "0")):
         path = str(tmp_path / ("tile%s_%s.npz" % (tile, fit)))
         env = dict(base_env, GPX_VAR_TILE=tile, GPX_VAR_FIT=fit)
@@ -952,12 +913,10 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         res[tile, fit] = np.load(path)
     # the same one-wave tiles launched the other way round (paired row tiles <-> plain heavy-first order: the light tile of a
-    # pair walks k downwards, so the fp32 sums differ in order only), and the inverse factor assembled without the one-wave
-    # [k][n] kernel (the 2305-point models have a K = 1024 level): same results to rounding
+    # pair walks k downwards, so the fp32 sums differ in order only): same results to rounding
     # and with the zero fragments of the diagonal block multiplied instead of skipped (GPX_VAR_DIAG_SKIP=0): they only ever
     # added 0 * k to an accumulator, so every variance is the same bit for bit
-    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("nn0", {"GPX_W1_NN": "0"}),
-                        ("diag0", {"GPX_VAR_DIAG_SKIP": "0"})):
+    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("diag0", {"GPX_VAR_DIAG_SKIP": "0"})):
         path = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", child, path], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
