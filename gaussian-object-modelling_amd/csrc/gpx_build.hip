@@ -732,6 +732,20 @@ static int demote_to_f32(gpx_model *m)
 // Taken for a fresh create (no rank-n append) of a model that trains in fp64 and has at most SMALL_CREATE_MAX_NP padded
 // rows -- every model of the reference's own sizes in every precision mode (F32 / F32_SPLIT models of this size train in
 // fp64, set_training_precision).  GPX_SMALL_CREATE=0 keeps the general chain (its tested twin).
+// Mid-size models (above the small-model path, up to MID_FACTOR_MAX_NP padded rows; fresh creates in either working precision):
+// GPX_MID_FACTOR=0 keeps the launch chain, GPX_MID_FACTOR_MAX moves the upper bound (sweeps).
+static bool mid_factor_eligible(const gpx_model *m)
+{
+    static const int max_np = [] {
+        if (const char *e = std::getenv("GPX_MID_FACTOR"))
+            if (std::atoi(e) == 0)
+                return 0;
+        const char *x = std::getenv("GPX_MID_FACTOR_MAX");
+        return x ? std::atoi(x) : MID_FACTOR_MAX_NP;
+    }();
+    return m->npad > SMALL_CREATE_MAX_NP && m->npad <= max_np;
+}
+
 static bool small_create_eligible(const gpx_model *m, const kept_factor *keep)
 {
     if (keep || m->prec != GPX_PREC_F64 || m->npad > SMALL_CREATE_MAX_NP)
@@ -943,13 +957,15 @@ static int build_model_small(gpx_model *m, bool *fell_back)
 }
 
 // ---- create: everything after the host arrays are in place ---------------------------------------
-int build_model(gpx_model *m, kept_factor *keep)
+int build_model(gpx_model *m, kept_factor *keep, bool no_dataflow)
 {
     const int n = m->n, np = m->npad;
     const size_t e = m->esz;
     HIPCHK(hipSetDevice(m->device));
     factor_init(m->prec);
     int64_t small_fallbacks = 0;
+    DevGuard mid_ws(nullptr, true);  // flags and per-tile results of the dataflow factorisation (released when this call returns)
+    bool used_dataflow = false;
     // Eigen's pivot order from the original diagonal k(0) + sigma2_i
     std::vector<double> diag(n);
     for (int i = 0; i < n; ++i)
@@ -1032,6 +1048,23 @@ int build_model(gpx_model *m, kept_factor *keep)
         (void)hipEventRecord(m->ev[EV_KBUILD], s);
         factor_append_rows(m, keep->t0);
         factorize(m, keep->t0);
+    } else if (mid_factor_eligible(m) && !no_dataflow) {
+        // kernel matrix + LDL^T as one dataflow launch (gpx_dataflow.hpp): mid-size models, where the chain of the blocked
+        // factorisation below -- 3-4 dependent launches per 128 columns -- and not its flops sets the time
+        small_create_init();
+        HIPCHK(big_alloc(&mid_ws.p, mid_ws_layout(np).bytes));
+        MidFactorArgs a;
+        a.n = n, a.np = np;
+        a.K = m->Kmat, a.linv = m->linv, a.d = m->t_d, a.dinv = m->t_dinv;
+        a.px = m->t_x, a.py = m->t_y, a.pz = m->t_z, a.ps2 = m->t_s2;
+        a.ws = mid_ws.p, a.info = m->d_info, a.epoch = small_create_epoch();
+        if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
+            a.spin_limit = std::max(1, std::atoi(sl));
+        (void)hipEventRecord(m->ev[EV_KBUILD], s);
+        launch_mid_factor(m->prec, m->cov, a, s);
+        m->gemm_ev_used_factor = 0;
+        m->factor_gemm_flops = 0;
+        used_dataflow = true;
     } else {
         const int nmax = launch_kbuild(m->prec, m->cov, n, np, m->t_x, m->t_y, m->t_z, m->t_s2, m->Kmat, m->d_tmax, m->d_tij, s);
         launch_reduce_tilemax(nmax, m->d_tmax, m->d_tij, m->d_info + 2, s);
@@ -1139,6 +1172,15 @@ int build_model(gpx_model *m, kept_factor *keep)
     m->stats.ir_steps_done = ir;
     m->stats.alpha_residual = rmax;
     m->stats.solve_fallbacks = solve_fallbacks + small_fallbacks;
+    if (used_dataflow && info[6] != 0) {
+        // a wait of the dataflow factorisation gave up (the GPU could not make progress on its grid): everything computed
+        // since is void -- the same create again through the launch chain
+        HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
+        mid_ws.reset();
+        const int rc = build_model(m, nullptr, true);
+        m->stats.solve_fallbacks += 1;
+        return rc;
+    }
     if (info[5] != 0)  // cannot happen: the step kernels never raise it
         return fail(GPX_E_HIP, "block substitution: give-up flag set after the launch-per-step fallback");
     if (info[0] != 0)

@@ -213,7 +213,7 @@ void carve_blob0(gpx_model *m);
 int alloc_model(gpx_model *m);
 hipEvent_t *gemm_events(gpx_model *m, size_t idx);
 int build_inverse(gpx_model *m);
-int build_model(gpx_model *m, kept_factor *keep = nullptr);
+int build_model(gpx_model *m, kept_factor *keep = nullptr, bool no_dataflow = false);  // no_dataflow: the launch chain only
 int alloc_factor_buffers(gpx_model *m);  // Kmat, linv, Wp for a model whose matrix is filled by the caller (gpx_dgp.hip)
 void factorize_matrix_append(gpx_model *m, int t0);
 void factorize_matrix(gpx_model *m);     // blocked LDL^T of m->Kmat in place (t_d, t_dinv, linv, d_info)

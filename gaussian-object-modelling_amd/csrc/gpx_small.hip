@@ -22,170 +22,15 @@
 #include <algorithm>
 #include <atomic>
 
-#include "gpx_blk.hpp"
-#include "gpx_cov.hpp"
-#include "gpx_small.hpp"
+#include "gpx_dataflow.hpp"
 
 namespace gpx {
 
+using namespace dataflow;  // flags, ld_cg / st_cg, the tile workgroup (gpx_dataflow.hpp)
+
 namespace {
-constexpr int ST = SMALL_TILE;       // 64
-constexpr int SBLK = NB * PLD;       // one 32 x 32 block in LDS (doubles)
-constexpr int SM_THREADS = 256;
-constexpr int SM_LDS_DOUBLES = 12 * SBLK + 2 * ST + 4 * ST + 3 * ST;
-typedef unsigned long long u64;
-#ifdef SM_TIMING
-#define SM_STAMP(k)                                                                                   \
-    do {                                                                                              \
-        if (threadIdx.x == 0)                                                                         \
-            a.dbg[(size_t)blockIdx.x * SMALL_DBG_STAMPS + (k)] = wall_clock64();                      \
-    } while (0)
-#else
-#define SM_STAMP(k)
-#endif
-
-__device__ __forceinline__ u64 ld_flag(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_flag(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Data that travels between workgroups INSIDE a launch is stored and loaded at agent scope (sc1: written through to /
-// read from the memory side, the point where the XCDs' L2s meet): the tiles and vectors validate themselves behind a flag
-// or a barrier without any L2 write-back or invalidation -- so everything else (the points, X and X^T in the second
-// launch) stays cached.  Same idea as tri_solve_kernel's entries (gpx_factor.hip).
-__device__ __forceinline__ double ld_cg(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_cg(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<u64 *>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// thread 0 of the workgroup: wait until *f == want (false: the abort flag went up, or the spin limit ran out and this
-// call raised it)
-__device__ bool poll_flag(const u64 *f, u64 want, u64 *abortf, int limit)
-{
-    for (int s = 0; s < limit; ++s) {
-        if (ld_flag(f) == want)
-            return true;
-        if ((s & 31) == 31 && ld_flag(abortf) == want)
-            return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    st_flag(abortf, want);
-    return false;
-}
-
-// all threads: wait for one or two tile flags (the tiles behind them are then read with ld_cg)
-__device__ __forceinline__ bool wait_tiles(const u64 *f1, const u64 *f2, const SmallArgs &a, int *s_ok)
-{
-    if (threadIdx.x == 0) {
-        bool ok = poll_flag(f1, a.epoch, a.flags + a.abort_idx, a.spin_limit);
-        if (ok && f2)
-            ok = poll_flag(f2, a.epoch, a.flags + a.abort_idx, a.spin_limit);
-        *s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    const bool ok = *s_ok != 0;
-    __syncthreads();  // (s_ok is reused by the next wait)
-    return ok;
-}
-
-// all threads: the tile this workgroup has just stored (st_cg) is complete, then the flag goes up
-__device__ __forceinline__ void publish_tile(u64 *f, u64 v)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0)
-        st_flag(f, v);
-}
-
-__device__ __forceinline__ int tidx(int i, int j) { return i * (i + 1) / 2 + j; }
-
-// 64 x 64 tile at g (leading dimension ld) -> four 32 x 32 LDS blocks [(r >> 5) * 2 + (c >> 5)], optionally with its
-// columns scaled by colscale[c]
-__device__ __forceinline__ void stage_tile(double *buf, const double *g, long ld, const double *colscale)
-{
-    const int tid = threadIdx.x;
-    double v[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-        v[e] = ld_cg(g + (size_t)r * ld + c);
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-        const double s = colscale ? colscale[c] : 1.0;
-        buf[((r >> 5) * 2 + (c >> 5)) * SBLK + (r & 31) * PLD + (c & 31)] = v[e] * s;
-    }
-}
-
-// sign * (32 x 32 accumulator block) -> LDS block (may be null) and / or global with write-through stores (may be null)
-__device__ __forceinline__ void store_blk_cg(const BlkAcc<double> &b, double sign, double *lds, double *g, long ldg, int lane)
-{
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * i2 + BlkMma<double>::crow(lane, r), col = 16 * j2 + (lane & 15);
-                const double v = sign * b.t[i2][j2][r];
-                if (lds)
-                    lds[row * PLD + col] = v;
-                if (g)
-                    st_cg(g + (size_t)row * ldg + col, v);
-            }
-}
-
-// one 16 x 16 tile of a product of two 32 x 32 LDS blocks (K = 32) on one wave: rows 16 i2.. of A, columns 16 j2.. of the
-// result; NT: B is [n][k] (A B^T), else [k][n].  The four waves of the workgroup share a 32 x 32 product this way.
-typedef BlkMma<double>::acc_t acc16_t;
-template <bool NT, bool NEG>
-__device__ __forceinline__ acc16_t mma16(const double *Ab, const double *Bb, int i2, int j2, int lane, acc16_t t)
-{
-    const int i = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-        const int k = 4 * kk + kq;
-        const double av = Ab[(16 * i2 + i) * PLD + k];
-        const double bv = NT ? Bb[(16 * j2 + i) * PLD + k] : Bb[k * PLD + 16 * j2 + i];
-        t = BlkMma<double>::mma(NEG ? -av : av, bv, t);
-    }
-    return t;
-}
-
-__device__ __forceinline__ double lds_tile(const double *buf, int r, int c)
-{
-    return buf[((r >> 5) * 2 + (c >> 5)) * SBLK + (r & 31) * PLD + (c & 31)];
-}
-
-// a tile that lies entirely in the padding: K and X are the identity there
-__device__ void trivial_tile(const SmallArgs &a, int i, int j)
-{
-    const int tid = threadIdx.x, np = a.np;
-    const bool same128 = (i >> 1) == (j >> 1);
-    for (int e = 0; e < 16; ++e) {
-        const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-        const double v = (i == j && r == c) ? 1.0 : 0.0;
-        const size_t lo = (size_t)(ST * i + r) * np + ST * j + c, up = (size_t)(ST * j + r) * np + ST * i + c;
-        a.K[lo] = v;
-        a.X[lo] = v;
-        if (i != j)
-            a.X[up] = 0.0;
-        a.XT[up] = (i == j && r == c) ? 1.0 : 0.0;  // (the transposed copy is only read on and above its diagonal)
-        if (same128) {
-            double *lb = a.linv + (size_t)(i >> 1) * TILE * TILE;
-            lb[(size_t)(ST * (i & 1) + r) * TILE + ST * (j & 1) + c] = v;
-            if (i == j && !(i & 1))
-                lb[(size_t)r * TILE + ST + c] = 0.0;
-        }
-    }
-    if (i == j && tid < ST) {
-        a.d[ST * i + tid] = 1.0;
-        a.dinv[ST * i + tid] = 1.0;
-    }
-}
+constexpr int SM_THREADS = DF_THREADS;
+constexpr int SM_LDS_DOUBLES = DF_LDS_ELEMS;
 
 // the tile's rows of the model's vectors, from the staging block (tiles of column 0 only)
 __device__ void scatter_rows(const SmallArgs &a, int i)
@@ -207,29 +52,13 @@ __device__ void scatter_rows(const SmallArgs &a, int i)
 }
 }  // namespace
 
+// first launch of the small-model create: the dataflow factorisation with the inverse factor (gpx_dataflow.hpp, FULL)
 template <int KID>
 __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(const SmallArgs *__restrict__ ap)
 {
     const SmallArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *bufA = sm, *bufB = sm + 4 * SBLK, *bufC = sm + 8 * SBLK;
-    double *dvec = sm + 12 * SBLK;   // [64] D of the diagonal tile | scale vector of a staged operand
-    double *dinvv = dvec + ST;       // [64] 1 / D
-    double *rowp = dinvv + ST;       // [4][64] x y z s2 of the tile's rows (centred coordinates)
-    double *colp = rowp + 4 * ST;    // [3][64] x y z of its columns
-    __shared__ int s_ok;
-    __shared__ double s_best[4];
-    __shared__ int s_bi[4], s_bj[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qi = wave >> 1, qj = wave & 1;
-    const int np = a.np, n = a.n;
-    int j = 0, rem = (int)blockIdx.x;
-    while (rem >= a.nbt - j) {
-        rem -= a.nbt - j;
-        ++j;
-    }
-    const int i = j + rem;
-    u64 *Ff = a.flags, *Xf = a.flags + a.ntiles, *Pf = a.flags + a.pre_idx;  // factor tiles, inverse tiles, handed-over sums (per row)
+    const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid < 16) {
         // state of the second launch: barrier counter, residual maxima (stream order: it starts after this grid has ended)
         if (tid == 0)
@@ -239,344 +68,68 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(const Small
         if (tid < BLOB_META)
             a.d_meta[tid] = tid < 3 ? a.cen[tid] : (tid == 3 ? 1.0 : 0.0);
     }
-    if (j == 0)
-        scatter_rows(a, i);
-    if (i >= a.nb) {
-        trivial_tile(a, i, j);
-        return;
+    if ((int)blockIdx.x < a.nbt)  // the tiles of column 0: (i, 0), i = blockIdx.x
+        scatter_rows(a, (int)blockIdx.x);
+    FactorArgs<double> f;
+    f.n = a.n, f.np = a.np, f.nbt = a.nbt, f.nb = a.nb, f.ntiles = a.ntiles;
+    f.cov = a.cov;
+    f.K = a.K, f.linv = a.linv, f.d = a.d, f.dinv = a.dinv;
+    f.flags = a.flags, f.epoch = a.epoch, f.spin_limit = a.spin_limit, f.abort_idx = a.abort_idx, f.pre_idx = a.pre_idx;
+    f.tmax = a.tmax, f.tij = a.tij, f.negcnt = a.negcnt, f.badrow = a.badrow;
+    f.dbg = a.dbg;
+    factor_tile<double, KID, true>(f, ap, sm);
+}
+
+// the same dataflow for mid-size models (no inverse factor, points already in the working type): replaces kbuild + the
+// launch chain of the blocked LDL^T where that chain, not the flops, sets the time (profiles/r05_ldlt_sweep.txt)
+template <typename T, int KID>
+__global__ __launch_bounds__(DF_THREADS, 1) void mid_factor_kernel(FactorArgs<T> f)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    factor_tile<T, KID, false>(f, nullptr, reinterpret_cast<T *>(sm_raw));
+}
+
+// ... and what the chain reads from d_info afterwards: [0] first bad pivot, [1] negative pivots, [2..3] arg-max pair of the
+// squared distance, [6] a wait gave up (the factor is void: the host redoes the create with the launch chain)
+__global__ __launch_bounds__(256) void mid_finish_kernel(int nbt, int nb, int ntiles, const int *__restrict__ negcnt,
+                                                         const int *__restrict__ badrow, const double *__restrict__ tmax,
+                                                         const int *__restrict__ tij, const u64 *__restrict__ abortf, u64 epoch,
+                                                         int *__restrict__ info)
+{
+    __shared__ double sb[256];
+    __shared__ int st[256];
+    const int tid = threadIdx.x;
+    double best = -2.0;
+    int bt = 0;
+    for (int t = tid; t < ntiles; t += 256) {
+        int jj = 0, rem = t;
+        while (rem >= nbt - jj) {
+            rem -= nbt - jj;
+            ++jj;
+        }
+        if (jj + rem >= nb)
+            continue;  // a tile in the padding wrote nothing
+        if (tmax[t] > best)
+            best = tmax[t], bt = t;
     }
-    // ---- the tile's entries of the kernel matrix, straight into the accumulator layout (gp_regressor.hpp:132-159) ----
-    if (tid < ST) {
-        const int r = ST * i + tid;
-        const bool in = r < n;
-        rowp[tid] = in ? a.stage[r] - a.cen[0] : 0.0;
-        rowp[ST + tid] = in ? a.stage[np + r] - a.cen[1] : 0.0;
-        rowp[2 * ST + tid] = in ? a.stage[2 * (size_t)np + r] - a.cen[2] : 0.0;
-        rowp[3 * ST + tid] = a.stage[4 * (size_t)np + r];
-    } else if (tid < 2 * ST) {
-        const int t = tid - ST, c = ST * j + t;
-        const bool in = c < n;
-        colp[t] = in ? a.stage[c] - a.cen[0] : 0.0;
-        colp[ST + t] = in ? a.stage[np + c] - a.cen[1] : 0.0;
-        colp[2 * ST + t] = in ? a.stage[2 * (size_t)np + c] - a.cen[2] : 0.0;
-    }
+    sb[tid] = best, st[tid] = bt;
     __syncthreads();
-    BlkAcc<double> acc;
-    {
-        const Cov<double> cov = a.cov;
-        double best = -1.0;
-        int bi = 0, bj = 0;
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 32 * qi + 16 * i2 + BlkMma<double>::crow(lane, r), col = 32 * qj + 16 * j2 + (lane & 15);
-                    const int gi = ST * i + row, gj = ST * j + col;
-                    const double dx = rowp[row] - colp[col], dy = rowp[ST + row] - colp[ST + col],
-                                 dz = rowp[2 * ST + row] - colp[2 * ST + col];
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    double kv = cov_k<double, KID>(cov, d2);
-                    if (gi == gj)
-                        kv += rowp[3 * ST + row];
-                    if (gi < n && gj < n) {
-                        if (d2 > best)
-                            best = d2, bi = gi, bj = gj;
-                    } else {
-                        kv = gi == gj ? 1.0 : 0.0;  // identity on the padding
-                    }
-                    acc.t[i2][j2][r] = kv;
-                }
-        // the tile's largest squared distance (Model::R = Kpp.maxCoeff(), :135); the host takes the maximum over the tiles
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
-            if (ob > best)
-                best = ob, bi = oi, bj = oj;
-        }
-        if (lane == 0)
-            s_best[wave] = best, s_bi[wave] = bi, s_bj[wave] = bj;
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (s_best[w] > best)
-                    best = s_best[w], bi = s_bi[w], bj = s_bj[w];
-            a.tmax[blockIdx.x] = best;
-            a.tij[2 * blockIdx.x] = bi;
-            a.tij[2 * blockIdx.x + 1] = bj;
-        }
-    }
-    // ---- A_ij -= sum_k (L_ik D_k) L_jk^T as the tiles of the earlier columns appear ----
-    // The chain of the factorisation is diagonal tile j -> panel tile (j+1, j) -> diagonal tile j+1.  The diagonal tile
-    // takes the middle link itself: tile (j+1, j) hands over its finished sums A_{j+1,j} BEFORE diagonal tile j is done
-    // (through the unused tile (j, j+1) above the diagonal), and diagonal tile j+1, which has staged them while it waited,
-    // forms W = A Xd_j^T, L = W D_j^-1 and its own last update as soon as Xd_j appears -- one publish, one poll and one
-    // round trip to memory less per 64 columns on the critical path; the panel tile does the same product again for
-    // everybody else.
-    const int kend = i == j ? j - 1 : j;  // (the diagonal tile's last step is the one described above)
-    SM_STAMP(0);
-    for (int k = 0; k < kend; ++k) {
-        if (!wait_tiles(Ff + tidx(i, k), i != j ? Ff + tidx(j, k) : nullptr, a, &s_ok))
-            return;
-        if (tid < ST)
-            dvec[tid] = ld_cg(a.d + ST * k + tid);
-        __syncthreads();
-        stage_tile(bufA, a.K + (size_t)(ST * i) * np + ST * k, np, dvec);
-        stage_tile(bufB, a.K + (size_t)(ST * j) * np + ST * k, np, nullptr);
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            acc.template mac_nt<true>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s && (sb[tid + s] > sb[tid] || (sb[tid + s] == sb[tid] && st[tid + s] < st[tid])))
+            sb[tid] = sb[tid + s], st[tid] = st[tid + s];
         __syncthreads();
     }
-    SM_STAMP(1);
-    if (i == j && j >= 1) {
-        const int k = j - 1;
-        if (!wait_tiles(Pf + i, nullptr, a, &s_ok))
-            return;
-        stage_tile(bufA, a.K + (size_t)(ST * k) * np + ST * i, np, nullptr);  // A_{i,k}, parked above the diagonal
-        SM_STAMP(2);
-        if (!wait_tiles(Ff + tidx(k, k), nullptr, a, &s_ok))
-            return;
-        SM_STAMP(3);
-        if (tid < ST)
-            dvec[tid] = ld_cg(a.dinv + ST * k + tid);
-        stage_tile(bufB, a.X + (size_t)(ST * k) * np + ST * k, np, nullptr);
-        __syncthreads();
-        SM_STAMP(4);
-        BlkAcc<double> w;
-        w.zero();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            w.template mac_nt<false>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
-        __syncthreads();  // every wave has read A before L takes its place
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i2 + BlkMma<double>::crow(lane, r), col = 16 * j2 + (lane & 15);
-                    const double wv = w.t[i2][j2][r];
-                    bufC[(qi * 2 + qj) * SBLK + row * PLD + col] = wv;
-                    bufA[(qi * 2 + qj) * SBLK + row * PLD + col] = wv * dvec[32 * qj + col];
-                }
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            acc.template mac_nt<true>(bufC + (qi * 2 + h) * SBLK, bufA + (qj * 2 + h) * SBLK, lane);
-        __syncthreads();
-        SM_STAMP(5);
+    if (tid == 0) {
+        int bad = 0, neg = 0;
+        for (int t = 0; t < nb; ++t) {
+            if (!bad && badrow[t])
+                bad = badrow[t];
+            neg += negcnt[t];
+        }
+        info[0] = bad, info[1] = neg;
+        info[2] = tij[2 * st[0]], info[3] = tij[2 * st[0] + 1];
+        info[6] = ld_flag(abortf) == epoch ? 1 : 0;
     }
-    if (i == j + 1) {
-        // hand the finished sums to the diagonal tile of this row (see above)
-        store_blk_cg(acc, 1.0, nullptr, a.K + (size_t)(ST * j + 32 * qi) * np + ST * i + 32 * qj, np, lane);
-        publish_tile(Pf + i, a.epoch);
-    }
-    double *Ktile = a.K + (size_t)(ST * i) * np + ST * j;
-    double *Xtile = a.X + (size_t)(ST * i) * np + ST * j;
-    const bool same128 = (i >> 1) == (j >> 1);
-    double *lb = a.linv + (size_t)(i >> 1) * TILE * TILE + (size_t)(ST * (i & 1)) * TILE + ST * (j & 1);
-    if (i == j) {
-        // ---- diagonal tile: LDL^T of the 64 x 64 block and the inverse of its L (gp_regressor.hpp:161-162) ----
-        acc.store(1.0, bufC + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
-        __syncthreads();
-        SM_STAMP(6);
-        double *Lx0 = bufA, *W21 = bufA + SBLK, *L21 = bufA + 2 * SBLK, *Lx1 = bufA + 3 * SBLK;
-        double *Xd0 = bufB, *T0 = bufB + SBLK, *X10 = bufB + 2 * SBLK, *Xd1 = bufB + 3 * SBLK;
-        double *A21 = bufC + 2 * SBLK, *A22 = bufC + 3 * SBLK;
-        // The two 32 x 32 sub-blocks are factorised (and their L inverted) by wave 0, one rank-1 MFMA update per column
-        // (gpx_blk.hpp: 6.9 us each in fp64); the products between them are shared by the four waves, a 16 x 16 tile each.
-        const int i2 = wave >> 1, j2 = wave & 1;
-        const int trow = 16 * i2 + (lane >> 4), tcol = 16 * j2 + (lane & 15);  // element r of the lane's tile: row trow + 4 r
-        double dv = 1.0;
-        unsigned long long mneg = 0, mbad = 0;
-        if (wave == 0) {
-            subblock_ldl(bufC, Lx0, Xd0, lane, dv);
-            if (lane < NB) {
-                dvec[lane] = dv;
-                dinvv[lane] = 1.0 / dv;
-            }
-            mneg = __ballot(lane < NB && dv < 0.0);
-            mbad = __ballot(lane < NB && (!(fabs(dv) > 0.0) || !(fabs(dv) < pivot_huge(0.0))));
-        }
-        __syncthreads();
-        SM_STAMP(16);
-        {   // W21 = A21 X11^T, L21 = W21 D^-1
-            acc16_t t = {0.0, 0.0, 0.0, 0.0};
-            t = mma16<true, false>(A21, Xd0, i2, j2, lane, t);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                W21[(trow + 4 * r) * PLD + tcol] = t[r];
-                L21[(trow + 4 * r) * PLD + tcol] = t[r] * dinvv[tcol];
-            }
-        }
-        __syncthreads();
-        SM_STAMP(17);
-        {   // A22 -= W21 L21^T ; T0 = L21 Xd0 (for X10, off the chain of the second sub-block)
-            acc16_t c, t = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                c[r] = A22[(trow + 4 * r) * PLD + tcol];
-            c = mma16<true, true>(W21, L21, i2, j2, lane, c);
-            t = mma16<false, false>(L21, Xd0, i2, j2, lane, t);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                A22[(trow + 4 * r) * PLD + tcol] = c[r];
-                T0[(trow + 4 * r) * PLD + tcol] = t[r];
-            }
-        }
-        __syncthreads();
-        SM_STAMP(18);
-        if (wave == 0) {
-            subblock_ldl(A22, Lx1, Xd1, lane, dv);
-            if (lane < NB) {
-                dvec[NB + lane] = dv;
-                dinvv[NB + lane] = 1.0 / dv;
-            }
-            const unsigned long long mneg1 = __ballot(lane < NB && dv < 0.0);
-            const unsigned long long mbad1 = __ballot(lane < NB && (!(fabs(dv) > 0.0) || !(fabs(dv) < pivot_huge(0.0))));
-            if (lane == 0) {
-                a.negcnt[i] = __builtin_popcountll(mneg) + __builtin_popcountll(mneg1);
-                int bad = 0;
-                if (mbad)
-                    bad = ST * i + __builtin_ctzll(mbad) + 1;
-                else if (mbad1)
-                    bad = ST * i + NB + __builtin_ctzll(mbad1) + 1;
-                a.badrow[i] = bad;
-            }
-        }
-        __syncthreads();
-        SM_STAMP(19);
-        {   // X10 = -Xd1 (L21 Xd0)
-            acc16_t t = {0.0, 0.0, 0.0, 0.0};
-            t = mma16<false, true>(Xd1, T0, i2, j2, lane, t);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                X10[(trow + 4 * r) * PLD + tcol] = t[r];
-        }
-        __syncthreads();
-        SM_STAMP(7);
-        // what the tiles below wait for first: Xd (to the tile of X), L, D, 1/D; then the flag; the rest afterwards
-        for (int e = 0; e < 16; ++e) {
-            const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-            double lv, xv;
-            if (r == c)
-                lv = dvec[r];
-            else if (r < c)
-                lv = 0.0;
-            else if (r < NB)
-                lv = Lx0[r * PLD + c];
-            else if (c < NB)
-                lv = L21[(r - NB) * PLD + c];
-            else
-                lv = Lx1[(r - NB) * PLD + (c - NB)];
-            if (r < NB)
-                xv = c < NB ? Xd0[r * PLD + c] : 0.0;
-            else
-                xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
-            st_cg(Ktile + (size_t)r * np + c, lv);
-            st_cg(Xtile + (size_t)r * np + c, xv);
-        }
-        if (tid < ST) {
-            st_cg(a.d + ST * i + tid, dvec[tid]);
-            st_cg(a.dinv + ST * i + tid, dinvv[tid]);
-        }
-        publish_tile(Ff + tidx(i, i), a.epoch);
-        SM_STAMP(8);
-        for (int e = 0; e < 16; ++e) {
-            const int idx = e * SM_THREADS + tid, r = idx >> 6, c = idx & 63;
-            double xv;
-            if (r < NB)
-                xv = c < NB ? Xd0[r * PLD + c] : 0.0;
-            else
-                xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
-            lb[(size_t)r * TILE + c] = xv;
-            if (!(i & 1))
-                lb[(size_t)r * TILE + ST + c] = 0.0;  // upper-right quadrant of the 128 x 128 inverse block
-        }
-        for (int e = 0; e < 16; ++e) {  // transposed copy, coalesced along its rows
-            const int idx = e * SM_THREADS + tid, c = idx >> 6, r = idx & 63;
-            double xv;
-            if (r < NB)
-                xv = c < NB ? Xd0[r * PLD + c] : 0.0;
-            else
-                xv = c < NB ? X10[(r - NB) * PLD + c] : Xd1[(r - NB) * PLD + (c - NB)];
-            a.XT[(size_t)(ST * i + c) * np + ST * i + r] = xv;
-        }
-        SM_STAMP(9);
-        return;
-    }
-    // ---- tile below the diagonal: L_ij = (A_ij Xd_j^T) D_j^-1 (the panel solve as a product with the inverse block) ----
-    SM_STAMP(10);
-    if (!wait_tiles(Ff + tidx(j, j), nullptr, a, &s_ok))
-        return;
-    SM_STAMP(11);
-    if (tid < ST)
-        dvec[tid] = ld_cg(a.dinv + ST * j + tid);
-    acc.store(1.0, bufA + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
-    stage_tile(bufB, a.X + (size_t)(ST * j) * np + ST * j, np, nullptr);
-    __syncthreads();
-    {
-        BlkAcc<double> w;
-        w.zero();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            w.template mac_nt<false>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    w.t[i2][j2][r] *= dvec[32 * qj + 16 * j2 + (lane & 15)];
-        store_blk_cg(w, 1.0, bufC + (qi * 2 + qj) * SBLK, Ktile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
-    }
-    SM_STAMP(12);
-    publish_tile(Ff + tidx(i, j), a.epoch);  // (its barrier also orders the LDS stores of L before the products below)
-    // ---- the tile of the inverse factor: X_ij = -Xd_i sum_{k = j}^{i-1} L_ik X_kj ----
-    acc.zero();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        acc.mac(bufC + (qi * 2 + h) * SBLK, bufB + (h * 2 + qj) * SBLK, lane);  // k = j: L_ij Xd_j
-    for (int k = j + 1; k < i; ++k) {
-        if (!wait_tiles(Ff + tidx(i, k), Xf + tidx(k, j), a, &s_ok))
-            return;
-        stage_tile(bufA, a.K + (size_t)(ST * i) * np + ST * k, np, nullptr);
-        stage_tile(bufB, a.X + (size_t)(ST * k) * np + ST * j, np, nullptr);
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            acc.mac(bufA + (qi * 2 + h) * SBLK, bufB + (h * 2 + qj) * SBLK, lane);
-    }
-    SM_STAMP(13);
-    if (!wait_tiles(Ff + tidx(i, i), nullptr, a, &s_ok))
-        return;
-    SM_STAMP(14);
-    stage_tile(bufA, a.X + (size_t)(ST * i) * np + ST * i, np, nullptr);
-    acc.store(1.0, bufC + (qi * 2 + qj) * SBLK, (double *)nullptr, 0, lane);
-    __syncthreads();
-    {
-        BlkAcc<double> x;
-        x.zero();
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            x.mac(bufA + (qi * 2 + h) * SBLK, bufC + (h * 2 + qj) * SBLK, lane);
-        store_blk_cg(x, -1.0, bufB + (qi * 2 + qj) * SBLK, Xtile + (size_t)(32 * qi) * np + 32 * qj, np, lane);
-        if (same128)
-            x.store(-1.0, (double *)nullptr, lb + (size_t)(32 * qi) * TILE + 32 * qj, TILE, lane);
-    }
-    __syncthreads();
-    for (int e = 0; e < 16; ++e) {
-        const int idx = e * SM_THREADS + tid, c = idx >> 6, r = idx & 63;
-        a.XT[(size_t)(ST * j + c) * np + ST * i + r] = lds_tile(bufB, r, c);
-        a.X[(size_t)(ST * j + c) * np + ST * i + r] = 0.0;  // the tile above the diagonal: structural zeros
-        a.K[(size_t)(ST * j + c) * np + ST * i + r] = 0.0;
-    }
-    publish_tile(Xf + tidx(i, j), a.epoch);
-    SM_STAMP(15);
 }
 
 // ---- alpha, refinement, row corrections ----------------------------------------------------------------------------
@@ -830,7 +383,47 @@ void small_create_init()
         GPX_SM_ATTR(GPX_KERNEL_MATERN32);
         GPX_SM_ATTR(GPX_KERNEL_MATERN52);
 #undef GPX_SM_ATTR
+#define GPX_MID_ATTR(T, KID)                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mid_factor_kernel<T, KID>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DF_LDS_ELEMS * sizeof(T)))
+        GPX_MID_ATTR(double, GPX_KERNEL_GAUSSIAN);
+        GPX_MID_ATTR(double, GPX_KERNEL_THINPLATE);
+        GPX_MID_ATTR(double, GPX_KERNEL_MATERN32);
+        GPX_MID_ATTR(double, GPX_KERNEL_MATERN52);
+        GPX_MID_ATTR(float, GPX_KERNEL_GAUSSIAN);
+        GPX_MID_ATTR(float, GPX_KERNEL_THINPLATE);
+        GPX_MID_ATTR(float, GPX_KERNEL_MATERN32);
+        GPX_MID_ATTR(float, GPX_KERNEL_MATERN52);
+#undef GPX_MID_ATTR
     });
+}
+
+template <typename T>
+static void mid_factor_t(const CovHost &h, const MidFactorArgs &m, hipStream_t st)
+{
+    FactorArgs<T> f;
+    f.n = m.n, f.np = m.np, f.nbt = m.np / ST, f.nb = (m.n + ST - 1) / ST, f.ntiles = f.nbt * (f.nbt + 1) / 2;
+    f.cov = lower_cov<T>(h);
+    f.K = (T *)m.K, f.linv = (T *)m.linv, f.d = (T *)m.d, f.dinv = (T *)m.dinv;
+    f.px = (const T *)m.px, f.py = (const T *)m.py, f.pz = (const T *)m.pz, f.ps2 = (const T *)m.ps2;
+    const MidWs lay = mid_ws_layout(m.np);
+    char *ws = (char *)m.ws;
+    f.flags = (u64 *)(ws + lay.flags), f.epoch = m.epoch, f.spin_limit = m.spin_limit;
+    f.abort_idx = 2 * f.ntiles, f.pre_idx = 2 * f.ntiles + 2;
+    f.tmax = (double *)(ws + lay.tmax), f.tij = (int *)(ws + lay.tij);
+    f.negcnt = (int *)(ws + lay.negcnt), f.badrow = (int *)(ws + lay.badrow);
+    const size_t lds = DF_LDS_ELEMS * sizeof(T);
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((mid_factor_kernel<T, KID>), dim3(f.ntiles), dim3(DF_THREADS), lds, st, f));
+    hipLaunchKernelGGL(mid_finish_kernel, dim3(1), dim3(256), 0, st, f.nbt, f.nb, f.ntiles, f.negcnt, f.badrow, f.tmax, f.tij,
+                       f.flags + f.abort_idx, f.epoch, m.info);
+}
+
+void launch_mid_factor(int prec, const CovHost &h, const MidFactorArgs &m, hipStream_t st)
+{
+    if (prec == GPX_PREC_F64)
+        mid_factor_t<double>(h, m, st);
+    else
+        mid_factor_t<float>(h, m, st);
 }
 
 u64 small_create_epoch()

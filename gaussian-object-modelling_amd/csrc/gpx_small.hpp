@@ -75,6 +75,37 @@ inline SmallWs small_ws_layout(int np)
     return w;
 }
 
+// ---- the same dataflow factorisation for mid-size models (kernel matrix + LDL^T in one launch; the chain goes on from there)
+constexpr int MID_FACTOR_MAX_NP = 6144;  // padded rows up to which a fresh create() factorises this way (GPX_MID_FACTOR_MAX)
+struct MidWs {
+    size_t flags, tmax, tij, negcnt, badrow, bytes;
+};
+inline MidWs mid_ws_layout(int np)
+{
+    const size_t nbt = (size_t)np / SMALL_TILE, nt = nbt * (nbt + 1) / 2;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    MidWs w{};
+    size_t o = 0;
+    w.flags = o, o += al(sizeof(unsigned long long) * (2 * nt + 2 + nbt));
+    w.tmax = o, o += al(sizeof(double) * nt);
+    w.tij = o, o += al(sizeof(int) * 2 * nt);
+    w.negcnt = o, o += al(sizeof(int) * nbt);
+    w.badrow = o, o += al(sizeof(int) * nbt);
+    w.bytes = o;
+    return w;
+}
+struct MidFactorArgs {
+    int n = 0, np = 0;
+    void *K = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;                    // working type
+    const void *px = nullptr, *py = nullptr, *pz = nullptr, *ps2 = nullptr;  // centred points, sigma2 (working type, np long)
+    void *ws = nullptr;  // mid_ws_layout(np).bytes
+    int *info = nullptr;  // the model's d_info: [0..3] as the chain leaves them, [6] = 1 when a wait gave up
+    unsigned long long epoch = 0;
+    int spin_limit = 1 << 20;
+};
+// kernel matrix + LDL^T (L, D in K; d, dinv; the 128 x 128 inverse diagonal blocks linv) + the info reduction; asynchronous
+void launch_mid_factor(int prec, const CovHost &cov, const MidFactorArgs &m, hipStream_t st);
+
 void small_create_init();                  // per-device kernel attributes
 unsigned long long small_create_epoch();   // a value no earlier create of this process has used (flags are never cleared)
 // factor (+ record ev_factor), alpha (+ record ev_solve) and, when demote, the fp32 state; asynchronous on st
