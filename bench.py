@@ -715,6 +715,16 @@ def main():
                     "timed_launches": fg, "timed_flops": st["factor_gemm_flops"], "timed_ms": st["t_factor_gemm_ms"],
                     "whole_ldlt": {"what": "N^3/3 flop / t_factor_ms (diagonal blocks, panel solves, strip and trailing updates)",
                                    "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
+            elif st["t_factor_ms"] > 0:
+                # kernel matrix + LDL^T as ONE dataflow launch (csrc/gpx_dataflow.hpp; fp32 up to 16384 rows): there is no separate
+                # trailing-update launch to time -- the figure is the whole launch against N^3/3 flop (the kernel-matrix entries it
+                # also forms are not counted)
+                whole = (n_train ** 3 / 3.0) / (st["t_factor_ms"] * 1e-3) / 1e12
+                out["roofline_factor"] = {
+                    "bound": "mfma", "kernel": "mid_factor_kernel<%s> (kernel matrix + LDL^T, dataflow over 64 x 64 tiles, one launch)" % gemm_t,
+                    "achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak, "ms": st["t_factor_ms"],
+                    "what": "N^3/3 flop / t_factor_ms (everything between the upload of the points and the alpha solve)",
+                    "whole_ldlt": {"what": "the same figure (one launch)", "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
             if want_v and st["t_inverse_ms"] > 0:
                 # the inverse factor X = L^-1 (recursive doubling, assembled in fp64 in every mode when the fp64 temporaries
                 # fit): N^3/3 flop over the whole stage, casts and the small levels on the LDS tiles included

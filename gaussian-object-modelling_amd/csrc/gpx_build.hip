@@ -732,17 +732,21 @@ static int demote_to_f32(gpx_model *m)
 // Taken for a fresh create (no rank-n append) of a model that trains in fp64 and has at most SMALL_CREATE_MAX_NP padded
 // rows -- every model of the reference's own sizes in every precision mode (F32 / F32_SPLIT models of this size train in
 // fp64, set_training_precision).  GPX_SMALL_CREATE=0 keeps the general chain (its tested twin).
-// Mid-size models (above the small-model path, up to MID_FACTOR_MAX_NP padded rows; fresh creates in either working precision):
-// GPX_MID_FACTOR=0 keeps the launch chain, GPX_MID_FACTOR_MAX moves the upper bound (sweeps).
+// Models above the small-model path (fresh creates in either working precision): kernel matrix + LDL^T as one dataflow
+// launch up to MID_FACTOR_MAX_NP_F32 / _F64 padded rows -- where it beats kbuild + the blocked launch chain on the same box
+// (profiles/r05_ldlt_sweep.txt: fp32 at every size up to 16384, 18.6 -> 16.5 ms there; fp64 up to 8192, 8.4 -> 5.8 ms; at
+// 16384 rows in fp64 the chain's 256-wide GEMM updates win, 35.6 against 41.3 ms).  GPX_MID_FACTOR=0 keeps the launch chain,
+// GPX_MID_FACTOR_MAX moves both upper bounds (sweeps).
 static bool mid_factor_eligible(const gpx_model *m)
 {
-    static const int max_np = [] {
+    static const int max_env = [] {
         if (const char *e = std::getenv("GPX_MID_FACTOR"))
             if (std::atoi(e) == 0)
                 return 0;
         const char *x = std::getenv("GPX_MID_FACTOR_MAX");
-        return x ? std::atoi(x) : MID_FACTOR_MAX_NP;
+        return x ? std::atoi(x) : -1;
     }();
+    const int max_np = max_env >= 0 ? max_env : (m->prec == GPX_PREC_F64 ? MID_FACTOR_MAX_NP_F64 : MID_FACTOR_MAX_NP_F32);
     return m->npad > SMALL_CREATE_MAX_NP && m->npad <= max_np;
 }
 

@@ -37,9 +37,13 @@ namespace gpx {
 namespace dataflow {
 
 constexpr int ST = SMALL_TILE;  // 64
-constexpr int SBLK = NB * PLD;  // one 32 x 32 block in LDS (elements)
+constexpr int SBLK = NB * PLD;  // one 32 x 32 block in LDS (elements), row stride PLD = 33: the layout of gpx_blk.hpp's products
+// The operands of the update loop -- where the flops are -- use a second layout of the same buffers: row stride WLD = 36
+// elements, so that a lane's eight consecutive k of a row are 16-byte aligned vector reads (ds_read_b128; at most 2-way bank
+// conflicts).  With the 33-element rows and one element per read the LDS reads of the four waves took as long as their MFMAs.
+constexpr int WLD = 36, WBLK = NB * WLD;
 constexpr int DF_THREADS = 256;
-constexpr int DF_LDS_ELEMS = 12 * SBLK + 2 * ST + 4 * ST + 3 * ST;
+constexpr int DF_LDS_ELEMS = 12 * WBLK + 2 * ST + 4 * ST + 3 * ST;
 typedef unsigned long long u64;
 
 #ifdef SM_TIMING
@@ -146,6 +150,49 @@ __device__ __forceinline__ void tile_to_lds(T *buf, const T (&v)[16], T s)
         buf[((r >> 5) * 2 + (c >> 5)) * SBLK + (r & 31) * PLD + (c & 31)] = v[e] * s;
     }
 }
+// the same tile in the WIDE layout (update loop only): four 32 x 32 blocks of row stride WLD
+template <typename T>
+__device__ __forceinline__ void tile_to_lds_wide(T *buf, const T (&v)[16], T s)
+{
+    const int tid = threadIdx.x, c = tid & 63;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = 4 * e + (tid >> 6);
+        buf[((r >> 5) * 2 + (c >> 5)) * WBLK + (r & 31) * WLD + (c & 31)] = v[e] * s;
+    }
+}
+// C (the wave's 32 x 32 quadrant) += A B^T for one pair of 32 x 32 blocks in the wide layout (A [row][k], B [col][k]).  The
+// summation index of MFMA step kk in lane group kq is k = 8 kq + kk -- any bijection serves, as long as A and B agree -- so a
+// lane's eight values of a row are contiguous: two (fp32) / four (fp64) 16-byte reads per row instead of eight scalar ones.
+template <typename T>
+__device__ __forceinline__ void mac_nt_wide(BlkAcc<T> &c, const T *Ab, const T *Bb, int lane)
+{
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int NV = 8 * sizeof(T) / 16;  // vectors per eight elements
+    const int i = lane & 15, kq = lane >> 4;
+    T a0[8], a1[8], b0[8], b1[8];
+    auto load8 = [&](T (&dst)[8], const T *src) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const vec_t v = reinterpret_cast<const vec_t *>(src)[q];
+#pragma unroll
+            for (int w = 0; w < (int)(16 / sizeof(T)); ++w)
+                dst[q * (16 / sizeof(T)) + w] = v[w];
+        }
+    };
+    load8(a0, Ab + i * WLD + 8 * kq);
+    load8(a1, Ab + (16 + i) * WLD + 8 * kq);
+    load8(b0, Bb + i * WLD + 8 * kq);
+    load8(b1, Bb + (16 + i) * WLD + 8 * kq);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        c.t[0][0] = BlkMma<T>::mma(a0[kk], b0[kk], c.t[0][0]);
+        c.t[0][1] = BlkMma<T>::mma(a0[kk], b1[kk], c.t[0][1]);
+        c.t[1][0] = BlkMma<T>::mma(a1[kk], b0[kk], c.t[1][0]);
+        c.t[1][1] = BlkMma<T>::mma(a1[kk], b1[kk], c.t[1][1]);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void stage_tile(T *buf, const T *g, long ld)
 {
@@ -230,8 +277,8 @@ template <typename T, int KID, bool FULL>
 __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallArgs *sa, T *sm)
 {
     typedef typename BlkMma<T>::acc_t acc16_t;
-    T *bufA = sm, *bufB = sm + 4 * SBLK, *bufC = sm + 8 * SBLK;
-    T *dvec = sm + 12 * SBLK;   // [64] D of the diagonal tile | scale vector of a staged operand
+    T *bufA = sm, *bufB = sm + 4 * WBLK, *bufC = sm + 8 * WBLK;  // (sized for the wide layout; the other phases use 33-element rows)
+    T *dvec = sm + 12 * WBLK;   // [64] D of the diagonal tile | scale vector of a staged operand
     T *dinvv = dvec + ST;       // [64] 1 / D
     T *rowp = dinvv + ST;       // [4][64] x y z s2 of the tile's rows (centred coordinates)
     T *colp = rowp + 4 * ST;    // [3][64] x y z of its columns
@@ -327,37 +374,92 @@ __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallA
     const int kend = i == j ? j - 1 : j;  // (a diagonal tile's last step is the hand-over described at the top)
     SM_STAMP(0);
     if (kend > 0) {
+        // fp32: the sum over k runs in CHUNKS of four tiles (256 columns, the panel width of the blocked chain) that start from
+        // zero and are then added to the running value -- accumulated straight onto K_ij every one of up to 16384 fp32
+        // roundings would be relative to the O(1) running value instead of to the small partial sum (measured at N = 16384:
+        // variance error 1.8e-5 of max|v| against 1.2e-6 for the chain, and one more refinement step of alpha); with the chunks
+        // the running value is rounded once per 256 columns, exactly as the chain's in-place updates round it
+        constexpr bool CHUNKED = sizeof(T) == 4;
+        T master[CHUNKED ? 16 : 1];
+        if constexpr (CHUNKED) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                master[q] = acc.t[q >> 3][(q >> 2) & 1][q & 3];
+            acc.zero();
+        }
         T va[16], vb[16];
         T dk = T(1);
-        u64 fa = 0, fb = 0;  // thread 0: the flags of the step after the one in flight, polled one step ahead
+        // Flags are polled in BATCHES by wave 0 -- lane l looks at step base + l -- and one iteration before the answer is
+        // needed: a tile of a late column finds a hundred earlier columns long finished, and one flag round trip to the
+        // memory side (1-2 us, as long as a whole step) per step would leave the matrix cores waiting at every barrier.
+        int kready = 1;  // steps [0, kready) are known to be published
+        bool poll_out = false;
+        int poll_base = 0;
+        u64 fa = 0, fb = 0;
         auto issue = [&](int k) {
             tile_load(va, f.K + (size_t)(ST * i) * np + ST * k, np);
             tile_load(vb, f.K + (size_t)(ST * j) * np + ST * k, np);
             dk = f.d[ST * k + (tid & 63)];
-            if (tid == 0 && k + 1 < kend) {
-                fa = ld_flag(Ff + tidx(i, k + 1));
-                fb = i != j ? ld_flag(Ff + tidx(j, k + 1)) : f.epoch;
+        };
+        auto poll_issue = [&](int base) {
+            if (wave == 0) {
+                const int kk = base + lane;
+                fa = fb = 0;
+                if (kk < kend) {
+                    fa = ld_flag(Ff + tidx(i, kk));
+                    fb = i != j ? ld_flag(Ff + tidx(j, kk)) : f.epoch;
+                }
             }
+            poll_out = true, poll_base = base;
         };
         if (!wait_tiles(Ff + tidx(i, 0), i != j ? Ff + tidx(j, 0) : nullptr, f, &s_ok))
             return;
         issue(0);
+        if (kend > 1)
+            poll_issue(1);
         for (int k = 0; k < kend; ++k) {
-            tile_to_lds(bufA, va, dk);
-            tile_to_lds(bufB, vb, T(1));
-            if (tid == 0)
-                s_next = (k + 1 < kend && fa == f.epoch && fb == f.epoch) ? 1 : 0;
+            tile_to_lds_wide(bufA, va, -dk);  // (the sign of the update goes into the operand)
+            tile_to_lds_wide(bufB, vb, T(1));
+            const bool consumed = poll_out;
+            if (poll_out) {  // the answer of the batch issued an iteration (or more) ago
+                if (wave == 0) {
+                    const u64 m = __ballot(fa == f.epoch && fb == f.epoch);
+                    const int cnt = ~m ? __builtin_ctzll(~m) : 64;
+                    if (lane == 0)
+                        s_next = poll_base + cnt;
+                }
+                poll_out = false;
+            }
             __syncthreads();
-            const bool ready = s_next != 0;
+            if (consumed)
+                kready = max(kready, s_next);
+            const bool ready = k + 1 < kend && k + 1 < kready;
             if (ready)
                 issue(k + 1);  // in flight while the matrix cores work on step k
+            if (k + 2 < kend && kready - (k + 1) < 8)
+                poll_issue(max(kready, k + 1));
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                acc.template mac_nt<true>(bufA + (qi * 2 + h) * SBLK, bufB + (qj * 2 + h) * SBLK, lane);
+                mac_nt_wide<T>(acc, bufA + (qi * 2 + h) * WBLK, bufB + (qj * 2 + h) * WBLK, lane);
+            if constexpr (CHUNKED) {
+                if ((k & 3) == 3 || k + 1 == kend) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        master[q] += acc.t[q >> 3][(q >> 2) & 1][q & 3];
+                    if (k + 1 < kend)
+                        acc.zero();
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            acc.t[q >> 3][(q >> 2) & 1][q & 3] = master[q];
+                    }
+                }
+            }
             __syncthreads();
             if (!ready && k + 1 < kend) {
                 if (!wait_tiles(Ff + tidx(i, k + 1), i != j ? Ff + tidx(j, k + 1) : nullptr, f, &s_ok))
                     return;
+                kready = max(kready, k + 2);
                 issue(k + 1);
             }
         }

@@ -76,7 +76,7 @@ inline SmallWs small_ws_layout(int np)
 }
 
 // ---- the same dataflow factorisation for mid-size models (kernel matrix + LDL^T in one launch; the chain goes on from there)
-constexpr int MID_FACTOR_MAX_NP = 6144;  // padded rows up to which a fresh create() factorises this way (GPX_MID_FACTOR_MAX)
+constexpr int MID_FACTOR_MAX_NP_F32 = 16384, MID_FACTOR_MAX_NP_F64 = 8192;  // padded rows up to which a fresh create() factorises this way
 struct MidWs {
     size_t flags, tmax, tij, negcnt, badrow, bytes;
 };
