@@ -739,13 +739,13 @@ static int demote_to_f32(gpx_model *m)
 // GPX_MID_FACTOR_MAX moves both upper bounds (sweeps).
 static bool mid_factor_eligible(const gpx_model *m)
 {
-    static const int max_env = [] {
-        if (const char *e = std::getenv("GPX_MID_FACTOR"))
-            if (std::atoi(e) == 0)
-                return 0;
-        const char *x = std::getenv("GPX_MID_FACTOR_MAX");
-        return x ? std::atoi(x) : -1;
-    }();
+    int max_env = -1;  // (read per call: tests and sweeps switch between the two paths inside one process)
+    if (const char *e = std::getenv("GPX_MID_FACTOR"))
+        if (std::atoi(e) == 0)
+            max_env = 0;
+    if (max_env < 0)
+        if (const char *x = std::getenv("GPX_MID_FACTOR_MAX"))
+            max_env = std::atoi(x);
     const int max_np = max_env >= 0 ? max_env : (m->prec == GPX_PREC_F64 ? MID_FACTOR_MAX_NP_F64 : MID_FACTOR_MAX_NP_F32);
     return m->npad > SMALL_CREATE_MAX_NP && m->npad <= max_np;
 }

@@ -106,3 +106,69 @@ def test_three_launch_create_then_update(gpu, orc, ds):
     out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
     assert nerr(gm.alpha, om.alpha) < 1e-9 and nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < 1e-9
     gm.close()
+
+
+def _mid_twin(gpu, kern, data, prec, dataflow, **kw):
+    old = os.environ.get("GPX_MID_FACTOR")
+    os.environ["GPX_MID_FACTOR"] = "1" if dataflow else "0"
+    try:
+        return gpu.Model(kern, *data, precision=prec, **kw)
+    finally:
+        if old is None:
+            del os.environ["GPX_MID_FACTOR"]
+        else:
+            os.environ["GPX_MID_FACTOR"] = old
+
+
+@pytest.mark.parametrize("n", [1025, 1100, 2305, 4096])
+def test_dataflow_factorisation_of_mid_size_models_matches_the_chain_and_the_oracle(gpu, orc, ds, n, monkeypatch):
+    """Above the small-model path the kernel matrix and the LDL^T are one dataflow launch (csrc/gpx_dataflow.hpp) where the
+    blocked launch chain (GPX_MID_FACTOR=0, its twin) is bound by its chain, not its flops.  Sizes: the first padded size above
+    1024, tile rows that end inside a 128-block, BASELINE's C2 size; fp64, and the fp32 factorisation at every size
+    (GPX_TRAIN_F64_MAX=0: chunked fp32 sums); the indefinite ThinPlate(2.0) keeps its inertia."""
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    data = ds.fibonacci_training_set(n)
+    qx, qy, qz = ds.query_grid(5, scale=1.2)
+    cases = [("matern52", (1.0, 1.0))] + ([("gaussian", (1.0, 1.0)), ("thinplate", (2.0,))] if n <= 2305 else [])
+    for kn, par in cases:
+        om = orc.Model(orc.make_kernel(kn, *par), *data) if n <= 2305 else None
+        for prec in (gpu.F64, gpu.F32):
+            if kn == "thinplate" and prec == gpu.F32:
+                continue  # (an fp32 LDL^T of the thin plate is outside every precision rule of the library)
+            md = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, True, prepare_variance=True)
+            mc = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, False, prepare_variance=True)
+            sd, sc = md.stats, mc.stats
+            assert sd["solve_fallbacks"] == 0 and sd["factor_gemm_launches"] == 0 and sc["factor_gemm_launches"] > 0  # each its own path
+            assert sd["n_negative_pivots"] == sc["n_negative_pivots"]
+            assert abs(md.R - mc.R) <= 1e-14 * mc.R
+            tol = 1e-10 if prec == gpu.F64 else 1e-5
+            assert nerr(md.alpha, mc.alpha) < (1e-9 if prec == gpu.F64 else 1e-5), (n, kn, prec)
+            assert nerr(md.D, mc.D) < (1e-10 if prec == gpu.F64 else 2e-4), (n, kn, prec)
+            a, b = (m.evaluate(qx, qy, qz, want_v=True) for m in (md, mc))
+            assert nerr(a["f"], b["f"]) < (1e-9 if prec == gpu.F64 else 1e-5)
+            assert verr_v(a["v"], b["v"]) < tol, (n, kn, prec)
+            if om is not None:
+                ref = om.evaluate(qx, qy, qz, want_v=True)
+                assert nerr(md.alpha, om.alpha) < (1e-9 if prec == gpu.F64 else 1e-5)
+                assert nerr(a["f"], ref["f"]) < (1e-9 if prec == gpu.F64 else 1e-5) and verr_v(a["v"], ref["v"]) < tol
+            md.close(), mc.close()
+
+
+def test_dataflow_factorisation_that_gives_up_is_redone_by_the_chain(gpu, orc, ds):
+    """Mid-size form of the give-up path: the factor of the dataflow launch is void (info[6]), the whole create is redone by
+    the launch chain -- same model, gpx_stats.solve_fallbacks = 1."""
+    data = ds.fibonacci_training_set(1500)
+    kern = gpu.make_kernel("matern52", 1.0, 1.0)
+    om = orc.Model(orc.make_kernel("matern52", 1.0, 1.0), *data)
+    os.environ["GPX_SMALL_SPIN_LIMIT"] = "1"
+    try:
+        gm = gpu.Model(kern, *data, precision=gpu.F64, prepare_variance=True)
+    finally:
+        del os.environ["GPX_SMALL_SPIN_LIMIT"]
+    st = gm.stats
+    assert st["solve_fallbacks"] == 1 and st["factor_gemm_launches"] > 0
+    assert nerr(gm.alpha, om.alpha) < 1e-9
+    qx, qy, qz = ds.query_grid(5)
+    out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
+    assert nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < 1e-10
+    gm.close()
