@@ -101,17 +101,13 @@ __global__ __launch_bounds__(256) void mid_finish_kernel(int nbt, int nb, int nt
     const int tid = threadIdx.x;
     double best = -2.0;
     int bt = 0;
-    for (int t = tid; t < ntiles; t += 256) {
-        int jj = 0, rem = t;
-        while (rem >= nbt - jj) {
-            rem -= nbt - jj;
-            ++jj;
+    // tiles column by column (index = first tile of the column + row offset); tiles in the padding (row >= nb) wrote nothing
+    for (int jj = 0, base = 0; jj < nb; base += nbt - jj, ++jj)
+        for (int ii = jj + tid; ii < nb; ii += 256) {
+            const int t = base + (ii - jj);
+            if (tmax[t] > best || (tmax[t] == best && t < bt))
+                best = tmax[t], bt = t;
         }
-        if (jj + rem >= nb)
-            continue;  // a tile in the padding wrote nothing
-        if (tmax[t] > best)
-            best = tmax[t], bt = t;
-    }
     sb[tid] = best, st[tid] = bt;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
