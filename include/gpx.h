@@ -101,7 +101,10 @@ typedef struct gpx_options {
 
 typedef struct gpx_model gpx_model; /* opaque; replaces struct Model, gp_regressor.hpp:71-87 */
 
-/* Per-stage device timings (HIP events) of the last create / evaluate on this model, ms. */
+/* Per-stage device timings (HIP events) of the last create / evaluate on this model, ms.  Models of up to 1024 padded rows are
+ * created by three launches (kernel matrix + LDL^T + inverse factor | alpha + refinement | rounding of the fp32 state): their
+ * times are reported as t_factor_ms, t_solve_ms and t_inverse_ms, t_kbuild_ms is 0.  Larger fresh creates up to 16384 rows (fp32)
+ * / 8192 (fp64) form the kernel matrix inside the factorisation launch: t_kbuild_ms ~ 0, factor_gemm_launches = 0. */
 typedef struct gpx_stats {
     double t_kbuild_ms, t_factor_ms, t_solve_ms, t_inverse_ms, t_normals_ms; /* create */
     double t_mean_ms, t_var_ms;                                              /* last evaluate */
@@ -110,8 +113,9 @@ typedef struct gpx_stats {
     int64_t n, n_padded, n_negative_pivots, ir_steps_done;
     double alpha_residual;  /* max |y - K alpha| after refinement (fp64, matrix-free) */
     int64_t var_gemm_launches, factor_gemm_launches;
-    int64_t solve_fallbacks; /* 1: the one-launch block substitution gave up waiting and alpha was recomputed with
-                                the launch-per-step kernels (same result; see gpx_factor.hip) */
+    int64_t solve_fallbacks; /* > 0: a one-launch dataflow kernel (block substitution, small-model create, dataflow
+                                factorisation) gave up waiting and the work was redone by its launch-per-step form (same
+                                result; see gpx_factor.hip, gpx_dataflow.hpp) */
     double t_var_kqp_ms;      /* the kernel-operand (Kqp) launches of the last evaluate only (subset of t_var_ms) */
     double factor_gemm_flops; /* algorithmic flops of the event-timed trailing-update launches (lower tiles x 2 x 128^2 x K) */
     double reserved[1];
