@@ -172,3 +172,47 @@ def test_dataflow_factorisation_that_gives_up_is_redone_by_the_chain(gpu, orc, d
     out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
     assert nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < 1e-10
     gm.close()
+
+
+def test_dataflow_launches_are_deterministic_and_survive_concurrent_creates(gpu, ds):
+    """The dataflow launches hand tiles from workgroup to workgroup through memory behind flags; every sum has a fixed order,
+    so repeated creates must agree BIT FOR BIT (a consumer that ever read a tile before -- or a stale copy after -- its flag
+    would show up here), also when four host threads create small, mid-size and large models at the same time on one device
+    (their grids compete for the CUs; a wait that gave up would only cost a fallback, never a different model)."""
+    import hashlib
+    import threading
+    cases = [(277, gpu.F64, "gaussian"), (724, gpu.F32, "matern52"), (1500, gpu.F64, "matern52"), (3000, gpu.F32, "gaussian"),
+             (5000, gpu.F64, "matern32")]
+    sets = {n: ds.fibonacci_training_set(n) for n, _, _ in cases}
+
+    def digest(n, prec, kn):
+        m = gpu.Model(gpu.make_kernel(kn, 1.0, 1.0), *sets[n], precision=prec, prepare_variance=True)
+        out = m.evaluate(*ds.query_grid(4), want_v=True)
+        h = hashlib.sha1(m.alpha.tobytes() + m.D.tobytes() + out["f"].tobytes() + out["v"].tobytes()).hexdigest()
+        fb = m.stats["solve_fallbacks"]
+        m.close()
+        return h, fb
+
+    ref = {c: digest(*c) for c in cases}
+    assert all(fb == 0 for _, fb in ref.values())
+    for c in cases:
+        for _ in range(4):
+            assert digest(*c)[0] == ref[c][0], c
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(6):
+                c = cases[(k + rep) % len(cases)]
+                h, _ = digest(*c)
+                if h != ref[c][0]:
+                    errors.append((k, rep, c))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
