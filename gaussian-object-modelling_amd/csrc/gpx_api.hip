@@ -15,6 +15,7 @@
 // This file: error state, model life cycle (create / update / destroy / shell / state blobs / commit), accessors.
 // gpx_build.hip: kernel matrix, factorisation, solves, inverse factor.  gpx_eval.hip: every prediction path.
 #include "gpx_model.hpp"
+#include "gpx_small.hpp"
 
 // ------------------------------------------------------------------------------------------------
 namespace gpxh {
@@ -433,7 +434,16 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     // rounding; anything else falls back to the rebuild.
     kept_factor keep;
     const char *app_env = std::getenv("GPX_UPDATE_APPEND");  // 0: always rebuild (tests compare the two)
-    const bool append_on = !app_env || std::atoi(app_env) != 0;
+    bool append_on = !app_env || std::atoi(app_env) != 0;
+    {
+        // A grown model that is still in the small-model range is rebuilt by the three dataflow launches (gpx_small.hip):
+        // 0.25 ms at N = 277 + 16 against 0.62 ms for the append's launch chain (scripts/update_bench.py) -- and a rebuild is
+        // what the reference does (:457-459)
+        const char *sc = std::getenv("GPX_SMALL_CREATE");
+        const bool small_on = !sc || std::atoi(sc) != 0;
+        if (small_on && gpx_padded_n(m->hx.size()) <= (size_t)SMALL_CREATE_MAX_NP)
+            append_on = false;
+    }
     if (append_on && m->ready && m->Kmat && m->linv && !m->x_packed && !m->train64 && n_old >= TILE) {
         const int n_tot = (int)m->hx.size();
         std::vector<double> diag(n_tot);

@@ -152,7 +152,8 @@ int gpx_model_create(const gpx_kernel *kernel, size_t n, const double *x, const 
  * reference refactors from scratch (:457-459); here the existing factor is extended (new kernel rows, their
  * update against the old column blocks, factorisation of the new trailing block, new solve) whenever the old
  * points stay first in Eigen's pivot order on the diagonal k(0) + sigma2 -- e.g. for one common sigma2 -- and the
- * old factor is still held in the training precision; otherwise the model is rebuilt.  Either way the results
+ * old factor is still held in the training precision; otherwise -- and whenever the grown model still has at most 1024 padded
+ * rows, where the three-launch create is faster than any append -- the model is rebuilt.  Either way the results
  * equal a fresh create on the concatenated data to rounding.  Model::R is not refreshed (:454-455). */
 int gpx_model_update(gpx_model *m, size_t n_new, const double *x, const double *y, const double *z,
                      const double *label, const double *sigma2);

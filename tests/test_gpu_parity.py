@@ -235,8 +235,10 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, kname, n0, n1, 
         if inv_first:
             gm.evaluate(qx, qy, qz, want_v=True)
         gm.update(x[n0:], y[n0:], z[n0:], lab[n0:], s2[n0:])
-        if inv_first and mode == "1" and (prec == 1 or forced32):
+        if inv_first and mode == "1" and (prec == 1 or forced32) and n0 + n1 > 1024:
             assert gm.stats["t_inverse_ms"] > 0  # extended inside update(), not left to the next query
+        # (a grown model of at most 1024 padded rows is rebuilt by the three-launch create in either mode -- faster than any
+        # append, scripts/update_bench.py -- and gets its inverse factor from the factorisation launch itself)
         o = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
         res[mode] = (gm.alpha.copy(), gm.D.copy(), o, gm.stats["n_negative_pivots"], gm.stats["alpha_residual"])
         gm.close()
