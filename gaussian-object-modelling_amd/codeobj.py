@@ -176,6 +176,46 @@ def guard_small_model_accumulator_reads(lib_path, tmp_dir):
                     reads += 1
                     assert n_mfma - last_write[r] >= 4 or nops_since[r] >= 16, (sym, text, n_mfma - last_write[r], nops_since[r])
         assert n_mfma >= 500 and reads >= 96, (sym, n_mfma, reads)
+    # The fp64 MFMAs of the add-back (asm as well) write VGPR quads that plain VALU code reads.  The matrix pipe completes in
+    # order, so ONE later MFMA issued between the last v_mfma_f64 that wrote a register and its first VALU read means the fp64
+    # result has left the pipe (the later MFMA could not start before it); an explicit run of >= 16 wait states serves too.
+    # (the source comment promised "at least NM" MFMAs in between, the 6-group chunk has one.)
+    def vregs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return range(int(m.group(1)), int(m.group(2)) + 1)
+        m = re.fullmatch(r"v(\d+)", tok)
+        return range(int(m.group(1)), int(m.group(1)) + 1) if m else range(0)
+    for sym, lines in dis.items():
+        last64 = {}  # VGPR -> (index in MFMAs of the last v_mfma_f64 that wrote it, wait states since)
+        n_mfma = checked = 0
+        for l in lines:
+            text = l.split("//")[0].strip()
+            if not text:
+                continue
+            op, _, rest = text.partition(" ")
+            toks = [t.strip() for t in rest.split(",")]
+            if op.startswith("v_mfma"):
+                n_mfma += 1
+                if op.startswith("v_mfma_f64"):
+                    for r in vregs(toks[0]):
+                        last64[r] = [n_mfma, 0]
+                continue
+            if op == "s_nop":
+                for v in last64.values():
+                    v[1] += int(toks[0]) + 1
+                continue
+            if not op.startswith("v_") or not last64:
+                continue
+            for t in toks[1:]:  # sources
+                for r in vregs(t):
+                    if r in last64:
+                        checked += 1
+                        w, nops = last64.pop(r)  # (only the FIRST read after the write is the hazard)
+                        assert n_mfma - w >= 1 or nops >= 16, (sym, text, n_mfma - w, nops)
+            for r in vregs(toks[0]):  # overwritten by plain VALU code: no longer an MFMA result
+                last64.pop(r, None)
+        assert checked >= 32, (sym, checked)
 
 
 def guard_split_contraction_staging(lib_path, tmp_dir):
