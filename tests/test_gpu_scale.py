@@ -264,3 +264,46 @@ def test_state_blobs_go_through_rccl_at_world_size_one(gpu, ds, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_bench_multi_gpu_configs_on_one_device(gpu, ds, tmp_path):
+    """bench.py's BASELINE configs 4 and 5 in their multi-GPU form (bench.multi_gpu_configs: the rank logic of
+    sharding.sharded_grid_step / objects_per_rank_step on libgpx models) rehearsed in a child at world size 1 through RCCL, on
+    small lattices: C4's two ways of getting the state (broadcast of both blobs into a shell, rebuild) must predict the SAME
+    sums bit for bit -- a shell committed from the blobs is the model -- and equal a plain evaluate of the lattice; C5 visits
+    every object once.  (The world-2 form of the same functions: tests/test_multirank_gloo.py on the oracle.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (
+        "import sys, os, importlib, json, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "gpx = importlib.import_module('gaussian-object-modelling_amd.gpx')\n"
+        "ds = importlib.import_module('gaussian-object-modelling_amd.datasets')\n"
+        "sh = importlib.import_module('gaussian-object-modelling_amd.sharding')\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')\n"
+        "torch.cuda.set_device(0); dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "bench.N_TRAIN = 1500\n"
+        "out = bench.multi_gpu_configs(torch, gpx, ds, sh, dist, 0, 1, dev, 0, grid4=24, grid5=16)\n"
+        "m = gpx.Model(gpx.make_kernel('thinplate', 4.0), *ds.fibonacci_training_set(1500), precision=gpx.F32, prepare_variance=True)\n"
+        "o = m.evaluate(*ds.query_grid(24), want_v=True)\n"
+        "out['direct'] = {'sum_f': float(torch.from_numpy(o['f']).sum()), 'sum_v': float(torch.from_numpy(o['v']).sum())}\n"
+        "dist.destroy_process_group()\n"
+        "print('RESULT ' + json.dumps(out))\n") % root
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    c4, c5 = out["C4_shard"], out["C5_per_rank"]
+    assert "error" not in c4 and "error" not in c5, (c4, c5)
+    b, rc = c4["broadcast"], c4["recompute"]
+    assert b["n_query"] == rc["n_query"] == 24 ** 3 and b["slabs"][0]["x_planes"] == [0, 24]
+    assert b["state_bytes"] > 0 and rc["state_bytes"] == 0 and b["t_train_ms"] > 0 and b["t_predict_max_ms"] > 0
+    assert b["sum_f"] == rc["sum_f"] and b["sum_v"] == rc["sum_v"] and b["v_min"] == rc["v_min"]  # shell from the blobs == the model
+    assert abs(b["sum_f"] - out["direct"]["sum_f"]) <= 1e-9 * abs(out["direct"]["sum_f"]) + 1e-9
+    assert abs(b["sum_v"] - out["direct"]["sum_v"]) <= 1e-9 * abs(out["direct"]["sum_v"])
+    assert [o["object"] for o in c5["objects"]] == list(range(8)) and all(o["rank"] == 0 and o["n_query"] == 16 ** 3 for o in c5["objects"])
+    assert [o["name"] for o in c5["objects"]] == ["bowlA", "bowlB", "containerA", "containerB", "jug", "kettle", "pot", "mugD"]
+    assert c5["n_query"] == 8 * 16 ** 3 and c5["ms_per_step"] > 0
