@@ -732,11 +732,12 @@ static int demote_to_f32(gpx_model *m)
 // Taken for a fresh create (no rank-n append) of a model that trains in fp64 and has at most SMALL_CREATE_MAX_NP padded
 // rows -- every model of the reference's own sizes in every precision mode (F32 / F32_SPLIT models of this size train in
 // fp64, set_training_precision).  GPX_SMALL_CREATE=0 keeps the general chain (its tested twin).
-// Models above the small-model path (fresh creates in either working precision): kernel matrix + LDL^T as one dataflow
-// launch up to MID_FACTOR_MAX_NP_F32 / _F64 padded rows -- where it beats kbuild + the blocked launch chain on the same box
-// (profiles/r05_ldlt_sweep.txt: fp32 at every size up to 16384, 18.6 -> 16.5 ms there; fp64 up to 8192, 8.4 -> 5.8 ms; at
-// 16384 rows in fp64 the chain's 256-wide GEMM updates win, 35.6 against 41.3 ms).  GPX_MID_FACTOR=0 keeps the launch chain,
-// GPX_MID_FACTOR_MAX moves both upper bounds (sweeps).
+// Models above the small-model path (fresh creates in either working precision, up to 16384 padded rows): kernel matrix +
+// LDL^T as one dataflow launch -- 64 x 64 tiles below 8192 rows, where the chain of diagonal tiles sets the time
+// (gpx_dataflow.hpp), 128 x 128 tiles from there on, where the 64 x 64 form is HBM-bound (gpx_dataflow_wide.hpp).  It beats
+// kbuild + the blocked launch chain at every size on the same box (profiles/r05_ldlt_sweep.txt: N = 16384 fp32 18.7 -> 15.6 ms,
+// fp64 35.5 -> 30.4 ms; N = 4096 fp64 3.43 -> 1.75 ms).  Larger models and rank-n appends keep the chain.  GPX_MID_FACTOR=0
+// keeps the launch chain, GPX_MID_FACTOR_MAX moves the upper bound, GPX_WIDE_FACTOR_MIN the switch to the wide tiles (sweeps).
 static bool mid_factor_eligible(const gpx_model *m)
 {
     int max_env = -1;  // (read per call: tests and sweeps switch between the two paths inside one process)
@@ -1062,6 +1063,12 @@ int build_model(gpx_model *m, kept_factor *keep, bool no_dataflow)
         a.K = m->Kmat, a.linv = m->linv, a.d = m->t_d, a.dinv = m->t_dinv;
         a.px = m->t_x, a.py = m->t_y, a.pz = m->t_z, a.ps2 = m->t_s2;
         a.ws = mid_ws.p, a.info = m->d_info, a.epoch = small_create_epoch();
+        {
+            int wide_min = 8192;  // padded rows from which the 128 x 128 tiles are used (GPX_WIDE_FACTOR_MIN: sweeps; 0 = never)
+            if (const char *w = std::getenv("GPX_WIDE_FACTOR_MIN"))
+                wide_min = std::atoi(w);
+            a.wide = wide_min > 0 && np >= wide_min;
+        }
         if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
             a.spin_limit = std::max(1, std::atoi(sl));
         (void)hipEventRecord(m->ev[EV_KBUILD], s);

@@ -168,28 +168,34 @@ template <typename T>
 __device__ __forceinline__ void mac_nt_wide(BlkAcc<T> &c, const T *Ab, const T *Bb, int lane)
 {
     typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-    constexpr int NV = 8 * sizeof(T) / 16;  // vectors per eight elements
+    constexpr int EPV = 16 / sizeof(T);      // elements per 16-byte vector
+    constexpr int KH = sizeof(T) == 8 ? 2 : 8;  // k values in flight: fp64 takes the eight in four steps (register budget)
     const int i = lane & 15, kq = lane >> 4;
-    T a0[8], a1[8], b0[8], b1[8];
-    auto load8 = [&](T (&dst)[8], const T *src) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const vec_t v = reinterpret_cast<const vec_t *>(src)[q];
+    for (int k0 = 0; k0 < 8; k0 += KH) {
+        T a0[KH], a1[KH], b0[KH], b1[KH];
+        auto loadk = [&](T (&dst)[KH], const T *src) {
 #pragma unroll
-            for (int w = 0; w < (int)(16 / sizeof(T)); ++w)
-                dst[q * (16 / sizeof(T)) + w] = v[w];
+            for (int q = 0; q < KH / EPV; ++q) {
+                const vec_t v = reinterpret_cast<const vec_t *>(src + k0)[q];
+#pragma unroll
+                for (int w = 0; w < EPV; ++w)
+                    dst[q * EPV + w] = v[w];
+            }
+        };
+        loadk(a0, Ab + i * WLD + 8 * kq);
+        loadk(a1, Ab + (16 + i) * WLD + 8 * kq);
+        loadk(b0, Bb + i * WLD + 8 * kq);
+        loadk(b1, Bb + (16 + i) * WLD + 8 * kq);
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            c.t[0][0] = BlkMma<T>::mma(a0[kk], b0[kk], c.t[0][0]);
+            c.t[0][1] = BlkMma<T>::mma(a0[kk], b1[kk], c.t[0][1]);
+            c.t[1][0] = BlkMma<T>::mma(a1[kk], b0[kk], c.t[1][0]);
+            c.t[1][1] = BlkMma<T>::mma(a1[kk], b1[kk], c.t[1][1]);
         }
-    };
-    load8(a0, Ab + i * WLD + 8 * kq);
-    load8(a1, Ab + (16 + i) * WLD + 8 * kq);
-    load8(b0, Bb + i * WLD + 8 * kq);
-    load8(b1, Bb + (16 + i) * WLD + 8 * kq);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        c.t[0][0] = BlkMma<T>::mma(a0[kk], b0[kk], c.t[0][0]);
-        c.t[0][1] = BlkMma<T>::mma(a0[kk], b1[kk], c.t[0][1]);
-        c.t[1][0] = BlkMma<T>::mma(a1[kk], b0[kk], c.t[1][0]);
-        c.t[1][1] = BlkMma<T>::mma(a1[kk], b1[kk], c.t[1][1]);
+        if constexpr (sizeof(T) == 8)  // fp64: keep the scheduler from hoisting the next half's operands above these MFMAs (the
+            __builtin_amdgcn_sched_barrier(0);  // 128 x 128 form runs two waves per SIMD on 256 registers each and would spill)
     }
 }
 

@@ -23,6 +23,7 @@
 #include <atomic>
 
 #include "gpx_dataflow.hpp"
+#include "gpx_dataflow_wide.hpp"
 
 namespace gpx {
 
@@ -89,6 +90,14 @@ __global__ __launch_bounds__(DF_THREADS, 1) void mid_factor_kernel(FactorArgs<T>
     factor_tile<T, KID, false>(f, nullptr, reinterpret_cast<T *>(sm_raw));
 }
 
+// the 128 x 128-tile form of the same dataflow for LARGE models, where the 64 x 64 form is HBM-bound (gpx_dataflow_wide.hpp)
+template <typename T, int KID>
+__global__ __launch_bounds__(WIDE_THREADS, 1) void wide_factor_kernel(FactorArgs<T> f, int *info)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    wide_factor_tile<T, KID>(f, info, reinterpret_cast<T *>(sm_raw));
+}
+
 // ... and what the chain reads from d_info afterwards: [0] first bad pivot, [1] negative pivots, [2..3] arg-max pair of the
 // squared distance, [6] a wait gave up (the factor is void: the host redoes the create with the launch chain)
 __global__ __launch_bounds__(256) void mid_finish_kernel(int nbt, int nb, int ntiles, const int *__restrict__ negcnt,
@@ -116,13 +125,15 @@ __global__ __launch_bounds__(256) void mid_finish_kernel(int nbt, int nb, int nt
         __syncthreads();
     }
     if (tid == 0) {
-        int bad = 0, neg = 0;
-        for (int t = 0; t < nb; ++t) {
-            if (!bad && badrow[t])
-                bad = badrow[t];
-            neg += negcnt[t];
+        if (negcnt) {  // (the 128 x 128 form counts its pivots in info[0..1] itself, as the launch chain's diagonal blocks do)
+            int bad = 0, neg = 0;
+            for (int t = 0; t < nb; ++t) {
+                if (!bad && badrow[t])
+                    bad = badrow[t];
+                neg += negcnt[t];
+            }
+            info[0] = bad, info[1] = neg;
         }
-        info[0] = bad, info[1] = neg;
         info[2] = tij[2 * st[0]], info[3] = tij[2 * st[0] + 1];
         info[6] = ld_flag(abortf) == epoch ? 1 : 0;
     }
@@ -391,6 +402,18 @@ void small_create_init()
         GPX_MID_ATTR(float, GPX_KERNEL_MATERN32);
         GPX_MID_ATTR(float, GPX_KERNEL_MATERN52);
 #undef GPX_MID_ATTR
+#define GPX_WIDE_ATTR(T, KID)                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wide_factor_kernel<T, KID>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<T>())
+        GPX_WIDE_ATTR(double, GPX_KERNEL_GAUSSIAN);
+        GPX_WIDE_ATTR(double, GPX_KERNEL_THINPLATE);
+        GPX_WIDE_ATTR(double, GPX_KERNEL_MATERN32);
+        GPX_WIDE_ATTR(double, GPX_KERNEL_MATERN52);
+        GPX_WIDE_ATTR(float, GPX_KERNEL_GAUSSIAN);
+        GPX_WIDE_ATTR(float, GPX_KERNEL_THINPLATE);
+        GPX_WIDE_ATTR(float, GPX_KERNEL_MATERN32);
+        GPX_WIDE_ATTR(float, GPX_KERNEL_MATERN52);
+#undef GPX_WIDE_ATTR
     });
 }
 
@@ -398,7 +421,8 @@ template <typename T>
 static void mid_factor_t(const CovHost &h, const MidFactorArgs &m, hipStream_t st)
 {
     FactorArgs<T> f;
-    f.n = m.n, f.np = m.np, f.nbt = m.np / ST, f.nb = (m.n + ST - 1) / ST, f.ntiles = f.nbt * (f.nbt + 1) / 2;
+    const int tile = m.wide ? WT : ST;
+    f.n = m.n, f.np = m.np, f.nbt = m.np / tile, f.nb = (m.n + tile - 1) / tile, f.ntiles = f.nbt * (f.nbt + 1) / 2;
     f.cov = lower_cov<T>(h);
     f.K = (T *)m.K, f.linv = (T *)m.linv, f.d = (T *)m.d, f.dinv = (T *)m.dinv;
     f.px = (const T *)m.px, f.py = (const T *)m.py, f.pz = (const T *)m.pz, f.ps2 = (const T *)m.ps2;
@@ -408,6 +432,12 @@ static void mid_factor_t(const CovHost &h, const MidFactorArgs &m, hipStream_t s
     f.abort_idx = 2 * f.ntiles, f.pre_idx = 2 * f.ntiles + 2;
     f.tmax = (double *)(ws + lay.tmax), f.tij = (int *)(ws + lay.tij);
     f.negcnt = (int *)(ws + lay.negcnt), f.badrow = (int *)(ws + lay.badrow);
+    if (m.wide) {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((wide_factor_kernel<T, KID>), dim3(f.ntiles), dim3(WIDE_THREADS), wide_lds_bytes<T>(), st, f, m.info));
+        hipLaunchKernelGGL(mid_finish_kernel, dim3(1), dim3(256), 0, st, f.nbt, f.nb, f.ntiles, (const int *)nullptr, (const int *)nullptr,
+                           f.tmax, f.tij, f.flags + f.abort_idx, f.epoch, m.info);
+        return;
+    }
     const size_t lds = DF_LDS_ELEMS * sizeof(T);
     GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((mid_factor_kernel<T, KID>), dim3(f.ntiles), dim3(DF_THREADS), lds, st, f));
     hipLaunchKernelGGL(mid_finish_kernel, dim3(1), dim3(256), 0, st, f.nbt, f.nb, f.ntiles, f.negcnt, f.badrow, f.tmax, f.tij,

@@ -76,7 +76,7 @@ inline SmallWs small_ws_layout(int np)
 }
 
 // ---- the same dataflow factorisation for mid-size models (kernel matrix + LDL^T in one launch; the chain goes on from there)
-constexpr int MID_FACTOR_MAX_NP_F32 = 16384, MID_FACTOR_MAX_NP_F64 = 8192;  // padded rows up to which a fresh create() factorises this way
+constexpr int MID_FACTOR_MAX_NP_F32 = 16384, MID_FACTOR_MAX_NP_F64 = 16384;  // padded rows up to which a fresh create() factorises this way
 struct MidWs {
     size_t flags, tmax, tij, negcnt, badrow, bytes;
 };
@@ -102,6 +102,7 @@ struct MidFactorArgs {
     int *info = nullptr;  // the model's d_info: [0..3] as the chain leaves them, [6] = 1 when a wait gave up
     unsigned long long epoch = 0;
     int spin_limit = 1 << 20;
+    bool wide = false;  // 128 x 128 tiles (gpx_dataflow_wide.hpp): large models, where the 64 x 64 form is HBM-bound
 };
 // kernel matrix + LDL^T (L, D in K; d, dinv; the 128 x 128 inverse diagonal blocks linv) + the info reduction; asynchronous
 void launch_mid_factor(int prec, const CovHost &cov, const MidFactorArgs &m, hipStream_t st);

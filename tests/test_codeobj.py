@@ -11,7 +11,9 @@ import codeobj
 # SGPR spills go to VGPR lanes (v_writelane / v_readlane), not to memory: tolerated where they sit outside the hot recurrences.
 # diag_ldlm_kernel<double>: 21 lane-group masks of its 32 elimination steps, parked at entry.  small_alpha_kernel (second launch
 # of the small-model create): ~20 pointers of its argument block live across its three phases, two of them go to VGPR lanes.
-SGPR_SPILL_LIMIT = {"diag_ldlm_kernelId": 24, "small_alpha_kernel": 4}
+# wide_factor_kernel<double>: the 128 x 128 dataflow tile with that diagonal-block routine inlined (its 21 + the tile's own
+# kernel arguments, parked across the routine).
+SGPR_SPILL_LIMIT = {"diag_ldlm_kernelId": 24, "small_alpha_kernel": 4, "wide_factor_kernelId": 48}
 
 
 @pytest.fixture(scope="module")
