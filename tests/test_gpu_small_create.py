@@ -182,7 +182,7 @@ def test_dataflow_launches_are_deterministic_and_survive_concurrent_creates(gpu,
     import hashlib
     import threading
     cases = [(277, gpu.F64, "gaussian"), (724, gpu.F32, "matern52"), (1500, gpu.F64, "matern52"), (3000, gpu.F32, "gaussian"),
-             (5000, gpu.F64, "matern32")]
+             (5000, gpu.F64, "matern32"), (9000, gpu.F32, "matern52")]  # (the last one: 128 x 128 tiles)
     sets = {n: ds.fibonacci_training_set(n) for n, _, _ in cases}
 
     def digest(n, prec, kn):
@@ -216,3 +216,32 @@ def test_dataflow_launches_are_deterministic_and_survive_concurrent_creates(gpu,
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n", [1100, 2305])
+def test_wide_tile_dataflow_factorisation_matches_the_chain_and_the_oracle(gpu, orc, ds, n, monkeypatch):
+    """From 8192 padded rows on the dataflow factorisation runs on 128 x 128 tiles (csrc/gpx_dataflow_wide.hpp: eight waves per
+    tile, the launch chain's diagonal-block routine on the tile's sums, the panel solve as a slice loop against the inverse
+    block).  Forced here at test sizes (GPX_WIDE_FACTOR_MIN): a last tile row that is mostly padding and one that is full, fp64
+    and the chunked fp32 sums, the indefinite ThinPlate(2.0)'s inertia; the product sizes run it in test_gpu_scale.py."""
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    monkeypatch.setenv("GPX_WIDE_FACTOR_MIN", "1024")
+    data = ds.fibonacci_training_set(n)
+    qx, qy, qz = ds.query_grid(5, scale=1.2)
+    for kn, par in (("matern52", (1.0, 1.0)), ("gaussian", (1.0, 1.0)), ("thinplate", (2.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), *data)
+        ref = om.evaluate(qx, qy, qz, want_v=True)
+        for prec in (gpu.F64, gpu.F32):
+            if kn == "thinplate" and prec == gpu.F32:
+                continue
+            md = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, True, prepare_variance=True)
+            mc = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, False, prepare_variance=True)
+            sd, sc = md.stats, mc.stats
+            assert sd["solve_fallbacks"] == 0 and sd["factor_gemm_launches"] == 0 and sc["factor_gemm_launches"] > 0
+            assert sd["n_negative_pivots"] == sc["n_negative_pivots"] and abs(md.R - mc.R) <= 1e-14 * mc.R
+            t64 = prec == gpu.F64
+            assert nerr(md.alpha, om.alpha) < (1e-9 if t64 else 1e-5) and nerr(md.D, mc.D) < (1e-10 if t64 else 2e-4)
+            a, b = (m.evaluate(qx, qy, qz, want_v=True) for m in (md, mc))
+            assert nerr(a["f"], ref["f"]) < (1e-9 if t64 else 1e-5) and nerr(a["f"], b["f"]) < (1e-9 if t64 else 1e-5)
+            assert verr_v(a["v"], ref["v"]) < (1e-10 if t64 else 1e-5) and verr_v(a["v"], b["v"]) < (1e-10 if t64 else 1e-5)
+            md.close(), mc.close()
