@@ -103,8 +103,8 @@ typedef struct gpx_model gpx_model; /* opaque; replaces struct Model, gp_regress
 
 /* Per-stage device timings (HIP events) of the last create / evaluate on this model, ms.  Models of up to 1024 padded rows are
  * created by three launches (kernel matrix + LDL^T + inverse factor | alpha + refinement | rounding of the fp32 state): their
- * times are reported as t_factor_ms, t_solve_ms and t_inverse_ms, t_kbuild_ms is 0.  Larger fresh creates up to 16384 rows (fp32)
- * / 8192 (fp64) form the kernel matrix inside the factorisation launch: t_kbuild_ms ~ 0, factor_gemm_launches = 0. */
+ * times are reported as t_factor_ms, t_solve_ms and t_inverse_ms, t_kbuild_ms is 0.  Larger fresh creates up to 16384 rows form the
+ * kernel matrix inside the factorisation launch: t_kbuild_ms ~ 0, factor_gemm_launches = 0. */
 typedef struct gpx_stats {
     double t_kbuild_ms, t_factor_ms, t_solve_ms, t_inverse_ms, t_normals_ms; /* create */
     double t_mean_ms, t_var_ms;                                              /* last evaluate */
