@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import nerr, verr_v
+from conftest import nerr, verr, verr_v
 
 pytestmark = pytest.mark.gpu
 
@@ -245,3 +245,31 @@ def test_wide_tile_dataflow_factorisation_matches_the_chain_and_the_oracle(gpu, 
             assert nerr(a["f"], ref["f"]) < (1e-9 if t64 else 1e-5) and nerr(a["f"], b["f"]) < (1e-9 if t64 else 1e-5)
             assert verr_v(a["v"], ref["v"]) < (1e-10 if t64 else 1e-5) and verr_v(a["v"], b["v"]) < (1e-10 if t64 else 1e-5)
             md.close(), mc.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 33])
+def test_three_launch_create_of_a_handful_of_points(gpu, orc, n):
+    """The smallest models: one training point, fewer points than a 32 x 32 sub-block, one row into the second sub-block --
+    almost the whole 64 x 64 tile is identity padding."""
+    rng = np.random.default_rng(100 + n)
+    P = rng.normal(size=(n, 3))
+    lab = rng.normal(size=n)
+    s2 = np.full(n, 0.05)
+    qx, qy, qz = (rng.normal(size=7) for _ in range(3))
+    for kn, par in (("gaussian", (1.0, 1.0)), ("thinplate", (6.0,))):
+        om = orc.Model(orc.make_kernel(kn, *par), P[:, 0], P[:, 1], P[:, 2], lab, s2)
+        ref = om.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+        for prec in (gpu.F64, gpu.F32):
+            gm = gpu.Model(gpu.make_kernel(kn, *par), P[:, 0], P[:, 1], P[:, 2], lab, s2, precision=prec, prepare_variance=True)
+            st = gm.stats
+            assert st["solve_fallbacks"] == 0 and st["t_kbuild_ms"] == 0.0 and gm.n == n
+            if n > 1:
+                assert abs(gm.R - om.R) <= 1e-14 * om.R
+            assert nerr(gm.alpha, om.alpha) < 1e-10
+            out = gm.evaluate(qx, qy, qz, want_v=True, want_grad=True)
+            assert nerr(out["f"], ref["f"]) < 1e-10 and nerr(out["grad"], ref["grad"]) < 1e-10
+            # (random points up to 6 apart under ThinPlate(6): k(0) = 216 against variances of 1-3 -- the fp32 mode is held to the
+            # k(0)-scaled metric there, as in test_gpu_parity.py; fp64 to the strict one)
+            k0 = 216.0 if kn == "thinplate" else 1.0
+            assert (verr_v(out["v"], ref["v"]) < 1e-10) if prec == gpu.F64 else (verr(out["v"], ref["v"], k0) < 1e-5)
+            gm.close()
