@@ -67,7 +67,9 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         // with the fit the epilogue of the contraction runs in fp64 and writes fp64 partial sums
         if (!use_cols && (rc = ensure(m, &m->ws_partial, &m->ws_partial_bytes, (m->var_fit ? sizeof(double) : e) * qb * m->nblk)))
             return rc;
-        if (m->var_fit && (rc = ensure(m, &m->ws_coef, &m->ws_coef_bytes, sizeof(double) * qb * VAR_NCOEF)))
+        // (the small-model kernel that forms its operand in the wave derives the 14 coefficients from a_q, b_q, c_q itself:
+        // 24 instead of 136 bytes per query)
+        if (m->var_fit && (rc = ensure(m, &m->ws_coef, &m->ws_coef_bytes, sizeof(double) * qb * (cols_gen ? VAR_NFIT : VAR_NCOEF))))
             return rc;
     }
     // The workspaces (prediction partials, K tile, variance partials) are shared by all evaluations of this model,
@@ -113,8 +115,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             const double *fab = nullptr;  // rows a_q, b_q, c_q of the batch's coefficient array
             if (m->var_fit) {
                 launch_var_fit(m->op64, m->cov, m->n, m->d_x, m->d_y, m->d_z, m->d_meta, (long)nv, (long)ntile, qx + q0,
-                               qy + q0, qz + q0, (double *)coef_buf, (long)qb, s);
-                fab = (const double *)coef_buf + qb * VAR_NCORR;
+                               qy + q0, qz + q0, (double *)coef_buf, (long)qb, s, cols_gen);
+                fab = (const double *)coef_buf + (cols_gen ? 0 : qb * VAR_NCORR);
             }
             const int part_prec = m->var_fit ? GPX_PREC_F64 : m->prec;  // type of the partial sums
             if (kev)
@@ -152,7 +154,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor + gi) : nullptr;
             if (use_cols) {
                 vc.Kq = (const float *)kqp_buf;
-                vc.colcoef = (const double *)coef_buf, vc.ldcc = (long)qb;
+                vc.colcoef = (const double *)coef_buf, vc.ldcc = (long)qb, vc.compact_coef = cols_gen;
                 vc.nq_valid = (long)nv, vc.nq_tile = (long)ntile, vc.v = v + q0;
                 vc.qx = qx + q0, vc.qy = qy + q0, vc.qz = qz + q0;
                 if (ev)

@@ -99,9 +99,32 @@ constexpr double VAR_FIT_WDELTA_DIV = 320.0;
 // px, py, pz: the model's fp64 points; cen (device): the model's meta block (centre in [0..2], weight offset in [4]).  op64: everything in fp64 (for the
 // operand kernel that forms k - fit in fp64); else centred points and query are rounded to fp32 and so are a, b, c --
 // the values the fp32 operand kernel uses, so that the identity fit = sum_c coef_c b_c holds exactly for what it subtracts.
+// compact: only rows a_q, b_q, c_q are written ([3][ldcc]); the consumer derives the 14 coefficients with var_fit_coefs()
 void launch_var_fit(bool op64, const CovHost &cov, int n, const double *px, const double *py, const double *pz,
                     const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
-                    const double *qz, double *coef, long ldcc, hipStream_t st);
+                    const double *qz, double *coef, long ldcc, hipStream_t st, bool compact = false);
+// query-side coefficients of the 14 basis functions (list above) for the fit a + b s + c s^2, s = |q' - p'|^2, from
+// (a, b, c) and the centred query q' -- ONE definition, so that the fit kernel and the kernels that derive the coefficients
+// themselves produce the same bits
+__device__ __forceinline__ void var_fit_coefs(double fa, double fb, double fc, double ax, double ay, double az, double (&cf)[VAR_NCORR])
+{
+    const double q2 = ax * ax + ay * ay + az * az;
+    const double lin = -2.0 * fb - 4.0 * fc * q2, dg = fb + 2.0 * fc * q2;
+    cf[0] = fa + q2 * (fb + fc * q2);
+    cf[1] = lin * ax;
+    cf[2] = lin * ay;
+    cf[3] = lin * az;
+    cf[4] = dg + 4.0 * fc * ax * ax;
+    cf[5] = dg + 4.0 * fc * ay * ay;
+    cf[6] = dg + 4.0 * fc * az * az;
+    cf[7] = 8.0 * fc * ax * ay;
+    cf[8] = 8.0 * fc * ax * az;
+    cf[9] = 8.0 * fc * ay * az;
+    cf[10] = -4.0 * fc * ax;
+    cf[11] = -4.0 * fc * ay;
+    cf[12] = -4.0 * fc * az;
+    cf[13] = fc;
+}
 // Kqp[q][j] = k(|q - p_j|) [- (a_q + b_q s + c_q s^2)], q in [0,nq_tile) (rows >= nq_valid and columns >= n are zero).
 // compute64: distances, kernel and fit in fp64 from fp64 points px.. (differences are translation invariant: no
 // centring), rounded once to the output type; else fp32 arithmetic on the centred fp32 points, queries centred by
@@ -242,6 +265,7 @@ struct VarColsArgs {
     const float *px = nullptr, *py = nullptr, *pz = nullptr;
     const double *qx = nullptr, *qy = nullptr, *qz = nullptr;
     double cen[3] = {0, 0, 0};
+    bool compact_coef = false;  // colcoef holds only rows a_q, b_q, c_q (launch_var_fit(compact)); operand formed in the wave only
 };
 bool var_cols_fits(int n, int np, long ldx, long ldk);
 bool var_cols_gen(const VarColsArgs &a);  // true: launch_var_cols forms the operand itself -- no launch_kqp needed

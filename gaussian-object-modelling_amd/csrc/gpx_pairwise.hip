@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void reduce_tilemax_kernel(int ntiles, const f
 // in three passes over their samples: 72 shuffles per query and coefficient stores from one lane in sixteen -- 3.8 instead
 // of 1.5 ms over the eight objects of C5.  What cancellation does to the expanded moments, a few digits of fp64, only moves
 // the fit, which any (a, b, c) may be; the variances agree to every printed digit, profiles/r04_fit_lane.txt.)
-template <bool R32, int KID>
+// COMPACT: only rows a, b, c are written (coef[0 .. 2][ldcc]) -- the small-model kernel that forms its operand in the wave derives
+// the 14 query-side coefficients from them with var_fit_coefs() below (gpx_internal.hpp): 24 instead of 136 bytes per query.
+template <bool R32, int KID, bool COMPACT>
 __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, int stride, int ns,
                                                            const double *__restrict__ px, const double *__restrict__ py,
                                                            const double *__restrict__ pz, const double *__restrict__ cen,
@@ -271,30 +273,25 @@ __global__ __launch_bounds__(256) void var_fit_kernel(Cov<double> cov, int n, in
         if constexpr (!P64)
             fa = (double)(float)fa, fb = (double)(float)fb, fc = (double)(float)fc;
     }
-    const double q2 = ax * ax + ay * ay + az * az;
-    const double lin = -2.0 * fb - 4.0 * fc * q2, dg = fb + 2.0 * fc * q2;
-    coef[q] = fa + q2 * (fb + fc * q2);
-    coef[1 * ldcc + q] = lin * ax;
-    coef[2 * ldcc + q] = lin * ay;
-    coef[3 * ldcc + q] = lin * az;
-    coef[4 * ldcc + q] = dg + 4.0 * fc * ax * ax;
-    coef[5 * ldcc + q] = dg + 4.0 * fc * ay * ay;
-    coef[6 * ldcc + q] = dg + 4.0 * fc * az * az;
-    coef[7 * ldcc + q] = 8.0 * fc * ax * ay;
-    coef[8 * ldcc + q] = 8.0 * fc * ax * az;
-    coef[9 * ldcc + q] = 8.0 * fc * ay * az;
-    coef[10 * ldcc + q] = -4.0 * fc * ax;
-    coef[11 * ldcc + q] = -4.0 * fc * ay;
-    coef[12 * ldcc + q] = -4.0 * fc * az;
-    coef[13 * ldcc + q] = fc;
-    coef[14 * ldcc + q] = fa;
-    coef[15 * ldcc + q] = fb;
-    coef[16 * ldcc + q] = fc;
+    if constexpr (COMPACT) {
+        coef[q] = fa;
+        coef[ldcc + q] = fb;
+        coef[2 * ldcc + q] = fc;
+    } else {
+        double cf[VAR_NCORR];
+        var_fit_coefs(fa, fb, fc, ax, ay, az, cf);
+#pragma unroll
+        for (int c = 0; c < VAR_NCORR; ++c)
+            coef[(size_t)c * ldcc + q] = cf[c];
+        coef[14 * ldcc + q] = fa;
+        coef[15 * ldcc + q] = fb;
+        coef[16 * ldcc + q] = fc;
+    }
 }
 
 void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const double *py, const double *pz,
                     const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
-                    const double *qz, double *coef, long ldcc, hipStream_t st)
+                    const double *qz, double *coef, long ldcc, hipStream_t st, bool compact)
 {
     static const int nsamp = [] {
         const char *e = std::getenv("GPX_VAR_FIT_SAMPLES");  // 16 .. 128 strided training points per query
@@ -310,10 +307,13 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
     const int ns16 = (ns + 15) / 16 * 16;  // (the sample counts are multiples of 16: what the 16-lane form of rounds 2-3 visited)
     const dim3 g1((unsigned)((nq_tile + 255) / 256));
     if (op64) {
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<false, KID, false>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
+                                                  cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
+    } else if (compact) {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID, true>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
                                                   cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     } else {
-        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_fit_kernel<true, KID, false>), g1, dim3(256), 0, st, c, n, stride, ns16, px, py, pz,
                                                   cen, nq_valid, nq_tile, qx, qy, qz, coef, ldcc));
     }
 }

@@ -38,6 +38,7 @@ void launch_var_cols(const VarColsArgs &a, hipStream_t st)
     g.n = a.n;
     g.cov = lower_cov<float>(a.cov);
     const bool gen = var_cols_gen(a);
+    g.compact_coef = gen && a.compact_coef ? 1 : 0;
     const unsigned nwg = (unsigned)((a.nq_tile + 16 * VC_CF - 1) / (16 * VC_CF));
 #ifdef VC_TIMING
     static long long *dbg = nullptr;

@@ -68,6 +68,7 @@ struct VarColsDev {
     double cen[3];
     int n;
     Cov<float> cov;
+    int compact_coef;  // GEN: colcoef = [3][ldcc] rows a_q, b_q, c_q; the 14 coefficients are derived here (var_fit_coefs)
 #ifdef VC_TIMING
     long long *dbg;  // diagnostic build (make EXTRA=-DVC_TIMING): in-kernel time stamps
 #endif
@@ -155,9 +156,10 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, (FS * CF <= 24 ? 
             lq[(6 * j + 0) * 64 + lane] = (float)(g.qx[q] - g.cen[0]);
             lq[(6 * j + 1) * 64 + lane] = (float)(g.qy[q] - g.cen[1]);
             lq[(6 * j + 2) * 64 + lane] = (float)(g.qz[q] - g.cen[2]);
-            lq[(6 * j + 3) * 64 + lane] = (float)g.colcoef[(size_t)VAR_NCORR * g.ldcc + q];
-            lq[(6 * j + 4) * 64 + lane] = (float)g.colcoef[(size_t)(VAR_NCORR + 1) * g.ldcc + q];
-            lq[(6 * j + 5) * 64 + lane] = (float)g.colcoef[(size_t)(VAR_NCORR + 2) * g.ldcc + q];
+            const size_t frow = g.compact_coef ? 0 : VAR_NCORR;  // row of a_q in the coefficient array
+            lq[(6 * j + 3) * 64 + lane] = (float)g.colcoef[(size_t)frow * g.ldcc + q];
+            lq[(6 * j + 4) * 64 + lane] = (float)g.colcoef[(size_t)(frow + 1) * g.ldcc + q];
+            lq[(6 * j + 5) * 64 + lane] = (float)g.colcoef[(size_t)(frow + 2) * g.ldcc + q];
         }
     }
 
@@ -165,14 +167,35 @@ __global__ __attribute__((aligned(256))) __launch_bounds__(64, (FS * CF <= 24 ? 
     // (kept in LDS, 4 CF doubles per lane, and read back one column fragment at a time in front of its fp64 MFMAs: 8 CF
     // registers that would otherwise be held for the whole kernel)
     __shared__ double lcb[4 * CF * 64];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+    if (GEN && g.compact_coef) {
+        // the 14 coefficients from (a_q, b_q, c_q) and the centred query, exactly as var_fit_kernel forms them (fp32 operand:
+        // q' and a, b, c are the float-rounded values) -- 136 bytes per query that never travel through memory
 #pragma unroll
         for (int j = 0; j < CF; ++j) {
-            const int c = 4 * s + lg;
-            const long q = GEN ? min(q0 + 16 * j + r16, g.nq_valid - 1) : q0 + 16 * j + r16;
-            lcb[(j * 4 + s) * 64 + lane] = c < VAR_NCORR ? g.colcoef[(size_t)c * g.ldcc + q] : 0.0;
+            const long q = min(q0 + 16 * j + r16, g.nq_valid - 1);
+            const double ax = (double)(float)(g.qx[q] - g.cen[0]), ay = (double)(float)(g.qy[q] - g.cen[1]),
+                         az = (double)(float)(g.qz[q] - g.cen[2]);
+            double cf[VAR_NCORR];
+            var_fit_coefs(g.colcoef[q], g.colcoef[g.ldcc + q], g.colcoef[2 * g.ldcc + q], ax, ay, az, cf);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < VAR_NCORR; ++c)
+                    v = (4 * s + lg == c) ? cf[c] : v;
+                lcb[(j * 4 + s) * 64 + lane] = v;
+            }
         }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < CF; ++j) {
+                const int c = 4 * s + lg;
+                const long q = GEN ? min(q0 + 16 * j + r16, g.nq_valid - 1) : q0 + 16 * j + r16;
+                lcb[(j * 4 + s) * 64 + lane] = c < VAR_NCORR ? g.colcoef[(size_t)c * g.ldcc + q] : 0.0;
+            }
+    }
     double sj[CF];
 #pragma unroll
     for (int j = 0; j < CF; ++j)
