@@ -20,6 +20,7 @@
 // tri_solve_kernel does.  Workgroups are enumerated column by column, so a factorisation job only ever waits for
 // workgroups with a lower index; the inverse jobs also wait for later ones, which is why all (<= 136) must be resident.
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 #include "gpx_dataflow.hpp"
@@ -465,7 +466,10 @@ void launch_small_create(int kernel_id, const SmallArgs &a, const SmallArgs *d_a
     GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_factor_kernel<KID>), dim3(a.ntiles), dim3(SM_THREADS), lds, st, d_args));
     if (ev_factor)
         (void)hipEventRecord(ev_factor, st);
-    const int g = std::max(16, std::min(128, a.np / 8));
+    // workgroups of the second launch: its phases are latency-bound (a row or two per wave, one trip to memory each), so more
+    // waves help until the barrier's cost takes over -- measured at N = 277 / 724 / 1024 (solve us): 16 workgroups 99 / 244 / 378,
+    // 32: 69 / 149 / 225, 64: 58 / 108 / 157, 128: 59 / 102 / 137, 256: 66 / 113 / 152
+    const int g = a.np <= 512 ? 64 : 128;
     GPX_DISPATCH_KID(kernel_id, hipLaunchKernelGGL((small_alpha_kernel<KID>), dim3(g), dim3(SM_THREADS), 0, st, d_args));
     if (ev_solve)
         (void)hipEventRecord(ev_solve, st);
