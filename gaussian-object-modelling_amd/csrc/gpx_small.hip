@@ -172,6 +172,24 @@ __device__ __forceinline__ bool grid_barrier(const SmallArgs &a, int index, int 
     return ok;
 }
 
+// sum over c = c0 + lane, c0 + lane + 64, ... < c1 of row[c] * v[c]: the loads of four steps are issued before the first is used
+// (one trip to memory per four steps instead of one per step: the phases of the second launch are latency-bound)
+__device__ __forceinline__ double dot_strided(const double *__restrict__ row, const double *v, int c0, int c1, int lane)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = c0 + lane;
+    for (; c + 192 < c1; c += 256) {
+        const double a0 = row[c], a1 = row[c + 64], a2 = row[c + 128], a3 = row[c + 192];
+        s0 = fma(a0, v[c], s0);
+        s1 = fma(a1, v[c + 64], s1);
+        s2 = fma(a2, v[c + 128], s2);
+        s3 = fma(a3, v[c + 192], s3);
+    }
+    for (; c < c1; c += 64)
+        s0 = fma(row[c], v[c], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+
 __device__ __forceinline__ double wave_sum(double s)
 {
 #pragma unroll
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
     const SmallArgs &a = *ap;
     __shared__ int s_ok;
     __shared__ double vec[SMALL_CREATE_MAX_NP];  // the vector the current phase multiplies with
+    __shared__ double pts[3][SMALL_CREATE_MAX_NP];  // the model's fp64 points (row corrections, residual)
     const int tid = threadIdx.x, lane = tid & 63;
     const int gw = (int)blockIdx.x * 4 + (tid >> 6), nw = (int)gridDim.x * 4;
     const int np = a.np, n = a.n, nrows = a.nb * ST;
@@ -198,6 +217,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
             vec[k] = ld_cg(src + k);
         __syncthreads();
     };
+    for (int k = tid; k < n; k += SM_THREADS)
+        pts[0][k] = a.d_x[k], pts[1][k] = a.d_y[k], pts[2][k] = a.d_z[k];
     if (!aborted) {
         for (int it = 0;; ++it) {
             // ---- t = X rhs, u = D^-1 t (L y = b and the scaling of LDLT::solve, gp_regressor.hpp:163) ----
@@ -205,10 +226,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
             for (int r = gw; r < np; r += nw) {
                 double s = 0.0;
                 if (r < nrows) {
-                    const double *row = a.X + (size_t)r * np;
-                    for (int c = lane; c <= r; c += 64)
-                        s = fma(row[c], vec[c], s);
-                    s = wave_sum(s);
+                    s = wave_sum(dot_strided(a.X + (size_t)r * np, vec, 0, r + 1, lane));
                 } else {
                     s = vec[r];
                 }
@@ -223,9 +241,16 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
                     if (r < nrows) {
                         const double *row = a.X + (size_t)r * np;
                         const int lend = min(n, r + 1);
-                        for (int l = lane; l < lend; l += 64) {
-                            const double xv = row[l];
-                            double x = a.d_x[l] - a.cen[0], y = a.d_y[l] - a.cen[1], z = a.d_z[l] - a.cen[2];
+                        double xrow[4];
+                        for (int l0 = lane; l0 < lend; l0 += 256) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                xrow[u] = l0 + 64 * u < lend ? row[l0 + 64 * u] : 0.0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                            const int l = min(l0 + 64 * u, lend - 1);  // (past the end: xr = 0, any valid point)
+                            const double xv = xrow[u];
+                            double x = pts[0][l] - a.cen[0], y = pts[1][l] - a.cen[1], z = pts[2][l] - a.cen[2];
                             if (!a.op64)
                                 x = (double)(float)x, y = (double)(float)y, z = (double)(float)z;
                             const double r2 = x * x + y * y + z * z;
@@ -244,6 +269,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
                             sc[11] = fma(xr, y, sc[11]);
                             sc[12] = fma(xr, z, sc[12]);
                             sc[13] = fma(xr, r2, sc[13]);
+                            }
                         }
                     }
 #pragma unroll
@@ -261,10 +287,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
             for (int c = gw; c < np; c += nw) {
                 double s = 0.0;
                 if (c < nrows) {
-                    const double *row = a.XT + (size_t)c * np;
-                    for (int r = c + lane; r < nrows; r += 64)
-                        s = fma(row[r], vec[r], s);
-                    s = wave_sum(s);
+                    s = wave_sum(dot_strided(a.XT + (size_t)c * np, vec, c, nrows, lane));
                 } else {
                     s = vec[c];
                 }
@@ -281,10 +304,10 @@ __global__ __launch_bounds__(SM_THREADS) void small_alpha_kernel(const SmallArgs
                 for (int r = gw; r < np; r += nw) {
                     double res = 0.0;
                     if (r < n) {
-                        const double px = a.d_x[r], py = a.d_y[r], pz = a.d_z[r];
+                        const double px = pts[0][r], py = pts[1][r], pz = pts[2][r];
                         double s = 0.0;
                         for (int c = lane; c < n; c += 64) {
-                            const double dx = px - a.d_x[c], dy = py - a.d_y[c], dz = pz - a.d_z[c];
+                            const double dx = px - pts[0][c], dy = py - pts[1][c], dz = pz - pts[2][c];
                             const double d2 = dx * dx + dy * dy + dz * dz;
                             s = fma(cov_k<double, KID, MathFast>(cov, d2 + 1e-300), vec[c], s);
                         }
