@@ -1,8 +1,9 @@
 // gpx_dataflow_wide.hpp -- the dataflow factorisation of gpx_dataflow.hpp with 128 x 128 tiles, for LARGE models.
 //
 // With 64 x 64 tiles every workgroup streams its own row panel L_i,0..j-1 from memory: 45 GB of tile reads at N = 16384, and the
-// PMC counters show the fp32 launch moving 61.7 GB at 3.6 TB/s (profiles/r05_pmc_traffic_w1.json) -- the kernel is HBM-bound
-// there.  A 128 x 128 tile does four times the flops of a 64 x 64 one on twice the operand bytes: half the traffic per flop.
+// PMC counters show the fp32 launch moving 61.7 GB at 3.6 TB/s (profiles/r05_pmc_traffic_64tiles.json) -- the kernel is HBM-bound
+// there.  A 128 x 128 tile does four times the flops of a 64 x 64 one on twice the operand bytes: half the traffic per flop
+// (measured: 36.4 GB per launch, profiles/r05_pmc_traffic_w1.json, at 15.5 ms).
 //
 //   * one workgroup of EIGHT waves per lower 128 x 128 tile (I, J), column by column; wave w owns rows 32 (w >> 1) .. +32 and
 //     columns 64 (w & 1) .. +64 of the tile (two 32 x 32 accumulator blocks);
