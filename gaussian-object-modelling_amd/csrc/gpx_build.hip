@@ -510,9 +510,22 @@ static void factor_append_rows(gpx_model *m, int t0)
 // F32_SPLIT: the fp32 inverse factor becomes packed fp16 hi/lo halves in place, the 1/D slot the scaled weights and
 // the row-correction vectors move to the accumulators' units.  No-op for the other modes, while the model still
 // trains in fp64 (the packing runs on the demoted fp32 state) and when already packed.
+// does an F32_SPLIT model of this size pack its inverse factor (a function of n and the options only: a shell committed from
+// the state blobs of such a model must agree -- gpx_model_commit)
+bool split_packs(const gpx_model *m)
+{
+    return !(m->n <= SPLIT_MIN_N && m->var_fit_opt && var_cols_fits(m->n, m->npad, m->npad, m->npad + KQP_LDPAD));
+}
+
 static int pack_split(gpx_model *m)
 {
     if (m->opt.precision != GPX_PREC_F32_SPLIT || m->x_packed || m->prec != GPX_PREC_F32 || !m->X)
+        return GPX_OK;
+    // Small models stay on the fp32 contraction of the small-model kernel (gpx_varcols_kernel.hpp), which needs no operand in
+    // memory: measured on the C5 objects (scripts/c5_breakdown.py split, variance stage of 2^21 queries, packed operands vs
+    // that kernel): N = 277 3.82 vs 2.24 ms, 354 3.82 vs 3.23, 447 4.95 vs 4.47, 481 4.99 vs 5.29, 724 9.18 vs 10.59 -- the
+    // split contraction pays from ~470 points on.  Same accuracy class (the mode promises at least the F32 one).
+    if (!split_packs(m))
         return GPX_OK;
     const int np = m->npad;
     if (!m->hD.size()) {  // keep D readable (GPX_FIELD_D) -- the 1/D slot is about to hold the weights

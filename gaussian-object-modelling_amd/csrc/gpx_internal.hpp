@@ -248,6 +248,7 @@ int gemm_tile_n(int cfg);
 // triangle of X skipped per 16-row fragment, ONE fp64 epilogue per accumulator fragment) and writes v = k(0) - sum w^2 / D
 // directly: no partial sums, no var_finish.  For fp32 contractions with the fit (var_fit) of up to VARCOLS_MAX_N points.
 constexpr int VARCOLS_MAX_N = 1024;
+constexpr int SPLIT_MIN_N = 464;  // F32_SPLIT models of up to this many points keep the fp32 small-model kernel (gpx_build.hip: pack_split)
 struct VarColsArgs {
     const float *X = nullptr;  // inverse factor [np][ldx]
     long ldx = 0;

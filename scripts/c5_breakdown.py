@@ -21,7 +21,7 @@ for rep in range(3):
     T0 = time.perf_counter()
     for nm, d_ in zip(names, sets):
         t0 = time.perf_counter()
-        m = gpx.Model(kern, *d_, precision=(gpx.F32_SPLIT if len(sys.argv) > 1 and sys.argv[1] == "split" else gpx.F32), prepare_variance=True)
+        m = gpx.Model(kern, *d_, precision={"split": gpx.F32_SPLIT, "f64": gpx.F64}.get(sys.argv[1] if len(sys.argv) > 1 else "", gpx.F32), prepare_variance=True)
         t1 = time.perf_counter()
         m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
         m.sync()
