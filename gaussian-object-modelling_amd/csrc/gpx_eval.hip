@@ -54,12 +54,20 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         vc.cen[0] = m->cen[0], vc.cen[1] = m->cen[1], vc.cen[2] = m->cen[2];
     }
     const bool cols_gen = use_cols && var_cols_gen(vc);
+    // small fp64 models (the header shim's default precision at the reference's own sizes): one kernel, no workspace
+    // (gpx_varcols64.hip)
+    const bool use_cols64 = v && m->prec == GPX_PREC_F64 && !m->var_fit && !m->x_packed && var_cols64_fits(m->n, np, np);
     const size_t nq_tiles = ((nq + TILE - 1) / TILE) * TILE;
     // (an explicitly set gpx_options.query_batch bounds the batch -- and with it the 136 bytes per query of ws_coef -- on
     // every path; the default of the small-model kernel is the whole call in slices of 2^21 queries)
     const size_t cols_cap = m->opt.query_batch > 0 ? (size_t)m->qbatch : (size_t)1 << 21;
     const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, cols_cap) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
-    if (v) {
+    if (use_cols64) {
+        int rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, var_cols64_ws_bytes(m->n));  // X^T of the call
+        if (rc)
+            return rc;
+    }
+    if (v && !use_cols64) {
         int rc;
         const size_t qb = qbatch;
         if (!cols_gen && (rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, e * qb * (np + KQP_LDPAD))))
@@ -85,7 +93,17 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         launch_tangent_basis((long)nq, g, tx, ty, s);
     (void)hipEventRecord(m->ev[EV_M1], s);
     m->gemm_ev_used_var = 0;
-    if (v) {
+    if (use_cols64) {
+        hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor) : nullptr;
+        if (ev)
+            (void)hipEventRecord(ev[0], s);
+        launch_var_cols64(m->cov, m->n, np, (const double *)m->X, np, m->d_x, m->d_y, m->d_z, m->d_dinv64, (long)nq, qx, qy, qz, v,
+                          (double *)m->ws_kqp, s);
+        if (ev)
+            (void)hipEventRecord(ev[1], s);
+        m->gemm_ev_used_var = ev ? 1 : 0;
+        m->kqp_ev_used = 0;
+    } else if (v) {
         const size_t qb = qbatch;
         const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
         const long ldk = (long)np + KQP_LDPAD;  // row stride of the operand buffer (not the power of two X's is)

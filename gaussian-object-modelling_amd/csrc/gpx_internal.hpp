@@ -272,6 +272,17 @@ bool var_cols_fits(int n, int np, long ldx, long ldk);
 bool var_cols_gen(const VarColsArgs &a);  // true: launch_var_cols forms the operand itself -- no launch_kqp needed
 void launch_var_cols(const VarColsArgs &a, hipStream_t st);
 
+// ---- variance of small fp64 models : gpx_varcols64.hip ----------------------------------------------
+// v = k(0) - sum_m (X k_q)_m^2 / D_m for nq queries in one launch: operand formed in the wave, every row fragment resident,
+// the triangle of X skipped per 16-row fragment, v written directly (X: np x ldx fp64 lower triangular; px..: the fp64 points)
+constexpr int VARCOLS64_MAX_N = 1024;    // points the kernel holds in LDS
+constexpr int VARCOLS64_DEFAULT_N = 992;  // models routed to it (GPX_VAR_COLS64_MAX overrides, up to VARCOLS64_MAX_N)
+bool var_cols64_fits(int n, int np, long ldx);
+void launch_var_cols64(const CovHost &cov, int n, int np, const double *X, long ldx, const double *px, const double *py,
+                       const double *pz, const double *dinv, long nq, const double *qx, const double *qy, const double *qz,
+                       double *v, double *xt_ws /* var_cols64_ws_bytes(n) */, hipStream_t st);
+size_t var_cols64_ws_bytes(int n);
+
 // ---- split-fp16 variance contraction : gpx_vsplit.hip ------------------------------------------
 // in place: X (fp32, np x np) -> packed hi/lo halves with a device-chosen power-of-two scale sx;
 // dinv -> w = dinv / (sx sk)^2 (the weights of the plain epilogue); *inv_scale = 1 / (sx sk) (the fp64 epilogue

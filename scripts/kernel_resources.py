@@ -10,6 +10,6 @@ with tempfile.TemporaryDirectory() as t:
 names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in ks), capture_output=True, text=True).stdout.split("\n")
 print("%-100s %5s %5s %5s %6s %6s %7s %7s" % ("kernel", "vgpr", "agpr", "sgpr", "vspill", "sspill", "scratch", "lds"))
 for k, nm in sorted(zip(ks, names), key=lambda t: t[1]):
-    nm = nm.replace("void gpx::", "").split("(")[0]
+    nm = nm.replace("void gpx::", "").replace("(anonymous namespace)::", "").split("(")[0]
     print("%-100s %5d %5d %5d %6d %6d %7d %7d" % (nm[:100], k["vgpr_count"], k["agpr_count"], k["sgpr_count"], k["vgpr_spill_count"],
                                              k["sgpr_spill_count"], k["private_segment_fixed_size"], k["group_segment_fixed_size"]))

@@ -1,0 +1,91 @@
+"""GPU suite: the variance of small fp64 models as one kernel (csrc/gpx_varcols64.hip) -- against the oracle and against its
+twin, the general fp64 path (operand tile -> one-wave contraction tiles -> finish; GPX_VAR_COLS64=0), in one process."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import verr_v
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = (("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0)), ("matern32", (1.0, 1.0)), ("matern52", (1.0, 1.0)),
+           ("thinplate", (4.0,)), ("thinplate", (2.0,)))
+
+
+def _eval(m, q, cols64, max_n=None, **kw):
+    """evaluate() with the kernel on or off (both switches are read per call); max_n: GPX_VAR_COLS64_MAX for this call"""
+    new = {"GPX_VAR_COLS64": "1" if cols64 else "0", "GPX_VAR_COLS64_MAX": None if max_n is None else str(max_n)}
+    old = {k: os.environ.get(k) for k in new}
+    for k, val in new.items():
+        os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
+    try:
+        return m.evaluate(*q, want_v=True, **kw)
+    finally:
+        for k, val in old.items():
+            os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
+
+
+@pytest.mark.parametrize("n", [16, 17, 33, 166, 256, 257, 277, 448, 512])
+def test_small_fp64_variance_matches_the_oracle_and_the_general_path(gpu, orc, ds, n):
+    """One row fragment, the fragment edges, one and two passes over the row fragments (256 / 257 rows), the largest size;
+    six kernels incl. the indefinite ThinPlate(2.0) (negative 1/D); a query count that is no multiple of 16."""
+    data = ds.fibonacci_training_set(n)
+    q = ds.query_grid(11, scale=1.3)  # 1331 queries: the last wave holds 3
+    for kn, par in KERNELS:
+        om = orc.Model(orc.make_kernel(kn, *par), *data)
+        ref = om.evaluate(*q, want_v=True)
+        m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
+        a, b = _eval(m, q, True), _eval(m, q, False)
+        assert verr_v(a["v"], ref["v"]) < 1e-10, (n, kn, par)
+        assert verr_v(a["v"], b["v"]) < 1e-12, (n, kn, par)
+        assert np.array_equal(a["f"], b["f"])
+        m.close()
+
+
+def test_small_fp64_variance_is_taken_by_promoted_models_and_after_update(gpu, orc, ds):
+    """A model asked for in fp32 but kept in fp64 by the promotion rule (indefinite thin plate) and a model grown by update()
+    go through the same kernel."""
+    data = ds.fibonacci_training_set(300)
+    q = ds.query_grid(9, scale=1.2)
+    om = orc.Model(orc.make_kernel("thinplate", 2.0), *data)
+    ref = om.evaluate(*q, want_v=True)
+    m = gpu.Model(gpu.make_kernel("thinplate", 2.0), *data, precision=gpu.F32, prepare_variance=True)
+    a, b = _eval(m, q, True), _eval(m, q, False)
+    assert m.stats["n_negative_pivots"] > 0  # (the promotion rule's condition: the state is fp64)
+    assert verr_v(a["v"], ref["v"]) < 1e-10 and verr_v(a["v"], b["v"]) < 1e-12
+    m.close()
+    rng = np.random.default_rng(7)  # a handful of points: one row fragment, almost all of it padding
+    for n in (1, 5):
+        P, lab = rng.normal(size=(n, 3)), rng.normal(size=n)
+        cols = (P[:, 0].copy(), P[:, 1].copy(), P[:, 2].copy(), lab, np.full(n, 0.05))
+        qs = tuple(rng.normal(size=7) for _ in range(3))
+        ref = orc.Model(orc.make_kernel("gaussian", 1.0, 1.0), *cols).evaluate(*qs, want_v=True)
+        m = gpu.Model(gpu.make_kernel("gaussian", 1.0, 1.0), *cols, precision=gpu.F64, prepare_variance=True)
+        assert verr_v(_eval(m, qs, True)["v"], ref["v"]) < 1e-10 and verr_v(_eval(m, qs, False)["v"], ref["v"]) < 1e-10
+        m.close()
+    full = ds.fibonacci_training_set(520)
+    head = tuple(np.ascontiguousarray(c[:500]) for c in full)
+    tail = tuple(np.ascontiguousarray(c[500:]) for c in full)
+    om = orc.Model(orc.make_kernel("matern52", 1.0, 1.0), *full)
+    ref = om.evaluate(*q, want_v=True)
+    m = gpu.Model(gpu.make_kernel("matern52", 1.0, 1.0), *head, precision=gpu.F64, prepare_variance=True)
+    v500 = _eval(m, q, True)["v"]
+    assert verr_v(v500, _eval(m, q, False)["v"]) < 1e-12
+    m.update(*tail)  # 520 points: one more pass over the row fragments
+    assert verr_v(_eval(m, q, True)["v"], ref["v"]) < 1e-10
+    m.close()
+
+
+@pytest.mark.parametrize("n", [600, 724, 1024])
+def test_small_fp64_variance_kernel_up_to_its_lds_limit(gpu, orc, ds, n):
+    """Three and four passes over the row fragments; the kernel holds up to 1024 points (above 992 only on request: the
+    general path is faster there)."""
+    data = ds.fibonacci_training_set(n)
+    q = ds.query_grid(8, scale=1.3)
+    for kn, par in (("matern32", (1.0, 1.0)), ("thinplate", (4.0,))):
+        ref = orc.Model(orc.make_kernel(kn, *par), *data).evaluate(*q, want_v=True)
+        m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
+        a, b = _eval(m, q, True, max_n=1024), _eval(m, q, False)
+        assert verr_v(a["v"], ref["v"]) < 1e-10 and verr_v(a["v"], b["v"]) < 1e-12, (n, kn)
+        m.close()
