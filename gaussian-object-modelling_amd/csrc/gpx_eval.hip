@@ -87,8 +87,16 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     (void)hipEventRecord(m->ev[EV_M0], s);
     // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
     // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
-    launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g,
-                   m->ws_pred, s, m->n);
+    // (small fp64 models without a gradient: the mean rides on the operand values of the variance kernel, gpx_varcols64.hip;
+    // GPX_VAR_COLS64_MEAN=0, read per call: the mean kernel as everywhere else)
+    bool mean_fused = use_cols64 && !g;
+    if (mean_fused) {
+        const char *e_ = std::getenv("GPX_VAR_COLS64_MEAN");
+        mean_fused = !e_ || std::atoi(e_) != 0;
+    }
+    if (!mean_fused)
+        launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred, s,
+                       m->n);
     if (want_basis)
         launch_tangent_basis((long)nq, g, tx, ty, s);
     (void)hipEventRecord(m->ev[EV_M1], s);
@@ -98,7 +106,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         if (ev)
             (void)hipEventRecord(ev[0], s);
         launch_var_cols64(m->cov, m->n, np, (const double *)m->X, np, m->d_x, m->d_y, m->d_z, m->d_dinv64, (long)nq, qx, qy, qz, v,
-                          (double *)m->ws_kqp, s);
+                          (double *)m->ws_kqp, s, mean_fused ? m->d_alpha : nullptr, f);
         if (ev)
             (void)hipEventRecord(ev[1], s);
         m->gemm_ev_used_var = ev ? 1 : 0;

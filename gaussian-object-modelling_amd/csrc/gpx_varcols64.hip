@@ -23,7 +23,9 @@
 //   * a workgroup (four waves side by side on the same fragments) is alone on its CU, so the grid is one workgroup per CU
 //     and each walks over its share of the query blocks: the prologue (points, table) runs once;
 //   * w^2 / D is summed per lane straight from the accumulators, the four lane groups are combined at the end, v is written
-//     directly: no operand buffer, no partial sums, no finish launch.
+//     directly: no operand buffer, no partial sums, no finish launch;
+//   * without a gradient request the mean f = sum_p alpha_p k(q, p) rides on the operand values of the last pass (which forms
+//     every chunk of the model): alpha in LDS, 8 FMAs per chunk, no launch of the mean kernel (GPX_VAR_COLS64_MEAN=0: that launch).
 // Measured (profiles/r05_var64_sweep.txt, 2^21 queries): N = 277 6.8 -> 3.65 ms (64 % of the fp64 MFMA peak on the algorithmic
 // triangle, general path 34 %), N = 512 11.1 -> 10.1 ms (71 %), N = 724 22.0 -> 20.2 ms (73 %), N = 900 36.1 -> 30.5 ms; the
 // general path, whose time is flat per 128 rows, is ahead again from ~1000 points.  Where the rest goes
@@ -65,6 +67,8 @@ struct VarCols64Dev {
     int fp;            // fragments per side of the packed copy
     int n, nfrag;  // F = ceil(n / 16)
     const double *px, *py, *pz, *dinv;
+    const double *alpha;  // with f: the GP weights -- the mean f[q] = sum_p alpha_p k(q, p) rides on the operand values of the
+    double *f;            // last pass (every chunk of the model is formed there): 8 FMAs per chunk instead of a launch
     const double *qx, *qy, *qz;
     double *v;
     long nq;
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
 {
     __shared__ double lp[3][VARCOLS64_MAX_N];
     __shared__ double ld[VARCOLS64_MAX_N];
+    __shared__ double la[VARCOLS64_MAX_N];
     const int lane = threadIdx.x & 63, r16 = lane & 15, lg = lane >> 4;
     const int F = g.nfrag, n = g.n;
     // The exponential kernels take e^(-s d) from the 512-entry table of the mean kernel (gpx_cov.hpp, ExpMean: 11 instructions,
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
         const bool in = k < n;
         lp[0][k] = in ? g.px[k] : 0.0, lp[1][k] = in ? g.py[k] : 0.0, lp[2][k] = in ? g.pz[k] : 0.0;
         ld[k] = in ? g.dinv[k] * w2 : 0.0;
+        la[k] = (in && g.f) ? g.alpha[k] * (EXPK ? cov.a : 1.0) : 0.0;
     }
     ExpMean<KID> em;
     if constexpr (EXPK) {
@@ -130,10 +136,10 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
     // passes over row blocks of at most FS64 fragments; the operand is formed once per pass up to the pass's last row, so the
     // SHORT pass comes first (F = 18: 2 + 18 chunks of operand instead of 9 + 18)
     const int npass = (F + FS64 - 1) / FS64;
-    double colsum[CF64];
+    double colsum[CF64], fsum[CF64];
 #pragma unroll
     for (int j = 0; j < CF64; ++j)
-        colsum[j] = 0.0;
+        colsum[j] = fsum[j] = 0.0;
     const unsigned lane_off = (unsigned)(lane * 2 * sizeof(double));  // (lg, r16) -> 16 bytes at (16 lg + r16) * 16
     int f_lo = 0;
     for (int p = 0; p < npass; ++p) {
@@ -191,6 +197,15 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
                         b[j][kk] = em.k(MathFast::sqrt_(d2));
                     else
                         b[j][kk] = cov_k<double, KID, MathFast>(cov, d2);
+                }
+            }
+            if (g.f && p == npass - 1) {  // (uniform; the last pass forms the operand of every chunk)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double al = la[16 * c + 4 * lg + kk];
+#pragma unroll
+                    for (int j = 0; j < CF64; ++j)
+                        fsum[j] = fma(b[j][kk], al, fsum[j]);
                 }
             }
             slot_chain<0, FS64>(nact, [&](auto slot) {
@@ -259,8 +274,16 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
         cs += __shfl_xor(cs, 16);
         cs += __shfl_xor(cs, 32);
         const long q = q0 + 16 * j + r16;
-        if (lg == 0 && q < g.nq)
+        double fs = fsum[j];
+        if (g.f) {
+            fs += __shfl_xor(fs, 16);
+            fs += __shfl_xor(fs, 32);
+        }
+        if (lg == 0 && q < g.nq) {
             g.v[q] = g.k0 - cs;
+            if (g.f)
+                g.f[q] = fs;
+        }
     }
     }
 }
@@ -296,7 +319,7 @@ bool var_cols64_fits(int n, int np, long ldx)
 
 void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ldx, const double *px, const double *py,
                        const double *pz, const double *dinv, long nq, const double *qx, const double *qy, const double *qz,
-                       double *v, double *xt_ws, hipStream_t st)
+                       double *v, double *xt_ws, hipStream_t st, const double *alpha, double *f)
 {
     // The kernel streams 16 x 16 fragments of X, and a lane's MFMA row is its lane number mod 16: read from X itself, every
     // quarter of a wave touches sixteen cache lines for sixteen bytes each, and the L1's tag rate -- not the MFMAs -- sets the
@@ -308,6 +331,7 @@ void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ld
     g.Xp = xt_ws, g.fp = rows / 16;
     g.n = n, g.nfrag = (n + 15) / 16;
     g.px = px, g.py = py, g.pz = pz, g.dinv = dinv;
+    g.alpha = alpha, g.f = alpha ? f : nullptr;
     g.qx = qx, g.qy = qy, g.qz = qz, g.v = v, g.nq = nq;
     g.k0 = h.k0;
     g.cov = lower_cov<double>(h);

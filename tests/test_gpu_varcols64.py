@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import verr_v
+from conftest import nerr, verr_v
 
 pytestmark = pytest.mark.gpu
 
@@ -13,9 +13,11 @@ KERNELS = (("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0)), ("matern32", (1.0,
            ("thinplate", (4.0,)), ("thinplate", (2.0,)))
 
 
-def _eval(m, q, cols64, max_n=None, **kw):
-    """evaluate() with the kernel on or off (both switches are read per call); max_n: GPX_VAR_COLS64_MAX for this call"""
-    new = {"GPX_VAR_COLS64": "1" if cols64 else "0", "GPX_VAR_COLS64_MAX": None if max_n is None else str(max_n)}
+def _eval(m, q, cols64, max_n=None, fused_mean=True, **kw):
+    """evaluate() with the kernel on or off (all switches are read per call); max_n: GPX_VAR_COLS64_MAX for this call;
+    fused_mean=False: the mean from the mean kernel although the variance kernel could carry it"""
+    new = {"GPX_VAR_COLS64": "1" if cols64 else "0", "GPX_VAR_COLS64_MAX": None if max_n is None else str(max_n),
+           "GPX_VAR_COLS64_MEAN": None if fused_mean else "0"}
     old = {k: os.environ.get(k) for k in new}
     for k, val in new.items():
         os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
@@ -36,10 +38,15 @@ def test_small_fp64_variance_matches_the_oracle_and_the_general_path(gpu, orc, d
         om = orc.Model(orc.make_kernel(kn, *par), *data)
         ref = om.evaluate(*q, want_v=True)
         m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
-        a, b = _eval(m, q, True), _eval(m, q, False)
+        a, b, c = _eval(m, q, True), _eval(m, q, False), _eval(m, q, True, fused_mean=False)
         assert verr_v(a["v"], ref["v"]) < 1e-10, (n, kn, par)
         assert verr_v(a["v"], b["v"]) < 1e-12, (n, kn, par)
-        assert np.array_equal(a["f"], b["f"])
+        # the mean: carried by the variance kernel (a), from the mean kernel (b, c); with a gradient always from the mean kernel
+        assert nerr(a["f"], ref["f"]) < 1e-10 and nerr(a["f"], b["f"]) < 1e-12, (n, kn, par)
+        assert np.array_equal(b["f"], c["f"]) and np.array_equal(a["v"], c["v"])
+        d = _eval(m, q, True, want_grad=True)
+        assert nerr(d["f"], b["f"]) < 1e-13 and np.array_equal(d["v"], a["v"])
+        assert nerr(d["grad"], om.evaluate(*q, want_grad=True)["grad"]) < 1e-9
         m.close()
 
 
