@@ -229,6 +229,42 @@ def small_model_roofline(torch, gpx, ds, dev, local_rank):
     return out
 
 
+def small_model_roofline64(torch, gpx, ds, dev, local_rank):
+    """The same at the reference's own arithmetic: fp64 models (what the header shim creates by default) of 277 / 512 / 724 points,
+    evaluate(f, v) on 2^19 lattice queries; var_cols64_kernel (gpx_varcols64.hip: variance AND mean in one launch) against the fp64
+    MFMA peak on the algorithmic flop per query -- the triangle of X per 16 x 16 fragment, 256 F (F + 1), F = ceil(N / 16)."""
+    g = 80
+    t = torch.linspace(-1.01, 1.01, g, dtype=torch.float64, device=dev)
+    idx = torch.arange(0, 2 ** 19, device=dev)
+    q = [t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()]
+    nq = int(idx.numel())
+    f = torch.empty(nq, dtype=torch.float64, device=dev)
+    v = torch.empty_like(f)
+    out = {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "n_query": nq, "traffic": None,
+           "kernel": "var_cols64_kernel<2 column x 16 row fragments, operand formed in the wave, mean carried along> (gpx_varcols64.hip)",
+           "note": "MFMAs, operand evaluation, requests for X and the epilogue run one after the other on a SIMD "
+                   "(profiles/r05_var64_parts.txt); the general fp64 path reaches 34 % at N = 277 (profiles/r05_var64_sweep.txt)",
+           "sizes": {}}
+    for n in (277, 512, 724):
+        m = gpx.Model(gpx.make_kernel("matern52", 1.0, 1.0), *ds.fibonacci_training_set(n), precision=gpx.F64, prepare_variance=True,
+                      device=local_rank)
+        runs = []
+        for i in range(5):
+            m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
+            m.sync()
+            if i:
+                runs.append(dict(m.stats))
+        m.close()
+        mean = {k: float(sum(r[k] for r in runs)) / len(runs) for k in ("t_var_gemm_ms", "t_var_ms", "t_mean_ms")}
+        nf = (n + 15) // 16
+        flops = 256.0 * nf * (nf + 1) * nq
+        a = flops / (mean["t_var_gemm_ms"] * 1e-3) / 1e12
+        out["sizes"][str(n)] = {"kernel_ms": mean["t_var_gemm_ms"], "launches": runs[-1]["var_gemm_launches"], "achieved": a,
+                                "frac": a / PEAK_F64_MFMA_TFLOPS, "variance_stage_ms": mean["t_var_ms"], "mean_ms": mean["t_mean_ms"],
+                                "timing": "mean of 4 evaluations after one warm-up"}
+    return out
+
+
 def surface_config(torch, gpx, ds, dev, local_rank, kern, data, n_train):
     """SURVEY 8f.2 on the headline model: the node's fakeDeterministicSampling (src/gp_node.cpp:998-1100) as ONE call --
     gpx_model_sample_surface over the full 128^3 lattice: mean everywhere, |f| <= 0.01 compacted on the device, variance of
@@ -309,9 +345,9 @@ def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
         f = torch.empty(nq, dtype=torch.float64, device=dev)
         v = torch.empty(nq, dtype=torch.float64, device=dev)
 
-        def all_objects():
+        def all_objects(prec=gpx.F32):
             for d_ in sets:
-                m = gpx.Model(kern, *d_, precision=gpx.F32, prepare_variance=True, device=local_rank)
+                m = gpx.Model(kern, *d_, precision=prec, prepare_variance=True, device=local_rank)
                 m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
                 m.sync()
                 m.close()
@@ -320,6 +356,14 @@ def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
         t0 = time.perf_counter()
         all_objects()
         dt = time.perf_counter() - t0
+        all_objects(gpx.F64)  # the same in the reference's own arithmetic (what the header shim creates by default)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        all_objects(gpx.F64)
+        dt64 = time.perf_counter() - t0
+        out["C5_f64"] = {"workload": "configs.C5 with fp64 models (small-model fp64 kernel, gpx_varcols64.hip: variance and mean in one launch)",
+                         "ms_per_step": dt64 * 1e3, "ms_per_object": dt64 * 1e3 / len(sets), "value": nq * len(sets) / dt64,
+                         "unit": "query-points/s", "n_query": nq * len(sets)}
         out["C5"] = {"workload": "8 objects (%s; N = %s), Gaussian(1,1), fp32 mode, 128^3 grid each, one after "
                                  "the other on ONE GPU (the 8-GPU form is one object per rank: bench.py --gpus 8)"
                                  % (", ".join(names), ", ".join(str(len(d_[0])) for d_ in sets)),
@@ -919,6 +963,10 @@ def main():
                 out["roofline_small"] = small_model_roofline(torch, gpx, ds, dev, local_rank)
             except Exception as e:
                 out["roofline_small"] = {"error": str(e)}
+            try:
+                out["roofline_small64"] = small_model_roofline64(torch, gpx, ds, dev, local_rank)
+            except Exception as e:
+                out["roofline_small64"] = {"error": str(e)}
         if mg:
             out.setdefault("configs", {}).update(mg)
         if world == 1:

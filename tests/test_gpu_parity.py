@@ -48,9 +48,14 @@ def _check(gm, om, q, prec, basis=True):
         ok = gn > 1e-2 * gn.max()
         for key in ("tx", "ty"):
             assert np.max(np.abs(out[key][ok] - ref[key][ok])) < mtol * 1e3, key
-    # the three evaluate overloads agree with each other
+    # the three evaluate overloads agree with each other: to the bit where the mean kernel answers all of them, to rounding for
+    # small fp64 models, whose evaluate(f, v) takes the mean from the variance kernel (another summation order, gpx_varcols64.hip)
     f_only = gm.evaluate(qx, qy, qz)["f"]
-    np.testing.assert_array_equal(f_only, gm.evaluate(qx, qy, qz, want_v=True)["f"])
+    f_with_v = gm.evaluate(qx, qy, qz, want_v=True)["f"]
+    if gm.n <= 992:  # (fp64 state: asked for, or kept by the promotion rule)
+        assert nerr(f_with_v, f_only) < 1e-12
+    else:
+        np.testing.assert_array_equal(f_only, f_with_v)
     return out
 
 
