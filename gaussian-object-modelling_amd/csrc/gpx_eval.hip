@@ -105,7 +105,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         hipEvent_t *ev = (s == m->stream) ? gemm_events(m, m->gemm_ev_used_factor) : nullptr;
         if (ev)
             (void)hipEventRecord(ev[0], s);
-        launch_var_cols64(m->cov, m->n, np, (const double *)m->X, np, m->d_x, m->d_y, m->d_z, m->d_dinv64, (long)nq, qx, qy, qz, v,
+        launch_var_cols64(m->cov, m->n, np, (const double *)m->X, np, m->d_x, m->d_y, m->d_z, (const double *)m->t_dinv /* fp64 model: T = double */, (long)nq, qx, qy, qz, v,
                           (double *)m->ws_kqp, s, mean_fused ? m->d_alpha : nullptr, f);
         if (ev)
             (void)hipEventRecord(ev[1], s);
