@@ -241,7 +241,7 @@ def small_model_roofline64(torch, gpx, ds, dev, local_rank):
     f = torch.empty(nq, dtype=torch.float64, device=dev)
     v = torch.empty_like(f)
     out = {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "n_query": nq, "traffic": None,
-           "kernel": "var_cols64_kernel<2 column x 16 row fragments, operand formed in the wave, mean carried along> (gpx_varcols64.hip)",
+           "kernel": "var_cols64_kernel<2 column x 22 row fragments, operand formed in the wave, mean carried along> (gpx_varcols64.hip)",
            "note": "MFMAs, operand evaluation, requests for X and the epilogue run one after the other on a SIMD "
                    "(profiles/r05_var64_parts.txt); the general fp64 path reaches 34 % at N = 277 (profiles/r05_var64_sweep.txt)",
            "sizes": {}}

@@ -8,8 +8,9 @@
 // its contraction kernel reaches 40 % of the fp64 MFMA peak on the flop it executes and the stage around it costs another third
 // (scripts/var64_sweep.py: 6.8 ms per 2^21 queries = 34 % on the algorithmic flop).  Here, as in the fp32 small-model kernel
 // (gpx_varcols_kernel.hpp) but without its fit:
-//   * a wave owns 32 queries (two column fragments) and up to FS = 16 row fragments (16 rows each) of the product in
-//     accumulators of v_mfma_f64_16x16x4_f64 -- 192 AGPRs + 64 VGPRs, one wave per SIMD; models with more fragments take
+//   * a wave owns 32 queries (two column fragments) and up to FS = 22 row fragments (16 rows each) of the product in
+//     accumulators of v_mfma_f64_16x16x4_f64 -- 224 AGPRs + 128 VGPRs, one wave per SIMD (16 slots: 2-4 % slower at every
+//     size, 24 slots: VGPRs spill into the AGPRs); models of more than 352 points take
 //     passes over row blocks, the short pass first (the operand is formed once per pass up to the pass's last row);
 //   * the k loop runs over 16-deep chunks; chunk c multiplies only the row fragments >= c.  That range always ENDS at the
 //     pass's last fragment, so the slots count from the end and the code of a chunk is a straight line with one exit;
@@ -27,7 +28,7 @@
 //   * without a gradient request the mean f = sum_p alpha_p k(q, p) rides on the operand values of the last pass (which forms
 //     every chunk of the model): alpha in LDS, 8 FMAs per chunk, no launch of the mean kernel (GPX_VAR_COLS64_MEAN=0: that launch).
 // Measured (profiles/r05_var64_sweep.txt, 2^21 queries): N = 277 6.8 -> 3.65 ms (64 % of the fp64 MFMA peak on the algorithmic
-// triangle, general path 34 %), N = 512 11.1 -> 10.1 ms (71 %), N = 724 22.0 -> 20.2 ms (73 %), N = 900 36.1 -> 30.5 ms; the
+// triangle, general path 34 %), N = 512 11.1 -> 10.1 ms (71 %), N = 724 22.0 -> 19.9 ms (74 %), N = 900 36.1 -> 30.0 ms; the
 // general path, whose time is flat per 128 rows, is ahead again from ~1000 points.  Where the rest goes
 // (profiles/r05_var64_parts.txt, N = 277): MFMAs + loop + epilogue 2.9 ms (the MFMAs alone: 2.4), operand 0.5, requests for X
 // 0.25 -- one after the other, since nothing but scalar work hides behind an MFMA of the same SIMD (a second wave per SIMD
@@ -47,7 +48,7 @@ namespace {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef VC64_FS
-#define VC64_FS 16
+#define VC64_FS 22
 #endif
 constexpr int FS64 = VC64_FS;  // row-fragment slots per pass
 constexpr int WGS_PER_CU64 = FS64 <= 8 ? 2 : 1;
@@ -56,7 +57,7 @@ constexpr int WGS_PER_CU64 = FS64 <= 8 ? 2 : 1;
 #endif
 constexpr int AHEAD64 = VC64_AHEAD, RING64 = AHEAD64 + 1;  // fragments of X requested ahead of their MFMAs; register sets
 #ifndef VC64_AGPR
-#define VC64_AGPR 12
+#define VC64_AGPR 14
 #endif
 constexpr int AGPR_SLOTS = VC64_AGPR;  // slots whose accumulators live in AGPRs (the others: VGPRs -- 256 of each per wave)
 constexpr int CF64 = 2;   // column fragments (16 queries each) per wave: a fragment of X feeds 8 MFMAs

@@ -28,9 +28,9 @@ def _eval(m, q, cols64, max_n=None, fused_mean=True, **kw):
             os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
 
 
-@pytest.mark.parametrize("n", [16, 17, 33, 166, 256, 257, 277, 448, 512])
+@pytest.mark.parametrize("n", [16, 17, 33, 166, 277, 352, 353, 448, 512])
 def test_small_fp64_variance_matches_the_oracle_and_the_general_path(gpu, orc, ds, n):
-    """One row fragment, the fragment edges, one and two passes over the row fragments (256 / 257 rows), the largest size;
+    """One row fragment, the fragment edges, one and two passes over the row fragments (352 / 353 rows), a larger size;
     six kernels incl. the indefinite ThinPlate(2.0) (negative 1/D); a query count that is no multiple of 16."""
     data = ds.fibonacci_training_set(n)
     q = ds.query_grid(11, scale=1.3)  # 1331 queries: the last wave holds 3
@@ -86,7 +86,7 @@ def test_small_fp64_variance_is_taken_by_promoted_models_and_after_update(gpu, o
 
 @pytest.mark.parametrize("n", [600, 724, 1024])
 def test_small_fp64_variance_kernel_up_to_its_lds_limit(gpu, orc, ds, n):
-    """Three and four passes over the row fragments; the kernel holds up to 1024 points (above 992 only on request: the
+    """Two and three passes over the row fragments; the kernel holds up to 1024 points (above 992 only on request: the
     general path is faster there)."""
     data = ds.fibonacci_training_set(n)
     q = ds.query_grid(8, scale=1.3)
