@@ -218,6 +218,61 @@ def guard_small_model_accumulator_reads(lib_path, tmp_dir):
         assert checked >= 32, (sym, checked)
 
 
+def guard_small_fp64_accumulators(lib_path, tmp_dir):
+    """gpx_varcols64.hip: 22 x 2 fp64 accumulator fragments per wave, 14 slots tied to AGPRs and 8 to VGPRs through inline-asm
+    MFMAs.  (1) Every definition of an AGPR accumulator is an MFMA (zeroing included): a v_accvgpr_write / _mov in the kernel
+    means the register allocator gave accumulators a second home again and copies them around the MFMA statements (one
+    build carried 430 such moves in the chunk loop).  (2) No scratch.  (3) hipcc pads no hazard behind an asm MFMA: the first
+    read of an accumulator by anything but an MFMA (v_accvgpr_read, or a VALU source for the VGPR slots) must lie behind
+    >= 16 wait states or two later MFMAs (the matrix pipe completes in order)."""
+    import re
+    dis = disassemble(lib_path, tmp_dir, "var_cols64_kernel")
+    assert len(dis) == 4, sorted(dis)
+
+    def regs(tok, cls):
+        m = re.fullmatch(cls + r"\[(\d+):(\d+)\]", tok)
+        if m:
+            return range(int(m.group(1)), int(m.group(2)) + 1)
+        m = re.fullmatch(cls + r"(\d+)", tok)
+        return range(int(m.group(1)), int(m.group(1)) + 1) if m else range(0)
+    for sym, lines in dis.items():
+        pending = {}  # ('a' | 'v', register) -> [MFMAs issued when it was last written by an MFMA, wait states since]
+        n_mfma = reads = 0
+        for l in lines:
+            text = l.split("//")[0].strip()
+            if not text:
+                continue
+            op, _, rest = text.partition(" ")
+            toks = [t.strip() for t in rest.split(",")]
+            assert not op.startswith("scratch_"), (sym, text)
+            assert op not in ("v_accvgpr_write_b32", "v_accvgpr_mov_b32"), (sym, text)
+            if op.startswith("v_mfma"):
+                n_mfma += 1
+                for cls in "av":
+                    for r in regs(toks[0], cls):
+                        pending[(cls, r)] = [n_mfma, 0]
+                continue
+            if op == "s_nop":
+                for v in pending.values():
+                    v[1] += int(toks[0]) + 1
+                continue
+            if op == "v_accvgpr_read_b32":
+                srcs = [("a", r) for r in regs(toks[1], "a")]
+            elif op.startswith("v_"):
+                srcs = [("v", r) for t in toks[1:] for r in regs(t, "v")]
+            else:
+                srcs = []
+            for key in srcs:
+                if key in pending:
+                    reads += 1
+                    w, nops = pending.pop(key)  # (only the first read behind the write is the hazard)
+                    assert n_mfma - w >= 2 or nops >= 16, (sym, text, n_mfma - w, nops)
+            if op.startswith("v_") or op.startswith("global_load") or op.startswith("ds_read"):
+                for r in regs(toks[0], "v"):  # overwritten by other code: no longer an MFMA result
+                    pending.pop(("v", r), None)
+        assert n_mfma >= 16 * 8 + 28 and reads >= 14 * 16, (sym, n_mfma, reads)
+
+
 def guard_split_contraction_staging(lib_path, tmp_dir):
     """gpx_vsplit.hip: the k-tiles of the F32_SPLIT contraction arrive by LDS-DMA (global_load_lds_dwordx4), 8 per wave and
     tile, with no ds_write in the main loop; two workgroups must fit a CU (<= 256 registers, 64 KiB of LDS each).  An
@@ -259,4 +314,5 @@ def check_library(lib_path):
         guard_one_wave_main_loops(lib_path, td)
         guard_one_wave_accumulators(lib_path, td)
         guard_small_model_accumulator_reads(lib_path, td)
+        guard_small_fp64_accumulators(lib_path, td)
         guard_split_contraction_staging(lib_path, td)

@@ -116,6 +116,13 @@ def test_small_model_variance_kernels_read_no_accumulator_in_flight(gpx, tmp_pat
 
 
 
+def test_small_fp64_variance_kernel_keeps_its_accumulators_in_place(gpx, tmp_path):
+    """gpx_varcols64.hip: 14 accumulator slots tied to AGPRs and 8 to VGPRs through inline-asm MFMAs -- no accumulator copies
+    (v_accvgpr_write / _mov) anywhere in the kernel, no scratch, and no read of an accumulator by anything but an MFMA before
+    16 wait states or two later MFMAs have passed."""
+    codeobj.guard_small_fp64_accumulators(gpx.LIB_PATH, tmp_path)
+
+
 def test_split_contraction_stages_by_lds_dma_behind_a_vmcnt_wait(gpx, tmp_path):
     """gpx_vsplit.hip: the k-tiles of the F32_SPLIT contraction arrive by LDS-DMA (global_load_lds_dwordx4), 8 per wave and
     tile, with no ds_write in the main loop; two workgroups must fit a CU (<= 256 registers, 64 KiB of LDS each).  An
