@@ -250,4 +250,147 @@ __device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, doubl
     }
 }
 
+// ---- the same on TWO waves: wave 0 factorises, wave 1 inverts one step behind -----------------------------------------------
+// The updates of X = L11^-1 take the same A operand as those of the block (the scaled column l_j) but feed nothing back into the
+// chain of pivots, and they are 2 of the 3-5 MFMAs of a step.  Wave 0 keeps the block: per step it publishes column j of L in
+// Lx and then the step count in *prog (LDS operations of a wave execute in order); wave 1 -- on another SIMD -- waits for the
+// count, reads the column back as its A operand and applies it to its rows of X.  prog counts from `base` (the caller zeroes it
+// behind a barrier and passes 32 * (number of sub-blocks done)).  Same arithmetic as subblock_ldl (the pivot of the next step is
+// formed ahead of the update, by the same fused multiply-add).  Measured: 7.3 -> 6.0 us per sub-block -- the step is a chain of
+// latencies (MFMA result -> lane broadcast -> scaled column -> MFMA), not of MFMA issue slots: wave 0 alone, with neither the
+// inverse nor the reciprocal on its chain, still needs 6.2 us.  fp64 only: the fp32 form of the same protocol (32 x 32 x 2 MFMA,
+// two workgroups per CU) gave results that differed from run to run in the inverse blocks; the cause was not found, so the
+// fp32 factorisations keep the one-wave routine above.
+// (the pointers are cast to the LDS address space by hand: through a generic volatile pointer hipcc emits flat loads and
+// stores with system scope, hundreds of cycles each -- the first build of the pair was no faster than one wave for that)
+#define GPX_LDS(T_) __attribute__((address_space(3))) T_
+__device__ __forceinline__ void ldl_publish(volatile int *prog, int v)
+{
+    asm volatile("" ::: "memory");
+    *(volatile GPX_LDS(int) *)prog = v;
+    asm volatile("" ::: "memory");
+}
+// wave 1: the value at `src` of a column that is complete once *prog >= need.  `seen` is the last count read: a column known to be
+// published is read without a poll; otherwise count and value are requested together, count first -- LDS operations execute in
+// order, so a value read behind a count that was high enough is the published one.
+template <typename T>
+__device__ __forceinline__ T ldl_column(volatile int *prog, int need, int &seen, const T *src, bool take)
+{
+    const volatile GPX_LDS(T) *vs = (const volatile GPX_LDS(T) *)src;
+    if (seen >= need)
+        return take ? *vs : T(0);
+    T val;
+    do {
+        seen = __builtin_amdgcn_readfirstlane(*(volatile GPX_LDS(int) *)prog);
+        val = take ? *vs : T(0);
+    } while (seen < need);
+    return val;
+}
+
+__device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, double *Xdb, int lane, int wave, double &dvec,
+                                                  volatile int *prog, int base)
+{
+    typedef double T;
+    const int g = lane >> 4, c = lane & 15;
+    // (stores of the columns through the LDS address space as well: a flat store and a ds_write of one wave are NOT ordered)
+    GPX_LDS(T) *LxL = (GPX_LDS(T) *)Lx;
+    if (wave == 0) {
+        f64x4 T00, T01, T11;
+        {
+            const T *b1 = Dn + g * PLD + c, *b2 = Dn + c * PLD + g;  // (row 4 r + g, col c) and its mirror image
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * r + g;
+                const T lo = b1[4 * r * PLD], up = b2[4 * r];
+                const T lo11 = b1[(16 + 4 * r) * PLD + 16], up11 = b2[16 * PLD + 16 + 4 * r];
+                T00[r] = row > c ? lo : up;
+                T01[r] = b2[16 * PLD + 4 * r];
+                T11[r] = row > c ? lo11 : up11;
+            }
+        }
+        // The pivot of step j + 1 does not wait for the MFMAs of step j: it is element (j + 1, j + 1) minus l_{j+1,j} times
+        // element (j, j + 1), both known before them -- the same fused multiply-add the matrix core applies to that element --
+        // so its reciprocal (an estimate and two Newton steps, the longest part of the chain between two steps) is formed
+        // while the update is in the pipe.
+        T dj = bcast_lane(T00[0], 0);
+        T rinv = fast_rcp(dj);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = j >> 2, gj = j & 3;
+            const T row0 = T00[r], row1 = T01[r];
+            const T l0 = row0 * rinv, l1 = row1 * rinv;
+            const bool ing = g == gj, act = ing && c > j;
+            const T a0 = act ? -l0 : 0.0, a1 = ing ? -l1 : 0.0;
+            if (lane == j)
+                dvec = dj;
+            if (act)
+                LxL[c * PLD + j] = l0;
+            if (ing)
+                LxL[(16 + c) * PLD + j] = l1;
+            ldl_publish(prog, base + j + 1);
+            // next pivot: j + 1 < 16 in T00 (row j + 1 = register (j + 1) / 4 of lane group (j + 1) % 4), else (16, 16) in T11
+            const T m = j < 15 ? bcast_lane(row0, 16 * gj + j + 1) : bcast_lane(row1, 16 * gj);
+            const T old = j < 15 ? bcast_lane(T00[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1) : bcast_lane(T11[0], 0);
+            T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row0, T00, 0, 0, 0);
+            T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row1, T01, 0, 0, 0);
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
+            dj = fma(-(m * rinv), m, old);
+            rinv = fast_rcp(dj);
+        }
+#pragma unroll
+        for (int j = 16; j < NB; ++j) {
+            const int jj = j - 16, r = jj >> 2, gj = jj & 3;
+            const T row1 = T11[r];
+            const T l1 = row1 * rinv;
+            const bool act = g == gj && c > jj;
+            const T a1 = act ? -l1 : 0.0;
+            if (lane == j)
+                dvec = dj;
+            if (act)
+                LxL[(16 + c) * PLD + j] = l1;
+            ldl_publish(prog, base + j + 1);
+            const T m = jj < 15 ? bcast_lane(row1, 16 * gj + jj + 1) : 0.0;
+            const T old = jj < 15 ? bcast_lane(T11[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1) : 1.0;
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
+            dj = fma(-(m * rinv), m, old);
+            rinv = fast_rcp(dj);
+        }
+    } else {
+        f64x4 X00, X10, X11;
+        int seen = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            X00[r] = 4 * r + g == c ? 1.0 : 0.0;
+            X10[r] = 0.0;
+            X11[r] = 4 * r + g == c ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = j >> 2, gj = j & 3;
+            const bool ing = g == gj, act = ing && c > j;
+            const T a0 = -ldl_column(prog, base + j + 1, seen, Lx + c * PLD + j, act);
+            const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, ing);
+            const T xr = X00[r];
+            X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xr, X00, 0, 0, 0);
+            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xr, X10, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 16; j < NB; ++j) {
+            const int jj = j - 16, r = jj >> 2, gj = jj & 3;
+            const bool act = g == gj && c > jj;
+            const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, act);
+            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X10[r], X10, 0, 0, 0);
+            X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X11[r], X11, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            Xdb[row * PLD + c] = X00[r];
+            Xdb[row * PLD + 16 + c] = 0.0;
+            Xdb[(16 + row) * PLD + c] = X10[r];
+            Xdb[(16 + row) * PLD + 16 + c] = X11[r];
+        }
+    }
+}
+
 }  // namespace gpx

@@ -29,6 +29,7 @@
 // wait for later ones: FULL needs the whole grid resident (<= 136 workgroups), the mid-size form only the next column's
 // first workgroup.
 #pragma once
+#include <type_traits>
 #include "gpx_blk.hpp"
 #include "gpx_cov.hpp"
 #include "gpx_small.hpp"
@@ -43,7 +44,8 @@ constexpr int SBLK = NB * PLD;  // one 32 x 32 block in LDS (elements), row stri
 // conflicts).  With the 33-element rows and one element per read the LDS reads of the four waves took as long as their MFMAs.
 constexpr int WLD = 36, WBLK = NB * WLD;
 constexpr int DF_THREADS = 256;
-constexpr int DF_LDS_ELEMS = 12 * WBLK + 2 * ST + 4 * ST + 3 * ST;
+constexpr int DF_LDS_PROG = 12 * WBLK + 2 * ST + 4 * ST + 3 * ST;  // step counter of the two-wave sub-block factorisation
+constexpr int DF_LDS_ELEMS = DF_LDS_PROG + 2;
 typedef unsigned long long u64;
 
 #ifdef SM_TIMING
@@ -520,19 +522,28 @@ __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallA
     if (i == j) {
         // ---- diagonal tile: LDL^T of the 64 x 64 block and the inverse of its L (gp_regressor.hpp:161-162) ----
         acc.store(T(1), bufC + (qi * 2 + qj) * SBLK, (T *)nullptr, 0, lane);
+        volatile int *prog = reinterpret_cast<volatile int *>(sm + DF_LDS_PROG);
+        if (tid == 0)
+            *prog = 0;
         __syncthreads();
         SM_STAMP(6);
         T *Lx0 = bufA, *W21 = bufA + SBLK, *L21 = bufA + 2 * SBLK, *Lx1 = bufA + 3 * SBLK;
         T *Xd0 = bufB, *T0 = bufB + SBLK, *X10 = bufB + 2 * SBLK, *Xd1 = bufB + 3 * SBLK;
         T *A21 = bufC + 2 * SBLK, *A22 = bufC + 3 * SBLK;
-        // The two 32 x 32 sub-blocks are factorised (and their L inverted) by wave 0, one rank-1 MFMA update per column
-        // (gpx_blk.hpp: 6.9 us each in fp64); the products between them are shared by the four waves, a 16 x 16 tile each.
+        // The two 32 x 32 sub-blocks are factorised by wave 0, one rank-1 MFMA update per column, and -- in fp64 -- their L
+        // inverted by wave 1 one step behind (gpx_blk.hpp, subblock_ldl_pair; fp32: both on wave 0); the products between them
+        // are shared by the four waves, a 16 x 16 tile each.
         const int i2 = wave >> 1, j2 = wave & 1;
         const int tcol = 16 * j2 + (lane & 15);
         T dv = T(1);
         unsigned long long mneg = 0, mbad = 0;
-        if (wave == 0) {
+        if constexpr (std::is_same<T, double>::value) {
+            if (wave <= 1)
+                subblock_ldl_pair(bufC, Lx0, Xd0, lane, wave, dv, prog, 0);
+        } else if (wave == 0) {
             subblock_ldl(bufC, Lx0, Xd0, lane, dv);
+        }
+        if (wave == 0) {
             if (lane < NB) {
                 dvec[lane] = dv;
                 dinvv[lane] = T(1) / dv;
@@ -570,8 +581,13 @@ __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallA
         }
         __syncthreads();
         SM_STAMP(18);
-        if (wave == 0) {
+        if constexpr (std::is_same<T, double>::value) {
+            if (wave <= 1)
+                subblock_ldl_pair(A22, Lx1, Xd1, lane, wave, dv, prog, NB);
+        } else if (wave == 0) {
             subblock_ldl(A22, Lx1, Xd1, lane, dv);
+        }
+        if (wave == 0) {
             if (lane < NB) {
                 dvec[NB + lane] = dv;
                 dinvv[NB + lane] = T(1) / dv;
