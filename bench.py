@@ -765,7 +765,10 @@ def main():
                 # also forms are not counted)
                 whole = (n_train ** 3 / 3.0) / (st["t_factor_ms"] * 1e-3) / 1e12
                 out["roofline_factor"] = {
-                    "bound": "mfma", "kernel": "mid_factor_kernel<%s> (kernel matrix + LDL^T, dataflow over 64 x 64 tiles, one launch)" % gemm_t,
+                    "bound": "mfma",
+                    "kernel": ("wide_factor_kernel<%s> (kernel matrix + LDL^T as one dataflow launch over 128 x 128 tiles, csrc/gpx_dataflow_wide.hpp)"
+                               if n_train >= 8192 else
+                               "mid_factor_kernel<%s> (kernel matrix + LDL^T as one dataflow launch over 64 x 64 tiles, csrc/gpx_dataflow.hpp)") % gemm_t,
                     "achieved": whole, "peak": peak, "unit": "TFLOP/s", "frac": whole / peak, "ms": st["t_factor_ms"],
                     "what": "N^3/3 flop / t_factor_ms (everything between the upload of the points and the alpha solve)",
                     "whole_ldlt": {"what": "the same figure (one launch)", "achieved": whole, "frac": whole / peak, "ms": st["t_factor_ms"]}}
