@@ -96,3 +96,30 @@ def test_small_fp64_variance_kernel_up_to_its_lds_limit(gpu, orc, ds, n):
         a, b = _eval(m, q, True, max_n=1024), _eval(m, q, False)
         assert verr_v(a["v"], ref["v"]) < 1e-10 and verr_v(a["v"], b["v"]) < 1e-12, (n, kn)
         m.close()
+
+
+def test_small_fp64_variance_on_random_clouds_kernels_and_query_counts(gpu, orc):
+    """Forty seeded cases: anisotropic, uncentred clouds of 16 .. 992 points, every kernel with hyper-parameters away from 1,
+    query counts from 1 to a few thousand (partial waves, partial workgroups): the kernel against the general fp64 path (v: 1e-11)
+    and -- for the smaller models -- the oracle."""
+    rng = np.random.default_rng(20151106)
+    kinds = ("gaussian", "laplace", "matern32", "matern52", "thinplate")
+    for case in range(40):
+        n = int(rng.integers(16, 993))
+        P = rng.normal(size=(n, 3)) * rng.uniform(0.2, 1.5, size=3) + rng.uniform(-2.0, 2.0, size=3)
+        lab = np.where(rng.uniform(size=n) < 0.1, 1.0, 0.0) + 0.01 * rng.normal(size=n)
+        s2 = np.full(n, float(rng.uniform(1e-3, 5e-2)))
+        kn = kinds[case % len(kinds)]
+        span = float(np.max(np.linalg.norm(P - P.mean(axis=0), axis=1)))
+        par = (2.5 * span,) if kn == "thinplate" else (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.3, 1.5)))
+        nq = int(rng.choice([1, 7, 31, 33, 127, 129, 1000, 4099]))
+        q = tuple(P[rng.integers(0, n, size=nq), k] + 0.3 * rng.normal(size=nq) for k in range(3))
+        cols = tuple(np.ascontiguousarray(P[:, k]) for k in range(3)) + (lab, s2)
+        m = gpu.Model(gpu.make_kernel(kn, *par), *cols, precision=gpu.F64, prepare_variance=True)
+        a, b = _eval(m, q, True), _eval(m, q, False)
+        # (the mean of a thin-plate model is an alternating sum of terms ~R^3: two summation orders differ by 1e-16 of THAT)
+        assert verr_v(a["v"], b["v"]) < 1e-11 and nerr(a["f"], b["f"]) < 1e-9, (case, n, kn, par, nq)
+        if n <= 300:
+            ref = orc.Model(orc.make_kernel(kn, *par), *cols).evaluate(*q, want_v=True)
+            assert verr_v(a["v"], ref["v"]) < 1e-9 and nerr(a["f"], ref["f"]) < 1e-9, (case, n, kn, par, nq)
+        m.close()
