@@ -280,7 +280,7 @@ constexpr int VARCOLS64_DEFAULT_N = 992;  // models routed to it (GPX_VAR_COLS64
 bool var_cols64_fits(int n, int np, long ldx);
 void launch_var_cols64(const CovHost &cov, int n, int np, const double *X, long ldx, const double *px, const double *py,
                        const double *pz, const double *dinv, long nq, const double *qx, const double *qy, const double *qz,
-                       double *v, double *xt_ws /* var_cols64_ws_bytes(n) */, hipStream_t st, const double *alpha = nullptr,
+                       double *v, double *xp_ws /* var_cols64_ws_bytes(n) */, hipStream_t st, const double *alpha = nullptr,
                        double *f = nullptr /* with alpha: the mean too, f[q] = sum_p alpha_p k(q, p) */);
 size_t var_cols64_ws_bytes(int n);
 

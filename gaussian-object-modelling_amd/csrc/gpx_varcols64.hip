@@ -125,179 +125,179 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
     // per 128 queries: the grid is one workgroup per CU and each walks over its share of the query blocks.
     const long per_wg = 16L * CF64 * WAVES64, nblk = (g.nq + per_wg - 1) / per_wg;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const long q0 = (blk * WAVES64 + (threadIdx.x >> 6)) * (16 * CF64);
-    if (q0 >= g.nq)
-        break;  // (a wave past the last query)
-    double ax[CF64], ay[CF64], az[CF64];
+        const long q0 = (blk * WAVES64 + (threadIdx.x >> 6)) * (16 * CF64);
+        if (q0 >= g.nq)
+            break;  // (a wave past the last query)
+        double ax[CF64], ay[CF64], az[CF64];
 #pragma unroll
-    for (int j = 0; j < CF64; ++j) {  // (columns past the last query work on the last query's data and are not written)
-        const long q = q0 + 16 * j + r16, qc = q < g.nq ? q : g.nq - 1;
-        ax[j] = g.qx[qc], ay[j] = g.qy[qc], az[j] = g.qz[qc];
-    }
-    // passes over row blocks of at most FS64 fragments; the operand is formed once per pass up to the pass's last row, so the
-    // SHORT pass comes first (F = 18: 2 + 18 chunks of operand instead of 9 + 18)
-    const int npass = (F + FS64 - 1) / FS64;
-    double colsum[CF64], fsum[CF64];
+        for (int j = 0; j < CF64; ++j) {  // (columns past the last query work on the last query's data and are not written)
+            const long q = q0 + 16 * j + r16, qc = q < g.nq ? q : g.nq - 1;
+            ax[j] = g.qx[qc], ay[j] = g.qy[qc], az[j] = g.qz[qc];
+        }
+        // passes over row blocks of at most FS64 fragments; the operand is formed once per pass up to the pass's last row, so the
+        // SHORT pass comes first (F = 18: 2 + 18 chunks of operand instead of 9 + 18)
+        const int npass = (F + FS64 - 1) / FS64;
+        double colsum[CF64], fsum[CF64];
 #pragma unroll
-    for (int j = 0; j < CF64; ++j)
-        colsum[j] = fsum[j] = 0.0;
-    const unsigned lane_off = (unsigned)(lane * 2 * sizeof(double));  // (lg, r16) -> 16 bytes at (16 lg + r16) * 16
-    int f_lo = 0;
-    for (int p = 0; p < npass; ++p) {
-        const int nfr = p == 0 ? F - FS64 * (npass - 1) : FS64, f_hi = f_lo + nfr;
-        f64x4 acc[FS64][CF64];
-        // (the AGPR accumulators are zeroed by an MFMA of zeros: every definition of them is then tied to an AGPR and the
-        // register allocator gives them no second home in VGPRs -- with a plain assignment it copies eight slots in and out
-        // around every MFMA statement)
-        const double zero = 0.0;
+        for (int j = 0; j < CF64; ++j)
+            colsum[j] = fsum[j] = 0.0;
+        const unsigned lane_off = (unsigned)(lane * 2 * sizeof(double));  // (lg, r16) -> 16 bytes at (16 lg + r16) * 16
+        int f_lo = 0;
+        for (int p = 0; p < npass; ++p) {
+            const int nfr = p == 0 ? F - FS64 * (npass - 1) : FS64, f_hi = f_lo + nfr;
+            f64x4 acc[FS64][CF64];
+            // (the AGPR accumulators are zeroed by an MFMA of zeros: every definition of them is then tied to an AGPR and the
+            // register allocator gives them no second home in VGPRs -- with a plain assignment it copies eight slots in and out
+            // around every MFMA statement)
+            const double zero = 0.0;
 #pragma unroll
-        for (int il = 0; il < FS64; ++il)
+            for (int il = 0; il < FS64; ++il)
 #pragma unroll
-            for (int j = 0; j < CF64; ++j)
-                if (il < AGPR_SLOTS)
-                    asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %1, 0" : "=a"(acc[il][j]) : "v"(zero));
-                else
-                    acc[il][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma nounroll
-        for (int c = 0; c < f_hi; ++c) {
-            // Row fragments max(c, f_lo) .. f_hi - 1 take part: a range that always ENDS at the pass's last fragment, so the slots
-            // count from the end (slot r = fragment f_hi - 1 - r) and the active ones are r < nact -- a straight line of code with
-            // one exit, in which the compiler counts the requests in flight exactly.  Slices of X are requested four fragments
-            // ahead of the MFMAs that use them, the first four before the operand is formed, into a ring of five register sets
-            // (the set a request lands in is never the one the current MFMAs read: no copy, no wait); past the last active
-            // fragment the request repeats it (an L1 hit, never used).
-            const int nact = f_hi - max(c, f_lo);
-            // fragment (c, f) of the packed copy: 2 KB at ((c fp + f) * 256) doubles, the lane's two halves 1 KB apart
-            const int xc = (c * g.fp + f_hi - 1) * 256;
-            f64x2 alo[RING64], ahi[RING64];
-            auto load_a = [&](int r, f64x2 &lo, f64x2 &hi) {
-                if constexpr (DBG >= 3) {
-                    lo = f64x2{ax[0], ay[0]}, hi = f64x2{az[0], ax[1]};
-                    return;
-                }
-                const char *src = reinterpret_cast<const char *>(g.Xp + (xc - 256 * min(r, nact - 1))) + lane_off;
-                lo = *reinterpret_cast<const f64x2 *>(src);
-                hi = *reinterpret_cast<const f64x2 *>(src + 1024);
-            };
-#pragma unroll
-            for (int u = 0; u < AHEAD64; ++u)
-                load_a(u, alo[u], ahi[u]);
-            // the lane's operand values of the chunk: k(|q - p|), p = 16 c + 4 lg + kk, for its query of either column fragment
-            double b[CF64][4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int pi = 16 * c + 4 * lg + kk;
-                const double x = lp[0][pi], y = lp[1][pi], z = lp[2][pi];
-#pragma unroll
-                for (int j = 0; j < CF64; ++j) {
-                    const double dx = ax[j] - x, dy = ay[j] - y, dz = az[j] - z;
-                    const double d2 = dx * dx + dy * dy + dz * dz + 1e-300;
-                    if constexpr (DBG == 1 || DBG == 4)
-                        b[j][kk] = d2;
-                    else if constexpr (EXPK)
-                        b[j][kk] = em.k(MathFast::sqrt_(d2));
+                for (int j = 0; j < CF64; ++j)
+                    if (il < AGPR_SLOTS)
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %1, 0" : "=a"(acc[il][j]) : "v"(zero));
                     else
-                        b[j][kk] = cov_k<double, KID, MathFast>(cov, d2);
-                }
-            }
-            if (g.f && p == npass - 1) {  // (uniform; the last pass forms the operand of every chunk)
+                        acc[il][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma nounroll
+            for (int c = 0; c < f_hi; ++c) {
+                // Row fragments max(c, f_lo) .. f_hi - 1 take part: a range that always ENDS at the pass's last fragment, so
+                // the slots count from the end (slot r = fragment f_hi - 1 - r) and the active ones are r < nact -- a straight
+                // line of code with one exit, in which the compiler counts the requests in flight exactly.  Slices of X are
+                // requested four fragments ahead of the MFMAs that use them, the first four before the operand is formed, into
+                // a ring of five register sets (the set a request lands in is never the one the current MFMAs read: no copy,
+                // no wait); past the last active fragment the request repeats it (an L1 hit, never used).
+                const int nact = f_hi - max(c, f_lo);
+                // fragment (c, f) of the packed copy: 2 KB at ((c fp + f) * 256) doubles, the lane's two halves 1 KB apart
+                const int xc = (c * g.fp + f_hi - 1) * 256;
+                f64x2 alo[RING64], ahi[RING64];
+                auto load_a = [&](int r, f64x2 &lo, f64x2 &hi) {
+                    if constexpr (DBG >= 3) {
+                        lo = f64x2{ax[0], ay[0]}, hi = f64x2{az[0], ax[1]};
+                        return;
+                    }
+                    const char *src = reinterpret_cast<const char *>(g.Xp + (xc - 256 * min(r, nact - 1))) + lane_off;
+                    lo = *reinterpret_cast<const f64x2 *>(src);
+                    hi = *reinterpret_cast<const f64x2 *>(src + 1024);
+                };
+#pragma unroll
+                for (int u = 0; u < AHEAD64; ++u)
+                    load_a(u, alo[u], ahi[u]);
+                // the lane's operand values of the chunk: k(|q - p|), p = 16 c + 4 lg + kk, for its query of either column fragment
+                double b[CF64][4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const double al = la[16 * c + 4 * lg + kk];
+                    const int pi = 16 * c + 4 * lg + kk;
+                    const double x = lp[0][pi], y = lp[1][pi], z = lp[2][pi];
 #pragma unroll
-                    for (int j = 0; j < CF64; ++j)
-                        fsum[j] = fma(b[j][kk], al, fsum[j]);
+                    for (int j = 0; j < CF64; ++j) {
+                        const double dx = ax[j] - x, dy = ay[j] - y, dz = az[j] - z;
+                        const double d2 = dx * dx + dy * dy + dz * dz + 1e-300;
+                        if constexpr (DBG == 1 || DBG == 4)
+                            b[j][kk] = d2;
+                        else if constexpr (EXPK)
+                            b[j][kk] = em.k(MathFast::sqrt_(d2));
+                        else
+                            b[j][kk] = cov_k<double, KID, MathFast>(cov, d2);
+                    }
                 }
-            }
-            slot_chain<0, FS64>(nact, [&](auto slot) {
-                constexpr int il = decltype(slot)::value;
-                {
-                    // (asm operands inside a lambda must be the lambda's own variables)
-                    f64x4 &c0 = acc[il][0], &c1 = acc[il][1];
-                    const double b00 = b[0][0], b01 = b[0][1], b02 = b[0][2], b03 = b[0][3];
-                    const double b10 = b[1][0], b11 = b[1][1], b12 = b[1][2], b13 = b[1][3];
-                    const f64x2 a0 = alo[il % RING64], a1 = ahi[il % RING64];
-                    load_a(il + AHEAD64, alo[(il + AHEAD64) % RING64], ahi[(il + AHEAD64) % RING64]);
-                    // (one statement: the two column fragments alternate, so consecutive MFMAs are independent, and no VALU
-                    // write can be scheduled into the two wait states in front of an MFMA that reads it)
+                if (g.f && p == npass - 1) {  // (uniform; the last pass forms the operand of every chunk)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double al = la[16 * c + 4 * lg + kk];
+#pragma unroll
+                        for (int j = 0; j < CF64; ++j)
+                            fsum[j] = fma(b[j][kk], al, fsum[j]);
+                    }
+                }
+                slot_chain<0, FS64>(nact, [&](auto slot) {
+                    constexpr int il = decltype(slot)::value;
+                    {
+                        // (asm operands inside a lambda must be the lambda's own variables)
+                        f64x4 &c0 = acc[il][0], &c1 = acc[il][1];
+                        const double b00 = b[0][0], b01 = b[0][1], b02 = b[0][2], b03 = b[0][3];
+                        const double b10 = b[1][0], b11 = b[1][1], b12 = b[1][2], b13 = b[1][3];
+                        const f64x2 a0 = alo[il % RING64], a1 = ahi[il % RING64];
+                        load_a(il + AHEAD64, alo[(il + AHEAD64) % RING64], ahi[(il + AHEAD64) % RING64]);
+                        // (one statement: the two column fragments alternate, so consecutive MFMAs are independent, and no VALU
+                        // write can be scheduled into the two wait states in front of an MFMA that reads it)
 #define VC64_MFMAS(CLS_)                                                                                                 \
-    asm volatile("s_nop 1\n"                                                                                             \
-                 "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n"                                                               \
-                 "v_mfma_f64_16x16x4_f64 %1, %2, %10, %1\n"                                                              \
-                 "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n"                                                               \
-                 "v_mfma_f64_16x16x4_f64 %1, %3, %11, %1\n"                                                              \
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n"                                                               \
-                 "v_mfma_f64_16x16x4_f64 %1, %4, %12, %1\n"                                                              \
-                 "v_mfma_f64_16x16x4_f64 %0, %5, %9, %0\n"                                                               \
-                 "v_mfma_f64_16x16x4_f64 %1, %5, %13, %1"                                                                 \
-                 : CLS_(c0), CLS_(c1)                                                                                    \
-                 : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10),     \
-                   "v"(b11), "v"(b12), "v"(b13))
-                    if constexpr (DBG == 2 && il < AGPR_SLOTS)
-                        asm volatile("" : "+a"(c0), "+a"(c1) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10), "v"(b11), "v"(b12), "v"(b13));
-                    else if constexpr (DBG == 2)
-                        asm volatile("" : "+v"(c0), "+v"(c1) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10), "v"(b11), "v"(b12), "v"(b13));
-                    else if constexpr (il < AGPR_SLOTS)
-                        VC64_MFMAS("+a");
-                    else
-                        VC64_MFMAS("+v");
+        asm volatile("s_nop 1\n"                                                                                             \
+                     "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %1, %2, %10, %1\n"                                                              \
+                     "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %1, %3, %11, %1\n"                                                              \
+                     "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %1, %4, %12, %1\n"                                                              \
+                     "v_mfma_f64_16x16x4_f64 %0, %5, %9, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %1, %5, %13, %1"                                                                 \
+                     : CLS_(c0), CLS_(c1)                                                                                    \
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03), "v"(b10),     \
+                       "v"(b11), "v"(b12), "v"(b13))
+                        if constexpr (DBG == 2 && il < AGPR_SLOTS)
+                            asm volatile("" : "+a"(c0), "+a"(c1) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01),
+                                         "v"(b02), "v"(b03), "v"(b10), "v"(b11), "v"(b12), "v"(b13));
+                        else if constexpr (DBG == 2)
+                            asm volatile("" : "+v"(c0), "+v"(c1) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01),
+                                         "v"(b02), "v"(b03), "v"(b10), "v"(b11), "v"(b12), "v"(b13));
+                        else if constexpr (il < AGPR_SLOTS)
+                            VC64_MFMAS("+a");
+                        else
+                            VC64_MFMAS("+v");
 #undef VC64_MFMAS
-                }
-            });
-        }
-        // the accumulators are read by the VALU from here on: the MFMA's wait states first (hipcc pads no hazard whose producer
-        // sits inside an asm string), every accumulator tied behind them (asm statements keep their order)
-        asm volatile("s_nop 15\n s_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]));
-#pragma unroll
-        for (int il = 1; il < FS64; ++il)
-            if (il < AGPR_SLOTS)
-                asm volatile("" : "+a"(acc[il][0]), "+a"(acc[il][1]));
-            else
-                asm volatile("" : "+v"(acc[il][0]), "+v"(acc[il][1]));
-        // w^2 / D of the pass's rows: register r of lane (lg, query) in slot il is row 16 (f_hi - 1 - il) + 4 r + lg
-#pragma unroll
-        for (int il = 0; il < FS64; ++il)
-            if (il < nfr) {
-                const int r0 = 16 * (f_hi - 1 - il) + lg;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double di = ld[r0 + 4 * r];
-#pragma unroll
-                    for (int j = 0; j < CF64; ++j)
-                        colsum[j] = fma(acc[il][j][r] * acc[il][j][r], di, colsum[j]);
-                }
+                    }
+                });
             }
-        f_lo = f_hi;
-    }
+            // the accumulators are read by the VALU from here on: the MFMA's wait states first (hipcc pads no hazard whose producer
+            // sits inside an asm string), every accumulator tied behind them (asm statements keep their order)
+            asm volatile("s_nop 15\n s_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]));
 #pragma unroll
-    for (int j = 0; j < CF64; ++j) {
-        double cs = colsum[j];
-        cs += __shfl_xor(cs, 16);
-        cs += __shfl_xor(cs, 32);
-        const long q = q0 + 16 * j + r16;
-        double fs = fsum[j];
-        if (g.f) {
-            fs += __shfl_xor(fs, 16);
-            fs += __shfl_xor(fs, 32);
+            for (int il = 1; il < FS64; ++il)
+                if (il < AGPR_SLOTS)
+                    asm volatile("" : "+a"(acc[il][0]), "+a"(acc[il][1]));
+                else
+                    asm volatile("" : "+v"(acc[il][0]), "+v"(acc[il][1]));
+            // w^2 / D of the pass's rows: register r of lane (lg, query) in slot il is row 16 (f_hi - 1 - il) + 4 r + lg
+#pragma unroll
+            for (int il = 0; il < FS64; ++il)
+                if (il < nfr) {
+                    const int r0 = 16 * (f_hi - 1 - il) + lg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double di = ld[r0 + 4 * r];
+#pragma unroll
+                        for (int j = 0; j < CF64; ++j)
+                            colsum[j] = fma(acc[il][j][r] * acc[il][j][r], di, colsum[j]);
+                    }
+                }
+            f_lo = f_hi;
         }
-        if (lg == 0 && q < g.nq) {
-            g.v[q] = g.k0 - cs;
-            if (g.f)
-                g.f[q] = fs;
+#pragma unroll
+        for (int j = 0; j < CF64; ++j) {
+            double cs = colsum[j];
+            cs += __shfl_xor(cs, 16);
+            cs += __shfl_xor(cs, 32);
+            const long q = q0 + 16 * j + r16;
+            double fs = fsum[j];
+            if (g.f) {
+                fs += __shfl_xor(fs, 16);
+                fs += __shfl_xor(fs, 32);
+            }
+            if (lg == 0 && q < g.nq) {
+                g.v[q] = g.k0 - cs;
+                if (g.f)
+                    g.f[q] = fs;
+            }
         }
-    }
     }
 }
 // X (lower triangular, leading rows x rows part, rows a multiple of 32) in the order the variance kernel reads it:
 // Xp[c][f][h][lg][r16][e] = X[16 f + r16][16 c + 4 lg + 2 h + e] for the fragments f >= c (the others are never read)
-__global__ __launch_bounds__(256) void pack64_kernel(const double *X, long ldx, double *Xp, int fp)
+__global__ __launch_bounds__(128) void pack64_kernel(const double *X, long ldx, double *Xp, int fp)
 {
     const int f = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
     if (f < c)
         return;
-    const int h = t >> 6, lg = (t >> 4) & 3, r16 = t & 15;  // (128 threads per half: t = 64 h + 16 lg + r16 < 128)
-    if (t >= 128)
-        return;
+    const int h = t >> 6, lg = (t >> 4) & 3, r16 = t & 15;  // (128 threads: t = 64 h + 16 lg + r16)
     const f64x2 val = *reinterpret_cast<const f64x2 *>(X + (size_t)(16 * f + r16) * ldx + 16 * c + 4 * lg + 2 * h);
     *reinterpret_cast<f64x2 *>(Xp + ((size_t)(c * fp + f) * 256 + t * 2)) = val;
 }
@@ -320,16 +320,16 @@ bool var_cols64_fits(int n, int np, long ldx)
 
 void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ldx, const double *px, const double *py,
                        const double *pz, const double *dinv, long nq, const double *qx, const double *qy, const double *qz,
-                       double *v, double *xt_ws, hipStream_t st, const double *alpha, double *f)
+                       double *v, double *xp_ws, hipStream_t st, const double *alpha, double *f)
 {
     // The kernel streams 16 x 16 fragments of X, and a lane's MFMA row is its lane number mod 16: read from X itself, every
     // quarter of a wave touches sixteen cache lines for sixteen bytes each, and the L1's tag rate -- not the MFMAs -- sets the
     // time (measured: 3.4 ms of 4.0 at N = 277 with the MFMAs taken out).  So X is first copied into fragment order (a wave's
     // request = two contiguous KB); for a model of <= 1024 points that costs microseconds and is redone per call: no state.
     const int rows = (n + 31) / 32 * 32;
-    hipLaunchKernelGGL(pack64_kernel, dim3(rows / 16, rows / 16), dim3(128), 0, st, X, ldx, xt_ws, rows / 16);
+    hipLaunchKernelGGL(pack64_kernel, dim3(rows / 16, rows / 16), dim3(128), 0, st, X, ldx, xp_ws, rows / 16);
     VarCols64Dev g;
-    g.Xp = xt_ws, g.fp = rows / 16;
+    g.Xp = xp_ws, g.fp = rows / 16;
     g.n = n, g.nfrag = (n + 15) / 16;
     g.px = px, g.py = py, g.pz = pz, g.dinv = dinv;
     g.alpha = alpha, g.f = alpha ? f : nullptr;
