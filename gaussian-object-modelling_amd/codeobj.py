@@ -225,9 +225,20 @@ def guard_small_fp64_accumulators(lib_path, tmp_dir):
     build carried 430 such moves in the chunk loop).  (2) No scratch.  (3) hipcc pads no hazard behind an asm MFMA: the first
     read of an accumulator by anything but an MFMA (v_accvgpr_read, or a VALU source for the VGPR slots) must lie behind
     >= 16 wait states or two later MFMAs (the matrix pipe completes in order)."""
+    _guard_asm_accumulators(lib_path, tmp_dir, "var_cols64_kernel", 4, "v_mfma_f64", 16 * 8 + 28, 14 * 16)
+
+
+def guard_small_split_accumulators(lib_path, tmp_dir):
+    """gpx_varcols16.hip, the same construction on v_mfma_f32_16x16x32_f16: 22 slots of a main and a correction accumulator for
+    two column fragments (16 registers per slot), 16 slots tied to AGPRs and 6 to VGPRs.  Same three conditions (the fp64
+    MFMAs of its add-back are compiler builtins, whose hazards hipcc pads itself: only the asm ones are tracked)."""
+    _guard_asm_accumulators(lib_path, tmp_dir, "var_cols16_kernel", 3, "v_mfma_f32_16x16x32", 22 * 6 + 64, 16 * 16)
+
+
+def _guard_asm_accumulators(lib_path, tmp_dir, name, n_kernels, mfma_op, min_mfma, min_reads):
     import re
-    dis = disassemble(lib_path, tmp_dir, "var_cols64_kernel")
-    assert len(dis) == 4, sorted(dis)
+    dis = disassemble(lib_path, tmp_dir, name)
+    assert len(dis) == n_kernels, sorted(dis)
 
     def regs(tok, cls):
         m = re.fullmatch(cls + r"\[(\d+):(\d+)\]", tok)
@@ -248,9 +259,10 @@ def guard_small_fp64_accumulators(lib_path, tmp_dir):
             assert op not in ("v_accvgpr_write_b32", "v_accvgpr_mov_b32"), (sym, text)
             if op.startswith("v_mfma"):
                 n_mfma += 1
-                for cls in "av":
-                    for r in regs(toks[0], cls):
-                        pending[(cls, r)] = [n_mfma, 0]
+                if op.startswith(mfma_op):
+                    for cls in "av":
+                        for r in regs(toks[0], cls):
+                            pending[(cls, r)] = [n_mfma, 0]
                 continue
             if op == "s_nop":
                 for v in pending.values():
@@ -270,7 +282,7 @@ def guard_small_fp64_accumulators(lib_path, tmp_dir):
             if op.startswith("v_") or op.startswith("global_load") or op.startswith("ds_read"):
                 for r in regs(toks[0], "v"):  # overwritten by other code: no longer an MFMA result
                     pending.pop(("v", r), None)
-        assert n_mfma >= 16 * 8 + 28 and reads >= 14 * 16, (sym, n_mfma, reads)
+        assert n_mfma >= min_mfma and reads >= min_reads, (sym, n_mfma, reads)
 
 
 def guard_split_contraction_staging(lib_path, tmp_dir):
@@ -315,4 +327,5 @@ def check_library(lib_path):
         guard_one_wave_accumulators(lib_path, td)
         guard_small_model_accumulator_reads(lib_path, td)
         guard_small_fp64_accumulators(lib_path, td)
+        guard_small_split_accumulators(lib_path, td)
         guard_split_contraction_staging(lib_path, td)

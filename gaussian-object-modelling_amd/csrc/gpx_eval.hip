@@ -54,6 +54,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         vc.cen[0] = m->cen[0], vc.cen[1] = m->cen[1], vc.cen[2] = m->cen[2];
     }
     const bool cols_gen = use_cols && var_cols_gen(vc);
+    // small models of the split-fp16 mode: the same structure on the fp16 matrix cores (gpx_varcols16.hip)
+    const bool use_cols16 = cols_gen && m->opt.precision == GPX_PREC_F32_SPLIT && var_cols16_takes(vc);
     // small fp64 models (the header shim's default precision at the reference's own sizes): one kernel, no workspace
     // (gpx_varcols64.hip)
     const bool use_cols64 = v && m->prec == GPX_PREC_F64 && !m->var_fit && !m->x_packed && var_cols64_fits(m->n, np, np);
@@ -62,6 +64,11 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     // every path; the default of the small-model kernel is the whole call in slices of 2^21 queries)
     const size_t cols_cap = m->opt.query_batch > 0 ? (size_t)m->qbatch : (size_t)1 << 21;
     const size_t qbatch = cols_gen ? std::min<size_t>(nq_tiles, cols_cap) : std::min<size_t>((size_t)m->qbatch, nq_tiles);
+    if (use_cols16) {
+        int rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, var_cols16_ws_bytes(m->n));  // X split and in fragment order (per call)
+        if (rc)
+            return rc;
+    }
     if (use_cols64) {
         int rc = ensure(m, &m->ws_kqp, &m->ws_kqp_bytes, var_cols64_ws_bytes(m->n));  // X^T of the call
         if (rc)
@@ -112,6 +119,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         m->gemm_ev_used_var = ev ? 1 : 0;
         m->kqp_ev_used = 0;
     } else if (v) {
+        if (use_cols16)
+            launch_var_cols16_pack(vc, m->sk, m->ws_kqp, s);
         const size_t qb = qbatch;
         const int np_rows = std::min(np, (m->n + TILE - 1) / TILE * TILE);  // 128-row blocks that hold training points
         const long ldk = (long)np + KQP_LDPAD;  // row stride of the operand buffer (not the power of two X's is)
@@ -185,7 +194,10 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
                 vc.qx = qx + q0, vc.qy = qy + q0, vc.qz = qz + q0;
                 if (ev)
                     (void)hipEventRecord(ev[0], s);
-                launch_var_cols(vc, s);
+                if (use_cols16)
+                    launch_var_cols16(vc, m->sk, m->ws_kqp, s);
+                else
+                    launch_var_cols(vc, s);
                 if (ev) {
                     (void)hipEventRecord(ev[1], s);
                     ++gi;

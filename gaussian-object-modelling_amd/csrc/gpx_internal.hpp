@@ -248,7 +248,7 @@ int gemm_tile_n(int cfg);
 // triangle of X skipped per 16-row fragment, ONE fp64 epilogue per accumulator fragment) and writes v = k(0) - sum w^2 / D
 // directly: no partial sums, no var_finish.  For fp32 contractions with the fit (var_fit) of up to VARCOLS_MAX_N points.
 constexpr int VARCOLS_MAX_N = 1024;
-constexpr int SPLIT_MIN_N = 464;  // F32_SPLIT models of up to this many points keep the fp32 small-model kernel (gpx_build.hip: pack_split)
+constexpr int SPLIT_MIN_N = 1024;  // F32_SPLIT models of up to this many points keep X in fp32: their variance kernel (gpx_varcols16.hip) splits and packs it per call
 struct VarColsArgs {
     const float *X = nullptr;  // inverse factor [np][ldx]
     long ldx = 0;
@@ -271,6 +271,14 @@ struct VarColsArgs {
 bool var_cols_fits(int n, int np, long ldx, long ldk);
 bool var_cols_gen(const VarColsArgs &a);  // true: launch_var_cols forms the operand itself -- no launch_kqp needed
 void launch_var_cols(const VarColsArgs &a, hipStream_t st);
+
+// ---- small models in the split-fp16 mode : gpx_varcols16.hip ------------------------------------------
+// the same contraction on v_mfma_f32_16x16x32_f16 with hi / lo halves (fp32 accuracy), operand formed in the wave, fit added
+// back in fp64; a: as for launch_var_cols with compact coefficients; ws: var_cols16_ws_bytes(n), filled by ..._pack once per call
+bool var_cols16_takes(const VarColsArgs &a);
+size_t var_cols16_ws_bytes(int n);
+void launch_var_cols16_pack(const VarColsArgs &a, float sk, void *ws, hipStream_t st);
+void launch_var_cols16(const VarColsArgs &a, float sk, const void *ws, hipStream_t st);
 
 // ---- variance of small fp64 models : gpx_varcols64.hip ----------------------------------------------
 // v = k(0) - sum_m (X k_q)_m^2 / D_m for nq queries in one launch: operand formed in the wave, every row fragment resident,

@@ -26,11 +26,9 @@
 //   kqp_split                 : Kqp[q][j] = k(|q-p_j|)     -> P16 directly (never stored in fp32)
 //   vsplit_gemm               : partial[mt][q] = sum_rows (X Kqp^T)^2 w[row],  w = 1/D / (sx sk)^2
 #include "gpx_cov.hpp"
+#include "gpx_split.hpp"
 
 namespace gpx {
-
-using half_t = _Float16;
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
 
 // ---- scale + split of the inverse factor ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_absmax_kernel(const float *__restrict__ X, size_t n,
@@ -47,16 +45,6 @@ __global__ __launch_bounds__(256) void split_absmax_kernel(const float *__restri
         atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like their bits
 }
 
-__device__ __forceinline__ float pow2_scale_below_one(float amax)
-{
-    // largest power of two s with s * amax < 1 (amax > 0); 1 for an all-zero matrix
-    if (!(amax > 0.0f))
-        return 1.0f;
-    int e;
-    (void)frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, -e);
-}
-
 // w[j] = dinv[j] / (sx sk)^2: the weights of the plain epilogue (accumulators in scaled units);
 // *inv_scale = 1 / (sx sk): what the fp64 epilogue multiplies the accumulators with before the fit is added back
 __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *dinv,
@@ -70,35 +58,6 @@ __global__ __launch_bounds__(256) void split_weights_kernel(int n, const float *
         w[i] = dinv[i] * inv * inv;
     if (i == 0 && inv_scale)
         *inv_scale = (double)inv;
-}
-
-// One call = the 8 consecutive k that ONE lane feeds to the fp16 MFMA (32x32x16 and 16x16x32 alike).  The matrix core adds the 8
-// products of such a group in fixed point, aligned to the largest of them and TRUNCATED 24 bits below it
-// (scripts/mfma_tree_probe.hip), i.e. with an error relative to the largest product, not to the (here heavily
-// cancelling) sum.  So the hi halves of a group share one quantum q = ulp_fp16(max |x|): every hi is an integer
-// multiple of q, every hi*hi product of the group is an integer multiple of q_x q_k within 22 bits of the largest
-// one, and the group sum is exact.  What hi loses on the small entries of a group moves into lo.
-__device__ __forceinline__ float group_quantum(float amax)
-{
-    int e;
-    (void)frexpf(amax, &e);  // amax in [2^(e-1), 2^e): fp16 ulp there is 2^(e-11), never below the subnormal 2^-24
-    return ldexpf(1.0f, max(e - 11, -24));
-}
-
-__device__ __forceinline__ void split8(const float (&v)[8], float s, half8 &hi, half8 &lo)
-{
-    float amax = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        amax = fmaxf(amax, fabsf(v[c] * s));
-    const float q = group_quantum(amax), qi = 1.0f / q;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float x = v[c] * s;
-        const float h = rintf(x * qi) * q;  // exact: q is a power of two
-        hi[c] = (half_t)h;
-        lo[c] = (half_t)((x - h) * 2048.0f);
-    }
 }
 
 // In place: the 32 fp32 values of one k-block (128 bytes) become the 128 bytes [hi(32) | lo(32)] of the same

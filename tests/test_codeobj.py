@@ -123,6 +123,11 @@ def test_small_fp64_variance_kernel_keeps_its_accumulators_in_place(gpx, tmp_pat
     codeobj.guard_small_fp64_accumulators(gpx.LIB_PATH, tmp_path)
 
 
+def test_small_split_fp16_variance_kernel_keeps_its_accumulators_in_place(gpx, tmp_path):
+    """gpx_varcols16.hip: the same construction on v_mfma_f32_16x16x32_f16 (16 AGPR + 6 VGPR slots of 16 registers)."""
+    codeobj.guard_small_split_accumulators(gpx.LIB_PATH, tmp_path)
+
+
 def test_split_contraction_stages_by_lds_dma_behind_a_vmcnt_wait(gpx, tmp_path):
     """gpx_vsplit.hip: the k-tiles of the F32_SPLIT contraction arrive by LDS-DMA (global_load_lds_dwordx4), 8 per wave and
     tile, with no ds_write in the main loop; two workgroups must fit a CU (<= 256 registers, 64 KiB of LDS each).  An

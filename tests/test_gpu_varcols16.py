@@ -1,0 +1,63 @@
+"""GPU suite: small models of the opt-in split-fp16 mode (GPX_PREC_F32_SPLIT) on the fp16 matrix cores (csrc/gpx_varcols16.hip)
+-- against the fp64 pipeline, the oracle and its twin, the fp32 small-model kernel (GPX_VAR_COLS16=0, read per call)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import nerr, verr_v
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval(m, q, cols16, **kw):
+    old = os.environ.get("GPX_VAR_COLS16")
+    os.environ["GPX_VAR_COLS16"] = "1" if cols16 else "0"
+    try:
+        return m.evaluate(*q, want_v=True, **kw)
+    finally:
+        os.environ.pop("GPX_VAR_COLS16", None) if old is None else os.environ.__setitem__("GPX_VAR_COLS16", old)
+
+
+@pytest.mark.parametrize("n", [16, 33, 166, 277, 352, 353, 512, 704, 705, 1024])
+def test_split_fp16_small_model_variance_matches_fp64_and_its_fp32_twin(gpu, orc, ds, n):
+    """One chunk, fragment and chunk edges, one / two / three passes over the row fragments (352 | 353, 704 | 705 rows), the
+    largest size; the four exponential kernels; a query count that fills neither the last wave nor the last workgroup.
+    The north star's tolerance for an fp32 mode: 1e-5 of max|v|; measured 5e-7 .. 2.5e-6 (scripts/var16_check.py)."""
+    data = ds.fibonacci_training_set(n)
+    q = ds.query_grid(11, scale=1.3)
+    for kn, par in (("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0)), ("matern32", (1.0, 1.0)), ("matern52", (1.0, 1.0))):
+        m64 = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
+        ref = m64.evaluate(*q, want_v=True)
+        m64.close()
+        m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F32_SPLIT, prepare_variance=True)
+        a, b = _eval(m, q, True), _eval(m, q, False)
+        assert verr_v(a["v"], ref["v"]) < 1e-5 and verr_v(b["v"], ref["v"]) < 1e-5, (n, kn)
+        assert not np.array_equal(a["v"], b["v"])  # (each took its own kernel)
+        assert np.array_equal(a["f"], b["f"]) and nerr(a["f"], ref["f"]) < 1e-5
+        if n <= 300:
+            o = orc.Model(orc.make_kernel(kn, *par), *data).evaluate(*q, want_v=True)
+            assert verr_v(a["v"], o["v"]) < 1e-5
+        m.close()
+
+
+def test_split_fp16_small_models_thin_plate_and_growth(gpu, orc, ds):
+    """The thin plate forms its operand in fp64: those models keep the fp32 kernel (the switch changes nothing); a model grown by
+    update() past 1024 points packs its inverse factor and moves to the 128 x 128 split contraction."""
+    data = ds.fibonacci_training_set(300)
+    q = ds.query_grid(9, scale=1.2)
+    m = gpu.Model(gpu.make_kernel("thinplate", 4.0), *data, precision=gpu.F32_SPLIT, prepare_variance=True)
+    a, b = _eval(m, q, True), _eval(m, q, False)
+    assert np.array_equal(a["v"], b["v"])
+    m.close()
+    full = ds.fibonacci_training_set(1100)
+    head = tuple(np.ascontiguousarray(c[:1000]) for c in full)
+    tail = tuple(np.ascontiguousarray(c[1000:]) for c in full)
+    m64 = gpu.Model(gpu.make_kernel("matern52", 1.0, 1.0), *full, precision=gpu.F64, prepare_variance=True)
+    ref = m64.evaluate(*q, want_v=True)
+    m64.close()
+    m = gpu.Model(gpu.make_kernel("matern52", 1.0, 1.0), *head, precision=gpu.F32_SPLIT, prepare_variance=True)
+    _eval(m, q, True)
+    m.update(*tail)
+    assert verr_v(_eval(m, q, True)["v"], ref["v"]) < 1e-5
+    m.close()
