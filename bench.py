@@ -361,6 +361,15 @@ def extra_configs(torch, gpx, ds, sharding, dev, local_rank):
         t0 = time.perf_counter()
         all_objects(gpx.F64)
         dt64 = time.perf_counter() - t0
+        all_objects(gpx.F32_SPLIT)  # ... and in the opt-in split-fp16 mode (small models: gpx_varcols16.hip)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        all_objects(gpx.F32_SPLIT)
+        dts = time.perf_counter() - t0
+        out["C5_split"] = {"workload": "configs.C5 in the opt-in GPX_PREC_F32_SPLIT mode (fp16 matrix cores, hi / lo halves, fp32 accuracy: "
+                                       "gpx_varcols16.hip for the models of <= 1024 points)",
+                           "ms_per_step": dts * 1e3, "ms_per_object": dts * 1e3 / len(sets), "value": nq * len(sets) / dts,
+                           "unit": "query-points/s", "n_query": nq * len(sets)}
         out["C5_f64"] = {"workload": "configs.C5 with fp64 models (small-model fp64 kernel, gpx_varcols64.hip: variance and mean in one launch)",
                          "ms_per_step": dt64 * 1e3, "ms_per_object": dt64 * 1e3 / len(sets), "value": nq * len(sets) / dt64,
                          "unit": "query-points/s", "n_query": nq * len(sets)}
