@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64 * WAVES16, 1) void var_cols16_kernel(VarCols16De
 #pragma unroll
         for (int c = 0; c < VAR_NCORR; ++c)
             rowc[c * nr + k] = g.rowcorr[(size_t)c * g.ldrc + k];
-        dinv[k] = g.dinv64[k];
+        dinv[k] = k < n ? g.dinv64[k] : 0.0;  // (rows of the padding: weight 0, so the operand needs no mask -- the points of the
+                                              // padding sit at the centre and meet zero columns of X in the rows of the model)
     }
     const Cov<float> cov = g.cov;
     const double inv = *g.inv_scale;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64 * WAVES16, 1) void var_cols16_kernel(VarCols16De
                             const float d2 = dx * dx + dy * dy + dz * dz;
                             float kv = cov_k<float, KID>(cov, d2);
                             kv -= fa[j] + d2 * (fb[j] + fc[j] * d2);
-                            val[e] = p0 + e < n ? kv : 0.0f;
+                            val[e] = kv;
                         }
                         split8(val, sk, bh[j], bl[j]);
                     }
