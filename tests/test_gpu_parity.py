@@ -133,6 +133,25 @@ def test_c5_objects_from_pcd(gpu, orc, ds, name):
     gm.close()
 
 
+@pytest.mark.parametrize("name", ["bowlA", "containerA", "kettle"])
+def test_c5_objects_in_the_fp64_and_the_split_fp16_mode(gpu, orc, ds, name):
+    """BASELINE config 5 in its two other forms (bench.py: configs.C5_f64, configs.C5_split): the reference's own arithmetic --
+    small fp64 models answer evaluate(f, v) with one kernel (gpx_varcols64.hip) -- and the opt-in split-fp16 mode on the fp16
+    matrix cores (gpx_varcols16.hip), 128^3 lattice, oracle on a sub-sample; split mode: 5e-6 of max v."""
+    x, y, z, lab, s2 = gpu.node_training_set(gpu.pcd_read(os.path.join(GOLDEN_DIR, "pcd", name + ".pcd")))
+    om = orc.Model(orc.make_kernel("gaussian", 1, 1), x, y, z, lab, s2)
+    qx, qy, qz = ds.query_grid(128)
+    sel = np.arange(0, 128 ** 3, 2999)
+    ref = om.evaluate(qx[sel], qy[sel], qz[sel], want_v=True)
+    for prec, tol_f, tol_v in ((gpu.F64, 1e-9, 1e-9), (gpu.F32_SPLIT, 1e-5, 5e-6)):
+        gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), x, y, z, lab, s2, precision=prec)
+        out = gm.evaluate(qx, qy, qz, want_v=True)
+        assert nerr(out["f"][sel], ref["f"]) < tol_f, (name, prec)
+        assert verr_v(out["v"][sel], ref["v"]) < tol_v, (name, prec)
+        assert float(out["v"].min()) > -1e-6  # (the whole lattice, not only the sub-sample)
+        gm.close()
+
+
 def test_single_training_point(gpu, orc):
     for prec in (1, 0):
         gm = gpu.Model(gpu.make_kernel("gaussian", 1, 1), [0.2], [0.0], [-0.1], [1.0], [0.1], precision=prec)
