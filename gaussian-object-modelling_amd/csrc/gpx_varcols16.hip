@@ -41,6 +41,11 @@ constexpr int AGPR16 = VC16_AGPR;  // slots whose accumulators (main + correctio
 constexpr int CF16 = 2;      // column fragments (16 queries each) per wave
 constexpr int WAVES16 = 4;   // waves per workgroup, one per SIMD
 constexpr int AHEAD16 = 4, RING16 = AHEAD16 + 1;
+// diagnostic builds only (make EXTRA=-DVC16_DBG=n OUTDIR=../lib_dn OBJDIR=../build_dn; results wrong by construction):
+// 1 operand not evaluated, 2 no MFMAs in the chunk loop, 3 no requests for X -- how the kernel's time splits
+#ifndef VC16_DBG
+#define VC16_DBG 0
+#endif
 
 struct VarCols16Dev {
     const half8 *Xq;  // X in fragment order (pack16_kernel)
@@ -161,6 +166,10 @@ __global__ __launch_bounds__(64 * WAVES16, 1) void var_cols16_kernel(VarCols16De
                 const int xc = (c * g.fp + f_hi - 1) * 128;  // in 16-byte units: 2 KB per (chunk, fragment)
                 half8 ahi[RING16], alo[RING16];
                 auto load_a = [&](int r, half8 &hi, half8 &lo) {
+                    if constexpr (VC16_DBG == 3) {
+                        hi = lo = half8{1, 1, 1, 1, 1, 1, 1, 1};
+                        return;
+                    }
                     const half8 *src = g.Xq + (xc - 128 * min(r, nact - 1)) + lane;
                     hi = src[0], lo = src[64];
                 };
@@ -182,11 +191,18 @@ __global__ __launch_bounds__(64 * WAVES16, 1) void var_cols16_kernel(VarCols16De
                         for (int e = 0; e < 8; ++e) {
                             const float dx = ax[j] - x[e], dy = ay[j] - y[e], dz = az[j] - z[e];
                             const float d2 = dx * dx + dy * dy + dz * dz;
-                            float kv = cov_k<float, KID>(cov, d2);
-                            kv -= fa[j] + d2 * (fb[j] + fc[j] * d2);
+                            float kv = VC16_DBG == 1 ? d2 : cov_k<float, KID>(cov, d2);
+                            if (VC16_DBG != 1)
+                                kv -= fa[j] + d2 * (fb[j] + fc[j] * d2);
                             val[e] = kv;
                         }
-                        split8(val, sk, bh[j], bl[j]);
+                        if constexpr (VC16_DBG == 1) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                bh[j][e] = bl[j][e] = (half_t)val[e];
+                        } else {
+                            split8(val, sk, bh[j], bl[j]);
+                        }
                     }
                 }
                 slot_chain16<0, FS16>(nact, [&](auto slot) {
@@ -205,7 +221,11 @@ __global__ __launch_bounds__(64 * WAVES16, 1) void var_cols16_kernel(VarCols16De
                  "v_mfma_f32_16x16x32_f16 %3, %4, %9, %3"                                              \
                  : CLS_(m0), CLS_(m1), CLS_(c0), CLS_(c1)                                              \
                  : "v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1))
-                    if constexpr (il < AGPR16)
+                    if constexpr (VC16_DBG == 2 && il < AGPR16)
+                        asm volatile("" : "+a"(m0), "+a"(m1), "+a"(c0), "+a"(c1) : "v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+                    else if constexpr (VC16_DBG == 2)
+                        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(c0), "+v"(c1) : "v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+                    else if constexpr (il < AGPR16)
                         VC16_MFMAS("+a");
                     else
                         VC16_MFMAS("+v");
