@@ -61,3 +61,32 @@ def test_split_fp16_small_models_thin_plate_and_growth(gpu, orc, ds):
     m.update(*tail)
     assert verr_v(_eval(m, q, True)["v"], ref["v"]) < 1e-5
     m.close()
+
+
+def test_split_fp16_small_models_on_random_clouds_kernels_and_query_counts(gpu):
+    """Thirty seeded cases: anisotropic, uncentred clouds of 16 .. 1024 points, the exponential kernels with hyper-parameters away
+    from 1, query counts from 1 to a few thousand (partial waves and workgroups): 1e-5 of max|v| against the fp64 pipeline, for the
+    fp16 matrix-core kernel and for its fp32 twin."""
+    rng = np.random.default_rng(20151107)
+    kinds = ("gaussian", "laplace", "matern32", "matern52")
+    worst = 0.0
+    for case in range(30):
+        n = int(rng.integers(16, 1025))
+        P = rng.normal(size=(n, 3)) * rng.uniform(0.3, 1.5, size=3) + rng.uniform(-2.0, 2.0, size=3)
+        lab = np.where(rng.uniform(size=n) < 0.1, 1.0, 0.0) + 0.01 * rng.normal(size=n)
+        s2 = np.full(n, float(rng.uniform(1e-3, 5e-2)))
+        kn = kinds[case % len(kinds)]
+        par = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.3, 1.5)))
+        nq = int(rng.choice([1, 7, 31, 33, 127, 129, 1000, 4099]))
+        q = tuple(P[rng.integers(0, n, size=nq), k] + 0.3 * rng.normal(size=nq) for k in range(3))
+        cols = tuple(np.ascontiguousarray(P[:, k]) for k in range(3)) + (lab, s2)
+        m64 = gpu.Model(gpu.make_kernel(kn, *par), *cols, precision=gpu.F64, prepare_variance=True)
+        ref = m64.evaluate(*q, want_v=True)
+        m64.close()
+        m = gpu.Model(gpu.make_kernel(kn, *par), *cols, precision=gpu.F32_SPLIT, prepare_variance=True)
+        a, b = _eval(m, q, True), _eval(m, q, False)
+        ea, eb = verr_v(a["v"], ref["v"]), verr_v(b["v"], ref["v"])
+        worst = max(worst, ea)
+        assert ea < 1e-5 and eb < 1e-5, (case, n, kn, par, nq, ea, eb)
+        m.close()
+    print("worst split-fp16 error over the random cases: %.2e" % worst)
