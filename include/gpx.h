@@ -85,8 +85,9 @@ typedef struct gpx_kernel {
  *   F32_SPLIT  as F32, but the variance contraction runs on the fp16 matrix cores with every fp32 operand
  *          carried as hi + lo fp16 halves (3 MFMA products, fp32 accumulation); the hi halves of each MFMA
  *          k-group share one quantum, which makes the matrix core's fixed-point product sums exact: measured
- *          as accurate as F32 (better for N >= 4096) at ~0.4x its time; opt-in.  Models of up to 464 points keep the fp32
- *          contraction (faster there: no operand travels through memory) */
+ *          as accurate as F32 (better for N >= 4096) at ~0.4x its time; opt-in.  Models of up to 1024 points form and split
+ *          the operand inside the kernel (no operand travels through memory): 1.3-2x the F32 small-model kernel; their
+ *          thin-plate form keeps the fp32 contraction */
 typedef enum { GPX_PREC_F32 = 0, GPX_PREC_F64 = 1, GPX_PREC_MIXED = 2, GPX_PREC_F32_SPLIT = 3 } gpx_precision;
 
 typedef struct gpx_options {
