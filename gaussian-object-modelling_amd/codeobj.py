@@ -319,6 +319,133 @@ def guard_split_contraction_staging(lib_path, tmp_dir):
 
 
 
+# ---- MFMA result hazards across the control-flow graph ------------------------------------------------------------------
+# gfx950 does not interlock a read of an MFMA result that is still in the pipe: the ISA asks for software wait states between
+# the MFMA and the first VALU / LDS / memory instruction that reads (or overwrites) its destination.  hipcc's hazard recogniser
+# pads them -- but it walks the CFG backwards with ONE visited set: a block first reached through a long path is not walked
+# again through a shorter one, so at a merge of a long path (a poll loop) and a short one (the poll skipped) the padding is
+# sized for the long path.  That was the "unexplained race" of the fp32 two-wave sub-block LDL^T (gpx_blk.hpp):
+# v_accvgpr_read of the inverse's accumulator 6-7 wait states behind a 16-pass v_mfma_f32_32x32x2_f32 on the path that needs
+# no poll, i.e. only when wave 0 happens to be two columns ahead -- results that differ from run to run.  This walk takes the
+# true minimum over all paths.
+def _mfma_wait_states(op):
+    """(wait states before a VALU read/write of the result, before an LDS / memory read) for the MFMA forms this library uses:
+    LLVM's GCNHazardRecognizer tables for gfx940 / gfx950 (SGEMM = f32 inputs: passes + 2; XDL = f16 / bf16 / i8 / f8: passes + 3,
+    one more for the 4-pass forms on gfx950; DGEMM 16x16x4: 11 / 18, 4x4x4: 6 / 9)."""
+    if op.startswith("v_mfma_f64_16x16x4"):
+        return 11, 18
+    if op.startswith("v_mfma_f64_4x4x4"):
+        return 6, 9
+    shape = op.split("_")[3] if op.count("_") >= 3 else ""
+    if op.startswith("v_mfma_f32") and op.endswith("_f32") and not op.endswith("xf32"):
+        passes = {"32x32x2": 16, "32x32x1": 16, "16x16x4": 8, "16x16x1": 8, "4x4x1": 2}.get(shape)
+        assert passes, op
+        return passes + 2, passes + 2
+    passes = {"32x32x16": 8, "16x16x32": 4, "32x32x8": 8, "16x16x16": 4, "32x32x4": 16, "16x16x8": 8, "4x4x4": 2,
+              "32x32x64": 16, "16x16x128": 8, "32x32x32": 8, "16x16x64": 4}.get(shape, 16)
+    w = passes + 3 + (1 if passes == 4 else 0)
+    return w, w
+
+
+def _reg_set(tok):
+    import re
+    m = re.fullmatch(r"-?\|?([av])\[(\d+):(\d+)\]\|?", tok)
+    if m:
+        return {(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.fullmatch(r"-?\|?([av])(\d+)\|?", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def mfma_hazard_violations(lines):
+    """lines: the disassembly of ONE kernel (codeobj.disassemble).  Returns [(mfma text, offending text, wait states found,
+    wait states required)] for every instruction that touches the destination of an MFMA on SOME path with fewer wait states
+    than the ISA requires (another MFMA accumulating into the same registers is interlocked and not counted)."""
+    import heapq
+    ins = [(int(l.split("//")[1].split(":")[0], 16), l.split("//")[0].strip(), l) for l in lines if "//" in l]
+    if not ins:
+        return []
+    first = ins[0][0]
+    at = {a: i for i, (a, _, _) in enumerate(ins)}
+    n = len(ins)
+    ops, toks, succ, ws = [], [], [], []
+    for i, (a, text, raw) in enumerate(ins):
+        op, _, rest = text.partition(" ")
+        ops.append(op)
+        toks.append([t.strip() for t in rest.split(",")] if rest else [])
+        nxt = [i + 1] if i + 1 < n else []
+        if op in ("s_endpgm", "s_setpc_b64", "s_swappc_b64", "s_trap"):
+            nxt = []
+        elif op == "s_branch" or op.startswith("s_cbranch"):
+            tgt = []
+            if "+0x" in raw:
+                t = first + int(raw[raw.rindex("+0x") + 3:raw.rindex(">")], 16)
+                if t in at:
+                    tgt = [at[t]]
+            elif raw.rstrip().endswith(">") and "<" in raw:  # '<symbol>' = offset 0
+                tgt = [0]
+            nxt = tgt if op == "s_branch" else tgt + nxt
+        succ.append(nxt)
+        ws.append(int(toks[-1][0]) + 1 if op == "s_nop" else 1)
+    stores = ("ds_write", "ds_store", "global_store", "flat_store", "buffer_store", "scratch_store", "global_atomic", "ds_add",
+              "ds_max", "ds_min", "buffer_atomic", "flat_atomic")
+    out = []
+    for i in range(n):
+        if not ops[i].startswith("v_mfma") and not ops[i].startswith("v_smfmac"):
+            continue
+        dst = _reg_set(toks[i][0])
+        need_valu, need_mem = _mfma_wait_states(ops[i])
+        limit = max(need_valu, need_mem)
+        best = {}
+        heap = [(0, j) for j in succ[i]]
+        while heap:
+            w, j = heapq.heappop(heap)
+            if w >= limit or best.get(j, limit) <= w:
+                continue
+            best[j] = w
+            op = ops[j]
+            if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+                # srcC / vdst on the same registers: the matrix pipe orders them itself; A / B operands are plain reads
+                touched = set().union(*[_reg_set(t) for t in toks[j][1:3]]) if len(toks[j]) >= 3 else set()
+                need = need_valu + 1
+            else:
+                src = toks[j] if op.startswith(stores) else toks[j][1:]
+                touched = set().union(*[_reg_set(t) for t in src]) if src else set()
+                if toks[j] and not op.startswith(stores):
+                    touched |= _reg_set(toks[j][0])  # overwriting a result in flight is the same hazard
+                need = need_valu if op.startswith("v_") else need_mem
+            if w < need and touched & dst:
+                out.append((ins[i][1], ins[j][1], w, need))
+                continue
+            if touched & dst and not (op.startswith("v_mfma") or op.startswith("v_smfmac")):
+                # (past the first legal touch of these registers the MFMA has retired as far as they are concerned; keep
+                # walking for the other registers of the destination)
+                pass
+            for k in succ[j]:
+                heapq.heappush(heap, (w + ws[j], k))
+    return out
+
+
+def guard_mfma_result_hazards(lib_path, tmp_dir):
+    """EVERY kernel of the library that issues an MFMA must have the ISA's wait states on every path from the MFMA to the first
+    touch of its result (56 kernels in the round-6 build; the two-wave sub-block LDL^T of the dataflow factorisation is the one
+    that failed: 26 short paths per kernel before its wave-1 MFMAs carried their own wait states)."""
+    seen = pairs = 0
+    for sym, lines in disassemble(lib_path, tmp_dir, "").items():
+        if not any("v_mfma" in l or "v_smfmac" in l for l in lines):
+            continue
+        seen += 1
+        bad = mfma_hazard_violations(lines)
+        assert not bad, (sym, bad[:6], len(bad))
+        if "factor_kernel" in sym and "wide" not in sym:
+            # the hand-over protocol itself: wave 1's updates are asm MFMAs followed by their wait states in the same statement
+            text = [l.split("//")[0].strip() for l in lines]
+            idx = [i for i, t in enumerate(text) if t.startswith(("v_mfma_f64_16x16x4_f64", "v_mfma_f32_32x32x2_f32"))
+                   and i + 2 < len(text) and text[i + 1] == "s_nop 15" and text[i + 2] == "s_nop 1"]
+            assert len(idx) >= 2 * 32, (sym, len(idx))
+            pairs += 1
+    assert seen >= 50 and pairs >= 12, (seen, pairs)
+
+
 def check_library(lib_path):
     """Every guard above on lib_path; raises AssertionError naming the kernel and the offending instructions."""
     import tempfile
@@ -329,3 +456,4 @@ def check_library(lib_path):
         guard_small_fp64_accumulators(lib_path, td)
         guard_small_split_accumulators(lib_path, td)
         guard_split_contraction_staging(lib_path, td)
+        guard_mfma_result_hazards(lib_path, td)

@@ -732,11 +732,10 @@ extern "C" int gpx_model_commit(gpx_model *m, int with_variance)
         if (!m->X)
             return fail(GPX_E_STATE, "inverse factor buffer missing");
         m->has_inverse = true;
-        if (m->opt.precision == GPX_PREC_F32_SPLIT && split_packs(m)) {  // the received blobs are already packed / scaled
-            int e2 = 0;
-            (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
-            m->sk = (float)std::ldexp(1.0, -e2);
-            m->x_packed = true;
+        if (m->opt.precision == GPX_PREC_F32_SPLIT) {
+            set_split_scale(m);
+            if (split_packs(m))  // the received blobs are already packed / scaled
+                m->x_packed = true;
         }
     }
     return GPX_OK;

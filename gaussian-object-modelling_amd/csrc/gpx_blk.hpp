@@ -258,9 +258,20 @@ __device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, doubl
 // behind a barrier and passes 32 * (number of sub-blocks done)).  Same arithmetic as subblock_ldl (the pivot of the next step is
 // formed ahead of the update, by the same fused multiply-add).  Measured: 7.3 -> 6.0 us per sub-block -- the step is a chain of
 // latencies (MFMA result -> lane broadcast -> scaled column -> MFMA), not of MFMA issue slots: wave 0 alone, with neither the
-// inverse nor the reciprocal on its chain, still needs 6.2 us.  fp64 only: the fp32 form of the same protocol (32 x 32 x 2 MFMA,
-// two workgroups per CU) gave results that differed from run to run in the inverse blocks; the cause was not found, so the
-// fp32 factorisations keep the one-wave routine above.
+// inverse nor the reciprocal on its chain, still needs 6.2 us.
+//
+// WAVE 1's MFMAs ARE INLINE ASM WITH THEIR OWN WAIT STATES, and that is the point (round 6).  gfx950 does not
+// interlock a read of an MFMA result still in the pipe; the ISA asks for 11 (fp64 16x16x4; 18 for LDS / memory reads) or 18
+// (fp32 32x32x2, 16 passes) software wait states, which hipcc pads behind a builtin MFMA -- walking the CFG backwards with ONE
+// visited set.  ldl_column has two ways to the next MFMA: the poll loop (long) and the poll skipped because the count read
+// earlier already covers the column (short).  The recogniser reached the MFMA through the loop first, marked its block visited,
+// never walked the short edge, and sized the s_nop for the long path: on the short one the fp32 build read the B operand of the
+// next step (v_accvgpr_read of X[r]) 6-7 wait states behind a 16-pass MFMA -- only when wave 0 happened to be two columns ahead,
+// hence inverse blocks that differed from run to run (round 5: "cause not found").  The fp64 build had the same padding error
+// and survived on arithmetic: its shortest feasible path holds 12 instructions and a DGEMM needs 11.  With the wait states
+// written behind the MFMA itself no path can be shorter; gaussian-object-modelling_amd/codeobj.py (guard_mfma_result_hazards,
+// run by build()) walks every path of the built code from every MFMA to the first touch of its result and fails the build on
+// a short one.
 // (the pointers are cast to the LDS address space by hand: through a generic volatile pointer hipcc emits flat loads and
 // stores with system scope, hundreds of cycles each -- the first build of the pair was no faster than one wave for that)
 #define GPX_LDS(T_) __attribute__((address_space(3))) T_
@@ -285,6 +296,25 @@ __device__ __forceinline__ T ldl_column(volatile int *prog, int need, int &seen,
         val = take ? *vs : T(0);
     } while (seen < need);
     return val;
+}
+
+// wave 1's rank-1 updates: the MFMA and the wait states the ISA wants before ANY later instruction may touch its result
+// (18 covers a VALU read and an LDS / memory read of either form) in one asm statement -- see the comment above; the two in front
+// cover a VALU write of an operand (hipcc pads nothing around an asm statement)
+typedef double f64x4_blk __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ldl_x_update(f64x4_blk &x, double a, double b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 1" : "+a"(x) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void ldl_x_update2(f64x4_blk &x0, f64x4_blk &x1, double a0, double a1, double b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %2, %4, %0\n\tv_mfma_f64_16x16x4_f64 %1, %3, %4, %1\n\ts_nop 15\n\ts_nop 1"
+                 : "+a"(x0), "+a"(x1)
+                 : "v"(a0), "v"(a1), "v"(b));
+}
+__device__ __forceinline__ void ldl_x_update(f32x16 &x, float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 1" : "+a"(x) : "v"(a), "v"(b));
 }
 
 __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, double *Xdb, int lane, int wave, double &dvec,
@@ -371,16 +401,16 @@ __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, 
             const T a0 = -ldl_column(prog, base + j + 1, seen, Lx + c * PLD + j, act);
             const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, ing);
             const T xr = X00[r];
-            X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xr, X00, 0, 0, 0);
-            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xr, X10, 0, 0, 0);
+            ldl_x_update2(X00, X10, a0, a1, xr);
         }
 #pragma unroll
         for (int j = 16; j < NB; ++j) {
             const int jj = j - 16, r = jj >> 2, gj = jj & 3;
             const bool act = g == gj && c > jj;
             const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, act);
-            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X10[r], X10, 0, 0, 0);
-            X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X11[r], X11, 0, 0, 0);
+            const T x10r = X10[r], x11r = X11[r];
+            ldl_x_update(X10, a1, x10r);
+            ldl_x_update(X11, a1, x11r);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -390,6 +420,67 @@ __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, 
             Xdb[(16 + row) * PLD + c] = X10[r];
             Xdb[(16 + row) * PLD + 16 + c] = X11[r];
         }
+    }
+}
+
+// fp32 twin: the block and its inverse are one 32 x 32 accumulator of v_mfma_f32_32x32x2_f32 each (layout of the one-wave routine
+// above: register r of lane (half, col) is element (8 (r >> 2) + 4 half + (r & 3), col)).
+__device__ __forceinline__ void subblock_ldl_pair(const float *Dn, float *Lx, float *Xdb, int lane, int wave, float &dvec,
+                                                  volatile int *prog, int base)
+{
+    typedef float T;
+    const int half = lane >> 5, col = lane & 31;
+    GPX_LDS(T) *LxL = (GPX_LDS(T) *)Lx;
+    if (wave == 0) {
+        f32x16 M;
+        {
+            const T *b1 = Dn + 4 * half * PLD + col, *b2 = Dn + col * PLD + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 8 * (r >> 2) + (r & 3), row = o + 4 * half;
+                const T v1 = b1[o * PLD], v2 = b2[o];
+                M[r] = row > col ? v1 : v2;
+            }
+        }
+        T dj = bcast_lane(M[0], 0);
+        T rinv = fast_rcp(dj);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;
+            const T rowj = M[rj];
+            const T lj = rowj * rinv;
+            const bool act = half == hj && col > j;
+            const T a = act ? -lj : 0.0f;
+            if (lane == j)
+                dvec = dj;
+            if (act)
+                LxL[col * PLD + j] = lj;
+            ldl_publish(prog, base + j + 1);
+            // next pivot: element (j + 1, j + 1) minus l_{j+1,j} times element (j, j + 1)
+            const int jn = j + 1, rn = (jn >> 3) * 4 + (jn & 3), hn = (jn >> 2) & 1;
+            const T m = j < NB - 1 ? bcast_lane(rowj, 32 * hj + jn) : 0.0f;
+            const T old = j < NB - 1 ? bcast_lane(M[rn & 15], 32 * hn + (jn & 31)) : 1.0f;
+            M = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rowj, M, 0, 0, 0);
+            dj = fmaf(-(m * rinv), m, old);
+            rinv = fast_rcp(dj);
+        }
+    } else {
+        f32x16 X;
+        int seen = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            X[r] = 8 * (r >> 2) + 4 * half + (r & 3) == col ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int rj = (j >> 3) * 4 + (j & 3), hj = (j >> 2) & 1;
+            const bool act = half == hj && col > j;
+            const T a = -ldl_column(prog, base + j + 1, seen, Lx + col * PLD + j, act);
+            const T xr = X[rj];
+            ldl_x_update(X, a, xr);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Xdb[(8 * (r >> 2) + 4 * half + (r & 3)) * PLD + col] = X[r];
     }
 }
 

@@ -517,8 +517,20 @@ bool split_packs(const gpx_model *m)
     return !(m->n <= SPLIT_MIN_N && m->var_fit_opt && var_cols_fits(m->n, m->npad, m->npad, m->npad + KQP_LDPAD));
 }
 
+// power-of-two scale of the kernel values in the split contraction: k(0) * sk in [0.5, 1).  Every F32_SPLIT model carries it,
+// packed or not: the small-model split kernel (gpx_varcols16.hip) splits (k - fit) * sk per call, and with the default of 1 an
+// amplitude of 1e5 overflowed the fp16 halves and one of 1e-6 fell into their subnormals.
+void set_split_scale(gpx_model *m)
+{
+    int e2 = 0;
+    (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
+    m->sk = (float)std::ldexp(1.0, -e2);
+}
+
 static int pack_split(gpx_model *m)
 {
+    if (m->opt.precision == GPX_PREC_F32_SPLIT)
+        set_split_scale(m);
     if (m->opt.precision != GPX_PREC_F32_SPLIT || m->x_packed || m->prec != GPX_PREC_F32 || !m->X)
         return GPX_OK;
     // Small models stay on the fp32 contraction of the small-model kernel (gpx_varcols_kernel.hpp), which needs no operand in
@@ -533,9 +545,6 @@ static int pack_split(gpx_model *m)
         HIPCHK(hipMemcpy(t.data(), m->t_d, sizeof(float) * (size_t)m->n, hipMemcpyDeviceToHost));
         m->hD.assign(t.begin(), t.end());
     }
-    int e2 = 0;
-    (void)std::frexp(m->cov.k0 > 0 ? m->cov.k0 : 1.0, &e2);
-    m->sk = (float)std::ldexp(1.0, -e2);  // k(0) * sk in [0.5, 1)
     launch_split_prepare((float *)m->X, np, (float *)m->t_dinv, m->sk, (unsigned *)(m->d_info + 4), m->stream,
                          m->d_meta + 3);
     HIPCHK(hipStreamSynchronize(m->stream));

@@ -524,25 +524,21 @@ __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallA
         acc.store(T(1), bufC + (qi * 2 + qj) * SBLK, (T *)nullptr, 0, lane);
         volatile int *prog = reinterpret_cast<volatile int *>(sm + DF_LDS_PROG);
         if (tid == 0)
-            *prog = 0;
+            *(volatile GPX_LDS(int) *)prog = 0;  // (a ds_write: through the generic pointer it is a flat store with system scope)
         __syncthreads();
         SM_STAMP(6);
         T *Lx0 = bufA, *W21 = bufA + SBLK, *L21 = bufA + 2 * SBLK, *Lx1 = bufA + 3 * SBLK;
         T *Xd0 = bufB, *T0 = bufB + SBLK, *X10 = bufB + 2 * SBLK, *Xd1 = bufB + 3 * SBLK;
         T *A21 = bufC + 2 * SBLK, *A22 = bufC + 3 * SBLK;
-        // The two 32 x 32 sub-blocks are factorised by wave 0, one rank-1 MFMA update per column, and -- in fp64 -- their L
-        // inverted by wave 1 one step behind (gpx_blk.hpp, subblock_ldl_pair; fp32: both on wave 0); the products between them
-        // are shared by the four waves, a 16 x 16 tile each.
+        // The two 32 x 32 sub-blocks are factorised by wave 0, one rank-1 MFMA update per column, and their L inverted by wave 1
+        // one step behind (gpx_blk.hpp, subblock_ldl_pair); the products between them are shared by the four waves, a
+        // 16 x 16 tile each.
         const int i2 = wave >> 1, j2 = wave & 1;
         const int tcol = 16 * j2 + (lane & 15);
         T dv = T(1);
         unsigned long long mneg = 0, mbad = 0;
-        if constexpr (std::is_same<T, double>::value) {
-            if (wave <= 1)
-                subblock_ldl_pair(bufC, Lx0, Xd0, lane, wave, dv, prog, 0);
-        } else if (wave == 0) {
-            subblock_ldl(bufC, Lx0, Xd0, lane, dv);
-        }
+        if (wave <= 1)
+            subblock_ldl_pair(bufC, Lx0, Xd0, lane, wave, dv, prog, 0);
         if (wave == 0) {
             if (lane < NB) {
                 dvec[lane] = dv;
@@ -581,12 +577,8 @@ __device__ __forceinline__ void factor_tile(const FactorArgs<T> &f, const SmallA
         }
         __syncthreads();
         SM_STAMP(18);
-        if constexpr (std::is_same<T, double>::value) {
-            if (wave <= 1)
-                subblock_ldl_pair(A22, Lx1, Xd1, lane, wave, dv, prog, NB);
-        } else if (wave == 0) {
-            subblock_ldl(A22, Lx1, Xd1, lane, dv);
-        }
+        if (wave <= 1)
+            subblock_ldl_pair(A22, Lx1, Xd1, lane, wave, dv, prog, NB);
         if (wave == 0) {
             if (lane < NB) {
                 dvec[NB + lane] = dv;

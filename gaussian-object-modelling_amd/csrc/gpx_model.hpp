@@ -219,6 +219,7 @@ void factorize_matrix_append(gpx_model *m, int t0);
 void factorize_matrix(gpx_model *m);     // blocked LDL^T of m->Kmat in place (t_d, t_dinv, linv, d_info)
 void solve_factored(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x);  // x = (L D L^T)^-1 b on T vectors
 void set_query_batch(gpx_model *m);
+void set_split_scale(gpx_model *m);  // F32_SPLIT: m->sk from the kernel's amplitude (every model of the mode, packed or not)
 bool split_packs(const gpx_model *m);  // F32_SPLIT: does a model of this size hold packed fp16 operands (small ones keep the fp32 kernel)
 void set_training_precision(gpx_model *m);
 // ---- gpx_eval.hip -----------------------------------------------------------------------------------

@@ -135,3 +135,45 @@ def test_split_contraction_stages_by_lds_dma_behind_a_vmcnt_wait(gpx, tmp_path):
     the barrier -- hipcc left that wait out of one of the loop's two barriers until it was written into the source, so every
     s_barrier of the main loop must have one in the instructions in front of it."""
     codeobj.guard_split_contraction_staging(gpx.LIB_PATH, tmp_path)
+
+
+def test_every_mfma_result_has_its_wait_states_on_every_path(gpx, tmp_path):
+    """Round 6: the cause of the fp32 two-wave sub-block LDL^T's run-to-run differences (gpx_blk.hpp) -- hipcc's
+    hazard recogniser sized the wait states behind an MFMA for the LONG way to the first read of its result (through the poll
+    loop) and left the short way (poll skipped) 6-7 wait states where the ISA wants 18.  The guard walks every path of every
+    MFMA kernel of the library."""
+    codeobj.guard_mfma_result_hazards(gpx.LIB_PATH, tmp_path)
+
+
+def _listing(rows):
+    """fake llvm-objdump lines 'text // ADDR: ENC [<sym+0xOFF>]' from (text, branch-target index | None) rows"""
+    out = []
+    for i, (text, tgt) in enumerate(rows):
+        tail = " <k+0x%x>" % (4 * tgt) if tgt is not None else ""
+        out.append("%s // %012X: BF800000%s" % (text, 0x1000 + 4 * i, tail))
+    return out
+
+
+def test_hazard_walk_finds_the_short_path_the_compiler_missed():
+    """The shape of the defect in miniature: behind a 16-pass MFMA a long path (a poll loop) and a short one (a taken branch)
+    merge in front of the read of the accumulator; the s_nop in front of the read is sized for the long path.  A walk with a
+    single visited set (long path first) calls this code safe; the guard's minimum over all paths must not."""
+    rows = [
+        ("v_mfma_f32_32x32x2_f32 a[0:15], v2, v3, a[0:15]", None),  # 0
+        ("s_cbranch_scc1 10", 10),                                   # 1: short way -> merge
+    ] + [("s_mov_b32 s0, s1", None)] * 8 + [                          # 2..9: the long way, 8 wait states
+        ("s_nop 7", None),                                            # 10: merge block; 2 + 8 + 8 = 18 on the long path
+        ("v_accvgpr_read_b32 v5, a3", None),                          # 11: read of the result
+        ("s_endpgm", None),
+    ]
+    bad = codeobj.mfma_hazard_violations(_listing(rows))
+    assert bad and bad[0][1] == "v_accvgpr_read_b32 v5, a3" and bad[0][2] == 9 and bad[0][3] == 18, bad
+    # the same read behind enough wait states on BOTH paths, and an interlocked accumulate in between: clean
+    rows[10] = ("s_nop 15", None)
+    rows.insert(11, ("s_nop 1", None))
+    assert not codeobj.mfma_hazard_violations(_listing(rows))
+    rows2 = [("v_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[4:5], a[0:7]", None),
+             ("v_mfma_f64_16x16x4_f64 a[0:7], v[2:3], v[4:5], a[0:7]", None)] + [("s_nop 4", None)] * 2 + [
+             ("v_accvgpr_read_b32 v5, a3", None), ("s_endpgm", None)]
+    bad = codeobj.mfma_hazard_violations(_listing(rows2))
+    assert len(bad) == 1 and bad[0][2] == 10 and bad[0][3] == 11, bad  # (the second MFMA: 10 < 11; the first has 11)

@@ -90,3 +90,42 @@ def test_split_fp16_small_models_on_random_clouds_kernels_and_query_counts(gpu):
         assert ea < 1e-5 and eb < 1e-5, (case, n, kn, par, nq, ea, eb)
         m.close()
     print("worst split-fp16 error over the random cases: %.2e" % worst)
+
+
+@pytest.mark.parametrize("amp", [1e-6, 1e5])
+def test_split_fp16_small_models_scale_the_kernel_amplitude(gpu, ds, amp):
+    """small split-mode models keep their inverse factor unpacked, and the power-of-two scale sk of the kernel values
+    used to be computed only on the packing path -- with sk = 1 an amplitude k(0) >= 65504 overflowed the fp16 halves (NaN
+    variances) and one around 1e-6 fell into their subnormals.  Every F32_SPLIT model now carries sk = 2^-e, k(0) * sk in
+    [0.5, 1): amplitudes of 1e-6 and 1e5 (noise in proportion) hold the mode's 1e-5 of max|v| against the fp64 pipeline, for the
+    model itself, a replica and a shell committed from its state blobs."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(400)
+    data = (x, y, z, lab * np.sqrt(amp), s2 * amp)
+    q = ds.query_grid(9, scale=1.2)
+    for kn, par in (("gaussian", (np.sqrt(amp), 1.0)), ("matern52", (np.sqrt(amp), 0.8)), ("laplace", (amp / 2.0, 1.0))):
+        kern = gpu.make_kernel(kn, *par)
+        m64 = gpu.Model(kern, *data, precision=gpu.F64, prepare_variance=True)
+        ref = m64.evaluate(*q, want_v=True)
+        m64.close()
+        assert 0.2 * amp < ref["v"].max() < 5.0 * amp
+        m = gpu.Model(kern, *data, precision=gpu.F32_SPLIT, prepare_variance=True)
+        a = _eval(m, q, True)
+        assert np.all(np.isfinite(a["v"])) and verr_v(a["v"], ref["v"]) < 1e-5, (kn, amp, verr_v(a["v"], ref["v"]))
+        r = m.replicate([0])[0]
+        assert np.array_equal(_eval(r, q, True)["v"], a["v"])
+        r.close()
+        m.close()
+
+
+@pytest.mark.parametrize("n,kn", [(512, "matern32"), (1024, "gaussian")])
+def test_split_fp16_small_model_kernel_against_the_oracle_at_its_largest_sizes(gpu, orc, ds, n, kn):
+    """above 300 points the fp16 matrix-core kernel was only ever held to the repo's own fp64 pipeline.  Two
+    and three passes over the row fragments against the CPU oracle (f, v; 1e-5 of max|v|)."""
+    data = ds.fibonacci_training_set(n)
+    q = ds.query_grid(8, scale=1.25)
+    o = orc.Model(orc.make_kernel(kn, 1.0, 1.0), *data).evaluate(*q, want_v=True)
+    m = gpu.Model(gpu.make_kernel(kn, 1.0, 1.0), *data, precision=gpu.F32_SPLIT, prepare_variance=True)
+    a = _eval(m, q, True)
+    assert m.stats["n"] == n
+    assert verr_v(a["v"], o["v"]) < 1e-5 and nerr(a["f"], o["f"]) < 1e-5
+    m.close()
