@@ -14,6 +14,8 @@
 //
 // This file: error state, model life cycle (create / update / destroy / shell / state blobs / commit), accessors.
 // gpx_build.hip: kernel matrix, factorisation, solves, inverse factor.  gpx_eval.hip: every prediction path.
+#include <atomic>
+
 #include "gpx_model.hpp"
 #include "gpx_small.hpp"
 
@@ -55,8 +57,8 @@ const bool g_backend_installed = (set_device_backend(&g_hip_backend), true);
 BigPool &pool()
 {
     static BigPool p([] {
-        const char *e = std::getenv("GPX_POOL_MB");
-        return (size_t)(e ? std::atol(e) : 16384) << 20;
+        const long mb = gpxh::switches().pool_mb;
+        return (size_t)(mb >= 0 ? mb : 16384) << 20;
     }());
     return p;
 }
@@ -172,6 +174,31 @@ static void pinned_trim()
         (void)hipHostFree(b.first);
 }
 }  // namespace gpxh
+
+namespace gpxh {
+long long wait_budget_ticks(int npad)
+{
+    const long us = gpxh::switches().wait_budget_us;
+    return 100LL * (us >= 0 ? us : (npad <= 8192 ? 20000L : 200000L));
+}
+int device_cu_count(int dev)
+{
+    static std::atomic<int> cus[MAX_DEVICES];
+    if (dev < 0 || dev >= MAX_DEVICES)
+        return 0;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+}  // namespace gpxh
+
+extern "C" void gpx_debug_reload(void) { gpxh::switches_reload(); }
 
 extern "C" void gpx_trim(void)
 {
@@ -314,12 +341,12 @@ static int new_model(const gpx_kernel *kernel, size_t n, const gpx_options &o, g
     m->nblk = m->npad / TILE;
     set_training_precision(m);  // MIXED and small F32 models train in fp64
     set_query_batch(m);
-    if (const char *e64 = std::getenv("GPX_INV64"))
-        m->inv64 = std::atoi(e64) != 0;
+    if (gpxh::switches().inv64 >= 0)
+        m->inv64 = gpxh::switches().inv64 != 0;
     // fp32 variance contraction: take the per-query fit out of the kernel operand (GPX_VAR_FIT=0: plain kernel values)
     m->var_fit = o.precision != GPX_PREC_F64;
-    if (const char *vf = std::getenv("GPX_VAR_FIT"))
-        m->var_fit = m->var_fit && std::atoi(vf) != 0;
+    if (gpxh::switches().var_fit >= 0)
+        m->var_fit = m->var_fit && gpxh::switches().var_fit != 0;
     // ... and form that operand, k - fit, in fp64 from the fp64 points, rounding once -- for the thin plate, whose
     // values are all of the size of k(0) = R^3 while the variance is ~k(0)/60 at N = 16384: forming k and the fit
     // separately in fp32 costs 8e-6 of max|v| there, against 4e-7 for Matern-5/2 (profiles/r03_fit_variants_*.txt), and the
@@ -433,14 +460,12 @@ extern "C" int gpx_model_update(gpx_model *m, size_t n_new, const double *x, con
     // diagonal k(0) + sigma2) keeps the old points first, in their old order.  Results agree with a rebuild to
     // rounding; anything else falls back to the rebuild.
     kept_factor keep;
-    const char *app_env = std::getenv("GPX_UPDATE_APPEND");  // 0: always rebuild (tests compare the two)
-    bool append_on = !app_env || std::atoi(app_env) != 0;
+    bool append_on = gpxh::switches().update_append != 0;  // GPX_UPDATE_APPEND=0: always rebuild (tests compare the two)
     {
         // A grown model that is still in the small-model range is rebuilt by the three dataflow launches (gpx_small.hip):
         // 0.25 ms at N = 277 + 16 against 0.62 ms for the append's launch chain (scripts/update_bench.py) -- and a rebuild is
         // what the reference does (:457-459)
-        const char *sc = std::getenv("GPX_SMALL_CREATE");
-        const bool small_on = !sc || std::atoi(sc) != 0;
+        const bool small_on = gpxh::switches().dataflow != 0;
         if (small_on && gpx_padded_n(m->hx.size()) <= (size_t)SMALL_CREATE_MAX_NP)
             append_on = false;
     }

@@ -158,17 +158,14 @@ hipEvent_t *gemm_events(gpx_model *m, size_t idx)
 }
 
 // ---- L y = b ; y *= 1/D ; L^T x = y on T vectors (block substitution with inverse blocks) ------
-// Default: one launch per direction (tri_solve_kernel).  force_steps (or GPX_SOLVE_STEPS=1): one launch per block
-// step -- the path build_model falls back to when a workgroup of the one-launch kernel gave up waiting (info[5]).
-// GPX_SOLVE_SPIN_LIMIT (read per call; tests use it to force the give-up) overrides the spin limit of the polls.
+// Default: one launch per direction (tri_solve_kernel).  force_steps: one launch per block step -- the path build_model
+// falls back to when a workgroup of the one-launch kernel gave up waiting (info[5]; GPX_WAIT_BUDGET_US=0 forces that in the
+// tests, which hold the two paths to each other).
 static void solve_ldl(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x, bool force_steps)
 {
-    const char *e = getenv("GPX_SOLVE_STEPS");  // 1: one launch per block step (the older path, kept for A/B runs)
-    const bool by_steps = force_steps || (e && atoi(e) != 0);
-    if (!by_steps) {
-        const char *sl = getenv("GPX_SOLVE_SPIN_LIMIT");
+    if (!force_steps) {
         launch_tri_solve(m->prec, m->nblk, m->Kmat, m->npad, m->linv, m->t_dinv, b, ytmp, x, m->d_info, m->stream,
-                         sl ? atoi(sl) : 0);
+                         wait_budget_ticks(m->npad));
         return;
     }
     for (int kb = 0; kb < m->nblk; ++kb)
@@ -311,19 +308,16 @@ static void factorize(gpx_model *m, int c_start = 0)
     // hipExtStreamCreateWithCUMask (round 1, twice: 47 ms -- kernels on masked streams pay far more than the hop),
     // stream priority / s_setprio (nothing), and a persistent update that leaves one CU per shader engine empty
     // (round 2: the chain then runs at its stand-alone speed, the update 25-30 % slower, the LDL^T the same:
-    // profiles/r02_ldlt_reserved_cus.txt).  GPX_LOOKAHEAD=0 selects the plain order.
-    const char *pw_e = std::getenv("GPX_PANEL");
-    const int wide_env = pw_e ? std::atoi(pw_e) : 0;
-    const char *la_e = std::getenv("GPX_LOOKAHEAD");
+    // profiles/r02_ldlt_reserved_cus.txt).
     // Default window, from measurements (LDL^T ms, look-ahead on / off): fp32, with the round-2 diagonal-block kernel and
     // schedule, N = 8192 5.35 / 5.50, 12288 10.0 / 11.3, 16384 18.3 / 20.6, 32768 111 / 119 -> from 8192 rows on (round 1:
     // 6.9 / 6.5, -, 21.3 / 22.8, 117 / 125 -> from 16384); fp64 N = 4096 4.15 / 3.95, 8192 9.7 / 10.5, 16384 36.9 / 40.0,
     // 32768 239 / 232 (there the 512-wide panels of the plain order win) -> 8192 <= rows < 32768; with the round-2 kernel
     // N = 4096 3.62 / 3.44, 6144 5.7 / 5.95, 8192 8.4 / 9.5, 16384 35.2 / 37.9 -> 6144 <= rows < 32768.
-    // GPX_LOOKAHEAD=1 forces it from 512 rows on, 0 switches it off; it works on 256-wide panels.
-    const bool la_forced = la_e && std::atoi(la_e) != 0;
+    // It works on 256-wide panels.  (The GPX_LOOKAHEAD / GPX_PANEL switches of rounds 1-5 are gone; bit-identical to the plain
+    // order at the same panel width: DESIGN_LEDGER.md.)
     const bool la_window = m->prec == GPX_PREC_F64 ? (np >= 24 * PANEL && np < 128 * PANEL) : np >= 32 * PANEL;
-    const bool la_env = (!la_e || la_forced) && wide_env != WIDE_PANEL && (la_forced ? np >= 2 * PANEL : la_window);
+    const bool la_env = la_window;
     if (la_env && c_start == 0 && !m->stream2 &&
         stream_acquire(m->device, &m->stream2) != hipSuccess) {
         (void)hipGetLastError();
@@ -433,8 +427,7 @@ static void factorize(gpx_model *m, int c_start = 0)
         c0 += TILE;
     }
     // fp64 has no accuracy to lose to the longer accumulations: 512-wide panels there (LDL^T at N = 16384: 43.1 -> 40.0 ms)
-    const int wide = wide_env == WIDE_PANEL ? WIDE_PANEL
-                                            : (wide_env == PANEL ? PANEL : (m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL));
+    const int wide = m->prec == GPX_PREC_F64 ? WIDE_PANEL : PANEL;
     while (c0 < np) {
         const int pw = std::min(wide, np - c0), nb = pw / TILE;
         for (int h = 0; h < nb; ++h) {
@@ -753,33 +746,36 @@ static int demote_to_f32(gpx_model *m)
 // ---- create of a small model in three launches (gpx_small.hip) ---------------------------------------------------
 // Taken for a fresh create (no rank-n append) of a model that trains in fp64 and has at most SMALL_CREATE_MAX_NP padded
 // rows -- every model of the reference's own sizes in every precision mode (F32 / F32_SPLIT models of this size train in
-// fp64, set_training_precision).  GPX_SMALL_CREATE=0 keeps the general chain (its tested twin).
+// fp64, set_training_precision).  GPX_DATAFLOW=0 keeps the general chain (its tested twin).
 // Models above the small-model path (fresh creates in either working precision, up to 16384 padded rows): kernel matrix +
 // LDL^T as one dataflow launch -- 64 x 64 tiles below 8192 rows, where the chain of diagonal tiles sets the time
 // (gpx_dataflow.hpp), 128 x 128 tiles from there on, where the 64 x 64 form is HBM-bound (gpx_dataflow_wide.hpp).  It beats
 // kbuild + the blocked launch chain at every size on the same box (profiles/r05_ldlt_sweep.txt: N = 16384 fp32 18.7 -> 15.6 ms,
-// fp64 35.5 -> 30.4 ms; N = 4096 fp64 3.43 -> 1.75 ms).  Larger models and rank-n appends keep the chain.  GPX_MID_FACTOR=0
-// keeps the launch chain, GPX_MID_FACTOR_MAX moves the upper bound, GPX_WIDE_FACTOR_MIN the switch to the wide tiles (sweeps).
+// fp64 35.5 -> 30.4 ms; N = 4096 fp64 3.43 -> 1.75 ms).  Larger models and rank-n appends keep the chain.  GPX_DATAFLOW=0
+// keeps the launch chain; GPX_DATAFLOW=64 | 128 forces that tile form at every size up to 32768 rows (tests, sweeps).
 static bool mid_factor_eligible(const gpx_model *m)
 {
-    int max_env = -1;  // (read per call: tests and sweeps switch between the two paths inside one process)
-    if (const char *e = std::getenv("GPX_MID_FACTOR"))
-        if (std::atoi(e) == 0)
-            max_env = 0;
-    if (max_env < 0)
-        if (const char *x = std::getenv("GPX_MID_FACTOR_MAX"))
-            max_env = std::atoi(x);
-    const int max_np = max_env >= 0 ? max_env : (m->prec == GPX_PREC_F64 ? MID_FACTOR_MAX_NP_F64 : MID_FACTOR_MAX_NP_F32);
-    return m->npad > SMALL_CREATE_MAX_NP && m->npad <= max_np;
+    const int df = gpxh::switches().dataflow;  // GPX_DATAFLOW: 0 = launch chain, 64 | 128 = that tile form at EVERY size
+    if (df == 0)
+        return false;
+    if (m->npad <= SMALL_CREATE_MAX_NP)
+        return false;
+    if (df == 64 || df == 128)
+        return m->npad <= MID_FACTOR_FORCED_MAX_NP;  // (the flags and per-tile results scale; tested at 20480 rows)
+    return m->npad <= (m->prec == GPX_PREC_F64 ? MID_FACTOR_MAX_NP_F64 : MID_FACTOR_MAX_NP_F32);
 }
 
+// The three-launch create needs its WHOLE grid resident (the inverse-factor jobs of the first launch wait for workgroups with
+// a higher index, the second launch has grid barriers): ntiles <= 136 workgroups at one per CU (115 KB of LDS each) and up to
+// 128 workgroups of the alpha kernel.  A device with fewer CUs (a partition, a CU mask) takes the launch chain.
 static bool small_create_eligible(const gpx_model *m, const kept_factor *keep)
 {
     if (keep || m->prec != GPX_PREC_F64 || m->npad > SMALL_CREATE_MAX_NP)
         return false;
-    if (const char *e = std::getenv("GPX_SMALL_CREATE"))
-        return std::atoi(e) != 0;
-    return true;
+    if (gpxh::switches().dataflow == 0)
+        return false;
+    const int nbt = m->npad / SMALL_TILE;
+    return device_cu_count(m->device) >= std::max(nbt * (nbt + 1) / 2, SMALL_ALPHA_MAX_GRID / 2);  // (alpha: two workgroups fit a CU)
 }
 
 // *fell_back = true: a wait inside the launches gave up (the GPU was too busy to hold the whole grid); nothing of the
@@ -854,8 +850,7 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     a.ir_max = a.ir_adaptive ? 4 : m->opt.ir_steps;
     a.ir_tol = 1e-9 * std::max(ymax, 1e-300);
     a.epoch = small_create_epoch();
-    if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
-        a.spin_limit = std::max(1, std::atoi(sl));
+    a.wait_ticks = wait_budget_ticks(np);
     a.abort_idx = 2 * a.ntiles, a.bar_idx = 2 * a.ntiles + 1, a.pre_idx = 2 * a.ntiles + 2;
     a.dbg = (unsigned long long *)(ws + lay.dbg);
     a.K = (double *)m->Kmat, a.X = (double *)m->X, a.linv = (double *)m->linv;
@@ -877,6 +872,11 @@ static int build_model_small(gpx_model *m, bool *fell_back)
 #ifdef SM_TIMING
     (void)hipMemsetAsync(ws + lay.dbg, 0, sizeof(unsigned long long) * (size_t)a.ntiles * SMALL_DBG_STAMPS, s);
 #endif
+    // Two of these grids on one device at the same time can starve each other -- each holds CUs with workgroups that wait for
+    // workgroups of their own grid the other one keeps from being dispatched -- until a wait's budget is spent and both fall
+    // back.  Small creates on one device therefore take turns, from the first launch to the result (0.2 - 0.5 ms each).
+    static std::mutex full_mtx[MAX_DEVICES];
+    std::unique_lock<std::mutex> full_lk(full_mtx[m->device >= 0 && m->device < MAX_DEVICES ? m->device : 0]);
     (void)hipEventRecord(m->ev[EV_T0], s);
     (void)hipEventRecord(m->ev[EV_KBUILD], s);
     launch_small_create(m->kern.id, a, (const SmallArgs *)(ws + lay.args), m->train64, s, m->ev[EV_FACTOR], m->ev[EV_SOLVE]);
@@ -885,6 +885,7 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     HIPCHK(hipMemcpyAsync(hres, ws + lay.res, res_bytes, hipMemcpyDeviceToHost, s));
     {
         const hipError_t se = hipStreamSynchronize(s);
+        full_lk.unlock();
         if (se != hipSuccess) {
             (void)hipDeviceSynchronize();
             return fail(GPX_E_HIP, std::string("small-model create: ") + hipGetErrorString(se));
@@ -941,7 +942,7 @@ static int build_model_small(gpx_model *m, bool *fell_back)
     m->has_inverse = true;
     m->var_fit = m->var_fit_opt;
     m->promoted = false;
-    if (m->train64 && m->stats.n_negative_pivots > 0 && !std::getenv("GPX_NO_PROMOTE")) {
+    if (m->train64 && m->stats.n_negative_pivots > 0 && gpxh::switches().no_promote <= 0) {
         m->train64 = false;  // an indefinite kernel matrix keeps its fp64 state (see build_model)
         m->var_fit = false;
         m->promoted = true;
@@ -1086,13 +1087,10 @@ int build_model(gpx_model *m, kept_factor *keep, bool no_dataflow)
         a.px = m->t_x, a.py = m->t_y, a.pz = m->t_z, a.ps2 = m->t_s2;
         a.ws = mid_ws.p, a.info = m->d_info, a.epoch = small_create_epoch();
         {
-            int wide_min = 8192;  // padded rows from which the 128 x 128 tiles are used (GPX_WIDE_FACTOR_MIN: sweeps; 0 = never)
-            if (const char *w = std::getenv("GPX_WIDE_FACTOR_MIN"))
-                wide_min = std::atoi(w);
-            a.wide = wide_min > 0 && np >= wide_min;
+            const int df = gpxh::switches().dataflow;  // (64 | 128: the tests run either tile form at their own sizes)
+            a.wide = df == 128 || (df != 64 && np >= WIDE_FACTOR_MIN_NP);  // 128 x 128 tiles from 8192 padded rows
         }
-        if (const char *sl = std::getenv("GPX_SMALL_SPIN_LIMIT"))  // tests: force the give-up path
-            a.spin_limit = std::max(1, std::atoi(sl));
+        a.wait_ticks = wait_budget_ticks(np);
         (void)hipEventRecord(m->ev[EV_KBUILD], s);
         launch_mid_factor(m->prec, m->cov, a, s);
         m->gemm_ev_used_factor = 0;
@@ -1239,7 +1237,7 @@ int build_model(gpx_model *m, kept_factor *keep, bool no_dataflow)
     // precision was asked for (twice the variance time of fp32, on models that are small in practice).
     m->var_fit = m->var_fit_opt;
     m->promoted = false;
-    if (m->train64 && m->stats.n_negative_pivots > 0 && !std::getenv("GPX_NO_PROMOTE")) {
+    if (m->train64 && m->stats.n_negative_pivots > 0 && gpxh::switches().no_promote <= 0) {
         m->train64 = false;  // no demotion below; the fp64 factor stays (update() can append to it)
         m->var_fit = false;  // the fp64 contraction carries no fit
         m->promoted = true;
@@ -1273,8 +1271,8 @@ void set_training_precision(gpx_model *m)
 {
     const int p = m->opt.precision;
     long thr = m->kern.id == GPX_KERNEL_THINPLATE ? (1L << 20) : 2048;
-    if (const char *e = std::getenv("GPX_TRAIN_F64_MAX"))
-        thr = std::atol(e);
+    if (gpxh::switches().train_f64_max >= 0)
+        thr = gpxh::switches().train_f64_max;
     bool f64_fits = true;
     if (m->kern.id == GPX_KERNEL_THINPLATE && m->npad > 8192 && (p == GPX_PREC_F32 || p == GPX_PREC_F32_SPLIT)) {
         size_t free_b = 0, total_b = 0;

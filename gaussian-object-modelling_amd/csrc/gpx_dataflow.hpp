@@ -23,7 +23,7 @@
 // L2s start every kernel clean, so no stale copy can exist -- no L2 write-back, no invalidation, and a tile that 30 workgroups
 // of an XCD read comes from memory once.
 //
-// Every wait has a spin limit; a workgroup that runs out of patience raises the abort flag, all others see it in their
+// Every wait has a time budget; a workgroup that runs out of patience raises the abort flag, all others see it in their
 // polls and leave, and the host falls back to the launch chain (as tri_solve_kernel does).  Factor jobs only wait for
 // workgroups with a LOWER index (in-order dispatch then guarantees progress however few are resident); the inverse jobs also
 // wait for later ones: FULL needs the whole grid resident (<= 136 workgroups), the mid-size form only the next column's
@@ -83,21 +83,28 @@ struct FactorArgs {
     const T *px = nullptr, *py = nullptr, *pz = nullptr, *ps2 = nullptr;  // !FULL: centred points and sigma2 in T, np long
     u64 *flags = nullptr;  // [ntiles] factor tiles, [ntiles] inverse tiles, abort, (barrier counter), [nbt] handed-over sums
     u64 epoch = 0;
-    int spin_limit = 1 << 20, abort_idx = 0, pre_idx = 0;
+    long long wait_ticks = 2000000;  // 20 ms of the 100 MHz wall clock: after that a wait gives up (wait_budget_ticks, gpx_internal.hpp)
+    int abort_idx = 0, pre_idx = 0;
     double *tmax = nullptr;
     int *tij = nullptr, *negcnt = nullptr, *badrow = nullptr;
     u64 *dbg = nullptr;
 };
 
-// thread 0 of the workgroup: wait until *f == want (false: the abort flag went up, or the spin limit ran out and this
-// call raised it)
-__device__ inline bool poll_flag(const u64 *f, u64 want, u64 *abortf, int limit)
+// thread 0 of the workgroup: wait until *f == want (false: the abort flag went up, or the time budget of the wait ran out and
+// this call raised it).  The budget is CLOCK time (the constant 100 MHz counter), looked at every 32 polls: a grid that cannot
+// make progress costs the caller milliseconds before the launch chain takes over (round 5 counted 2^20 polls: about a second).
+__device__ inline bool poll_flag(const u64 *f, u64 want, u64 *abortf, long long budget_ticks)
 {
-    for (int s = 0; s < limit; ++s) {
+    const u64 t0 = wall_clock64();
+    for (int s = 0;; ++s) {
         if (ld_flag(f) == want)
             return true;
-        if ((s & 31) == 31 && ld_flag(abortf) == want)
-            return false;
+        if ((s & 31) == 31) {
+            if (ld_flag(abortf) == want)
+                return false;
+            if ((long long)(wall_clock64() - t0) > budget_ticks)
+                break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
     st_flag(abortf, want);
@@ -109,9 +116,9 @@ template <typename T>
 __device__ __forceinline__ bool wait_tiles(const u64 *f1, const u64 *f2, const FactorArgs<T> &f, int *s_ok)
 {
     if (threadIdx.x == 0) {
-        bool ok = poll_flag(f1, f.epoch, f.flags + f.abort_idx, f.spin_limit);
+        bool ok = poll_flag(f1, f.epoch, f.flags + f.abort_idx, f.wait_ticks);
         if (ok && f2)
-            ok = poll_flag(f2, f.epoch, f.flags + f.abort_idx, f.spin_limit);
+            ok = poll_flag(f2, f.epoch, f.flags + f.abort_idx, f.wait_ticks);
         *s_ok = ok ? 1 : 0;
     }
     __syncthreads();

@@ -14,7 +14,7 @@
 //     (gpx_diag128.hpp: LDL^T + the inverse of L, 27 us fp32 / 49 us fp64) -- L, D, 1/D and the inverse block `linv` come out of it;
 //   * a tile BELOW the diagonal stores its sums the same way and forms L_IJ = (A_IJ Linv_J^T) D_J^-1 with the same slice loop
 //     (A from its own tile, B = the inverse block);
-//   * flags, write-through publication, ordinary loads on the consumer side, spin limits and the give-up path: as gpx_dataflow.hpp.
+//   * flags, write-through publication, ordinary loads on the consumer side, time budgets of the waits and the give-up path: as gpx_dataflow.hpp.
 // No inverse-factor jobs: every wait is for a workgroup with a lower index.
 #pragma once
 #include "gpx_dataflow.hpp"

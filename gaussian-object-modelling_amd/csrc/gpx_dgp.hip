@@ -548,8 +548,8 @@ extern "C" int gpx_dgp_add(gpx_dgp *g, size_t n_new, const double *x, const doub
     un.resize(3 * n, 0.0);
     if (normals)
         std::copy(normals, normals + 3 * n_new, un.begin() + 3 * n0);
-    const char *app_env = std::getenv("GPX_DGP_APPEND");  // 0: rebuild on the union (tests compare the two)
-    const bool append = (!app_env || std::atoi(app_env) != 0) && 4 * n0 >= (size_t)TILE;
+    const int app_env = gpxh::switches().dgp_append;  // GPX_DGP_APPEND=0: rebuild on the union (tests compare the two)
+    const bool append = app_env != 0 && 4 * n0 >= (size_t)TILE;
     gpx_dgp *fresh = nullptr;
     gpx_options o = g->opt;
     o.device = g->m->device;

@@ -36,10 +36,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     // 16-row fragment, the fp64 epilogue inside the triangle, v written directly; where the operand's arithmetic is fp32
     // the wave forms it in registers and neither launch_kqp nor an operand buffer is needed (gpx_varcols.hip) -- the
     // query batch is then bounded only by the fit's coefficient array (136 bytes per query).
-    static const bool var_cols_on = [] {
-        const char *ev = std::getenv("GPX_VAR_COLS");
-        return !ev || std::atoi(ev) != 0;
-    }();
+    const bool var_cols_on = gpxh::switches().var_cols != 0;
     const bool use_cols = v && var_cols_on && m->var_fit && !m->x_packed && m->prec != GPX_PREC_F64 &&
                           var_cols_fits(m->n, np, np, np + KQP_LDPAD);
     VarColsArgs vc;
@@ -95,12 +92,8 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     // mean and gradient always in fp64 from the fp64 points and alpha (cheap next to the variance, and
     // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
     // (small fp64 models without a gradient: the mean rides on the operand values of the variance kernel, gpx_varcols64.hip;
-    // GPX_VAR_COLS64_MEAN=0, read per call: the mean kernel as everywhere else)
-    bool mean_fused = use_cols64 && !g;
-    if (mean_fused) {
-        const char *e_ = std::getenv("GPX_VAR_COLS64_MEAN");
-        mean_fused = !e_ || std::atoi(e_) != 0;
-    }
+    // with a gradient request the mean kernel runs as everywhere else -- the tests compare the two)
+    const bool mean_fused = use_cols64 && !g;
     if (!mean_fused)
         launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred, s,
                        m->n);
@@ -215,11 +208,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             // (gpx_vargemm.hip; 152 TFLOP/s at N = 16384).  GPX_VAR_TILE=3 selects the documented fallback, the LDS-staged
             // 128 x 128 tile with 64-byte k rows at three workgroups per CU (139-140 TFLOP/s) -- also what 6 falls back to
             // for a shape the one-wave kernel does not take.
-            static const int var_tile = [] {
-                const char *e = std::getenv("GPX_VAR_TILE");
-                return e && std::atoi(e) == 3 ? 3 : 6;
-            }();
-            a.cfg = var_tile;
+            a.cfg = gpxh::switches().var_tile == 3 ? 3 : 6;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)
@@ -320,10 +309,7 @@ static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
            *dg = d + 5 * total, *dtx = d + 8 * total, *dty = d + 11 * total;
     hipStream_t s = m->stream;
     // a handful of queries on a small model: one launch that reads and writes the pinned buffer directly
-    static const bool small_on = [] {
-        const char *e = std::getenv("GPX_SMALL_EVAL");
-        return !e || std::atoi(e) != 0;
-    }();
+    const bool small_on = gpxh::switches().small_eval != 0;
     if (small_on && total <= SMALL_EVAL_MAX_NQ && m->npad <= SMALL_EVAL_NP_MAX &&
         !(wv && m->opt.precision == GPX_PREC_F32_SPLIT)) {
         if (wv && (rc = build_inverse(m)))
@@ -775,9 +761,7 @@ extern "C" int gpx_model_project(const gpx_model *cm, size_t nq, const double *x
     HIPCHK(hipMemcpyAsync(cz, z, sizeof(double) * nq, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g, normal, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(iter, 0, sizeof(int) * 2 * nq, s));
-    bool fused = true;
-    if (const char *e = std::getenv("GPX_PROJECT_FUSED"))
-        fused = std::atoi(e) != 0;
+    bool fused = gpxh::switches().project_fused != 0;
     if (fused)  // the whole loop in one launch when the model fits the LDS (N <= 4096)
         fused = launch_project_fused(m->cov, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, o.f_tol,
                                      o.improve_tol, o.step_mul, o.max_iter, cx, cy, cz, g, fcur, iter, status, s);

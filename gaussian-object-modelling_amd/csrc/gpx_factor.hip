@@ -225,11 +225,10 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(int kb, const T *__restri
 // the current one, so a block costs a poll round trip and a register matvec (~2.5 us) -- with the loads behind the
 // poll it was 8 us and the 127 blocks of the last row took as long as 256 step launches.  In-order dispatch is what
 // the hardware does, not a guarantee of the programming model (other streams, host threads and processes share the
-// GPU): a poll that exceeds the spin limit gives up with 0 and raises info[5], every workgroup still reaches its
+// GPU): a poll that exceeds its time budget gives up with 0 and raises info[5], every workgroup still reaches its
 // end, and the host then REDOES the solve with the launch-per-step kernels below (build_model, gpx_build.hip;
 // gpx_stats.solve_fallbacks) -- neither a hung GPU nor a failed call.
 // The backward direction runs the same scheme bottom-up on L^T, with D^-1 folded into its start.
-constexpr int SOLVE_SPIN_LIMIT = 1 << 21;
 
 template <typename T>
 __device__ __forceinline__ void block_load(const T *__restrict__ M, long ldm, T (&m0)[32], T (&m1)[32])
@@ -294,26 +293,35 @@ __device__ __forceinline__ void block_mv_regs_t(const T (&mv)[64], const T *v_ld
         out_lds[c] = s + scratch_lds[c];
 }
 
-// entry *p of the shared vector once it is no sentinel any more (0 and info[5] = 1 after spin_limit polls)
-__device__ __forceinline__ float poll_entry(const float *p, int *info, int spin_limit)
+// entry *p of the shared vector once it is no sentinel any more (0 and info[5] = 1 once the time budget of the wait -- ticks of
+// the constant 100 MHz clock, looked at every 32 polls -- is spent, or at once when the factor itself is void: info[6])
+__device__ __forceinline__ float poll_entry(const float *p, int *info, long long wait_ticks)
 {
     const unsigned *u = reinterpret_cast<const unsigned *>(p);
-    for (int spins = 0; spins < spin_limit; ++spins) {
+    const unsigned long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
         const unsigned b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffu)
             return __uint_as_float(b);
+        if ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
+                                   __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+            break;
         __builtin_amdgcn_s_sleep(1);
     }
     atomicExch(&info[5], 1);
     return 0.0f;
 }
-__device__ __forceinline__ double poll_entry(const double *p, int *info, int spin_limit)
+__device__ __forceinline__ double poll_entry(const double *p, int *info, long long wait_ticks)
 {
     const unsigned long long *u = reinterpret_cast<const unsigned long long *>(p);
-    for (int spins = 0; spins < spin_limit; ++spins) {
+    const unsigned long long t0 = wall_clock64();
+    for (int spins = 0;; ++spins) {
         const unsigned long long b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffffffffffull)
             return __longlong_as_double((long long)b);
+        if ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
+                                   __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+            break;
         __builtin_amdgcn_s_sleep(1);
     }
     atomicExch(&info[5], 1);
@@ -334,7 +342,7 @@ __device__ __forceinline__ void publish_entry(double *p, double v)
 template <typename T, bool TRANS>
 __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__restrict__ L, long ld,
                                                         const T *__restrict__ linv, const T *__restrict__ scale,
-                                                        const T *__restrict__ rhs, T *out, int *info, int spin_limit)
+                                                        const T *__restrict__ rhs, T *out, int *info, long long wait_ticks)
 {
     __shared__ T vk[TILE], upd[TILE], scratch[TILE];
     constexpr int RS = TRANS ? 64 : 32;  // registers of one half block set
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__res
     auto step = [&](int s, const T(&r0)[RS], const T(&r1)[TRANS ? 1 : 32]) {
         const int k = TRANS ? nblk - 1 - s : s;
         if (tid < TILE)
-            vk[tid] = poll_entry(out + k * TILE + tid, info, spin_limit);
+            vk[tid] = poll_entry(out + k * TILE + tid, info, wait_ticks);
         __syncthreads();
         mv(r0, r1);
         __syncthreads();
@@ -401,10 +409,8 @@ __global__ __launch_bounds__(256) void tri_solve_kernel(int nblk, const T *__res
 
 template <typename T>
 static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b, void *y,
-                        void *x, int *info, hipStream_t st, int spin_limit)
+                        void *x, int *info, hipStream_t st, long long wait_ticks)
 {
-    if (spin_limit <= 0)
-        spin_limit = SOLVE_SPIN_LIMIT;
     const size_t words = (size_t)nblk * TILE * (sizeof(T) / 4);
     if ((char *)x == (char *)y + words * 4) {  // adjacent (the model's vectors are): one fill
         (void)hipMemsetD32Async((hipDeviceptr_t)y, (int)0xffffffff, 2 * words, st);
@@ -413,19 +419,19 @@ static void tri_solve_t(int nblk, const void *L, long ld, const void *linv, cons
         (void)hipMemsetD32Async((hipDeviceptr_t)x, (int)0xffffffff, words, st);
     }
     hipLaunchKernelGGL((tri_solve_kernel<T, false>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
-                       (const T *)nullptr, (const T *)b, (T *)y, info, spin_limit);
+                       (const T *)nullptr, (const T *)b, (T *)y, info, wait_ticks);
     hipLaunchKernelGGL((tri_solve_kernel<T, true>), dim3(nblk), dim3(256), 0, st, nblk, (const T *)L, ld, (const T *)linv,
-                       (const T *)dinv, (const T *)y, (T *)x, info, spin_limit);
+                       (const T *)dinv, (const T *)y, (T *)x, info, wait_ticks);
 }
 
 // x = (L D L^T)^-1 b (y: scratch of the same length), two launches
 void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv, const void *dinv, const void *b,
-                      void *y, void *x, int *info, hipStream_t st, int spin_limit)
+                      void *y, void *x, int *info, hipStream_t st, long long wait_ticks)
 {
     if (prec == GPX_PREC_F64)
-        tri_solve_t<double>(nblk, L, ld, linv, dinv, b, y, x, info, st, spin_limit);
+        tri_solve_t<double>(nblk, L, ld, linv, dinv, b, y, x, info, st, wait_ticks);
     else
-        tri_solve_t<float>(nblk, L, ld, linv, dinv, b, y, x, info, st, spin_limit);
+        tri_solve_t<float>(nblk, L, ld, linv, dinv, b, y, x, info, st, wait_ticks);
 }
 
 void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const void *linv, void *b, void *y,

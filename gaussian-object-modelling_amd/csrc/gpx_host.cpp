@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace gpxh {
@@ -141,4 +142,59 @@ void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm)
     }
 }
 
+}  // namespace gpxh
+
+// ---- switches ---------------------------------------------------------------------------------------------------------------
+namespace gpxh {
+namespace {
+std::atomic<const Switches *> g_switches{nullptr};
+std::mutex g_switches_mtx;
+
+const Switches *parse_switches()
+{
+    Switches *s = new Switches();
+    auto num = [](const char *name, long unset) {
+        const char *e = std::getenv(name);
+        return (e && *e) ? std::atol(e) : unset;
+    };
+    s->pool_mb = num("GPX_POOL_MB", -1);
+    s->train_f64_max = (int)num("GPX_TRAIN_F64_MAX", -1);
+    s->dataflow = (int)num("GPX_DATAFLOW", -1);
+    s->wait_budget_us = num("GPX_WAIT_BUDGET_US", -1);
+    s->update_append = (int)num("GPX_UPDATE_APPEND", -1);
+    s->dgp_append = (int)num("GPX_DGP_APPEND", -1);
+    s->var_cols = (int)num("GPX_VAR_COLS", -1);
+    s->var_cols16 = (int)num("GPX_VAR_COLS16", -1);
+    s->var_cols64 = (int)num("GPX_VAR_COLS64", -1);
+    s->var_tile = (int)num("GPX_VAR_TILE", -1);
+    s->var_fit = (int)num("GPX_VAR_FIT", -1);
+    s->no_promote = (int)num("GPX_NO_PROMOTE", -1);
+    s->small_eval = (int)num("GPX_SMALL_EVAL", -1);
+    s->project_fused = (int)num("GPX_PROJECT_FUSED", -1);
+    s->inv64 = (int)num("GPX_INV64", -1);
+    return s;
+}
+}  // namespace
+
+const Switches &switches()
+{
+    const Switches *s = g_switches.load(std::memory_order_acquire);
+    if (!s) {
+        std::lock_guard<std::mutex> lk(g_switches_mtx);
+        s = g_switches.load(std::memory_order_acquire);
+        if (!s) {
+            s = parse_switches();
+            g_switches.store(s, std::memory_order_release);
+        }
+    }
+    return *s;
+}
+
+// (the previous block is leaked on purpose: a caller that fetched the reference a moment ago may still read it; a test hook,
+// a few hundred bytes per call)
+void switches_reload()
+{
+    std::lock_guard<std::mutex> lk(g_switches_mtx);
+    g_switches.store(parse_switches(), std::memory_order_release);
+}
 }  // namespace gpxh

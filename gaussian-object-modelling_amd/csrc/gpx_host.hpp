@@ -9,6 +9,7 @@
 //                       finds no leader (the node issues one evaluate per grid point from hundreds of threads,
 //                       reference src/gp_node.cpp:1027-1038)
 //   * eigen_pivot_order : Eigen 3.2 LDLT's pivot sequence from the diagonal (reference gp_regressor.hpp:161-162)
+//   * Switches        : the developer / test switches of DESIGN section 10, parsed from the environment ONCE
 #pragma once
 #include <condition_variable>
 #include <cstddef>
@@ -122,5 +123,31 @@ private:
 // swap it to k.  The left-looking algorithm never updates the trailing diagonal before it is chosen, so the sequence
 // depends on diag(K) only.  perm: internal position -> caller index.
 void eigen_pivot_order(const std::vector<double> &diag, std::vector<int> &perm);
+
+// ---- developer / test switches -----------------------------------------------------------------------
+// Every switch the library honours, read from the environment once per process (first use) and again only on
+// gpx_debug_reload() (include/gpx.h) -- no getenv on any call path (round 5 had 32 sites, several per evaluate).  -1 = unset:
+// the default, which is the product; each twin a switch selects is held to the default by a test.
+struct Switches {
+    long pool_mb = -1;         // GPX_POOL_MB         cap of the buffer pool (read when the pool is first used)
+    int train_f64_max = -1;    // GPX_TRAIN_F64_MAX   F32 / F32_SPLIT models of up to this many padded rows train in fp64 (default 2048)
+    int dataflow = -1;         // GPX_DATAFLOW        0: the launch chain at every size (twin of the one-launch creates);
+                               //                     64 | 128: that tile form of the dataflow factorisation at every size above the small models
+    long wait_budget_us = -1;  // GPX_WAIT_BUDGET_US  time after which a wait inside a dataflow launch / the one-launch substitution gives up
+                               //                     (tests: 0 forces the give-up and with it the fallback paths)
+    int update_append = -1;    // GPX_UPDATE_APPEND   0: update() always rebuilds (twin of the rank-n append)
+    int dgp_append = -1;       // GPX_DGP_APPEND      0: gpx_dgp_add rebuilds on the union
+    int var_cols = -1;         // GPX_VAR_COLS        0: small models through the general 128 x 128 tiles
+    int var_cols16 = -1;       // GPX_VAR_COLS16      0: small split-mode models on the fp32 small-model kernel
+    int var_cols64 = -1;       // GPX_VAR_COLS64      0: small fp64 models through the general path
+    int var_tile = -1;         // GPX_VAR_TILE        3: the LDS-staged four-wave tile instead of the one-wave tile
+    int var_fit = -1;          // GPX_VAR_FIT         0: plain kernel values in the fp32 contraction (no per-query fit)
+    int no_promote = -1;       // GPX_NO_PROMOTE      1: an indefinite fp32-mode model is rounded to fp32 all the same
+    int small_eval = -1;       // GPX_SMALL_EVAL      0: few-query calls through the general path
+    int project_fused = -1;    // GPX_PROJECT_FUSED   0: gpx_model_project as a host loop over evaluate calls
+    int inv64 = -1;            // GPX_INV64           0: the inverse factor of fp32 models assembled in fp32
+};
+const Switches &switches();
+void switches_reload();  // re-read the environment (tests); not while other threads are inside the library
 
 }  // namespace gpxh

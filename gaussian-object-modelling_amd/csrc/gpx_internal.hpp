@@ -284,7 +284,7 @@ void launch_var_cols16(const VarColsArgs &a, float sk, const void *ws, hipStream
 // v = k(0) - sum_m (X k_q)_m^2 / D_m for nq queries in one launch: operand formed in the wave, every row fragment resident,
 // the triangle of X skipped per 16-row fragment, v written directly (X: np x ldx fp64 lower triangular; px..: the fp64 points)
 constexpr int VARCOLS64_MAX_N = 1024;    // points the kernel holds in LDS
-constexpr int VARCOLS64_DEFAULT_N = 992;  // models routed to it (GPX_VAR_COLS64_MAX overrides, up to VARCOLS64_MAX_N)
+constexpr int VARCOLS64_DEFAULT_N = 992;  // models routed to it (the general path is ahead again from ~1000 points)
 bool var_cols64_fits(int n, int np, long ldx);
 void launch_var_cols64(const CovHost &cov, int n, int np, const double *X, long ldx, const double *px, const double *py,
                        const double *pz, const double *dinv, long nq, const double *qx, const double *qy, const double *qz,
@@ -326,10 +326,10 @@ void launch_fwd_step(int prec, int kb, int nblk, const void *L, long ld, const v
 void launch_bwd_step(int prec, int kb, const void *L, long ld, const void *linv_blocks, void *y, void *x,
                      hipStream_t st);
 // the same substitution, one launch per direction (workgroup per block row, self-validating entries between them):
-// x = (L D L^T)^-1 b, y: scratch of the same length; info[5] = 1 when a wait gave up after spin_limit polls
+// x = (L D L^T)^-1 b, y: scratch of the same length; info[5] = 1 when a wait gave up after wait_ticks of the 100 MHz clock
 // (<= 0: the default limit) -- the result is then invalid and the caller redoes the solve with the step kernels
 void launch_tri_solve(int prec, int nblk, const void *L, long ld, const void *linv_blocks, const void *dinv,
-                      const void *b, void *y, void *x, int *info, hipStream_t st, int spin_limit = 0);
+                      const void *b, void *y, void *x, int *info, hipStream_t st, long long wait_ticks);
 void factor_init(int prec);  // per-device one-time kernel attributes (LDS size of diag_ldl)
 void launch_scale_vec(int prec, int npad, void *b, const void *dinv, hipStream_t st);
 

@@ -219,6 +219,11 @@ void factorize_matrix_append(gpx_model *m, int t0);
 void factorize_matrix(gpx_model *m);     // blocked LDL^T of m->Kmat in place (t_d, t_dinv, linv, d_info)
 void solve_factored(gpx_model *m, void *b /*consumed*/, void *ytmp, void *x);  // x = (L D L^T)^-1 b on T vectors
 void set_query_batch(gpx_model *m);
+// Time after which a wait inside a dataflow launch / the one-launch substitution gives up, in ticks of the constant 100 MHz
+// clock: 20 ms up to 8192 padded rows (such a launch takes 0.1 - 6 ms), 200 ms above (N = 16384 fp64: 30 ms); GPX_WAIT_BUDGET_US
+// overrides (tests: 0 = give up at once).  A fallback costs the caller this much, not the second of round 5's poll counts.
+long long wait_budget_ticks(int npad);
+int device_cu_count(int dev);  // hipDeviceAttributeMultiprocessorCount, cached per ordinal (0 when it cannot be told)
 void set_split_scale(gpx_model *m);  // F32_SPLIT: m->sk from the kernel's amplitude (every model of the mode, packed or not)
 bool split_packs(const gpx_model *m);  // F32_SPLIT: does a model of this size hold packed fp16 operands (small ones keep the fp32 kernel)
 void set_training_precision(gpx_model *m);

@@ -293,11 +293,7 @@ void launch_var_fit(bool op64, const CovHost &h, int n, const double *px, const 
                     const double *cen, long nq_valid, long nq_tile, const double *qx, const double *qy,
                     const double *qz, double *coef, long ldcc, hipStream_t st, bool compact)
 {
-    static const int nsamp = [] {
-        const char *e = std::getenv("GPX_VAR_FIT_SAMPLES");  // 16 .. 128 strided training points per query
-        const int v = e ? std::atoi(e) : VAR_FIT_SAMPLES_DEFAULT;
-        return v < 16 ? 16 : (v > VAR_FIT_SAMPLES ? VAR_FIT_SAMPLES : v);
-    }();
+    constexpr int nsamp = VAR_FIT_SAMPLES_DEFAULT;  // strided training points per query (sweep of 16 .. 128: profiles/r03_fit_variants_*.txt)
     // Small models (the small-model variance kernel's range): 32 samples.  The fit kernel's time is proportional to the
     // samples and independent of N -- 0.19 ms for 2^21 queries at 32 samples, 8 % of the variance stage at N = 277 -- while
     // the accuracy is not (see gpx_internal.hpp: 3.6 / 3.7e-6 and 1.5 / 1.2e-6 at 32 / 64 samples).

@@ -15,7 +15,7 @@
 //                        a grid of workgroups with an atomic-counter barrier between the phases.
 //   small_demote_kernel  (fp32-mode models, which train in fp64 at this size) the fp32 state: blob part 0 and X rounded once.
 //
-// Every wait has a spin limit: a workgroup that runs out of patience raises the abort flag, all others see it in their
+// Every wait has a time budget: a workgroup that runs out of patience raises the abort flag, all others see it in their
 // polls and leave, and the host redoes the create with the general chain (gpx_stats.solve_fallbacks = 1) -- as
 // tri_solve_kernel does.  Workgroups are enumerated column by column, so a factorisation job only ever waits for
 // workgroups with a lower index; the inverse jobs also wait for later ones, which is why all (<= 136) must be resident.
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SM_THREADS, 1) void small_factor_kernel(const Small
     f.n = a.n, f.np = a.np, f.nbt = a.nbt, f.nb = a.nb, f.ntiles = a.ntiles;
     f.cov = a.cov;
     f.K = a.K, f.linv = a.linv, f.d = a.d, f.dinv = a.dinv;
-    f.flags = a.flags, f.epoch = a.epoch, f.spin_limit = a.spin_limit, f.abort_idx = a.abort_idx, f.pre_idx = a.pre_idx;
+    f.flags = a.flags, f.epoch = a.epoch, f.wait_ticks = a.wait_ticks, f.abort_idx = a.abort_idx, f.pre_idx = a.pre_idx;
     f.tmax = a.tmax, f.tij = a.tij, f.negcnt = a.negcnt, f.badrow = a.badrow;
     f.dbg = a.dbg;
     factor_tile<double, KID, true>(f, ap, sm);
@@ -153,12 +153,13 @@ __device__ __forceinline__ bool grid_barrier(const SmallArgs &a, int index, int 
         __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u64 target = (u64)gridDim.x * (u64)index;
         bool ok = false;
-        for (int s = 0; s < a.spin_limit; ++s) {
+        const u64 t0 = wall_clock64();
+        for (int s = 0;; ++s) {
             if (ld_flag(cnt) >= target) {
                 ok = true;
                 break;
             }
-            if ((s & 31) == 31 && ld_flag(abortf) == a.epoch)
+            if ((s & 31) == 31 && (ld_flag(abortf) == a.epoch || (long long)(wall_clock64() - t0) > a.wait_ticks))
                 break;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -452,7 +453,7 @@ static void mid_factor_t(const CovHost &h, const MidFactorArgs &m, hipStream_t s
     f.px = (const T *)m.px, f.py = (const T *)m.py, f.pz = (const T *)m.pz, f.ps2 = (const T *)m.ps2;
     const MidWs lay = mid_ws_layout(m.np);
     char *ws = (char *)m.ws;
-    f.flags = (u64 *)(ws + lay.flags), f.epoch = m.epoch, f.spin_limit = m.spin_limit;
+    f.flags = (u64 *)(ws + lay.flags), f.epoch = m.epoch, f.wait_ticks = m.wait_ticks;
     f.abort_idx = 2 * f.ntiles, f.pre_idx = 2 * f.ntiles + 2;
     f.tmax = (double *)(ws + lay.tmax), f.tij = (int *)(ws + lay.tij);
     f.negcnt = (int *)(ws + lay.negcnt), f.badrow = (int *)(ws + lay.badrow);

@@ -7,6 +7,7 @@ namespace gpx {
 
 constexpr int SMALL_TILE = 64;          // tile edge of the dataflow factorisation
 constexpr int SMALL_CREATE_MAX_NP = 1024;  // padded rows up to which create() takes this path (fp64 training only)
+constexpr int SMALL_ALPHA_MAX_GRID = 128;  // workgroups of the second launch (64 up to 512 padded rows), all resident: it has grid barriers
 
 // what the host reads back after the launches (one copy)
 struct SmallResult {
@@ -27,7 +28,8 @@ struct SmallArgs {
     int want_corr = 0, op64 = 0, ir_max = 4, ir_adaptive = 1;
     double ir_tol = 0;
     unsigned long long epoch = 0;
-    int spin_limit = 1 << 20, abort_idx = 0, bar_idx = 0, pre_idx = 0;
+    long long wait_ticks = 2000000;  // time budget of every wait, 100 MHz ticks (wait_budget_ticks)
+    int abort_idx = 0, bar_idx = 0, pre_idx = 0;
     // ---- model state written by the launches ----
     double *K = nullptr, *X = nullptr, *linv = nullptr, *d = nullptr, *dinv = nullptr;
     double *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *t_x = nullptr, *t_y = nullptr, *t_z = nullptr;
@@ -77,6 +79,8 @@ inline SmallWs small_ws_layout(int np)
 
 // ---- the same dataflow factorisation for mid-size models (kernel matrix + LDL^T in one launch; the chain goes on from there)
 constexpr int MID_FACTOR_MAX_NP_F32 = 16384, MID_FACTOR_MAX_NP_F64 = 16384;  // padded rows up to which a fresh create() factorises this way
+constexpr int MID_FACTOR_FORCED_MAX_NP = 32768;  // ... when GPX_DATAFLOW=64|128 forces a tile form (tests run it at 20480 rows)
+constexpr int WIDE_FACTOR_MIN_NP = 8192;         // padded rows from which the 128 x 128 tiles are used
 struct MidWs {
     size_t flags, tmax, tij, negcnt, badrow, bytes;
 };
@@ -101,7 +105,7 @@ struct MidFactorArgs {
     void *ws = nullptr;  // mid_ws_layout(np).bytes
     int *info = nullptr;  // the model's d_info: [0..3] as the chain leaves them, [6] = 1 when a wait gave up
     unsigned long long epoch = 0;
-    int spin_limit = 1 << 20;
+    long long wait_ticks = 2000000;  // time budget of every wait, 100 MHz ticks (wait_budget_ticks)
     bool wide = false;  // 128 x 128 tiles (gpx_dataflow_wide.hpp): large models, where the 64 x 64 form is HBM-bound
 };
 // kernel matrix + LDL^T (L, D in K; d, dinv; the 128 x 128 inverse diagonal blocks linv) + the info reduction; asynchronous

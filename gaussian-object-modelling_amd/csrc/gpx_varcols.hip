@@ -11,14 +11,10 @@ bool var_cols_fits(int n, int np, long ldx, long ldk)
 }
 
 // the operand can be formed inside the wave when its arithmetic is fp32 (every kernel but the thin plate, whose operand is
-// formed in fp64 and rounded once: gpx_internal.hpp, "low-rank fit"); GPX_VAR_COLS_GEN=0: always read the operand buffer
+// formed in fp64 and rounded once: gpx_internal.hpp, "low-rank fit" -- that model reads the operand buffer)
 bool var_cols_gen(const VarColsArgs &a)
 {
-    static const bool gen_on = [] {
-        const char *e = std::getenv("GPX_VAR_COLS_GEN");
-        return !e || std::atoi(e) != 0;
-    }();
-    return gen_on && !a.op64 && a.cov.id != GPX_KERNEL_THINPLATE && a.px && a.qx;
+    return !a.op64 && a.cov.id != GPX_KERNEL_THINPLATE && a.px && a.qx;
 }
 
 void launch_var_cols(const VarColsArgs &a, hipStream_t st)

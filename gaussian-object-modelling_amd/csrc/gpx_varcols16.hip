@@ -330,11 +330,10 @@ size_t var_cols16_ws_bytes(int n)
 }
 
 // the kernel forms its operand in fp32 from the centred points: every kernel but the thin plate (whose operand is formed in
-// fp64: those models keep the fp32 small-model kernel); GPX_VAR_COLS16=0, read per call: never
+// fp64: those models keep the fp32 small-model kernel); GPX_VAR_COLS16=0: never
 bool var_cols16_takes(const VarColsArgs &a)
 {
-    const char *e = std::getenv("GPX_VAR_COLS16");
-    if (e && std::atoi(e) == 0)
+    if (gpxh::switches().var_cols16 == 0)
         return false;
     return !a.op64 && a.cov.id != GPX_KERNEL_THINPLATE && a.px && a.qx && a.n > 0 && a.n <= VARCOLS_MAX_N &&
            a.ldx % 4 == 0 && a.np % 32 == 0;

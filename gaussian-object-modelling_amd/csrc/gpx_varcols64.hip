@@ -33,8 +33,8 @@
 // (profiles/r05_var64_parts.txt, N = 277): MFMAs + loop + epilogue 2.9 ms (the MFMAs alone: 2.4), operand 0.5, requests for X
 // 0.25 -- one after the other, since nothing but scalar work hides behind an MFMA of the same SIMD (a second wave per SIMD
 // with half the slots was built and measured: no gain).
-// Models of up to VARCOLS64_DEFAULT_N points are routed here (GPX_VAR_COLS64_MAX overrides, up to the VARCOLS64_MAX_N points
-// the LDS arrays hold); GPX_VAR_COLS64=0: the general path.  Both switches are read per call.
+// Models of up to VARCOLS64_DEFAULT_N points are routed here (the kernel's LDS arrays hold up to VARCOLS64_MAX_N points);
+// GPX_VAR_COLS64=0: the general path.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -311,11 +311,8 @@ size_t var_cols64_ws_bytes(int n)
 
 bool var_cols64_fits(int n, int np, long ldx)
 {
-    const char *e = std::getenv("GPX_VAR_COLS64");  // (read per call: the tests compare both routes in one process)
-    const bool on = !e || std::atoi(e) != 0;
-    const char *mx = std::getenv("GPX_VAR_COLS64_MAX");
-    const int max_n = mx ? std::min(std::atoi(mx), VARCOLS64_MAX_N) : VARCOLS64_DEFAULT_N;
-    return on && n > 0 && n <= max_n && ldx % 2 == 0 && np % 32 == 0;
+    const bool on = gpxh::switches().var_cols64 != 0;  // GPX_VAR_COLS64=0: the general path (tests compare the routes)
+    return on && n > 0 && n <= VARCOLS64_DEFAULT_N && ldx % 2 == 0 && np % 32 == 0;
 }
 
 void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ldx, const double *px, const double *py,

@@ -37,15 +37,9 @@
 
 namespace gpx {
 
-// GPX_VAR_DIAG_SKIP=0: the one-wave tiles multiply the zero fragments of their diagonal block (tests compare: bit-identical)
-static int var_diag_skip()
-{
-    static const int on = [] {
-        const char *e = std::getenv("GPX_VAR_DIAG_SKIP");
-        return e ? std::atoi(e) : 1;
-    }();
-    return on;
-}
+// the one-wave tiles leave the zero fragments of their diagonal block out (round 4; bit-identical to multiplying them, which
+// the deleted GPX_VAR_DIAG_SKIP=0 selected: profiles/r04_diag_skip.txt)
+static int var_diag_skip() { return 1; }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef double d4v __attribute__((ext_vector_type(4)));
@@ -500,17 +494,11 @@ bool var_w1_f64_fits(const GemmArgs &a)
 }
 
 // Paired launch (see var_w1_kernel) when the row tiles pair up and the pairs fill the SIMDs in whole rounds -- equal-length
-// workgroups would otherwise leave a partly filled last round that nothing balances.  GPX_VAR_PAIR=0/1 overrides.
+// workgroups would otherwise leave a partly filled last round that nothing balances.
 static bool var_w1_paired(int MT, int NT)
 {
-    static const int pair_env = [] {
-        const char *e = std::getenv("GPX_VAR_PAIR");
-        return e ? std::atoi(e) : -1;
-    }();
     if (MT < 2 || MT % 2)
         return false;
-    if (pair_env >= 0)
-        return pair_env != 0;
     static std::atomic<int> cu_count[MAX_DEVICES];  // per device, 0 = not asked yet
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES)

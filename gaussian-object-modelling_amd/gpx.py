@@ -68,7 +68,7 @@ EXPORTS = [
     "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
-    "gpx_model_replicate", "gpx_trim", "gpx_model_march_surface",
+    "gpx_model_replicate", "gpx_trim", "gpx_debug_reload", "gpx_model_march_surface",
     "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_dgp_create", "gpx_dgp_evaluate", "gpx_dgp_get",
     "gpx_dgp_add", "gpx_dgp_destroy", "gpx_dgp_loglik_gradient", "gpx_rprop_default", "gpx_dgp_optimise", "gpx_pcd_read", "gpx_node_training_set",
 ]
@@ -147,6 +147,7 @@ def lib():
     L.gpx_model_march_surface.argtypes = [vp, dp, C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_size_t, dp, dp, dp,
                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.gpx_trim.restype = None
+    L.gpx_debug_reload.restype = None
     L.gpx_model_replicate.restype = C.c_int
     L.gpx_model_replicate.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.gpx_dev_kbuild.restype = C.c_int
@@ -193,6 +194,39 @@ def device_count():
 def trim():
     """Free the pool of parked large device buffers (gpx_trim)."""
     lib().gpx_trim()
+
+
+def debug_reload():
+    """gpx_debug_reload: parse the GPX_* switches from the environment again (the library reads them once per process)."""
+    lib().gpx_debug_reload()
+
+
+class switches:
+    """with gpx.switches(GPX_DATAFLOW="0", ...): set the named switches, reload; restore the environment and reload on exit
+    (the test suites hold every twin path to the default one this way).  A value of None unsets the variable."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            assert k.startswith("GPX_"), k
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        debug_reload()
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        debug_reload()
+        return False
 
 
 def make_kernel(name, *params):

@@ -232,6 +232,12 @@ void gpx_model_destroy(gpx_model *m);
  * hundreds of milliseconds; GPX_POOL_MB (default 16384, 0 = off) caps the parked bytes.  gpx_trim() frees them. */
 void gpx_trim(void);
 
+/* The developer / test switches (GPX_* environment variables) are parsed ONCE per process, at the first
+ * call that needs one; no call path reads the environment.  gpx_debug_reload() parses them again -- the test suites change a
+ * switch between two calls of one process.  Not to be called while other threads are inside the library.  (No reference
+ * counterpart: gp_regressor.hpp has no switches.) */
+void gpx_debug_reload(void);
+
 /* ---- one model, query grid sharded over ranks (one process per GPU) -----------------------
  * The rank that factorised exports its read-only state as two contiguous device blobs (part 0: points, alpha, 1/D, the
  * 14 row vectors of the variance fit, the centre of the cloud; part 1: the inverse factor); the host moves them with

@@ -1,4 +1,4 @@
-"""LDL^T above the dataflow's upper bound (N = 24576, 32768; GPX_MID_FACTOR_MAX=65536 extends the 128 x 128-tile dataflow there):
+"""LDL^T above the dataflow's upper bound (N = 24576, 32768; GPX_DATAFLOW=128 extends the 128 x 128-tile dataflow there):
 where the launch chain's big GEMM updates take over again -- profiles/r05_ldlt_sweep.txt, last block."""
 import importlib, os, sys
 sys.path.insert(0, '/root/repo')

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel timeline of create() at the node's model sizes (N = 277 and 724, fp64 and fp32 mode) -- the three launches of
-# csrc/gpx_small.hip; GPX_SMALL_CREATE=0 in the environment gives the general chain for comparison
+# csrc/gpx_small.hip; GPX_DATAFLOW=0 in the environment gives the general chain for comparison
 set -o pipefail
 out=$PWD/gpurun_out/r5t${GPX_SMALL_CREATE:+_chain}; mkdir -p $out
 for n in 277 724; do

@@ -1,4 +1,4 @@
-"""Three-launch create of small models (gpx_small.hip) against its twin, the general chain (GPX_SMALL_CREATE=0), and the
+"""Three-launch create of small models (gpx_small.hip) against its twin, the general chain (GPX_DATAFLOW=0), and the
 oracle: alpha, D, R, f, v at several sizes / kernels / precisions, and the wall time of create().
 Usage: python scripts/small_create_check.py [reps]"""
 import importlib, os, sys, time
@@ -15,7 +15,8 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 def build(kern, data, prec, small):
-    os.environ["GPX_SMALL_CREATE"] = "1" if small else "0"
+    os.environ.pop("GPX_DATAFLOW", None) if small else os.environ.__setitem__("GPX_DATAFLOW", "0")
+    gpx.debug_reload()
     m = gpx.Model(kern, *data, precision=prec, prepare_variance=True)
     return m
 

@@ -10,6 +10,7 @@ for n0, n1, prec, pname in ((16384 - 256, 256, gpx.F32, "f32"), (4096 - 64, 64, 
     kern = gpx.make_kernel("matern52", 1.0, 1.0)
     for mode in ("1", "0"):
         os.environ["GPX_UPDATE_APPEND"] = mode
+        gpx.debug_reload()
         ts = []
         for rep in range(3):
             gm = gpx.Model(kern, x[:n0], y[:n0], z[:n0], lab[:n0], s2[:n0], precision=prec)

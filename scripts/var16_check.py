@@ -27,6 +27,7 @@ for kn in ("matern52", "gaussian"):
         out = []
         for on in ("1", "0"):
             os.environ["GPX_VAR_COLS16"] = on
+            gpx.debug_reload()
             v = torch.empty(nq, dtype=torch.float64, device=dev)
             for _ in range(4):
                 m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr()); m.sync()
@@ -50,6 +51,7 @@ for nm in names:
     vref = torch.empty(nq, dtype=torch.float64, device=dev)
     m64.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), vref.data_ptr()); m64.sync(); m64.close()
     os.environ["GPX_VAR_COLS16"] = "1"
+    gpx.debug_reload()
     m = gpx.Model(kern, *data, precision=gpx.F32_SPLIT, prepare_variance=True)
     v = torch.empty(nq, dtype=torch.float64, device=dev)
     m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr()); m.sync()

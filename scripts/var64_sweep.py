@@ -14,14 +14,15 @@ idx = torch.arange(g ** 3, device=dev)
 q = [t[(idx // (g * g)) % g].contiguous(), t[(idx // g) % g].contiguous(), t[idx % g].contiguous()]
 nq = g ** 3
 f = torch.empty(nq, dtype=torch.float64, device=dev); v = torch.empty_like(f)
-sizes = [int(a) for a in sys.argv[1:]] or [64, 128, 200, 256, 277, 320, 400, 480, 512, 600, 724, 800, 900, 1024]
+sizes = [int(a) for a in sys.argv[1:]] or [64, 128, 200, 256, 277, 320, 400, 480, 512, 600, 724, 800, 900, 992]
 kern = gpx.make_kernel("gaussian", 1.0, 1.0)
 print("%6s %36s %40s" % ("N", "small-model kernel: stage ms (of fp64 peak)", "general path: stage ms (of peak; its kernel ms)"))
 for n in sizes:
     m = gpx.Model(kern, *ds.fibonacci_training_set(n), precision=gpx.F64, prepare_variance=True)
     row = []
     for on in ("1", "0"):
-        os.environ["GPX_VAR_COLS64"], os.environ["GPX_VAR_COLS64_MAX"] = on, "1024"
+        os.environ["GPX_VAR_COLS64"] = on
+        gpx.debug_reload()
         for _ in range(3):
             m.evaluate_device(nq, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), f.data_ptr(), v.data_ptr())
             m.sync()

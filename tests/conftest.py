@@ -55,6 +55,17 @@ def gpu(gpx):
     return gpx
 
 
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment():
+    """libgpx parses its GPX_* switches once per process (gpx_debug_reload parses them again): a test that changes one calls
+    gpu.debug_reload() / uses gpu.switches(...); whatever it left behind -- monkeypatch has restored the environment by the time
+    this finaliser runs, autouse fixtures are set up first and torn down last -- is re-read here."""
+    yield
+    mod = sys.modules.get(PKG + ".gpx")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        mod.debug_reload()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(GOLDEN_DIR, "gp_golden.npz"))

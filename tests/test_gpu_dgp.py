@@ -104,6 +104,7 @@ def test_derivative_gp_add_patterns_equals_create_on_the_union(gpu, orc, kern, a
     second 896 of 920, and the model says so) and, bit for bit, with GPX_DGP_APPEND=0 (rebuild on the union); a failing
     append (non-finite sample) leaves the model as it was; a model with fewer than 128 rows is rebuilt."""
     monkeypatch.setenv("GPX_DGP_APPEND", append)
+    gpu.debug_reload()
     P, t, nr = _cloud(300, 77)
     gk = gpu.make_kernel("se", kern[1], kern[2]) if kern[0] == "se" else gpu.make_kernel("thinplate", kern[1])
     a, b = 120, 230

@@ -253,8 +253,10 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, kname, n0, n1, 
     forced32 = prec == 0 and not tp
     if forced32:
         monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+        gpu.debug_reload()
     for mode in ("1", "0"):
         monkeypatch.setenv("GPX_UPDATE_APPEND", mode)
+        gpu.debug_reload()
         gm = gpu.Model(kern, x[:n0], y[:n0], z[:n0], lab[:n0], s2[:n0], precision=prec)
         if inv_first:
             gm.evaluate(qx, qy, qz, want_v=True)
@@ -282,30 +284,6 @@ def test_update_rank_n_append_equals_rebuild(gpu, orc, ds, prec, kname, n0, n1, 
     fresh.close()
 
 
-@pytest.mark.parametrize("prec", [1, 0])
-@pytest.mark.parametrize("n", [600, 2048, 2305, 3000])
-def test_lookahead_factorisation_is_bit_identical(gpu, ds, prec, n, monkeypatch):
-    """Eigen::LDLT::compute (gp_regressor.hpp:161-162): with the next panel factorised on a second stream beside the
-    trailing update (GPX_LOOKAHEAD=1 forces it; by default only at sizes where it pays) every tile sees the same products in the same
-    order: D, alpha and the predictions are bit-identical to the plain order with the same (256-wide) panels.
-    Sizes: 3 panels, exactly 8 panels, a last panel of one block, a ragged end."""
-    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
-    kern = gpu.make_kernel("thinplate", 2.0)
-    qx, qy, qz = ds.query_grid(4)
-    res = {}
-    monkeypatch.setenv("GPX_PANEL", "256")  # the plain fp64 order would use 512-wide panels
-    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # prec 0: the fp32 factorisation at every size
-    for mode in ("1", "0"):
-        monkeypatch.setenv("GPX_LOOKAHEAD", mode)
-        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
-        o = gm.evaluate(qx, qy, qz, want_v=True)
-        res[mode] = (gm.D.copy(), gm.alpha.copy(), o["f"].copy(), o["v"].copy(), gm.stats["n_negative_pivots"])
-        gm.close()
-    for a, b in zip(res["1"][:4], res["0"][:4]):
-        np.testing.assert_array_equal(a, b)
-    assert res["1"][4] == res["0"][4]
-
-
 @pytest.mark.parametrize("n", [16, 129, 300, 600, 1500])
 def test_forced_fp32_training_of_small_models(gpu, orc, ds, n, monkeypatch):
     """GPX_PREC_F32 models of up to 2048 padded rows are trained in fp64 (free at that size).  With the switch off the
@@ -313,6 +291,7 @@ def test_forced_fp32_training_of_small_models(gpu, orc, ds, n, monkeypatch):
     larger sizes (the thin plate never is while fp64 fits the device: its fp32 factorisation cost the variance up to
     9e-6 of max|v| here and 4.4e-5 on random clouds -- set_training_precision): everything at 1e-5."""
     monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    gpu.debug_reload()
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     q = _queries(ds, x, y, z, g=5)
     for kn, par in (("matern52", (1, 1)), ("gaussian", (1, 1))):
@@ -330,27 +309,25 @@ def test_forced_fp32_training_of_small_models(gpu, orc, ds, n, monkeypatch):
 @pytest.mark.parametrize("prec", [1, 0])
 @pytest.mark.parametrize("n", [1500, 2305])
 def test_substitution_give_up_falls_back_to_step_launches(gpu, ds, prec, n, monkeypatch):
-    """The one-launch block substitution hands results from lower to higher block rows through polled entries; a poll
-    that runs out of patience (GPX_SOLVE_SPIN_LIMIT=1 forces that: one look, then give up) voids the solve, and
-    create() then recomputes alpha in-process with the launch-per-step kernels: success, gpx_stats.solve_fallbacks
-    == 1, and exactly the alpha of GPX_SOLVE_STEPS=1."""
+    """The one-launch block substitution hands results from lower to higher block rows through polled entries; a poll whose
+    time budget is spent (GPX_WAIT_BUDGET_US=0 forces that -- and the same for the dataflow factorisation in front of it, which
+    the launch chain then redoes) voids the solve, and create() recomputes alpha in-process with the launch-per-step kernels:
+    success, gpx_stats.solve_fallbacks >= 1, the same alpha on every such run bit for bit, and the alpha of the default path to
+    the working precision."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     kern = gpu.make_kernel("matern52", 1.0, 1.0)
     monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
-    monkeypatch.setenv("GPX_SOLVE_STEPS", "1")
-    gs = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
-    a_steps, st_steps = gs.alpha.copy(), gs.stats
-    gs.close()
-    monkeypatch.setenv("GPX_SOLVE_STEPS", "0")
-    monkeypatch.setenv("GPX_SOLVE_SPIN_LIMIT", "1")
-    gf = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
-    assert gf.stats["solve_fallbacks"] == 1 and st_steps["solve_fallbacks"] == 0
-    np.testing.assert_array_equal(gf.alpha, a_steps)
-    assert gf.stats["alpha_residual"] == st_steps["alpha_residual"]
-    gf.update(x[:5] * 0.5, y[:5] * 0.5, z[:5] * 0.5, lab[:5], s2[:5])  # the update path takes the same fallback
-    assert gf.stats["solve_fallbacks"] == 1
-    gf.close()
-    monkeypatch.delenv("GPX_SOLVE_SPIN_LIMIT")
+    with gpu.switches(GPX_WAIT_BUDGET_US="0"):
+        gf = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+        assert gf.stats["solve_fallbacks"] >= 1 and gf.stats["factor_gemm_launches"] > 0
+        a_steps, res_steps = gf.alpha.copy(), gf.stats["alpha_residual"]
+        g2 = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
+        np.testing.assert_array_equal(g2.alpha, a_steps)
+        assert g2.stats["alpha_residual"] == res_steps
+        g2.close()
+        gf.update(x[:5] * 0.5, y[:5] * 0.5, z[:5] * 0.5, lab[:5], s2[:5])  # the update path takes the same fallback
+        assert gf.stats["solve_fallbacks"] >= 1
+        gf.close()
     gn = gpu.Model(kern, x, y, z, lab, s2, precision=prec)
     assert gn.stats["solve_fallbacks"] == 0
     assert nerr(gn.alpha, a_steps) < (1e-10 if prec == 1 else 1e-5)
@@ -399,15 +376,17 @@ def test_replicas_are_bit_identical_to_their_source(gpu, ds, prec):
 @pytest.mark.parametrize("n", [100, 277, 1500, 2305])
 def test_one_launch_substitution_equals_step_launches(gpu, ds, prec, kname, kpar, n, monkeypatch):
     """LDLT::solve (gp_regressor.hpp:163): the substitution in one launch per direction (workgroup per block row,
-    self-validating hand-over) gives the alpha of the launch-per-block-step path (GPX_SOLVE_STEPS=1); 1 .. 19 block
-    rows, a well-conditioned and an indefinite, ill-conditioned system.  No refinement: the raw solve."""
+    self-validating hand-over) gives the alpha of the launch-per-block-step path (its fallback, forced by a wait budget of zero);
+    both behind the launch chain's factor (GPX_DATAFLOW=0: no other wait gives up); 1 .. 19 block rows, a well-conditioned
+    and an indefinite, ill-conditioned system.  No refinement: the raw solve."""
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     kern = gpu.make_kernel(kname, *kpar)
     res = {}
     monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # prec 0: the fp32 substitution kernels at every size
     for mode in ("0", "1"):
-        monkeypatch.setenv("GPX_SOLVE_STEPS", mode)
-        gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, ir_steps=0)
+        with gpu.switches(GPX_DATAFLOW="0", GPX_WAIT_BUDGET_US="0" if mode == "1" else None):
+            gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, ir_steps=0)
+        assert gm.stats["solve_fallbacks"] == int(mode)
         res[mode] = (gm.alpha.copy(), gm.stats["alpha_residual"])
         gm.close()
     # the two paths sum in different orders: equal up to the conditioning of the system times the working precision
@@ -468,6 +447,7 @@ def test_project_matches_atlas_restatement(gpu, orc, ds, golden, prec, fused, mo
     restatement on the node's own model (mugD, ThinPlate(2.0)): same exits, same iteration counts, same points.
     fused = the whole loop in one launch (models that fit the LDS); otherwise one mean+gradient pass per iteration."""
     monkeypatch.setenv("GPX_PROJECT_FUSED", fused)
+    gpu.debug_reload()
     x, y, z, lab, s2 = (golden["mugD/" + k] for k in ("x", "y", "z", "label", "sigma2"))
     om = orc.Model(orc.make_kernel("thinplate", 2.0), x, y, z, lab, s2)
     gm = gpu.Model(gpu.make_kernel("thinplate", 2.0), x, y, z, lab, s2, precision=prec)
@@ -831,9 +811,8 @@ def test_error_codes_on_device(gpu):
 def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
     """Models of up to 1024 points take the variance contraction of gpx_varcols_kernel.hpp (every row fragment resident in one
     wave, the triangle of X skipped per 16-row fragment, fp64 add-back inside the triangle, operand formed in the wave).
-    Against the general path (GPX_VAR_COLS=0: kqp_kernel -> 128 x 128 tiles -> var_finish) and against its own form that
-    reads the operand buffer (GPX_VAR_COLS_GEN=0) the fp32 contraction is the same k-ordered sum: 5e-7 of max|v|; each
-    within 1e-5 of the fp64 oracle.  Sizes: one pass (<= 192 rows), 2 .. 6 passes, a last fragment with 1 and with 15
+    Against the general path (GPX_VAR_COLS=0: kqp_kernel -> 128 x 128 tiles -> var_finish) the fp32 contraction is the same
+    k-ordered sum: 5e-7 of max|v|; each within 1e-5 of the fp64 oracle.  Sizes: one pass (<= 192 rows), 2 .. 6 passes, a last fragment with 1 and with 15
     padding rows, a cloud translated by (10, -7, 3); every covariance function (the thin plate's operand is formed in fp64
     and always read from the buffer)."""
     import subprocess, sys
@@ -854,7 +833,7 @@ def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base_env = {k: v for k, v in os.environ.items() if not k.startswith("GPX_VAR_")}
     res = {}
-    for name, extra in (("cols", {}), ("general", {"GPX_VAR_COLS": "0"}), ("buffer", {"GPX_VAR_COLS_GEN": "0"})):
+    for name, extra in (("cols", {}), ("general", {"GPX_VAR_COLS": "0"})):
         path = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", child, path], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -864,8 +843,7 @@ def test_small_model_variance_paths_agree(gpu, orc, ds, tmp_path):
     for key in res["cols"].files:
         n, kn = key.split("/")
         vmax = np.max(np.abs(res["general"][key]))
-        for other in ("general", "buffer"):
-            assert np.max(np.abs(res["cols"][key] - res[other][key])) / vmax < 5e-7, (key, other)
+        assert np.max(np.abs(res["cols"][key] - res["general"][key])) / vmax < 5e-7, key
     # the fp64 oracle on a subset (it is the slow side)
     for n, kn, par in ((277, "matern52", (1.0, 1.0)), (724, "gaussian", (1.0, 1.0)), (193, "matern32", (1.0, 0.7)), (511, "thinplate", (4.0,))):
         x, y, z, lab, s2 = ds.fibonacci_training_set(n)
@@ -931,35 +909,13 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
         "            gm.close()\n"
         "np.savez(sys.argv[1], **out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_PAIR", "GPX_VAR_TILE", "GPX_VAR_FIT", "GPX_VAR_DIAG_SKIP")}
+    base_env = {k: v for k, v in os.environ.items() if k not in ("GPX_VAR_TILE", "GPX_VAR_FIT")}
     for tile, fit in (("6", "1"), ("3", "1"), ("6", "0"), ("3", "0")):
         path = str(tmp_path / ("tile%s_%s.npz" % (tile, fit)))
         env = dict(base_env, GPX_VAR_TILE=tile, GPX_VAR_FIT=fit)
         r = subprocess.run([sys.executable, "-c", child, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tile, fit] = np.load(path)
-    # the same one-wave tiles launched the other way round (paired row tiles <-> plain heavy-first order: the light tile of a
-    # pair walks k downwards, so the fp32 sums differ in order only): same results to rounding
-    # and with the zero fragments of the diagonal block multiplied instead of skipped (GPX_VAR_DIAG_SKIP=0): they only ever
-    # added 0 * k to an accumulator, so every variance is the same bit for bit
-    for name, extra in (("pair0", {"GPX_VAR_PAIR": "0"}), ("pair1", {"GPX_VAR_PAIR": "1"}), ("diag0", {"GPX_VAR_DIAG_SKIP": "0"})):
-        path = str(tmp_path / (name + ".npz"))
-        r = subprocess.run([sys.executable, "-c", child, path], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        alt = np.load(path)
-        for key in alt.files:
-            if name == "diag0":
-                np.testing.assert_array_equal(alt[key], res["6", "1"][key], err_msg=key)
-                continue
-            n, kn, prec = key.split("/")
-            vmax = np.max(np.abs(res["6", "1"]["%s/%s/%d" % (n, kn, gpu.F64)]))
-            # (a thin-plate operand is ~k(0) / max|v| = 60 times larger than the variance it contributes to: the order of
-            # the fp32 sums shows there first)
-            # (the order of a 1100- / 2305-term fp32 sum -- ascending against descending k in the paired launch -- is worth
-            # ~5e-7 of max|v|: 5.3e-7 measured at 1100 rows)
-            tol = 1e-12 if int(prec) == gpu.F64 else (3e-6 if kn == "thinplate" else 1e-6)
-            assert np.max(np.abs(alt[key] - res["6", "1"][key])) / vmax < tol, (name, key)
-            assert np.max(np.abs(alt[key] - res["6", "1"]["%s/%s/%d" % (n, kn, gpu.F64)])) / vmax < 1e-5, (name, key)
     keys = sorted(res["6", "1"].files)
     assert len(keys) == 12
     for key in keys:
@@ -976,9 +932,8 @@ def test_variance_tiles_agree(gpu, ds, tmp_path):
             # (and without the fit the thin plate's operand and quadratic form are of size k(0) = R^3 = 64, not of size v)
             scale = vmax if fit == "1" or kn != "thinplate" else 64.0
             # Without the fit (GPX_VAR_FIT=0) the operand keeps k's full magnitude and the plain epilogue sums w^2 / D in fp32:
-            # the result then depends on the ORDER of the k sum at the 4e-6 level (round 3, gpurun_out/alt.log: 3.95e-6 between
-            # tile 3 and tile 6 when the run inherited GPX_VAR_PAIR, the one switch that turns tile 6's walk of k around;
-            # 2.6e-6 in the default order) -- 5e-6 covers both orders, the fit path below stays at 5e-7.
+            # the result then depends on the ORDER of the k sum at the 4e-6 level (round 3: 3.95e-6 between tile 3 and tile 6 with
+            # tile 6's walk of k turned around, 2.6e-6 in the default order) -- 5e-6 covers both, the fit path stays at 5e-7.
             assert np.max(np.abs(r[key] - res["6", fit][key])) / scale < (5e-7 if fit == "1" else 5e-6), (key, tile, fit)
 
 

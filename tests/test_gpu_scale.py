@@ -34,25 +34,26 @@ def test_c2_n4096_fp64_gaussian_against_oracle(gpu, orc, ds):
     g32.close()
 
 
-def test_n8192_fp32_in_the_default_lookahead_window(gpu, ds, monkeypatch):
-    """From 8192 padded rows on the fp32 factorisation runs the look-ahead schedule by default (second stream, 4-wave
-    diagonal-block kernel beside the trailing update): bit-identical to the plain order, and the F32 pipeline within
-    its tolerances of the F64 one."""
+def test_n8192_fp32_dataflow_and_the_lookahead_chain(gpu, ds):
+    """N = 8192 fp32: the default create is one dataflow launch on 128 x 128 tiles; its twin (GPX_DATAFLOW=0) is the blocked
+    launch chain, which from 8192 padded rows on runs its look-ahead schedule (second stream, 4-wave diagonal-block kernel beside
+    the trailing update).  Same inertia, D to the rounding of an fp32 factorisation, alpha / f / v inside the F32 tolerances of
+    each other and of the F64 pipeline.  (The GPX_LOOKAHEAD / GPX_PANEL switches that compared the chain's two schedules bit
+    for bit are gone with round 6: DESIGN_LEDGER.md.)"""
     n = 8192
     x, y, z, lab, s2 = ds.fibonacci_training_set(n)
     kern = gpu.make_kernel("matern32", 1.0, 0.8)
     qx, qy, qz = ds.query_grid(12)
     res = {}
     for mode in (None, "0"):
-        if mode is not None:
-            monkeypatch.setenv("GPX_LOOKAHEAD", mode)
-        gm = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32)
+        with gpu.switches(GPX_DATAFLOW=mode):
+            gm = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F32)
         o = gm.evaluate(qx, qy, qz, want_v=True)
         res[mode] = (gm.D.copy(), gm.alpha.copy(), o["f"].copy(), o["v"].copy())
+        assert (gm.stats["factor_gemm_launches"] > 0) == (mode == "0") and gm.stats["solve_fallbacks"] == 0
         gm.close()
-    monkeypatch.delenv("GPX_LOOKAHEAD")
-    for a, b in zip(res[None], res["0"]):
-        np.testing.assert_array_equal(a, b)
+    assert nerr(res[None][0], res["0"][0]) < 2e-4 and nerr(res[None][1], res["0"][1]) < 1e-5
+    assert nerr(res[None][2], res["0"][2]) < 1e-6 and verr(res[None][3], res["0"][3], 1.0) < 1e-5
     g64 = gpu.Model(kern, x, y, z, lab, s2, precision=gpu.F64)
     o64 = g64.evaluate(qx, qy, qz, want_v=True)
     assert nerr(res[None][1], g64.alpha) < 1e-5

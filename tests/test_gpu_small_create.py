@@ -1,5 +1,5 @@
 """GPU suite: GPRegressor::create for the reference's own model sizes in three launches (csrc/gpx_small.hip) -- against the
-oracle, against its twin (the general launch chain, GPX_SMALL_CREATE=0) and through its give-up path."""
+oracle, against its twin (the general launch chain, GPX_DATAFLOW=0) and through its give-up path."""
 import os
 
 import numpy as np
@@ -11,15 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _twin(gpu, kern, data, prec, small, **kw):
-    old = os.environ.get("GPX_SMALL_CREATE")
-    os.environ["GPX_SMALL_CREATE"] = "1" if small else "0"
-    try:
+    with gpu.switches(GPX_DATAFLOW=None if small else "0"):
         return gpu.Model(kern, *data, precision=prec, **kw)
-    finally:
-        if old is None:
-            del os.environ["GPX_SMALL_CREATE"]
-        else:
-            os.environ["GPX_SMALL_CREATE"] = old
 
 
 @pytest.mark.parametrize("n", [17, 63, 64, 65, 129, 277, 320, 321, 513, 724, 1024])
@@ -69,24 +62,25 @@ def test_three_launch_create_with_normals_and_noise_order(gpu, orc, ds, golden):
 
 
 def test_a_wait_that_gives_up_falls_back_to_the_chain(gpu, orc, ds):
-    """Every wait of the dataflow launches has a spin limit; with the limit forced to one poll some workgroup gives up, the
-    host sees the flag, and the create is redone by the general chain: same model, gpx_stats.solve_fallbacks = 1."""
+    """Every wait of the dataflow launches has a time budget; with the budget forced to zero some workgroup gives up, the
+    host sees the flag, and the create is redone by the general chain (whose one-launch substitution gives up as well and is
+    redone by the step launches): same model, gpx_stats.solve_fallbacks >= 1."""
     data = ds.fibonacci_training_set(300)
     kern = gpu.make_kernel("matern52", 1.0, 1.0)
     om = orc.Model(orc.make_kernel("matern52", 1.0, 1.0), *data)
-    os.environ["GPX_SMALL_SPIN_LIMIT"] = "1"
-    try:
+    import time
+    with gpu.switches(GPX_WAIT_BUDGET_US="0"):
         for prec in (gpu.F64, gpu.F32):
+            t0 = time.perf_counter()
             gm = gpu.Model(kern, *data, precision=prec, prepare_variance=True)
+            assert time.perf_counter() - t0 < 1.0  # (a give-up costs milliseconds: the budget is clock time, not a poll count)
             st = gm.stats
-            assert st["solve_fallbacks"] == 1 and st["t_kbuild_ms"] > 0.0
+            assert st["solve_fallbacks"] >= 1 and st["t_kbuild_ms"] > 0.0
             assert nerr(gm.alpha, om.alpha) < 1e-9
             qx, qy, qz = ds.query_grid(5)
             out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
             assert nerr(out["f"], ref["f"]) < 1e-9 and verr_v(out["v"], ref["v"]) < (1e-10 if prec == gpu.F64 else 1e-5)
             gm.close()
-    finally:
-        del os.environ["GPX_SMALL_SPIN_LIMIT"]
     gm = gpu.Model(kern, *data, precision=gpu.F64)
     assert gm.stats["solve_fallbacks"] == 0
     gm.close()
@@ -108,25 +102,20 @@ def test_three_launch_create_then_update(gpu, orc, ds):
     gm.close()
 
 
-def _mid_twin(gpu, kern, data, prec, dataflow, **kw):
-    old = os.environ.get("GPX_MID_FACTOR")
-    os.environ["GPX_MID_FACTOR"] = "1" if dataflow else "0"
-    try:
+def _mid_twin(gpu, kern, data, prec, dataflow, tiles=None, **kw):
+    """dataflow False: the launch chain (GPX_DATAFLOW=0); True: the dataflow factorisation, tiles = 64 | 128 forces that form"""
+    with gpu.switches(GPX_DATAFLOW=(str(tiles) if tiles else None) if dataflow else "0"):
         return gpu.Model(kern, *data, precision=prec, **kw)
-    finally:
-        if old is None:
-            del os.environ["GPX_MID_FACTOR"]
-        else:
-            os.environ["GPX_MID_FACTOR"] = old
 
 
 @pytest.mark.parametrize("n", [1025, 1100, 2305, 4096])
 def test_dataflow_factorisation_of_mid_size_models_matches_the_chain_and_the_oracle(gpu, orc, ds, n, monkeypatch):
     """Above the small-model path the kernel matrix and the LDL^T are one dataflow launch (csrc/gpx_dataflow.hpp) where the
-    blocked launch chain (GPX_MID_FACTOR=0, its twin) is bound by its chain, not its flops.  Sizes: the first padded size above
+    blocked launch chain (GPX_DATAFLOW=0, its twin) is bound by its chain, not its flops.  Sizes: the first padded size above
     1024, tile rows that end inside a 128-block, BASELINE's C2 size; fp64, and the fp32 factorisation at every size
     (GPX_TRAIN_F64_MAX=0: chunked fp32 sums); the indefinite ThinPlate(2.0) keeps its inertia."""
-    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # (_mid_twin reloads the switches)
+    gpu.debug_reload()
     data = ds.fibonacci_training_set(n)
     qx, qy, qz = ds.query_grid(5, scale=1.2)
     cases = [("matern52", (1.0, 1.0))] + ([("gaussian", (1.0, 1.0)), ("thinplate", (2.0,))] if n <= 2305 else [])
@@ -160,13 +149,10 @@ def test_dataflow_factorisation_that_gives_up_is_redone_by_the_chain(gpu, orc, d
     data = ds.fibonacci_training_set(1500)
     kern = gpu.make_kernel("matern52", 1.0, 1.0)
     om = orc.Model(orc.make_kernel("matern52", 1.0, 1.0), *data)
-    os.environ["GPX_SMALL_SPIN_LIMIT"] = "1"
-    try:
+    with gpu.switches(GPX_WAIT_BUDGET_US="0"):
         gm = gpu.Model(kern, *data, precision=gpu.F64, prepare_variance=True)
-    finally:
-        del os.environ["GPX_SMALL_SPIN_LIMIT"]
     st = gm.stats
-    assert st["solve_fallbacks"] == 1 and st["factor_gemm_launches"] > 0
+    assert st["solve_fallbacks"] >= 1 and st["factor_gemm_launches"] > 0
     assert nerr(gm.alpha, om.alpha) < 1e-9
     qx, qy, qz = ds.query_grid(5)
     out, ref = gm.evaluate(qx, qy, qz, want_v=True), om.evaluate(qx, qy, qz, want_v=True)
@@ -222,10 +208,10 @@ def test_dataflow_launches_are_deterministic_and_survive_concurrent_creates(gpu,
 def test_wide_tile_dataflow_factorisation_matches_the_chain_and_the_oracle(gpu, orc, ds, n, monkeypatch):
     """From 8192 padded rows on the dataflow factorisation runs on 128 x 128 tiles (csrc/gpx_dataflow_wide.hpp: eight waves per
     tile, the launch chain's diagonal-block routine on the tile's sums, the panel solve as a slice loop against the inverse
-    block).  Forced here at test sizes (GPX_WIDE_FACTOR_MIN): a last tile row that is mostly padding and one that is full, fp64
+    block).  Forced here at test sizes (GPX_DATAFLOW=128): a last tile row that is mostly padding and one that is full, fp64
     and the chunked fp32 sums, the indefinite ThinPlate(2.0)'s inertia; the product sizes run it in test_gpu_scale.py."""
-    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")
-    monkeypatch.setenv("GPX_WIDE_FACTOR_MIN", "1024")
+    monkeypatch.setenv("GPX_TRAIN_F64_MAX", "0")  # (_mid_twin reloads the switches)
+    gpu.debug_reload()
     data = ds.fibonacci_training_set(n)
     qx, qy, qz = ds.query_grid(5, scale=1.2)
     for kn, par in (("matern52", (1.0, 1.0)), ("gaussian", (1.0, 1.0)), ("thinplate", (2.0,))):
@@ -234,7 +220,7 @@ def test_wide_tile_dataflow_factorisation_matches_the_chain_and_the_oracle(gpu, 
         for prec in (gpu.F64, gpu.F32):
             if kn == "thinplate" and prec == gpu.F32:
                 continue
-            md = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, True, prepare_variance=True)
+            md = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, True, tiles=128, prepare_variance=True)
             mc = _mid_twin(gpu, gpu.make_kernel(kn, *par), data, prec, False, prepare_variance=True)
             sd, sc = md.stats, mc.stats
             assert sd["solve_fallbacks"] == 0 and sd["factor_gemm_launches"] == 0 and sc["factor_gemm_launches"] > 0
@@ -273,3 +259,29 @@ def test_three_launch_create_of_a_handful_of_points(gpu, orc, n):
             k0 = 216.0 if kn == "thinplate" else 1.0
             assert (verr_v(out["v"], ref["v"]) < 1e-10) if prec == gpu.F64 else (verr(out["v"], ref["v"], k0) < 1e-5)
             gm.close()
+
+
+@pytest.mark.parametrize("tiles", [128, 64])
+def test_dataflow_factorisation_above_16384_rows_matches_the_chain(gpu, ds, tiles, monkeypatch):
+    """by default the dataflow factorisation stops at 16384 padded rows, but its flags, per-tile results and
+    tile enumeration scale; forced (GPX_DATAFLOW=128 | 64) at N = 20480 in fp32 -- 160 tile rows of 128, 320 of 64: 12880 /
+    51360 workgroups -- it must agree with the launch chain (pivot signs, D to the fp32 factorisation's rounding, alpha after
+    the fp64 refinement, mean and variance at a few queries)."""
+    n = 20480 - 15
+    data = ds.fibonacci_training_set(n)
+    kern = gpu.make_kernel("matern52", 1.0, 1.0)
+    qx, qy, qz = ds.query_grid(4, scale=1.1)
+    md = _mid_twin(gpu, kern, data, gpu.F32, True, tiles=tiles, prepare_variance=True)
+    sd = md.stats
+    assert sd["n_padded"] == 20480 and sd["solve_fallbacks"] == 0 and sd["factor_gemm_launches"] == 0
+    a = md.evaluate(qx, qy, qz, want_v=True)
+    aD, aal = md.D.copy(), md.alpha.copy()
+    md.close()
+    mc = _mid_twin(gpu, kern, data, gpu.F32, False, prepare_variance=True)
+    sc = mc.stats
+    assert sc["factor_gemm_launches"] > 0 and sc["n_negative_pivots"] == sd["n_negative_pivots"] == 0
+    b = mc.evaluate(qx, qy, qz, want_v=True)
+    assert nerr(aD, mc.D) < 2e-4 and nerr(aal, mc.alpha) < 1e-5
+    assert nerr(a["f"], b["f"]) < 1e-5 and verr_v(a["v"], b["v"]) < 1e-5
+    mc.close()
+    gpu.trim()

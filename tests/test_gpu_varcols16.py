@@ -1,5 +1,5 @@
 """GPU suite: small models of the opt-in split-fp16 mode (GPX_PREC_F32_SPLIT) on the fp16 matrix cores (csrc/gpx_varcols16.hip)
--- against the fp64 pipeline, the oracle and its twin, the fp32 small-model kernel (GPX_VAR_COLS16=0, read per call)."""
+-- against the fp64 pipeline, the oracle and its twin, the fp32 small-model kernel (GPX_VAR_COLS16=0)."""
 import os
 
 import numpy as np
@@ -11,12 +11,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _eval(m, q, cols16, **kw):
-    old = os.environ.get("GPX_VAR_COLS16")
-    os.environ["GPX_VAR_COLS16"] = "1" if cols16 else "0"
-    try:
+    import importlib
+    gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
+    with gpx.switches(GPX_VAR_COLS16=None if cols16 else "0"):
         return m.evaluate(*q, want_v=True, **kw)
-    finally:
-        os.environ.pop("GPX_VAR_COLS16", None) if old is None else os.environ.__setitem__("GPX_VAR_COLS16", old)
 
 
 @pytest.mark.parametrize("n", [16, 33, 166, 277, 352, 353, 512, 704, 705, 1024])

@@ -13,19 +13,12 @@ KERNELS = (("gaussian", (1.0, 1.0)), ("laplace", (1.0, 1.0)), ("matern32", (1.0,
            ("thinplate", (4.0,)), ("thinplate", (2.0,)))
 
 
-def _eval(m, q, cols64, max_n=None, fused_mean=True, **kw):
-    """evaluate() with the kernel on or off (all switches are read per call); max_n: GPX_VAR_COLS64_MAX for this call;
-    fused_mean=False: the mean from the mean kernel although the variance kernel could carry it"""
-    new = {"GPX_VAR_COLS64": "1" if cols64 else "0", "GPX_VAR_COLS64_MAX": None if max_n is None else str(max_n),
-           "GPX_VAR_COLS64_MEAN": None if fused_mean else "0"}
-    old = {k: os.environ.get(k) for k in new}
-    for k, val in new.items():
-        os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
-    try:
+def _eval(m, q, cols64, **kw):
+    """evaluate() with the kernel on or off (GPX_VAR_COLS64; the library re-reads its switches on gpx_debug_reload)"""
+    import importlib
+    gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
+    with gpx.switches(GPX_VAR_COLS64=None if cols64 else "0"):
         return m.evaluate(*q, want_v=True, **kw)
-    finally:
-        for k, val in old.items():
-            os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
 
 
 @pytest.mark.parametrize("n", [16, 17, 33, 166, 277, 352, 353, 448, 512])
@@ -38,14 +31,13 @@ def test_small_fp64_variance_matches_the_oracle_and_the_general_path(gpu, orc, d
         om = orc.Model(orc.make_kernel(kn, *par), *data)
         ref = om.evaluate(*q, want_v=True)
         m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
-        a, b, c = _eval(m, q, True), _eval(m, q, False), _eval(m, q, True, fused_mean=False)
+        a, b = _eval(m, q, True), _eval(m, q, False)
         assert verr_v(a["v"], ref["v"]) < 1e-10, (n, kn, par)
         assert verr_v(a["v"], b["v"]) < 1e-12, (n, kn, par)
-        # the mean: carried by the variance kernel (a), from the mean kernel (b, c); with a gradient always from the mean kernel
+        # the mean: carried by the variance kernel (a), from the mean kernel (b; and d: with a gradient always from the mean kernel)
         assert nerr(a["f"], ref["f"]) < 1e-10 and nerr(a["f"], b["f"]) < 1e-12, (n, kn, par)
-        assert np.array_equal(b["f"], c["f"]) and np.array_equal(a["v"], c["v"])
         d = _eval(m, q, True, want_grad=True)
-        assert nerr(d["f"], b["f"]) < 1e-13 and np.array_equal(d["v"], a["v"])
+        assert np.array_equal(d["f"], b["f"]) and np.array_equal(d["v"], a["v"])
         assert nerr(d["grad"], om.evaluate(*q, want_grad=True)["grad"]) < 1e-9
         m.close()
 
@@ -84,16 +76,15 @@ def test_small_fp64_variance_is_taken_by_promoted_models_and_after_update(gpu, o
     m.close()
 
 
-@pytest.mark.parametrize("n", [600, 724, 1024])
-def test_small_fp64_variance_kernel_up_to_its_lds_limit(gpu, orc, ds, n):
-    """Two and three passes over the row fragments; the kernel holds up to 1024 points (above 992 only on request: the
-    general path is faster there)."""
+@pytest.mark.parametrize("n", [600, 724, 992])
+def test_small_fp64_variance_kernel_up_to_its_routing_limit(gpu, orc, ds, n):
+    """Two and three passes over the row fragments, up to the 992 points the kernel is routed (above, the general path is faster)."""
     data = ds.fibonacci_training_set(n)
     q = ds.query_grid(8, scale=1.3)
     for kn, par in (("matern32", (1.0, 1.0)), ("thinplate", (4.0,))):
         ref = orc.Model(orc.make_kernel(kn, *par), *data).evaluate(*q, want_v=True)
         m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
-        a, b = _eval(m, q, True, max_n=1024), _eval(m, q, False)
+        a, b = _eval(m, q, True), _eval(m, q, False)
         assert verr_v(a["v"], ref["v"]) < 1e-10 and verr_v(a["v"], b["v"]) < 1e-12, (n, kn)
         m.close()
 
