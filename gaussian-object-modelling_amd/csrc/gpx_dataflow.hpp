@@ -99,6 +99,8 @@ __device__ inline bool poll_flag(const u64 *f, u64 want, u64 *abortf, long long 
     for (int s = 0;; ++s) {
         if (ld_flag(f) == want)
             return true;
+        if (budget_ticks <= 0)  // (tests: one look, then give up)
+            break;
         if ((s & 31) == 31) {
             if (ld_flag(abortf) == want)
                 return false;

