@@ -93,8 +93,9 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     // the long alternating sum of a thin-plate GP at N = 16k is not within 1e-5 in fp32)
     // (small fp64 models without a gradient: the mean rides on the operand values of the variance kernel, gpx_varcols64.hip;
     // with a gradient request the mean kernel runs as everywhere else -- the tests compare the two)
-    const bool mean_fused = use_cols64 && !g;
-    if (!mean_fused)
+    // (f == nullptr: variance only -- sample_surface already holds the fp64 mean of its survivors)
+    const bool mean_fused = use_cols64 && !g && f;
+    if (!mean_fused && f)
         launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred, s,
                        m->n);
     if (want_basis)
@@ -476,7 +477,11 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
 }
 
 // mean on all queries -> deterministic compaction of |f| <= f_tol -> variance of the survivors only; the caller holds
-// m->mtx and has set the device
+// m->mtx and has set the device.
+// Round 6, large grids of an exponential kernel: the mean on ALL queries is the fp32 screen of gpx_predict.hip (a proved lower
+// bound of |f|), the fp64 mean kernel then runs on its candidates only and the exact test on those -- the same selected set, the
+// same f and v, bit for bit (every fp64 value is computed per query, independent of the batch it sits in).
+constexpr size_t SURFACE_SCREEN_MIN_NQ = 32768;  // below: the fp64 mean of the whole grid costs less than the extra launches
 static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
                                  double f_tol, size_t capacity, int64_t *idx, double *f, double *v, size_t *n_out)
 {
@@ -484,8 +489,11 @@ static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, cons
     hipStream_t s = m->stream;
     const size_t cap = std::min(capacity, nq);
     const size_t nb = (nq + 255) / 256;
-    // device staging: qx qy qz f_all | compacted sx sy sz fs vs (cap each) | idx (cap int64) | block counters | total
-    const size_t doubles = nq * 4 + cap * 5 + cap + nb / 2 + 4;
+    const bool screen = nq >= SURFACE_SCREEN_MIN_NQ && f_tol > 0.0 && surface_screen_takes(m->cov);
+    // device staging: qx qy qz f_all | compacted sx sy sz fs vs (cap each) | idx (cap int64) | block counters | totals
+    // screen: + candidates cx cy cz cf (nq each), cidx (nq int64) | the fp32 copy of the model
+    const size_t scr_doubles = screen ? nq * 5 + surface_screen_ws_doubles(m->npad) : 0;
+    const size_t doubles = nq * 4 + cap * 5 + cap + nb / 2 + 4 + scr_doubles;
     if ((rc = ensure(m, (void **)&m->ws_host_io, &m->ws_host_io_doubles, sizeof(double) * doubles)))
         return rc;
     double *d = m->ws_host_io;
@@ -493,21 +501,42 @@ static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, cons
     double *sx = d + 4 * nq, *sy = sx + cap, *sz = sy + cap, *fs = sz + cap, *vs = fs + cap;
     long long *didx = (long long *)(vs + cap);
     unsigned *bc = (unsigned *)(didx + cap);
-    unsigned long long *dtotal = (unsigned long long *)(d + doubles - 2);
+    unsigned long long *dtotal = (unsigned long long *)(bc + 2 * (nb / 2 + 1));
+    double *cxs = (double *)(dtotal + 2), *cys = cxs + nq, *czs = cys + nq, *cfs = czs + nq;
+    long long *cidx = (long long *)(cfs + nq);
+    double *scr_ws = (double *)(cidx + nq);
     HIPCHK(hipMemcpyAsync(dqx, qx, sizeof(double) * nq, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dqy, qy, sizeof(double) * nq, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dqz, qz, sizeof(double) * nq, hipMemcpyHostToDevice, s));
-    if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s)))
-        return rc;
-    launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, cap, dqx, dqy, dqz, didx, fs, sx, sy, sz, s);
     unsigned long long total = 0;
-    HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (screen) {
+        launch_surface_screen(m->cov, m->n, m->npad, m->d_x, m->d_y, m->d_z, m->d_alpha, m->d_meta, (long)nq, dqx, dqy, dqz,
+                              dfa, scr_ws, s);
+        launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, nq, dqx, dqy, dqz, cidx, cfs, cxs, cys, czs, s);
+        unsigned long long ncand = 0;
+        HIPCHK(hipMemcpyAsync(&ncand, dtotal, sizeof(ncand), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        m->stats.surface_candidates = (double)ncand;
+        if (ncand > 0) {
+            if ((rc = evaluate_locked(m, (size_t)ncand, cxs, cys, czs, cfs, nullptr, nullptr, nullptr, nullptr, s)))
+                return rc;
+            launch_surface_select((long)ncand, cfs, f_tol, bc, dtotal, cap, cxs, cys, czs, didx, fs, sx, sy, sz, s, cidx);
+            HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    } else {
+        if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s)))
+            return rc;
+        launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, cap, dqx, dqy, dqz, didx, fs, sx, sy, sz, s);
+        HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        m->stats.surface_candidates = (double)nq;
+    }
     *n_out = (size_t)total;
     const size_t ns = std::min((size_t)total, cap);
     if (ns > 0) {
-        if (v) {  // variance of the survivors only (their mean is recomputed by the same call; it is cheap)
-            if ((rc = evaluate_locked(m, ns, sx, sy, sz, fs, vs, nullptr, nullptr, nullptr, s)))
+        if (v) {  // variance of the survivors only
+            if ((rc = evaluate_locked(m, ns, sx, sy, sz, nullptr, vs, nullptr, nullptr, nullptr, s)))
                 return rc;
             HIPCHK(hipMemcpyAsync(v, vs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
         }

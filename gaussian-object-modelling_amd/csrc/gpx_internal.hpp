@@ -156,7 +156,14 @@ void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *pa
 // survivors of |f| <= tol in query order: idx / f / coordinates compacted (capacity entries at most), *total = count
 void launch_surface_select(long nq, const double *f, double tol, unsigned *block_cnt, unsigned long long *total,
                            size_t capacity, const double *qx, const double *qy, const double *qz, long long *idx,
-                           double *fs, double *sx, double *sy, double *sz, hipStream_t st);
+                           double *fs, double *sx, double *sy, double *sz, hipStream_t st,
+                           const long long *idx_map = nullptr);  // idx_map: idx[pos] = idx_map[q] instead of q
+// fp32 screen in front of that selection (gpx_predict.hip): g[q] = a proved lower bound of |f(q)|; ws: surface_screen_ws_doubles
+bool surface_screen_takes(const CovHost &cov);
+size_t surface_screen_ws_doubles(int npts);
+void launch_surface_screen(const CovHost &cov, int n, int npts, const double *px, const double *py, const double *pz,
+                           const double *alpha, const double *cen, long nq, const double *qx, const double *qy,
+                           const double *qz, double *g, double *ws, hipStream_t st);
 void launch_tangent_basis(long nq, const double *grad, double *tx, double *ty, hipStream_t st);
 // AtlasBase::project, one iteration = pre (tolerance test + step) -> mean/gradient at the new points -> post
 constexpr int SMALL_EVAL_NP_MAX = 1024;  // one launch for a handful of queries: models up to this padded size

@@ -724,7 +724,8 @@ __global__ __launch_bounds__(256) void surf_scatter_kernel(long nq, const double
                                                            const double *__restrict__ qy,
                                                            const double *__restrict__ qz, long long *__restrict__ idx,
                                                            double *__restrict__ fs, double *__restrict__ sx,
-                                                           double *__restrict__ sy, double *__restrict__ sz)
+                                                           double *__restrict__ sy, double *__restrict__ sz,
+                                                           const long long *__restrict__ idx_map)
 {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const bool keep = q < nq && fabs(f[q]) <= tol;
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(256) void surf_scatter_kernel(long nq, const double
     if (keep) {
         const size_t pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         if (pos < capacity) {
-            idx[pos] = q;
+            idx[pos] = idx_map ? idx_map[q] : q;  // (second stage of the screened selection: q counts candidates)
             fs[pos] = f[q];
             sx[pos] = qx[q];
             sy[pos] = qy[q];
@@ -751,13 +752,146 @@ __global__ __launch_bounds__(256) void surf_scatter_kernel(long nq, const double
 
 void launch_surface_select(long nq, const double *f, double tol, unsigned *block_cnt, unsigned long long *total,
                            size_t capacity, const double *qx, const double *qy, const double *qz, long long *idx,
-                           double *fs, double *sx, double *sy, double *sz, hipStream_t st)
+                           double *fs, double *sx, double *sy, double *sz, hipStream_t st, const long long *idx_map)
 {
     const long nb = (nq + 255) / 256;
     hipLaunchKernelGGL(surf_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, nq, f, tol, block_cnt);
     hipLaunchKernelGGL(surf_scan_kernel, dim3(1), dim3(1024), 0, st, nb, block_cnt, total);
     hipLaunchKernelGGL(surf_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, nq, f, tol, block_cnt, capacity, qx,
-                       qy, qz, idx, fs, sx, sy, sz);
+                       qy, qz, idx, fs, sx, sy, sz, idx_map);
+}
+
+// ---- fp32 screen in front of the iso-surface selection (round 6; reference src/gp_node.cpp:1066-1100) -------------------
+// gpx_model_sample_surface keeps the lattice points with |f| <= f_tol; deciding that for the 97 % of a grid that lie far from
+// the surface does not need the 1e-10 of the fp64 mean kernel (29 fp64 instructions per pair: 30 ms of C3_surface's 133).
+// Stage 1 (here): fhat = the mean in fp32 -- points relative to the cloud's centre, native v_sqrt_f32 / v_exp_f32, the
+// amplitude folded into alpha, 64-term fp32 partial sums added up in fp64 -- and a PROVED bound on |fhat - f|; a query is a
+// candidate when |fhat| - bound <= f_tol.  Stage 2 (caller): the fp64 mean of the candidates, then the exact test -- the
+// selected set and every returned f are those of the fp64 filter, bit for bit.
+// The bound, u = 2^-24, B = |q - c|_inf + max_k |p_k - c|_inf, t = s d, exponential kernels k = a e^-t P(t), P' <= P:
+//   coordinates rounded to fp32 and subtracted: the difference vector is off by <= 2 u B per component, so d by <= 2 sqrt(3) u B,
+//   plus 2.5 u d for the fma chain and the square root (d <= sqrt(3) B):            |dhat - d| <= 8 u B
+//   t = fl(s) dhat and the argument of v_exp_f32 (t log2 e, 1 ulp instruction):      e^-t off by <= u (8 s B + 3.5) absolutely
+//   the Matern factor P(t) (3 roundings, P' <= P, e^-t t^j bounded):                 |khat - k| / a <= u (16 s B + 12)
+//   alpha_k a rounded once, 64-term fp32 fma chains (<= 64 u sum |terms|), fp64 sums of the chains (negligible):
+//        |fhat - f| <= u (16 s B + 80) sum_k |alpha_k| a            -- the kernel applies it with a factor 2 in hand.
+// The thin plate is not screened (its weights sum to 10^3 .. 10^5 k(0): the bound exceeds any f_tol).
+struct alignas(16) ScreenPt {
+    float x, y, z, a;
+};
+// one workgroup: the model's points relative to the centre and alpha a in fp32 (padding: zeros), and -- in a fixed order -- the two
+// model constants of the bound: stats[0] = sum |alpha_k a|, stats[1] = max_k |p_k - c|_inf
+// (coordinates are stored times sc = s log2 e, so that the kernel's distance IS the argument of v_exp_f32 and the Matern factor a
+// polynomial in it: two packed instructions less per pair; a relative change of scale, the bound is unaffected)
+__global__ __launch_bounds__(1024) void screen_pack_kernel(int n, int npts, double amp, double sc, const double *__restrict__ px,
+                                                           const double *__restrict__ py, const double *__restrict__ pz,
+                                                           const double *__restrict__ alpha, const double *__restrict__ cen,
+                                                           ScreenPt *__restrict__ out, double *__restrict__ stats)
+{
+    __shared__ double s_sum[1024], s_max[1024];
+    const int t = threadIdx.x;
+    const double cx = cen[0], cy = cen[1], cz = cen[2];
+    double sum = 0.0, mx = 0.0;
+    for (int j = t; j < npts; j += 1024) {
+        ScreenPt p{0.0f, 0.0f, 0.0f, 0.0f};
+        if (j < n) {
+            const double x = px[j] - cx, y = py[j] - cy, z = pz[j] - cz, a = alpha[j] * amp;
+            p = ScreenPt{(float)(x * sc), (float)(y * sc), (float)(z * sc), (float)a};
+            sum += fabs(a);
+            mx = fmax(mx, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+        }
+        out[j] = p;
+    }
+    s_sum[t] = sum, s_max[t] = mx;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (t < off)
+            s_sum[t] += s_sum[t + off], s_max[t] = fmax(s_max[t], s_max[t + off]);
+        __syncthreads();
+    }
+    if (t == 0)
+        stats[0] = s_sum[0], stats[1] = s_max[0];
+}
+
+// g[q] = max(|fhat(q)| - bound(q), 0): a lower bound of |f(q)| (0 for a query whose fp32 arithmetic went non-finite: stage 2
+// decides).  Two queries per thread as packed pairs; the training points broadcast from an LDS tile.
+template <int KID>
+__global__ __launch_bounds__(256) void screen_kernel(float s, int npts, const ScreenPt *__restrict__ pts,
+                                                     const double *__restrict__ cen, const double *__restrict__ stats, long nq,
+                                                     const double *__restrict__ qx, const double *__restrict__ qy,
+                                                     const double *__restrict__ qz, double *__restrict__ g)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __shared__ ScreenPt tile[PT];
+    const int tid = threadIdx.x;
+    const long qa = (long)blockIdx.x * QPB + tid, qb = qa + 256;
+    const bool va = qa < nq, vb = qb < nq;
+    const double cx = cen[0], cy = cen[1], cz = cen[2];
+    const double sc = (double)s * 1.44269504088896340736;  // coordinates in units of 1 / (s log2 e): d = the argument of v_exp_f32
+    const double ax = va ? qx[qa] - cx : 0.0, ay = va ? qy[qa] - cy : 0.0, az = va ? qz[qa] - cz : 0.0;
+    const double bx = vb ? qx[qb] - cx : 0.0, by = vb ? qy[qb] - cy : 0.0, bz = vb ? qz[qb] - cz : 0.0;
+    const f2 X = {(float)(ax * sc), (float)(bx * sc)}, Y = {(float)(ay * sc), (float)(by * sc)}, Z = {(float)(az * sc), (float)(bz * sc)};
+    // Matern factors in t = d ln 2: 1 + t = fma(d, ln 2, 1); 1 + t + t^2 / 3 = fma(d, fma(d, ln2^2 / 3, ln 2), 1)
+    constexpr float LN2 = 0.69314718055994530942f, C52 = 0.16015100463940046f;
+    double fa = 0.0, fb = 0.0;
+    for (int jt = 0; jt < npts; jt += PT) {
+        __syncthreads();
+        tile[tid] = jt + tid < npts ? pts[jt + tid] : ScreenPt{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+        const int jn = min(PT, npts - jt);  // a multiple of 4 (the caller rounds the point count up: alpha = 0 there)
+        for (int j0 = 0; j0 < jn; j0 += 64) {
+            f2 acc = {0.0f, 0.0f};
+            const int j1 = min(64, jn - j0);
+#pragma unroll 4
+            for (int jj = 0; jj < j1; ++jj) {
+                const ScreenPt p = tile[j0 + jj];
+                const f2 dx = X - p.x, dy = Y - p.y, dz = Z - p.z;
+                const f2 d2 = dz * dz + (dy * dy + dx * dx);
+                const f2 d = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                const f2 e = {__builtin_amdgcn_exp2f(-d.x), __builtin_amdgcn_exp2f(-d.y)};
+                f2 k;
+                if constexpr (KID == GPX_KERNEL_MATERN32) {
+                    k = e * (d * LN2 + 1.0f);
+                } else if constexpr (KID == GPX_KERNEL_MATERN52) {
+                    k = e * (d * (d * C52 + LN2) + 1.0f);
+                } else {
+                    k = e;
+                }
+                acc += k * p.a;
+            }
+            fa += (double)acc.x;
+            fb += (double)acc.y;
+        }
+    }
+    constexpr double U2 = 2.0 * 5.9604644775390625e-08;  // 2 u
+    const double l1 = stats[0], pmax = stats[1], sd = (double)s;
+    if (va) {
+        const double B = fmax(fabs(ax), fmax(fabs(ay), fabs(az))) + pmax;
+        g[qa] = fmax(fabs(fa) - U2 * l1 * (16.0 * sd * B + 80.0), 0.0);
+    }
+    if (vb) {
+        const double B = fmax(fabs(bx), fmax(fabs(by), fabs(bz))) + pmax;
+        g[qb] = fmax(fabs(fb) - U2 * l1 * (16.0 * sd * B + 80.0), 0.0);
+    }
+}
+
+size_t surface_screen_ws_doubles(int npts) { return 2 * (size_t)npts + 2; }
+
+// the kernels the screen exists for: a positive finite decay parameter of an exponential kernel (gpx_predict.hip, predict_t)
+bool surface_screen_takes(const CovHost &h) { return h.id != GPX_KERNEL_THINPLATE && h.s > 0 && h.s < 1e30 && h.a > 0 && h.a < 1e300; }
+
+void launch_surface_screen(const CovHost &h, int n, int npts, const double *px, const double *py, const double *pz,
+                           const double *alpha, const double *cen, long nq, const double *qx, const double *qy,
+                           const double *qz, double *g, double *ws, hipStream_t st)
+{
+    ScreenPt *pts = reinterpret_cast<ScreenPt *>(ws);
+    double *stats = ws + 2 * (size_t)npts;
+    const int nlim = std::min(npts, (n + 3) / 4 * 4);
+    hipLaunchKernelGGL(screen_pack_kernel, dim3(1), dim3(1024), 0, st, n, npts, h.a, (double)(float)h.s * 1.44269504088896340736,
+                       px, py, pz, alpha, cen, pts, stats);
+    const dim3 grid((unsigned)((nq + QPB - 1) / QPB));
+    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((screen_kernel<KID>), grid, dim3(256), 0, st, (float)h.s, nlim, pts, cen, stats,
+                                              nq, qx, qy, qz, g));
 }
 
 // ---- iterative-refinement helpers ------------------------------------------------------------

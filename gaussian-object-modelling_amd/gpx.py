@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("ir_steps_done", C.c_int64), ("alpha_residual", C.c_double),
                 ("var_gemm_launches", C.c_int64), ("factor_gemm_launches", C.c_int64),
                 ("solve_fallbacks", C.c_int64), ("t_var_kqp_ms", C.c_double), ("factor_gemm_flops", C.c_double),
-                ("reserved", C.c_double * 1)]
+                ("surface_candidates", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -120,7 +120,8 @@ typedef struct gpx_stats {
                                 result; see gpx_factor.hip, gpx_dataflow.hpp) */
     double t_var_kqp_ms;      /* the kernel-operand (Kqp) launches of the last evaluate only (subset of t_var_ms) */
     double factor_gemm_flops; /* algorithmic flops of the event-timed trailing-update launches (lower tiles x 2 x 128^2 x K) */
-    double reserved[1];
+    double surface_candidates; /* last gpx_model_sample_surface / _march_surface batch: queries whose mean was evaluated in fp64
+                                  (= all of them unless the fp32 screen of large grids ran; gpx_predict.hip) */
 } gpx_stats;
 
 typedef enum {

@@ -792,6 +792,49 @@ def test_sample_surface_matches_filtered_evaluate(gpu, orc, ds):
         gm.close()
 
 
+@pytest.mark.parametrize("kn,par,n", [("matern52", (1.0, 1.0), 2300), ("gaussian", (1.3, 0.7), 600), ("laplace", (0.8, 1.2), 277),
+                                      ("matern32", (1.0, 0.5), 1500)])
+def test_sample_surface_screen_selects_exactly_the_fp64_set(gpu, ds, kn, par, n):
+    """Round 6: on grids of >= 32768 queries gpx_model_sample_surface screens the lattice with an fp32 mean
+    and a proved bound on its error (csrc/gpx_predict.hip, screen_kernel), evaluates the fp64 mean of the candidates only and
+    applies the exact test to those.  The selected indices, f and v must be those of the fp64 filter BIT FOR BIT: against
+    evaluate() on the whole grid, in every precision mode, on a cloud far from the origin, with a few non-finite queries in the
+    middle of the grid (which neither survive nor disturb anything else), and the screen must actually have run (candidates <
+    queries) and be worth it (candidates within a small multiple of the survivors)."""
+    x, y, z, lab, s2 = ds.fibonacci_training_set(n)
+    off = (40.0, -25.0, 7.5)
+    x, y, z = x + off[0], y + off[1], z + off[2]
+    qx, qy, qz = (c.copy() for c in ds.query_grid(40))  # 64000 lattice points
+    qx += off[0]; qy += off[1]; qz += off[2]
+    bad = [1234, 30000, 63999]
+    qx[bad[0]], qy[bad[1]], qz[bad[2]] = np.nan, np.inf, -np.inf
+    tol = 0.01
+    for prec in (gpu.F64, gpu.F32, gpu.MIXED):
+        gm = gpu.Model(gpu.make_kernel(kn, *par), x, y, z, lab, s2, precision=prec, prepare_variance=True)
+        full = gm.evaluate(qx, qy, qz, want_v=True)
+        fmean = gm.evaluate(qx, qy, qz)["f"]  # (the mean kernel; small fp64 models carry f on the variance kernel when v is asked)
+        keep = np.nonzero(np.abs(fmean) <= tol)[0]
+        assert 100 < len(keep) < len(qx) // 4, len(keep)
+        out = gm.sample_surface(qx, qy, qz, f_tol=tol)
+        cand = gm.stats["surface_candidates"]
+        np.testing.assert_array_equal(out["idx"], keep)
+        np.testing.assert_array_equal(out["f"], fmean[keep])
+        if prec == gpu.F64:  # (the fp32 contractions batch their queries: the last bits of v depend on the batch, as before)
+            np.testing.assert_array_equal(out["v"], full["v"][keep])
+        else:  # (an infinite query has f = 0 -- it survives -- and no finite variance, in either path)
+            fin = np.isfinite(full["v"][keep])
+            assert np.array_equal(fin, np.isfinite(out["v"])) and fin.sum() >= len(keep) - 3
+            assert verr_v(out["v"][fin], full["v"][keep][fin]) < 1e-6
+        assert len(keep) <= cand < len(qx) and cand < 6 * len(keep) + 2000, (cand, len(keep))
+        # a small grid takes the plain path: the same answer
+        sl = slice(20000, 50000)
+        small = gm.sample_surface(qx[sl], qy[sl], qz[sl], f_tol=tol)
+        k2 = keep[(keep >= 20000) & (keep < 50000)] - 20000
+        np.testing.assert_array_equal(small["idx"], k2)
+        assert gm.stats["surface_candidates"] == 30000
+        gm.close()
+
+
 def test_error_codes_on_device(gpu):
     k = gpu.make_kernel("gaussian", 1, 1)
     m = gpu.Model(k, [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.1, 0.1, 0.1])
