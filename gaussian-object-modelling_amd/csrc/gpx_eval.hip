@@ -3,6 +3,7 @@
 // one-launch path for a handful of queries, the pipelined large-batch path), iso-surface sampling and the batched
 // AtlasBase::project.
 #include "gpx_model.hpp"
+#include <thread>
 
 
 namespace gpxh {
@@ -565,6 +566,157 @@ extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const do
     std::lock_guard<std::mutex> lk(m->mtx);
     HIPCHK(hipSetDevice(m->device));
     return sample_surface_locked(m, nq, qx, qy, qz, f_tol, capacity, idx, f, v, n_out);
+}
+
+// ---- one call, several replicas: the query grid of ONE evaluate / sampleSurface call cut into contiguous slabs ------------------
+// (north star: "query-grid shards"; the caller is the reference node's single process, src/gp_node.cpp:1025-1038.)  replicas[i]
+// are models that predict alike -- a model and its gpx_model_replicate copies, on any devices; slab i (gpx_slab_range: the
+// remainder spread over the low ranks, the same rule as sharding.slab_range of the one-process-per-GPU form) goes to replica i
+// from its own host thread through the ordinary host entry, results written in place into the caller's arrays.  Every value is
+// computed per query and does not depend on the batch it sits in, so the result equals the single call bit for bit.
+extern "C" void gpx_slab_range(size_t nq, int rank, int world, size_t *lo, size_t *hi)
+{
+    size_t a = 0, b = 0;
+    if (world > 0 && rank >= 0 && rank < world) {
+        const size_t base = nq / (size_t)world, rem = nq % (size_t)world, r = (size_t)rank;
+        a = r * base + std::min(r, rem);
+        b = a + base + (r < rem ? 1 : 0);
+    }
+    if (lo)
+        *lo = a;
+    if (hi)
+        *hi = b;
+}
+
+namespace {
+int check_replicas(const gpx_model *const *replicas, int n)
+{
+    if (!replicas)
+        return fail(GPX_E_NULL, "Empty Model pointer");
+    if (n <= 0)
+        return fail(GPX_E_BAD_ARG, "n_replicas must be positive");
+    for (int i = 0; i < n; ++i) {
+        if (!replicas[i])
+            return fail(GPX_E_NULL, "Empty Model pointer");
+        if (!replicas[i]->ready)
+            return fail(GPX_E_STATE, "model is not ready (shell not committed or create failed)");
+        if (replicas[i]->n != replicas[0]->n || replicas[i]->cov.id != replicas[0]->cov.id)
+            return fail(GPX_E_BAD_ARG, "replicas are not copies of one model");
+        for (int j = 0; j < i; ++j)
+            if (replicas[j] == replicas[i])
+                return fail(GPX_E_BAD_ARG, "the same model handle twice (use gpx_model_replicate for a second copy on a device)");
+    }
+    return GPX_OK;
+}
+// run work(i) for every i in [0, n) with a non-empty slab on its own host thread (the caller's thread takes the first);
+// the first failing slab's status and message are the call's
+template <typename F>
+int run_slabs(int n, const std::vector<size_t> &len, F work)
+{
+    std::vector<int> rcs((size_t)n, GPX_OK);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<std::thread> th;
+    int first = -1;
+    for (int i = 0; i < n; ++i) {
+        if (!len[(size_t)i])
+            continue;
+        if (first < 0) {
+            first = i;
+            continue;
+        }
+        th.emplace_back([&, i]() {
+            rcs[(size_t)i] = work(i);
+            if (rcs[(size_t)i])
+                errs[(size_t)i] = g_err;
+        });
+    }
+    if (first >= 0) {
+        rcs[(size_t)first] = work(first);
+        if (rcs[(size_t)first])
+            errs[(size_t)first] = g_err;
+    }
+    for (std::thread &t : th)
+        t.join();
+    for (int i = 0; i < n; ++i)
+        if (rcs[(size_t)i] && rcs[(size_t)i] != GPX_E_SIZE_MISMATCH)
+            return fail(rcs[(size_t)i], "slab " + std::to_string(i) + ": " + errs[(size_t)i]);
+    return GPX_OK;
+}
+}  // namespace
+
+extern "C" int gpx_model_evaluate_sharded(const gpx_model *const *replicas, int n_replicas, size_t nq, const double *qx,
+                                          const double *qy, const double *qz, double *f, double *v, double *grad, double *tx,
+                                          double *ty)
+{
+    int rc = check_replicas(replicas, n_replicas);
+    if (rc || (rc = check_query(replicas[0], nq, qx, qy, qz, f)))
+        return rc;
+    // a call too small to give every replica more than the one-launch path's handful of queries (which is another kernel,
+    // equal to rounding only) stays whole on replicas[0]
+    if (nq / (size_t)n_replicas <= SMALL_EVAL_MAX_NQ)
+        return gpx_model_evaluate(replicas[0], nq, qx, qy, qz, f, v, grad, tx, ty);
+    std::vector<size_t> lo((size_t)n_replicas), len((size_t)n_replicas);
+    for (int i = 0; i < n_replicas; ++i) {
+        size_t hi;
+        gpx_slab_range(nq, i, n_replicas, &lo[(size_t)i], &hi);
+        len[(size_t)i] = hi - lo[(size_t)i];
+    }
+    return run_slabs(n_replicas, len, [&](int i) {
+        const size_t a = lo[(size_t)i];
+        return gpx_model_evaluate(replicas[i], len[(size_t)i], qx + a, qy + a, qz + a, f + a, v ? v + a : nullptr,
+                                  grad ? grad + 3 * a : nullptr, tx ? tx + 3 * a : nullptr, ty ? ty + 3 * a : nullptr);
+    });
+}
+
+// gpx_model_sample_surface over the slabs: every replica selects and evaluates the survivors of its slab into its own
+// staging, the slabs are then laid end to end (positions ascending, as the single call returns them).
+extern "C" int gpx_model_sample_surface_sharded(const gpx_model *const *replicas, int n_replicas, size_t nq, const double *qx,
+                                                const double *qy, const double *qz, double f_tol, size_t capacity, int64_t *idx,
+                                                double *f, double *v, size_t *n_out)
+{
+    if (!n_out || !idx)
+        return fail(GPX_E_NULL, "Empty output pointer");
+    *n_out = 0;
+    int rc = check_replicas(replicas, n_replicas);
+    if (rc || (rc = check_query(replicas[0], nq, qx, qy, qz, f)))
+        return rc;
+    if (!(f_tol >= 0.0))
+        return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
+    const size_t nr = (size_t)n_replicas;
+    std::vector<size_t> lo(nr), len(nr), got(nr, 0);
+    std::vector<std::vector<int64_t>> sidx(nr);
+    std::vector<std::vector<double>> sf(nr), sv(nr);
+    for (size_t i = 0; i < nr; ++i) {
+        size_t hi;
+        gpx_slab_range(nq, (int)i, n_replicas, &lo[i], &hi);
+        len[i] = hi - lo[i];
+    }
+    rc = run_slabs(n_replicas, len, [&](int ii) {
+        const size_t i = (size_t)ii, a = lo[i], cap = std::min(capacity, len[i]);
+        sidx[i].resize(cap + 1);  // (+1: never a null data() for a capacity of 0)
+        sf[i].resize(cap + 1);
+        if (v)
+            sv[i].resize(cap + 1);
+        return gpx_model_sample_surface(replicas[i], len[i], qx + a, qy + a, qz + a, f_tol, cap, sidx[i].data(), sf[i].data(),
+                                        v ? sv[i].data() : nullptr, &got[i]);
+    });
+    if (rc)
+        return rc;
+    size_t total = 0, w = 0;
+    for (size_t i = 0; i < nr; ++i) {
+        const size_t have = std::min(got[i], std::min(capacity, len[i]));
+        for (size_t k = 0; k < have && w < capacity; ++k, ++w) {
+            idx[w] = sidx[i][k] + (int64_t)lo[i];
+            f[w] = sf[i][k];
+            if (v)
+                v[w] = sv[i][k];
+        }
+        total += got[i];
+    }
+    *n_out = total;
+    if (total > capacity)
+        return fail(GPX_E_SIZE_MISMATCH, "more surface points than capacity");
+    return GPX_OK;
 }
 
 // ---- the surface-following sampler of the node (src/gp_node.cpp:1102-1291: marchingSampling + marchingCubes) -------

@@ -68,7 +68,7 @@ EXPORTS = [
     "gpx_model_evaluate", "gpx_model_evaluate_device", "gpx_model_sample_surface", "gpx_model_project",
     "gpx_model_prepare_variance", "gpx_model_get",
     "gpx_model_sync", "gpx_model_destroy", "gpx_model_create_shell", "gpx_model_state_blob", "gpx_model_commit",
-    "gpx_model_replicate", "gpx_trim", "gpx_debug_reload", "gpx_model_march_surface",
+    "gpx_model_replicate", "gpx_slab_range", "gpx_model_evaluate_sharded", "gpx_model_sample_surface_sharded", "gpx_trim", "gpx_debug_reload", "gpx_model_march_surface",
     "gpx_dev_kbuild", "gpx_dev_kqp", "gpx_dev_kqp_f32", "gpx_padded_n", "gpx_dgp_create", "gpx_dgp_evaluate", "gpx_dgp_get",
     "gpx_dgp_add", "gpx_dgp_destroy", "gpx_dgp_loglik_gradient", "gpx_rprop_default", "gpx_dgp_optimise", "gpx_pcd_read", "gpx_node_training_set",
 ]
@@ -126,6 +126,13 @@ def lib():
     L.gpx_model_sample_surface.restype = C.c_int
     L.gpx_model_sample_surface.argtypes = [vp, C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t,
                                            C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_size_t)]
+    L.gpx_slab_range.restype = None
+    L.gpx_slab_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.gpx_model_evaluate_sharded.restype = C.c_int
+    L.gpx_model_evaluate_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_size_t, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.gpx_model_sample_surface_sharded.restype = C.c_int
+    L.gpx_model_sample_surface_sharded.argtypes = [C.POINTER(vp), C.c_int, C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t,
+                                                   C.POINTER(C.c_int64), dp, dp, C.POINTER(C.c_size_t)]
     L.gpx_model_project.restype = C.c_int
     L.gpx_model_project.argtypes = [vp, C.c_size_t, dp, dp, dp, dp, C.POINTER(ProjectOptions), dp, dp,
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -466,6 +473,64 @@ class Model:
             r._L, r._h, r.kernel, r.precision = self._L, C.c_void_p(h), self.kernel, self.precision
             reps.append(r)
         return reps
+
+
+def slab_range(nq, rank, world):
+    """gpx_slab_range: the contiguous slab [lo, hi) of nq queries that replica `rank` of `world` receives."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    lib().gpx_slab_range(int(nq), int(rank), int(world), C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+def _handles(models):
+    arr = (C.c_void_p * len(models))(*[m._h.value if isinstance(m._h, C.c_void_p) else m._h for m in models])
+    return arr
+
+
+def evaluate_sharded(models, qx, qy, qz, want_v=False, want_grad=False, want_basis=False):
+    """gpx_model_evaluate_sharded: ONE evaluate call cut into contiguous slabs over `models` (a model and its replicas)."""
+    L = lib()
+    qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)
+    nq = len(qx)
+    f = np.empty(nq)
+    v = np.empty(nq) if want_v else None
+    g = np.empty((nq, 3)) if want_grad else None
+    tx = np.empty((nq, 3)) if want_basis else None
+    ty = np.empty((nq, 3)) if want_basis else None
+    p = lambda a: _dptr(a) if a is not None else None
+    _check(L.gpx_model_evaluate_sharded(_handles(models), len(models), nq, _dptr(qx), _dptr(qy), _dptr(qz), p(f), p(v), p(g),
+                                        p(tx), p(ty)))
+    out = {"f": f}
+    if v is not None:
+        out["v"] = v
+    if g is not None:
+        out["grad"] = g
+    if tx is not None:
+        out["tx"], out["ty"] = tx, ty
+    return out
+
+
+def sample_surface_sharded(models, qx, qy, qz, f_tol=0.01, capacity=None, want_v=True):
+    """gpx_model_sample_surface_sharded: ONE sampleSurface call over `models`; same dict as Model.sample_surface."""
+    L = lib()
+    qx, qy, qz = _as_d(qx), _as_d(qy), _as_d(qz)
+    nq = len(qx)
+    cap = nq if capacity is None else int(capacity)
+    idx = np.empty(max(cap, 1), dtype=np.int64)
+    f = np.empty(max(cap, 1))
+    v = np.empty(max(cap, 1)) if want_v else None
+    n_out = C.c_size_t(0)
+    rc = L.gpx_model_sample_surface_sharded(_handles(models), len(models), nq, _dptr(qx), _dptr(qy), _dptr(qz), float(f_tol), cap,
+                                            idx.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(f),
+                                            _dptr(v) if v is not None else None, C.byref(n_out))
+    n = int(n_out.value)
+    if rc != OK and rc != E_SIZE_MISMATCH:
+        _check(rc)
+    k = min(n, cap)
+    out = {"idx": idx[:k], "f": f[:k], "n_total": n, "truncated": rc == E_SIZE_MISMATCH}
+    if v is not None:
+        out["v"] = v[:k]
+    return out
 
 
 class RProp(C.Structure):

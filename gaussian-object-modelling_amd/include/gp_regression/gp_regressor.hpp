@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -105,10 +106,17 @@ struct Model {
     Model &operator=(const Model &) = delete;
     ~Model()
     {
+        drop_shards();
         if (handle_)
             gpx_model_destroy(handle_);
     }
     gpx_model *handle() const { return handle_; }
+    // number of replicas (this model included) a large evaluate / sampleSurface call is cut over; 1 = not sharded
+    size_t shards() const
+    {
+        std::lock_guard<std::mutex> lk(shard_mtx_);
+        return shards_.empty() ? 1 : shards_.size();
+    }
     size_t size() const
     {
         int64_t n = 0;
@@ -142,6 +150,18 @@ private:
         return out;
     }
     gpx_model *handle_ = nullptr;
+    // replicas of this model for GPRegressor::devices_ (made at the first large call, dropped by update); [0] == handle_
+    mutable std::mutex shard_mtx_;
+    mutable std::vector<gpx_model *> shards_;
+    mutable bool shards_failed_ = false;
+    void drop_shards() const
+    {
+        std::lock_guard<std::mutex> lk(shard_mtx_);
+        for (size_t i = 1; i < shards_.size(); ++i)
+            gpx_model_destroy(shards_[i]);
+        shards_.clear();
+        shards_failed_ = false;
+    }
 };
 
 // ---- kernel object -> C ABI descriptor -----------------------------------------------------------
@@ -160,6 +180,14 @@ public:
     // Device / precision knobs (new).  Default fp64 = the reference's arithmetic; GPX_PREC_F32 trades
     // 1e-5 norm-wise accuracy for speed.  Environment overrides: GPX_PRECISION=f32|f64, GPX_DEVICE=<n>.
     gpx_options options_;
+    // Several GPUs behind the UNCHANGED caller (new; north star: query-grid shards).  devices_ = HIP ordinals; with more than one
+    // entry create() places the model on devices_[0] and every evaluate / sampleSurface call of at least shard_min_nq_ queries
+    // is cut into contiguous slabs over replicas on all entries (gpx_model_evaluate_sharded; replicas are made at the first
+    // such call and after every update).  Environment: GPX_DEVICES=0,1,2,3 and GPX_SHARD_MIN_NQ.  The same ordinal twice is
+    // allowed (two replicas on one GPU: what a one-GPU box can run).  Smaller calls -- the node's one-point evaluate from 841
+    // threads -- stay on the model itself.
+    std::vector<int> devices_;
+    size_t shard_min_nq_ = (size_t)1 << 16;
 
     GPRegressor() : kernel_(std::make_shared<CovType>())  // :497-500
     {
@@ -171,6 +199,18 @@ public:
             options_.precision = (std::strcmp(p, "f32") == 0) ? GPX_PREC_F32 : GPX_PREC_F64;
         if (const char *d = std::getenv("GPX_DEVICE"))
             options_.device = std::atoi(d);
+        if (const char *l = std::getenv("GPX_DEVICES")) {
+            for (const char *c = l; *c;) {
+                char *end = nullptr;
+                const long o = std::strtol(c, &end, 10);
+                if (end == c)
+                    break;
+                devices_.push_back((int)o);
+                c = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (const char *q = std::getenv("GPX_SHARD_MIN_NQ"))
+            shard_min_nq_ = (size_t)std::strtoull(q, nullptr, 10);
     }
     virtual ~GPRegressor() {}
 
@@ -190,6 +230,8 @@ public:
             throw GPRegressionException("Input data vectors have different lengths");
         gpx_options o = options_;
         o.with_normals = withNormals ? 1 : 0;
+        if (devices_.size() > 1)
+            o.device = devices_[0];
         const gpx_kernel k = gpx_kernel_of(*kernel_);
         gpx_model *h = nullptr;
         const int rc = gpx_model_create(&k, n, data->coord_x.data(), data->coord_y.data(), data->coord_z.data(),
@@ -262,8 +304,13 @@ public:
         f.assign(nq, 0.0);
         v.assign(nq, 0.0);
         size_t n = 0;
-        const int rc = gpx_model_sample_surface(gp->handle_, nq, query->coord_x.data(), query->coord_y.data(),
-                                                query->coord_z.data(), f_tol, nq, pos.data(), f.data(), v.data(), &n);
+        std::vector<gpx_model *> sh = shards_for(*gp, nq);
+        const int rc = sh.size() > 1
+                           ? gpx_model_sample_surface_sharded(sh.data(), (int)sh.size(), nq, query->coord_x.data(),
+                                                              query->coord_y.data(), query->coord_z.data(), f_tol, nq,
+                                                              pos.data(), f.data(), v.data(), &n)
+                           : gpx_model_sample_surface(gp->handle_, nq, query->coord_x.data(), query->coord_y.data(),
+                                                      query->coord_z.data(), f_tol, nq, pos.data(), f.data(), v.data(), &n);
         if (rc != GPX_OK)
             throw GPRegressionException(message(rc));
         idx.assign(pos.begin(), pos.begin() + n);
@@ -383,6 +430,7 @@ public:
         if (new_data->coord_x.size() != n || new_data->coord_y.size() != n || new_data->coord_z.size() != n ||
             (!new_data->sigma2.empty() && new_data->sigma2.size() != n))
             throw GPRegressionException("Input data vectors have different lengths");
+        gp->drop_shards();  // replicas of the old model: made again at the next large call
         const int rc = gpx_model_update(gp->handle_, n, new_data->coord_x.data(), new_data->coord_y.data(),
                                         new_data->coord_z.data(), new_data->label.data(),
                                         new_data->sigma2.empty() ? nullptr : new_data->sigma2.data());
@@ -424,12 +472,37 @@ private:
             tx->assign(3 * nq, 0.0);
         if (ty)
             ty->assign(3 * nq, 0.0);
-        const int rc = gpx_model_evaluate(gp->handle_, nq, query->coord_x.data(), query->coord_y.data(),
-                                          query->coord_z.data(), f.data(), v ? v->data() : nullptr,
-                                          grad ? grad->data() : nullptr, tx ? tx->data() : nullptr,
-                                          ty ? ty->data() : nullptr);
+        std::vector<gpx_model *> sh = shards_for(*gp, nq);
+        const int rc = sh.size() > 1
+                           ? gpx_model_evaluate_sharded(sh.data(), (int)sh.size(), nq, query->coord_x.data(),
+                                                        query->coord_y.data(), query->coord_z.data(), f.data(),
+                                                        v ? v->data() : nullptr, grad ? grad->data() : nullptr,
+                                                        tx ? tx->data() : nullptr, ty ? ty->data() : nullptr)
+                           : gpx_model_evaluate(gp->handle_, nq, query->coord_x.data(), query->coord_y.data(),
+                                                query->coord_z.data(), f.data(), v ? v->data() : nullptr,
+                                                grad ? grad->data() : nullptr, tx ? tx->data() : nullptr,
+                                                ty ? ty->data() : nullptr);
         if (rc != GPX_OK)
             throw GPRegressionException(message(rc));
+    }
+    // the handles a call of nq queries is cut over: the model alone, or the model and its replicas on devices_[1..] (made
+    // here, once, under the model's shard lock; a failed replication is not retried and leaves the call on the model alone)
+    std::vector<gpx_model *> shards_for(const Model &gp, size_t nq) const
+    {
+        if (devices_.size() < 2 || nq < shard_min_nq_ || nq < devices_.size())
+            return {gp.handle_};
+        std::lock_guard<std::mutex> lk(gp.shard_mtx_);
+        if (gp.shards_.empty() && !gp.shards_failed_) {
+            std::vector<int> rest(devices_.begin() + 1, devices_.end());
+            std::vector<gpx_model *> h(rest.size(), nullptr);
+            if (gpx_model_replicate(gp.handle_, (int)rest.size(), rest.data(), h.data()) == GPX_OK) {
+                gp.shards_.push_back(gp.handle_);
+                gp.shards_.insert(gp.shards_.end(), h.begin(), h.end());
+            } else {
+                gp.shards_failed_ = true;
+            }
+        }
+        return gp.shards_.empty() ? std::vector<gpx_model *>{gp.handle_} : gp.shards_;
     }
 #ifdef GPX_SHIM_HAVE_EIGEN
     static void to_eigen(const std::vector<double> &rm, Eigen::MatrixXd &M)

@@ -268,6 +268,22 @@ int gpx_model_commit(gpx_model *m, int with_variance);
  * torch.distributed broadcast (backend "nccl" = RCCL over xGMI). */
 int gpx_model_replicate(const gpx_model *src, int ndev, const int *devs, gpx_model **out);
 
+/* ONE evaluate / sampleSurface call over several replicas (the "query-grid shards" of the one-process C / C++ caller:
+ * src/gp_node.cpp:1025-1038 is one process; no reference equivalent).  replicas: n_replicas DISTINCT handles that predict alike
+ * -- a model and its gpx_model_replicate copies, on any devices (the same ordinal twice is allowed and is what the one-GPU test
+ * boxes run).  Replica i receives the contiguous slab gpx_slab_range(nq, i, n_replicas) of the queries (remainder spread over
+ * the low slabs; empty slabs are skipped; an evaluate call of at most 64 queries per replica stays whole on replicas[0]) from
+ * its own host thread and writes its results in place into the caller's arrays; arguments and statuses otherwise as gpx_model_evaluate / gpx_model_sample_surface (survivor positions
+ * refer to the whole query array, ascending).  Every output value is computed per query, independent of the batch it sits in:
+ * the results equal the single call's bit for bit (tests/test_gpu_sharded_call.py).  The first failing slab's status is
+ * returned, its message prefixed with the slab.  STATUS: a second ORDINAL has not run (see gpx_model_replicate). */
+void gpx_slab_range(size_t nq, int rank, int world, size_t *lo, size_t *hi);
+int gpx_model_evaluate_sharded(const gpx_model *const *replicas, int n_replicas, size_t nq, const double *qx,
+                               const double *qy, const double *qz, double *f, double *v, double *grad, double *tx, double *ty);
+int gpx_model_sample_surface_sharded(const gpx_model *const *replicas, int n_replicas, size_t nq, const double *qx,
+                                     const double *qy, const double *qz, double f_tol, size_t capacity, int64_t *idx, double *f,
+                                     double *v, size_t *n_out);
+
 /* ---- GP with derivative observations: first slice of the reference's second library, gp::GaussianProcess -----------
  * (include/gp/GaussianProcess.h)  Training data: a value AND a gradient (surface normal) at every point;
  * the model is the 4n x 4n covariance of values and derivatives -- compute() :532-583, layout [values (n) | d/dx d/dy

@@ -122,6 +122,28 @@ def test_argument_validation_and_reference_messages(gpx):
     assert h.value is None
 
 
+def test_slab_rule_and_sharded_call_validation_at_the_c_boundary(gpx):
+    """gpx_slab_range is sharding.slab_range (the one-process-per-GPU form cuts the grid by the same rule); the sharded entry
+    points validate their handle list before anything touches a device."""
+    import importlib
+    sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
+    for nq, w in ((10, 3), (1 << 20, 8), (7, 8), (16777216, 4), (0, 2), (5, 1)):
+        assert [gpx.slab_range(nq, r, w) for r in range(w)] == [sh.slab_range(nq, r, w) for r in range(w)]
+    assert gpx.slab_range(10, 3, 3) == (0, 0) and gpx.slab_range(10, -1, 3) == (0, 0)  # out of range: the empty slab
+    lib = gpx.lib()
+    one = (C.c_double * 1)(0.5)
+    n_out = C.c_size_t(7)
+    idx = (C.c_int64 * 1)()
+    assert lib.gpx_model_evaluate_sharded(None, 2, 1, one, one, one, one, None, None, None, None) == gpx.E_NULL
+    assert lib.gpx_last_error() == b"Empty Model pointer"
+    arr = (C.c_void_p * 2)(None, None)
+    assert lib.gpx_model_evaluate_sharded(arr, 2, 1, one, one, one, one, None, None, None, None) == gpx.E_NULL
+    assert lib.gpx_model_evaluate_sharded(arr, 0, 1, one, one, one, one, None, None, None, None) == gpx.E_BAD_ARG
+    assert lib.gpx_model_sample_surface_sharded(arr, 2, 1, one, one, one, 0.01, 1, idx, one, one, C.byref(n_out)) == gpx.E_NULL
+    assert n_out.value == 0
+    assert lib.gpx_model_sample_surface_sharded(arr, 2, 1, one, one, one, 0.01, 1, idx, one, one, None) == gpx.E_NULL
+
+
 def test_derivative_gp_argument_validation(gpx):
     """gpx_dgp_* (first slice of the reference's gp::GaussianProcess): argument checks at the C boundary, no GPU needed.
     "No training data available" is the reference's message (include/gp/GaussianProcess.h:239)."""
