@@ -10,9 +10,10 @@ namespace gpxh {
 
 // ---- evaluate ------------------------------------------------------------------------------------
 int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
-                           double *f, double *v, double *grad, double *tx, double *ty, hipStream_t s)
+                           double *f, double *v, double *grad, double *tx, double *ty, hipStream_t s, bool fixed_order)
 {
     const int np = m->npad;
+    const long plan_nq = fixed_order ? FIXED_ORDER_PLAN_NQ : 0;
     const size_t e = m->esz;
     const bool want_basis = tx || ty;
     double *g = grad;
@@ -22,7 +23,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             return rc;
         g = m->ws_grad;
     }
-    size_t need = predict_ws_doubles((long)nq, np, g != nullptr) * sizeof(double);
+    size_t need = predict_ws_doubles((long)nq, np, g != nullptr, plan_nq) * sizeof(double);
     if (need) {
         int rc = ensure(m, (void **)&m->ws_pred, &m->ws_pred_doubles, need);
         if (rc)
@@ -98,7 +99,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
     const bool mean_fused = use_cols64 && !g && f;
     if (!mean_fused && f)
         launch_predict(GPX_PREC_F64, m->cov, np, m->d_x, m->d_y, m->d_z, m->d_alpha, (long)nq, qx, qy, qz, f, g, m->ws_pred, s,
-                       m->n);
+                       m->n, plan_nq);
     if (want_basis)
         launch_tangent_basis((long)nq, g, tx, ty, s);
     (void)hipEventRecord(m->ev[EV_M1], s);
@@ -211,6 +212,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
             // 128 x 128 tile with 64-byte k rows at three workgroups per CU (139-140 TFLOP/s) -- also what 6 falls back to
             // for a shape the one-wave kernel does not take.
             a.cfg = gpxh::switches().var_tile == 3 ? 3 : 6;
+            a.no_pair = fixed_order ? 1 : 0;
             a.rowweight = m->t_dinv;
             a.partial = m->ws_partial, a.ldp = (long)qb;
             if (m->var_fit)
@@ -230,6 +232,7 @@ int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy,
         m->kqp_ev_used = (s == m->stream) ? gi : 0;
     }
     (void)hipEventRecord(m->ev[EV_V1], s);
+    launch_poison_nonfinite((long)nq, qx, qy, qz, f, v, grad, tx, ty, s);  // (outside the stage events: 24 bytes per query)
     (void)hipEventRecord(m->ev[EV_WS], s);
     m->ws_in_flight = true;
     m->stats_eval_pending = true;
@@ -377,9 +380,10 @@ static int run_requests(gpx_model *m, const std::vector<gpx_pending *> &reqs)
 // copy-in / kernels / copy-out of slice i while the host fills the other buffer with slice i+1 and, once slice i-1 has
 // signalled, hands its results to the caller -- so the pageable <-> pinned copies (the larger part of the PCIe-side
 // cost) hide behind the device work, and the staging stays bounded (a 256^3 grid would be 1.9 GB in one piece).
+constexpr size_t EVAL_SLICE = (size_t)1 << 18;
 static int run_large(gpx_model *m, const gpx_pending &r)
 {
-    constexpr size_t SLICE = (size_t)1 << 18;
+    constexpr size_t SLICE = EVAL_SLICE;
     const size_t per_q = 3 + 1 + 1 + 3 + 3 + 3;  // qx qy qz | f | v | grad | tx | ty
     std::lock_guard<std::mutex> lk(m->mtx);
     HIPCHK(hipSetDevice(m->device));
@@ -481,7 +485,9 @@ extern "C" int gpx_model_evaluate(const gpx_model *cm, size_t nq, const double *
 // m->mtx and has set the device.
 // Round 6, large grids of an exponential kernel: the mean on ALL queries is the fp32 screen of gpx_predict.hip (a proved lower
 // bound of |f|), the fp64 mean kernel then runs on its candidates only and the exact test on those -- the same selected set, the
-// same f and v, bit for bit (every fp64 value is computed per query, independent of the batch it sits in).
+// same f and v, bit for bit: every fp64 evaluation of this function runs in evaluate_locked's fixed_order form, in which a
+// query's value does not depend on the batch it sits in (the whole grid, the candidates, the survivors, a slab of
+// gpx_model_sample_surface_sharded).
 constexpr size_t SURFACE_SCREEN_MIN_NQ = 32768;  // below: the fp64 mean of the whole grid costs less than the extra launches
 static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz,
                                  double f_tol, size_t capacity, int64_t *idx, double *f, double *v, size_t *n_out)
@@ -519,14 +525,14 @@ static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, cons
         HIPCHK(hipStreamSynchronize(s));
         m->stats.surface_candidates = (double)ncand;
         if (ncand > 0) {
-            if ((rc = evaluate_locked(m, (size_t)ncand, cxs, cys, czs, cfs, nullptr, nullptr, nullptr, nullptr, s)))
+            if ((rc = evaluate_locked(m, (size_t)ncand, cxs, cys, czs, cfs, nullptr, nullptr, nullptr, nullptr, s, true)))
                 return rc;
             launch_surface_select((long)ncand, cfs, f_tol, bc, dtotal, cap, cxs, cys, czs, didx, fs, sx, sy, sz, s, cidx);
             HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         }
     } else {
-        if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s)))
+        if ((rc = evaluate_locked(m, nq, dqx, dqy, dqz, dfa, nullptr, nullptr, nullptr, nullptr, s, true)))
             return rc;
         launch_surface_select((long)nq, dfa, f_tol, bc, dtotal, cap, dqx, dqy, dqz, didx, fs, sx, sy, sz, s);
         HIPCHK(hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, s));
@@ -537,7 +543,7 @@ static int sample_surface_locked(gpx_model *m, size_t nq, const double *qx, cons
     const size_t ns = std::min((size_t)total, cap);
     if (ns > 0) {
         if (v) {  // variance of the survivors only
-            if ((rc = evaluate_locked(m, ns, sx, sy, sz, nullptr, vs, nullptr, nullptr, nullptr, s)))
+            if ((rc = evaluate_locked(m, ns, sx, sy, sz, nullptr, vs, nullptr, nullptr, nullptr, s, true)))
                 return rc;
             HIPCHK(hipMemcpyAsync(v, vs, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
         }
@@ -570,10 +576,14 @@ extern "C" int gpx_model_sample_surface(const gpx_model *cm, size_t nq, const do
 
 // ---- one call, several replicas: the query grid of ONE evaluate / sampleSurface call cut into contiguous slabs ------------------
 // (north star: "query-grid shards"; the caller is the reference node's single process, src/gp_node.cpp:1025-1038.)  replicas[i]
-// are models that predict alike -- a model and its gpx_model_replicate copies, on any devices; slab i (gpx_slab_range: the
-// remainder spread over the low ranks, the same rule as sharding.slab_range of the one-process-per-GPU form) goes to replica i
-// from its own host thread through the ordinary host entry, results written in place into the caller's arrays.  Every value is
-// computed per query and does not depend on the batch it sits in, so the result equals the single call bit for bit.
+// are models that predict alike -- a model and its gpx_model_replicate copies, on any devices -- and slab i goes to replica i from
+// its own host thread, results written in place into the caller's arrays.  The cut follows gpx_slab_range (the remainder spread
+// over the low ranks: sharding.slab_range of the one-process-per-GPU form), applied
+//   * by evaluate to the SLICES of 2^18 queries the single call itself is pipelined in (run_large): the order of the mean's and
+//     the variance's sums depends on the size of the device batch a query sits in (how the point range is split over workgroups,
+//     whether the variance tiles are launched in pairs), so a slab is made of whole slices and every slice is evaluated exactly
+//     as the single call evaluates it -- equal bit for bit, for every model size; a call of one slice is not cut;
+//   * by sample_surface to the queries themselves: all of its fp64 arithmetic is in evaluate_locked's fixed_order form.
 extern "C" void gpx_slab_range(size_t nq, int rank, int world, size_t *lo, size_t *hi)
 {
     size_t a = 0, b = 0;
@@ -651,20 +661,21 @@ extern "C" int gpx_model_evaluate_sharded(const gpx_model *const *replicas, int 
     int rc = check_replicas(replicas, n_replicas);
     if (rc || (rc = check_query(replicas[0], nq, qx, qy, qz, f)))
         return rc;
-    // a call too small to give every replica more than the one-launch path's handful of queries (which is another kernel,
-    // equal to rounding only) stays whole on replicas[0]
-    if (nq / (size_t)n_replicas <= SMALL_EVAL_MAX_NQ)
+    const size_t nslices = (nq + EVAL_SLICE - 1) / EVAL_SLICE;
+    if (nslices < 2 || n_replicas < 2)  // one slice: the single call's own path (flat combining, the one-launch path, ...)
         return gpx_model_evaluate(replicas[0], nq, qx, qy, qz, f, v, grad, tx, ty);
     std::vector<size_t> lo((size_t)n_replicas), len((size_t)n_replicas);
     for (int i = 0; i < n_replicas; ++i) {
-        size_t hi;
-        gpx_slab_range(nq, i, n_replicas, &lo[(size_t)i], &hi);
-        len[(size_t)i] = hi - lo[(size_t)i];
+        size_t a, b;
+        gpx_slab_range(nslices, i, n_replicas, &a, &b);
+        lo[(size_t)i] = std::min(nq, a * EVAL_SLICE);
+        len[(size_t)i] = std::min(nq, b * EVAL_SLICE) - lo[(size_t)i];
     }
     return run_slabs(n_replicas, len, [&](int i) {
         const size_t a = lo[(size_t)i];
-        return gpx_model_evaluate(replicas[i], len[(size_t)i], qx + a, qy + a, qz + a, f + a, v ? v + a : nullptr,
-                                  grad ? grad + 3 * a : nullptr, tx ? tx + 3 * a : nullptr, ty ? ty + 3 * a : nullptr);
+        gpx_pending req{len[(size_t)i], qx + a, qy + a, qz + a, f + a, v ? v + a : nullptr, grad ? grad + 3 * a : nullptr,
+                        tx ? tx + 3 * a : nullptr, ty ? ty + 3 * a : nullptr};
+        return run_large(const_cast<gpx_model *>(replicas[i]), req);  // (the pipelined slices, whatever the slab's length)
     });
 }
 

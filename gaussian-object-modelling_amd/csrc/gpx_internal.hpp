@@ -144,12 +144,18 @@ void launch_var_rowcorr(bool x_is_f64, bool op64, int n, int np, const void *X, 
 
 // ---- prediction : gpx_predict.hip -----------------------------------------------------------
 // f[q] = sum_j k(|q-p_j|) alpha_j ; grad[q] = sum_j alpha_j k'(.)(q-p_j)  (double outputs).
+// NaN into every given output of the queries that have a NaN or infinite coordinate (last launch of an evaluate; gpx_predict.hip)
+void launch_poison_nonfinite(long nq, const double *qx, const double *qy, const double *qz, double *f, double *v, double *grad,
+                             double *tx, double *ty, hipStream_t st);
 // ws: device doubles, at least predict_ws_doubles(nq, n, grad) long.
-size_t predict_ws_doubles(long nq, int n_chunk_src, bool grad);
+// plan_nq > 0: the split of the point range over workgroups (and with it the order of the sum) is the one a call of plan_nq
+// queries would get, whatever nq is (iso-surface sampling: the same arithmetic for the whole grid, a candidate set, a slab)
+size_t predict_ws_doubles(long nq, int n_chunk_src, bool grad, long plan_nq = 0);
 void launch_predict(int prec, const CovHost &cov, int n_pad_pts, const void *px, const void *py, const void *pz,
                     const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
                     double *grad /*nq x 3 row-major or null*/, double *ws, hipStream_t st,
-                    int nvalid = 0);  // > 0: points from nvalid on are padding with alpha = 0 and are skipped
+                    int nvalid = 0,  // > 0: points from nvalid on are padding with alpha = 0 and are skipped
+                    long plan_nq = 0);
 // v[q] = k0 - sum_m partial[m][q]
 void launch_var_finish(int prec, double k0, int mtiles, long ldp, const void *partial, long nq, double *v,
                        hipStream_t st);
@@ -229,6 +235,9 @@ struct GemmArgs {
     const double *colcoef = nullptr;     // [VAR_NCORR][ldcc]
     const double *rowweight64 = nullptr; // 1/D in fp64
     long ldrc = 0, ldcc = 0;             // (partial then holds doubles)
+    int no_pair = 0;  // EPI_COLSQ one-wave tiles: 1 = never the paired launch (which walks half of the row tiles in descending k
+                      // WHEN the number of column tiles fills the SIMDs in whole rounds): the order of every sum is then the same
+                      // whatever the batch a query sits in (iso-surface sampling)
 };
 void launch_gemm(int prec, const GemmArgs &g, hipStream_t st);
 // cfg 6 (fp32 EPI_COLSQ with a lower-triangular A only): one wave per workgroup, 128 x 128 tile, operands from global memory

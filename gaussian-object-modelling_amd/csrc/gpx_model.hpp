@@ -228,8 +228,13 @@ void set_split_scale(gpx_model *m);  // F32_SPLIT: m->sk from the kernel's ampli
 bool split_packs(const gpx_model *m);  // F32_SPLIT: does a model of this size hold packed fp16 operands (small ones keep the fp32 kernel)
 void set_training_precision(gpx_model *m);
 // ---- gpx_eval.hip -----------------------------------------------------------------------------------
+// fixed_order: the order of every sum (the mean's split of the point range, the walk of the variance tiles) is made independent
+// of nq -- the mean takes the plan of a FIXED_ORDER_PLAN_NQ-query call, the variance tiles are never launched in pairs -- so that
+// a query receives the same bits in whatever batch it is evaluated: iso-surface sampling (whole grid, candidate set, survivors,
+// the slab of a sharded call)
+constexpr long FIXED_ORDER_PLAN_NQ = 32768;
 int evaluate_locked(gpx_model *m, size_t nq, const double *qx, const double *qy, const double *qz, double *f, double *v,
-                    double *grad, double *tx, double *ty, hipStream_t s);
+                    double *grad, double *tx, double *ty, hipStream_t s, bool fixed_order = false);
 int check_query(const gpx_model *m, size_t nq, const void *qx, const void *qy, const void *qz, const void *f);
 void resolve_eval_stats(gpx_model *m);
 }  // namespace gpxh

@@ -36,10 +36,10 @@ static void predict_plan(long nq, int npts, int &chunks, int &chunk_len)
     chunks = (npts + chunk_len - 1) / chunk_len;
 }
 
-size_t predict_ws_doubles(long nq, int npts, bool grad)
+size_t predict_ws_doubles(long nq, int npts, bool grad, long plan_nq)
 {
     int chunks, chunk_len;
-    predict_plan(nq, npts, chunks, chunk_len);
+    predict_plan(plan_nq > 0 ? plan_nq : nq, npts, chunks, chunk_len);
     return chunks > 1 ? (size_t)chunks * (size_t)nq * (grad ? 4 : 1) : 0;
 }
 
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(256) void predict_reduce_kernel(int chunks, long nq
 template <typename T, bool GRAD>
 static void predict_t(const CovHost &h, int npts, const void *px, const void *py, const void *pz,
                       const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
-                      double *grad, double *ws, hipStream_t st, int nvalid)
+                      double *grad, double *ws, hipStream_t st, int nvalid, long plan_nq)
 {
     const int nlim = nvalid > 0 ? std::min(npts, (nvalid + 3) / 4 * 4) : npts;
     int chunks, chunk_len;
-    predict_plan(nq, npts, chunks, chunk_len);
+    predict_plan(plan_nq > 0 ? plan_nq : nq, npts, chunks, chunk_len);
     Cov<T> c = lower_cov<T>(h);
     dim3 grid((unsigned)((nq + QPB - 1) / QPB), chunks);
     double *pf = chunks > 1 ? ws : f;
@@ -214,13 +214,49 @@ static void predict_t(const CovHost &h, int npts, const void *px, const void *py
 
 void launch_predict(int prec, const CovHost &cov, int npts, const void *px, const void *py, const void *pz,
                     const void *alpha, long nq, const double *qx, const double *qy, const double *qz, double *f,
-                    double *grad, double *ws, hipStream_t st, int nvalid)
+                    double *grad, double *ws, hipStream_t st, int nvalid, long plan_nq)
 {
     (void)prec;  // fp64 only (see the header of this file); px, py, pz, alpha are fp64 arrays
     if (grad)
-        predict_t<double, true>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid);
+        predict_t<double, true>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid, plan_nq);
     else
-        predict_t<double, false>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid);
+        predict_t<double, false>(cov, npts, px, py, pz, alpha, nq, qx, qy, qz, f, grad, ws, st, nvalid, plan_nq);
+}
+
+// ---- non-finite queries ----------------------------------------------------------------------------------------------------
+// The reference's arithmetic answers NaN for a query with a NaN or infinite coordinate (gp_regressor.hpp:300-319: the distance is
+// NaN, and so is everything computed from it).  The device kernels evaluate k with clamped fast paths (table exponential, seeded
+// square root) that turn such a distance into some finite number: this pass, the last launch of every evaluate, writes NaN into
+// every requested output of such a query.  It reads 24 bytes per query and writes nothing for finite ones.
+__global__ __launch_bounds__(256) void poison_nonfinite_kernel(long nq, const double *__restrict__ qx, const double *__restrict__ qy,
+                                                               const double *__restrict__ qz, double *f, double *v, double *grad,
+                                                               double *tx, double *ty)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq)
+        return;
+    const double p = (qx[q] + qy[q] + qz[q]) * 0.0;
+    if (p == 0.0)
+        return;
+    if (f)
+        f[q] = p;
+    if (v)
+        v[q] = p;
+    for (int c = 0; c < 3; ++c) {
+        if (grad)
+            grad[3 * q + c] = p;
+        if (tx)
+            tx[3 * q + c] = p;
+        if (ty)
+            ty[3 * q + c] = p;
+    }
+}
+
+void launch_poison_nonfinite(long nq, const double *qx, const double *qy, const double *qz, double *f, double *v, double *grad,
+                             double *tx, double *ty, hipStream_t st)
+{
+    hipLaunchKernelGGL(poison_nonfinite_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, qx, qy, qz, f, v, grad, tx,
+                       ty);
 }
 
 // ---- variance epilogue: v[q] = k(0) - sum_m partial[m][q]  (gp_regressor.hpp:318-319, diagonal only)
@@ -338,6 +374,9 @@ __global__ __launch_bounds__(256) void small_eval_kernel(Cov<double> cov, double
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int iq = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x;
     const double c0 = q[iq], c1 = q[nq + iq], c2 = q[2 * nq + iq];
+    // a query with a NaN or infinite coordinate answers NaN, as the reference's arithmetic does (the fast kernel evaluators
+    // clamp their arguments and would answer with finite numbers): 0 for every finite query, NaN otherwise
+    const double poison = (c0 + c1 + c2) * 0.0;
     double af = 0, a0 = 0, a1 = 0, a2 = 0;
     // every row block needs k(q, .) up to its last row; block 0 also reduces the mean and the gradient
     const int kmax = v ? min(npts, (rb + 1) * SE_ROWS) : 0;
@@ -372,10 +411,10 @@ __global__ __launch_bounds__(256) void small_eval_kernel(Cov<double> cov, double
     }
     __syncthreads();  // publishes kq (and red)
     if (rb == 0 && tid == 0) {
-        const double fs = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        const double g0 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-        const double g1 = red[0][2] + red[1][2] + red[2][2] + red[3][2];
-        const double g2 = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+        const double fs = red[0][0] + red[1][0] + red[2][0] + red[3][0] + poison;
+        const double g0 = red[0][1] + red[1][1] + red[2][1] + red[3][1] + poison;
+        const double g1 = red[0][2] + red[1][2] + red[2][2] + red[3][2] + poison;
+        const double g2 = red[0][3] + red[1][3] + red[2][3] + red[3][3] + poison;
         f[iq] = fs;
         if (grad) {
             grad[3 * iq] = g0;
@@ -430,7 +469,7 @@ __global__ __launch_bounds__(256) void small_eval_kernel(Cov<double> cov, double
             double s = 0.0;
             for (int r = 0; r < nrb; ++r)
                 s += __hip_atomic_load(&part[(size_t)iq * nrb + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v[iq] = k0 - s;
+            v[iq] = k0 - s + poison;
             done[iq] = 0;  // ready for the next launch
         }
     }

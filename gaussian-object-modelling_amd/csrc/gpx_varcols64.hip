@@ -50,18 +50,34 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 #ifndef VC64_FS
 #define VC64_FS 22
 #endif
-constexpr int FS64 = VC64_FS;  // row-fragment slots per pass
-constexpr int WGS_PER_CU64 = FS64 <= 8 ? 2 : 1;
 #ifndef VC64_AHEAD
 #define VC64_AHEAD 4
 #endif
-constexpr int AHEAD64 = VC64_AHEAD, RING64 = AHEAD64 + 1;  // fragments of X requested ahead of their MFMAs; register sets
 #ifndef VC64_AGPR
 #define VC64_AGPR 14
 #endif
-constexpr int AGPR_SLOTS = VC64_AGPR;  // slots whose accumulators live in AGPRs (the others: VGPRs -- 256 of each per wave)
-constexpr int CF64 = 2;   // column fragments (16 queries each) per wave: a fragment of X feeds 8 MFMAs
-constexpr int WAVES64 = 4;  // waves per workgroup: one per SIMD, side by side on the same fragments of X (L1 hits)
+// The shape of a wave's share.  ONE wave per SIMD (round 5): 32 queries (two column fragments: a fragment of X feeds 8 MFMAs) and
+// 22 row-fragment slots, all 512 registers of a SIMD lane.  TWO waves per SIMD (round 6): 16 queries (one column fragment, 4 MFMAs
+// per fragment of X) and VC64_FS2 slots in 256 registers each -- the same rows per pass, hence the same number of operand
+// evaluations per query as the one-wave form (round 5's two-wave build halved the SLOTS and so evaluated the operand 1.7 times as
+// often), at twice the requests for X; what the second wave buys is that its operand evaluation, requests and epilogue issue
+// while the other wave's MFMAs occupy the matrix pipe (profiles/r05_mfma_filler_probe2.txt: MFMA + 4 independent vector
+// instructions of ONE wave 157 cycles, of two alternating waves 97 each).
+struct VC64One {
+    static constexpr int CF = 2, FS = VC64_FS, WAVES = 4, AGPR = VC64_AGPR, AHEAD = VC64_AHEAD;
+};
+#ifndef VC64_FS2
+#define VC64_FS2 20
+#endif
+#ifndef VC64_AHEAD2
+#define VC64_AHEAD2 3
+#endif
+#ifndef VC64_AGPR2
+#define VC64_AGPR2 16
+#endif
+struct VC64Two {
+    static constexpr int CF = 1, FS = VC64_FS2, WAVES = 8, AGPR = VC64_AGPR2, AHEAD = VC64_AHEAD2;
+};
 
 struct VarCols64Dev {
     const double *Xp;  // X in fragment order (pack64_kernel): a wave's request for a 16 x 16 fragment is two contiguous KB
@@ -95,9 +111,14 @@ __device__ __forceinline__ void slot_chain(int nact, Fn &&f)
 #ifndef VC64_DBG
 #define VC64_DBG 0
 #endif
-template <int KID, int DBG = VC64_DBG>
-__global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(VarCols64Dev g)
+template <int KID, class CFG, int DBG = VC64_DBG>
+__global__ __launch_bounds__(64 * CFG::WAVES, 1) void var_cols64_kernel(VarCols64Dev g)
 {
+    constexpr int FS64 = CFG::FS;        // row-fragment slots per pass
+    constexpr int CF64 = CFG::CF;        // column fragments (16 queries each) per wave
+    constexpr int WAVES64 = CFG::WAVES;  // waves per workgroup, side by side on the same fragments of X (L1 hits)
+    constexpr int AGPR_SLOTS = CFG::AGPR;  // slots whose accumulators live in AGPRs (the others: VGPRs)
+    constexpr int AHEAD64 = CFG::AHEAD, RING64 = AHEAD64 + 1;  // fragments of X requested ahead of their MFMAs; register sets
     __shared__ double lp[3][VARCOLS64_MAX_N];
     __shared__ double ld[VARCOLS64_MAX_N];
     __shared__ double la[VARCOLS64_MAX_N];
@@ -172,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
                 f64x2 alo[RING64], ahi[RING64];
                 auto load_a = [&](int r, f64x2 &lo, f64x2 &hi) {
                     if constexpr (DBG >= 3) {
-                        lo = f64x2{ax[0], ay[0]}, hi = f64x2{az[0], ax[1]};
+                        lo = f64x2{ax[0], ay[0]}, hi = f64x2{az[0], ax[CF64 - 1]};
                         return;
                     }
                     const char *src = reinterpret_cast<const char *>(g.Xp + (xc - 256 * min(r, nact - 1))) + lane_off;
@@ -211,11 +232,11 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
                 }
                 slot_chain<0, FS64>(nact, [&](auto slot) {
                     constexpr int il = decltype(slot)::value;
-                    {
+                    if constexpr (CF64 == 2) {
                         // (asm operands inside a lambda must be the lambda's own variables)
-                        f64x4 &c0 = acc[il][0], &c1 = acc[il][1];
+                        f64x4 &c0 = acc[il][0], &c1 = acc[il][CF64 - 1];
                         const double b00 = b[0][0], b01 = b[0][1], b02 = b[0][2], b03 = b[0][3];
-                        const double b10 = b[1][0], b11 = b[1][1], b12 = b[1][2], b13 = b[1][3];
+                        const double b10 = b[CF64 - 1][0], b11 = b[CF64 - 1][1], b12 = b[CF64 - 1][2], b13 = b[CF64 - 1][3];
                         const f64x2 a0 = alo[il % RING64], a1 = ahi[il % RING64];
                         load_a(il + AHEAD64, alo[(il + AHEAD64) % RING64], ahi[(il + AHEAD64) % RING64]);
                         // (one statement: the two column fragments alternate, so consecutive MFMAs are independent, and no VALU
@@ -244,18 +265,44 @@ __global__ __launch_bounds__(64 * WAVES64, WGS_PER_CU64) void var_cols64_kernel(
                         else
                             VC64_MFMAS("+v");
 #undef VC64_MFMAS
+                    } else {
+                        // one column fragment: the four MFMAs of a slot form an accumulate chain (which issues at the full rate,
+                        // scripts/mfma_f64_chain_probe.hip); the other wave of the SIMD fills the pipe between the statements
+                        f64x4 &c0 = acc[il][0];
+                        const double b00 = b[0][0], b01 = b[0][1], b02 = b[0][2], b03 = b[0][3];
+                        const f64x2 a0 = alo[il % RING64], a1 = ahi[il % RING64];
+                        load_a(il + AHEAD64, alo[(il + AHEAD64) % RING64], ahi[(il + AHEAD64) % RING64]);
+#define VC64_MFMAS1(CLS_)                                                                                                \
+        asm volatile("s_nop 1\n"                                                                                             \
+                     "v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n"                                                               \
+                     "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0"                                                                  \
+                     : CLS_(c0)                                                                                              \
+                     : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03))
+                        if constexpr (DBG == 2 && il < AGPR_SLOTS)
+                            asm volatile("" : "+a"(c0) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03));
+                        else if constexpr (DBG == 2)
+                            asm volatile("" : "+v"(c0) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(b00), "v"(b01), "v"(b02), "v"(b03));
+                        else if constexpr (il < AGPR_SLOTS)
+                            VC64_MFMAS1("+a");
+                        else
+                            VC64_MFMAS1("+v");
+#undef VC64_MFMAS1
                     }
                 });
             }
             // the accumulators are read by the VALU from here on: the MFMA's wait states first (hipcc pads no hazard whose producer
             // sits inside an asm string), every accumulator tied behind them (asm statements keep their order)
-            asm volatile("s_nop 15\n s_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]));
+            asm volatile("s_nop 15\n s_nop 15" : "+a"(acc[0][0]));
 #pragma unroll
-            for (int il = 1; il < FS64; ++il)
-                if (il < AGPR_SLOTS)
-                    asm volatile("" : "+a"(acc[il][0]), "+a"(acc[il][1]));
-                else
-                    asm volatile("" : "+v"(acc[il][0]), "+v"(acc[il][1]));
+            for (int il = 0; il < FS64; ++il)
+#pragma unroll
+                for (int j = 0; j < CF64; ++j)
+                    if (il < AGPR_SLOTS)
+                        asm volatile("" : "+a"(acc[il][j]));
+                    else
+                        asm volatile("" : "+v"(acc[il][j]));
             // w^2 / D of the pass's rows: register r of lane (lg, query) in slot il is row 16 (f_hi - 1 - il) + 4 r + lg
 #pragma unroll
             for (int il = 0; il < FS64; ++il)
@@ -334,14 +381,19 @@ void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ld
     g.k0 = h.k0;
     g.cov = lower_cov<double>(h);
     (void)np;
-    const long per_wg = 16L * CF64 * WAVES64;
+    const bool two = gpxh::switches().var_cols64 == 2;  // (round 6, under measurement: two waves per SIMD)
+    const long per_wg = two ? 16L * VC64Two::CF * VC64Two::WAVES : 16L * VC64One::CF * VC64One::WAVES;
     const long nblk = (nq + per_wg - 1) / per_wg;
     int devid = 0, ncu = 0;
     (void)hipGetDevice(&devid);
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || ncu <= 0)
         ncu = 256;
-    const unsigned nwg = (unsigned)std::min<long>(nblk, (long)ncu * WGS_PER_CU64);
-    GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_cols64_kernel<KID>), dim3(nwg), dim3(64 * WAVES64), 0, st, g));
+    const unsigned nwg = (unsigned)std::min<long>(nblk, (long)ncu);
+    if (two) {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_cols64_kernel<KID, VC64Two>), dim3(nwg), dim3(64 * VC64Two::WAVES), 0, st, g));
+    } else {
+        GPX_DISPATCH_KID(h.id, hipLaunchKernelGGL((var_cols64_kernel<KID, VC64One>), dim3(nwg), dim3(64 * VC64One::WAVES), 0, st, g));
+    }
 }
 
 }  // namespace gpx

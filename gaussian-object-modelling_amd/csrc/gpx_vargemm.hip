@@ -521,7 +521,7 @@ void launch_var_w1_f64(const GemmArgs &a, hipStream_t st)
     g.dinv = (const double *)a.rowweight;
     g.partial = (double *)a.partial, g.ldp = a.ldp;
     const int MT = a.M / 128, NT = a.N / 64;
-    const bool paired = var_w1_paired(MT, NT);
+    const bool paired = !a.no_pair && var_w1_paired(MT, NT);
     g.paired = paired ? 1 : 0;
     g.diag_skip = var_diag_skip();
     hipLaunchKernelGGL(var_w1_f64_kernel, dim3(NT, paired ? MT / 2 : MT), dim3(64), 0, st, g);
@@ -729,7 +729,7 @@ void launch_var_w1(const GemmArgs &a, hipStream_t st)
     }
     if (mt_main <= 0)
         return;
-    const bool paired = var_w1_paired(mt_main, NT);
+    const bool paired = !a.no_pair && var_w1_paired(mt_main, NT);
     g.paired = paired ? 1 : 0, g.mt_base = 0;
     var_w1_launch_ni<8>(g, corr, dim3(NT, paired ? mt_main / 2 : mt_main), st);
 }

@@ -182,8 +182,9 @@ public:
     gpx_options options_;
     // Several GPUs behind the UNCHANGED caller (new; north star: query-grid shards).  devices_ = HIP ordinals; with more than one
     // entry create() places the model on devices_[0] and every evaluate / sampleSurface call of at least shard_min_nq_ queries
-    // is cut into contiguous slabs over replicas on all entries (gpx_model_evaluate_sharded; replicas are made at the first
-    // such call and after every update).  Environment: GPX_DEVICES=0,1,2,3 and GPX_SHARD_MIN_NQ.  The same ordinal twice is
+    // is cut into contiguous slabs over replicas on all entries (gpx_model_evaluate_sharded: whole slices of 2^18 queries,
+    // so an evaluate of up to 2^18 queries stays on the model; gpx_model_sample_surface_sharded: any grid; replicas are made at
+    // the first such call and after every update).  Results equal the unsharded call's bit for bit.  Environment: GPX_DEVICES=0,1,2,3 and GPX_SHARD_MIN_NQ.  The same ordinal twice is
     // allowed (two replicas on one GPU: what a one-GPU box can run).  Smaller calls -- the node's one-point evaluate from 841
     // threads -- stay on the model itself.
     std::vector<int> devices_;

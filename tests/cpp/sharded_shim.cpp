@@ -38,7 +38,7 @@ int main()
     reg.setCovFunction(std::make_shared<Gaussian>(1.0, 1.0));
     Model::Ptr gp;
     reg.create<false>(data, gp);
-    const int g = 23;  // 12167 queries: three uneven slabs
+    const int g = 81;  // 531441 queries = 3 slices of the evaluate pipeline (two of 2^18, one of 7153): one per replica
     Data::Ptr q = std::make_shared<Data>();
     for (int i = 0; i < g; ++i)
         for (int j = 0; j < g; ++j)

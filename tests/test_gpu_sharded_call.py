@@ -20,13 +20,17 @@ def _queries(nq, seed):
     return tuple(rng.uniform(-1.05, 1.05, nq) for _ in range(3))
 
 
+SLICE = 1 << 18  # the single call's own pipeline unit (csrc/gpx_eval.hip: EVAL_SLICE): the sharded evaluate distributes whole slices
+
+
 @pytest.mark.parametrize("kernel, n, prec, nrep, nq", [
-    (("matern52", 1.0, 1.0), 300, "F32", 2, 10007),        # small-model fp32 kernel, uneven slabs, flat-combined host path
-    (("gaussian", 1.0, 1.0), 277, "F64", 3, 5000),         # small fp64 kernel (mean fused into the variance launch)
-    (("thinplate", 2.0), 277, "F64", 2, 4099),             # indefinite model
-    (("gaussian", 1.0, 1.0), 700, "F32_SPLIT", 2, 9001),   # split-fp16 small kernel
-    (("matern32", 1.0, 1.0), 1500, "F32", 3, 300001),      # large-model tiles; above COMBINE_MAX_NQ: the pipelined slices
-    (("laplace", 1.0, 1.0), 1500, "F64", 2, 70001),
+    (("matern52", 1.0, 1.0), 300, "F32", 2, 2 * SLICE + 10007),   # small-model fp32 kernel; slices 2 + 1 (the partial one last)
+    (("gaussian", 1.0, 1.0), 277, "F64", 3, 3 * SLICE),           # small fp64 kernel (mean fused into the variance launch); 1 + 1 + 1
+    (("thinplate", 2.0), 277, "F64", 2, SLICE + 1),               # indefinite model; a last slice of ONE query
+    (("gaussian", 1.0, 1.0), 700, "F32_SPLIT", 4, 2 * SLICE + 5),  # split-fp16 small kernel; more replicas than slices: 1 + 1 + 1 + 0
+    (("matern32", 1.0, 1.0), 1500, "F32", 3, 4 * SLICE + 4099),   # large-model tiles (the mean's point split and the paired
+    (("laplace", 1.0, 1.0), 1500, "F64", 2, 2 * SLICE + 70001),   #  variance launch depend on the batch: whole slices keep them)
+    (("matern52", 1.0, 1.0), 2100, "F32_SPLIT", 2, 2 * SLICE + 333),
 ])
 def test_sharded_evaluate_is_bit_identical_to_the_single_call(gpu, ds, kernel, n, prec, nrep, nq):
     m = gpu.Model(gpu.make_kernel(*kernel), *ds.fibonacci_training_set(n), precision=getattr(gpu, prec), prepare_variance=True)
@@ -36,6 +40,7 @@ def test_sharded_evaluate_is_bit_identical_to_the_single_call(gpu, ds, kernel, n
     many = gpu.evaluate_sharded(reps, *q, want_v=True, want_grad=True, want_basis=True)
     for key in ("f", "v", "grad", "tx", "ty"):
         np.testing.assert_array_equal(one[key], many[key], err_msg=key)
+    del one, many
     # the other overloads: mean only; mean + variance (small fp64 models take their mean from the variance kernel there)
     np.testing.assert_array_equal(m.evaluate(*q)["f"], gpu.evaluate_sharded(reps, *q)["f"])
     a, b = m.evaluate(*q, want_v=True), gpu.evaluate_sharded(reps, *q, want_v=True)
@@ -47,10 +52,10 @@ def test_sharded_evaluate_is_bit_identical_to_the_single_call(gpu, ds, kernel, n
 
 
 def test_sharded_evaluate_small_calls_and_slab_rule(gpu, ds):
-    """nq < n_replicas, nq of a few queries per replica (whole call on replicas[0]) and the slab rule itself."""
+    """Calls of one slice stay whole on replicas[0] (nq < n_replicas, a handful of queries, a full slice); the slab rule."""
     m = gpu.Model(gpu.make_kernel("gaussian", 1.0, 1.0), *ds.fibonacci_training_set(277), precision=gpu.F64, prepare_variance=True)
     reps = [m] + m.replicate([0, 0, 0])
-    for nq in (1, 3, 4, 5, 255, 256, 257, 261):
+    for nq in (1, 3, 5, 257, 4097, SLICE):
         q = _queries(nq, nq)
         one = m.evaluate(*q, want_v=True, want_grad=True)
         many = gpu.evaluate_sharded(reps, *q, want_v=True, want_grad=True)
@@ -60,7 +65,7 @@ def test_sharded_evaluate_small_calls_and_slab_rule(gpu, ds):
     sh = importlib.import_module("gaussian-object-modelling_amd.sharding")
     for nq, w in ((10, 3), (1 << 20, 8), (7, 8), (16777216, 4), (0, 2)):
         assert [gpu.slab_range(nq, r, w) for r in range(w)] == [sh.slab_range(nq, r, w) for r in range(w)]
-    # errors: the same handle twice, a null entry, an empty call
+    # errors: the same handle twice, a null entry, an empty call, a null array
     L = gpu.lib()
     one = (C.c_double * 1)(0.5)
     arr = (C.c_void_p * 2)(m._h.value, m._h.value)
@@ -71,7 +76,6 @@ def test_sharded_evaluate_small_calls_and_slab_rule(gpu, ds):
     arr = (C.c_void_p * 2)(reps[0]._h.value, reps[1]._h.value)
     assert L.gpx_model_evaluate_sharded(arr, 2, 0, one, one, one, one, None, None, None, None) == gpu.E_EMPTY
     assert L.gpx_model_evaluate_sharded(arr, 0, 1, one, one, one, one, None, None, None, None) == gpu.E_BAD_ARG
-    # a failing slab: its status and message come back, prefixed with the slab (a NaN query is not an error -- a null output is)
     q = _queries(1000, 5)
     assert L.gpx_model_evaluate_sharded(arr, 2, 1000, q[0].ctypes.data_as(C.POINTER(C.c_double)), None,
                                         q[2].ctypes.data_as(C.POINTER(C.c_double)), one, None, None, None, None) == gpu.E_NULL
@@ -84,6 +88,11 @@ def test_sharded_evaluate_small_calls_and_slab_rule(gpu, ds):
     (("gaussian", 1.0, 1.0), 724, "F32", 48),   # 110592 lattice points: slabs of 36864 take the fp32 screen, like the whole
     (("matern52", 1.0, 1.0), 300, "F64", 24),   # 13824: no screen
     (("thinplate", 2.0), 277, "F64", 30),
+    # large models: the mean of the whole grid, of the candidates and of a slab's candidates, and the variance of differently
+    # composed survivor batches must not depend on the batch (evaluate_locked's fixed_order form)
+    (("matern52", 1.0, 1.0), 3000, "F32", 45),  # 91125: whole grid screened, slabs of 30375 not
+    (("gaussian", 1.0, 1.0), 2500, "F64", 40),
+    (("thinplate", 4.0), 1800, "F32", 36),      # no screen for the thin plate: the fp64 mean of the whole grid / of the slabs
 ])
 def test_sharded_sample_surface_returns_the_single_calls_set(gpu, ds, kernel, n, prec, g):
     m = gpu.Model(gpu.make_kernel(*kernel), *ds.fibonacci_training_set(n), precision=getattr(gpu, prec), prepare_variance=True)

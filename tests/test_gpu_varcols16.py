@@ -33,9 +33,11 @@ def test_split_fp16_small_model_variance_matches_fp64_and_its_fp32_twin(gpu, orc
         assert verr_v(a["v"], ref["v"]) < 1e-5 and verr_v(b["v"], ref["v"]) < 1e-5, (n, kn)
         assert not np.array_equal(a["v"], b["v"])  # (each took its own kernel)
         assert np.array_equal(a["f"], b["f"]) and nerr(a["f"], ref["f"]) < 1e-5
-        if n <= 300:
+        # the ORACLE itself (not the repo's own fp64 pipeline): every kernel up to 300 points, one exponential kernel each at 512
+        # and at the largest size (the oracle's N = 1024 create + 1331 per-query solves take seconds)
+        if n <= 300 or (n, kn) in ((512, "gaussian"), (512, "laplace"), (1024, "matern52"), (1024, "matern32")):
             o = orc.Model(orc.make_kernel(kn, *par), *data).evaluate(*q, want_v=True)
-            assert verr_v(a["v"], o["v"]) < 1e-5
+            assert verr_v(a["v"], o["v"]) < 1e-5 and nerr(a["f"], o["f"]) < 1e-5, (n, kn)
         m.close()
 
 
