@@ -36,6 +36,29 @@ PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 matrix peak (the opt-in split contraction runs three fp16 products per fp32 one)
 # VALU instructions per (query, training point) pair in the inner loop of predict_kernel<double, KID, false> (mean only),
 # counted in the gfx950 ISA of the shipped library (scripts/predict_isa.py -> profiles/r02_predict_isa.txt)
+# Vector-ALU work of the two small-model variance kernels per QUERY at the three sizes of roofline_small / roofline_small64, as
+# wave-instructions: (vector instructions that are not MFMAs, of which transcendentals, fp64 MFMAs of the fit's add-back) --
+# properties of the shipped code, counted by rocprofv3 --pmc (SQ_INSTS_VALU - SQ_INSTS_MFMA, SQ_INSTS_VALU_TRANS_*,
+# SQ_INSTS_VALU_MFMA_F64 over 2^21 queries; profiles/r06_pmc_small_kernels.txt).  On gfx950 these MFMAs never co-execute with the
+# vector ALU (SQ_VALU_MFMA_COEXEC_CYCLES = 0 there): a kernel's issue-slot bound is the SUM of its MFMA and vector cycles.
+SMALL_VECTOR_WORK = {"f32": {277: (119.4, 12.0, 4.5), 512: (251.5, 30.0, 8.0), 724: (431.1, 56.0, 11.5)},
+                     "f64": {277: (174.5, 4.5, 0.0), 512: (394.3, 10.5, 0.0), 724: (669.4, 18.0, 0.0)}}
+NOMINAL_CLOCK_HZ = 2.4e9  # the clock the MFMA peaks are quoted at
+N_SIMD = 1024
+
+
+def issue_bound(prec, n, nq, kernel_ms, alg_mfma_cycles_per_query):
+    """(algorithmic MFMA cycles + the fit's fp64 MFMAs + 4 cycles per vector instruction, 16 per transcendental) / measured cycles
+    of a SIMD at the nominal clock: how far the kernel is from the bound that binds it (MFMA and vector work in series)."""
+    valu, trans, fit = SMALL_VECTOR_WORK[prec][n]
+    vec = (valu - trans) * 4.0 + trans * 16.0
+    bound = (alg_mfma_cycles_per_query + fit * 64.0 + vec) * nq / N_SIMD
+    measured = kernel_ms * 1e-3 * NOMINAL_CLOCK_HZ
+    return {"issue_bound_frac": bound / measured, "issue_bound": {"algorithmic_mfma_cycles_per_query": alg_mfma_cycles_per_query,
+            "fit_mfma_cycles_per_query": fit * 64.0, "vector_issue_cycles_per_query": vec,
+            "what": "SIMD cycles per query; frac = their sum x queries / 1024 SIMDs / (kernel ms x 2.4 GHz)"}}
+
+
 MEAN_VALU_PER_PAIR = {"gaussian": 26.125, "laplace": 26.125, "thinplate": 16.125, "matern32": 28.125, "matern52": 29.125}
 
 
@@ -205,6 +228,9 @@ def small_model_roofline(torch, gpx, ds, dev, local_rank):
            "traffic": "0.35 GB per 2^21-query launch (queries + fit coefficients read, v written; the operand never exists in memory): "
                       "profiles/r04_pmc_var_cols.txt (committed rocprofv3 --pmc passes of scripts/c5_stages.py, not this run)",
            "kernel": "var_cols_kernel<2 x 12 fragments, operand formed in the wave> (gpx_varcols_kernel.hpp)",
+           "issue_note": "issue_bound_frac: (algorithmic MFMA + fit MFMA + vector-instruction cycles) / measured cycles at the NOMINAL 2.4 GHz; the "
+                         "kernel runs at 2.02-2.16 GHz under power, where the PMC passes show 94-96 % of the SIMD cycles busy with MFMAs or vector "
+                         "issue (profiles/r06_pmc_small_kernels.txt)",
            "note": "the fp32-input MFMA issues on the vector ALU's slots (profiles/r04_mfma_filler_probe.txt): the fp64 add-back of "
                    "the fit, the accumulator reads and the in-wave evaluation of the operand add to the MFMA time instead of hiding "
                    "behind it -- at N = 277 they are as long as the algorithmic MFMAs (DESIGN.md section 4)", "sizes": {}}
@@ -224,6 +250,8 @@ def small_model_roofline(torch, gpx, ds, dev, local_rank):
         a = flops / (mean["t_var_gemm_ms"] * 1e-3) / 1e12
         out["sizes"][str(n)] = {"kernel_ms": mean["t_var_gemm_ms"], "launches": runs[-1]["var_gemm_launches"], "achieved": a,
                                 "frac": a / PEAK_F32_MFMA_TFLOPS, "variance_stage_ms": mean["t_var_ms"],
+                                # fp32 16x16x4 MFMA: 1024 MAC in 32 cycles -> N^2 / 2 MAC per query = N^2 / 64 cycles
+                                **issue_bound("f32", n, nq, mean["t_var_gemm_ms"], float(n) ** 2 / 64.0),
                                 "variance_stage_frac": flops / (mean["t_var_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                 "mean_ms": mean["t_mean_ms"], "timing": "mean of 4 evaluations after one warm-up",
                                 "kernel_ms_min": min(r["t_var_gemm_ms"] for r in runs)}
@@ -242,9 +270,11 @@ def small_model_roofline64(torch, gpx, ds, dev, local_rank):
     f = torch.empty(nq, dtype=torch.float64, device=dev)
     v = torch.empty_like(f)
     out = {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "n_query": nq, "traffic": None,
-           "kernel": "var_cols64_kernel<2 column x 22 row fragments, operand formed in the wave, mean carried along> (gpx_varcols64.hip)",
-           "note": "MFMAs, operand evaluation, requests for X and the epilogue run one after the other on a SIMD "
-                   "(profiles/r05_var64_parts.txt); the general fp64 path reaches 34 % at N = 277 (profiles/r05_var64_sweep.txt)",
+           "kernel": "var_cols64_kernel<two waves per SIMD: 1 column x 22 row fragments each, operand formed in the wave, mean carried along> (gpx_varcols64.hip)",
+           "note": "the fp64 MFMA runs at the fp64 vector rate and never co-executes with the vector ALU (SQ_VALU_MFMA_COEXEC_CYCLES = 0, "
+                   "profiles/r06_pmc_small_kernels.txt): MFMAs and operand evaluation add up -- issue_bound_frac prices the kernel against "
+                   "that sum; the requests for X cost what the L2 behind them costs (profiles/r06_var64_parts.txt); round 5's "
+                   "one-wave-per-SIMD form: 0.61 / 0.68 / 0.71 of the MFMA peak",
            "sizes": {}}
     for n in (277, 512, 724):
         m = gpx.Model(gpx.make_kernel("matern52", 1.0, 1.0), *ds.fibonacci_training_set(n), precision=gpx.F64, prepare_variance=True,
@@ -262,6 +292,8 @@ def small_model_roofline64(torch, gpx, ds, dev, local_rank):
         a = flops / (mean["t_var_gemm_ms"] * 1e-3) / 1e12
         out["sizes"][str(n)] = {"kernel_ms": mean["t_var_gemm_ms"], "launches": runs[-1]["var_gemm_launches"], "achieved": a,
                                 "frac": a / PEAK_F64_MFMA_TFLOPS, "variance_stage_ms": mean["t_var_ms"], "mean_ms": mean["t_mean_ms"],
+                                # fp64 16x16x4 MFMA: 2048 flop in 64 cycles -> 256 F (F + 1) flop per query = 8 F (F + 1) cycles
+                                **issue_bound("f64", n, nq, mean["t_var_gemm_ms"], 8.0 * nf * (nf + 1)),
                                 "timing": "mean of 4 evaluations after one warm-up"}
     return out
 

@@ -225,7 +225,14 @@ def guard_small_fp64_accumulators(lib_path, tmp_dir):
     build carried 430 such moves in the chunk loop).  (2) No scratch.  (3) hipcc pads no hazard behind an asm MFMA: the first
     read of an accumulator by anything but an MFMA (v_accvgpr_read, or a VALU source for the VGPR slots) must lie behind
     >= 16 wait states or two later MFMAs (the matrix pipe completes in order)."""
-    _guard_asm_accumulators(lib_path, tmp_dir, "var_cols64_kernel", 4, "v_mfma_f64", 16 * 8 + 28, 14 * 16)
+    _guard_asm_accumulators(lib_path, tmp_dir, "VC64One", 4, "v_mfma_f64", 16 * 8 + 28, 14 * 16)
+    # round 6, two waves per SIMD: 22 x 1 fragments per wave, 16 slots in AGPRs and 6 in VGPRs -- the one split that fits the 128 +
+    # 128 registers hipcc gives a kernel of 512 threads; every other split measured made it copy accumulators right behind the asm
+    # MFMAs (wrong variances): conditions (1) and (3) are what fail such a build
+    _guard_asm_accumulators(lib_path, tmp_dir, "VC64Two", 4, "v_mfma_f64", 16 + 22 * 4, 16 * 8)
+    for k in kernels(lib_path, tmp_dir):
+        if "var_cols64_kernel" in k["name"] and "VC64Two" in k["name"]:
+            assert k["vgpr_count"] <= 256 and k["private_segment_fixed_size"] == 0, k
 
 
 def guard_small_split_accumulators(lib_path, tmp_dir):

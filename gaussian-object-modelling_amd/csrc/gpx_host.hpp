@@ -139,7 +139,7 @@ struct Switches {
     int dgp_append = -1;       // GPX_DGP_APPEND      0: gpx_dgp_add rebuilds on the union
     int var_cols = -1;         // GPX_VAR_COLS        0: small models through the general 128 x 128 tiles
     int var_cols16 = -1;       // GPX_VAR_COLS16      0: small split-mode models on the fp32 small-model kernel
-    int var_cols64 = -1;       // GPX_VAR_COLS64      0: small fp64 models through the general path
+    int var_cols64 = -1;       // GPX_VAR_COLS64      0: small fp64 models through the general path; 1: the one-wave-per-SIMD form of the small kernel
     int var_tile = -1;         // GPX_VAR_TILE        3: the LDS-staged four-wave tile instead of the one-wave tile
     int var_fit = -1;          // GPX_VAR_FIT         0: plain kernel values in the fp32 contraction (no per-query fit)
     int no_promote = -1;       // GPX_NO_PROMOTE      1: an indefinite fp32-mode model is rounded to fp32 all the same

@@ -60,17 +60,25 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // 22 row-fragment slots, all 512 registers of a SIMD lane.  TWO waves per SIMD (round 6): 16 queries (one column fragment, 4 MFMAs
 // per fragment of X) and VC64_FS2 slots in 256 registers each -- the same rows per pass, hence the same number of operand
 // evaluations per query as the one-wave form (round 5's two-wave build halved the SLOTS and so evaluated the operand 1.7 times as
-// often), at twice the requests for X; what the second wave buys is that its operand evaluation, requests and epilogue issue
-// while the other wave's MFMAs occupy the matrix pipe (profiles/r05_mfma_filler_probe2.txt: MFMA + 4 independent vector
-// instructions of ONE wave 157 cycles, of two alternating waves 97 each).
+// often) and, with the same 22 slots, the same order of every sum (bit-identical results), at twice the requests for X.  What the
+// second wave buys is latency: the vector work itself cannot hide (on gfx950 the fp64 MFMA runs at the fp64 VECTOR rate -- it
+// occupies the lanes the vector ALU would use: profiles/r06_pmc_small_kernels.txt, SQ_VALU_MFMA_COEXEC_CYCLES), but one wave's
+// waits -- LDS, the requests for X, the MFMA's own result latency in front of the epilogue -- are filled by the other.  Measured
+// (profiles/r06_var64_two.txt, 2^21 queries, Matern-5/2): N = 277 3.81 -> 3.49 ms, 512 10.5 -> 9.97, 724 20.5 -> 19.65 (+4.5 .. 8.5 %).
+// Accumulators: 16 slots in AGPRs + 6 in VGPRs is the ONLY split hipcc compiles without copies (it gives a kernel of 512 threads
+// 128 registers of each class): builds with 20, 8 or 0 AGPR slots moved accumulators through the other class right behind asm
+// MFMAs and returned wrong variances (dv up to 100 x max v) -- codeobj.py's guard fails them.
+// Tried on top and dropped (ledger, round 6): the chunk's fragments of X staged once per workgroup in LDS by LDS-DMA, a chunk
+// ahead (L2 requests 119 -> 36 GB per launch): 19.65 -> 21.5 ms at N = 724 -- the barrier per chunk and the DMA's own cost exceed
+// what the requests cost (1.8 ms; a build whose requests always hit the L1 shows that this cost is the L2's, not their issue).
 struct VC64One {
     static constexpr int CF = 2, FS = VC64_FS, WAVES = 4, AGPR = VC64_AGPR, AHEAD = VC64_AHEAD;
 };
 #ifndef VC64_FS2
-#define VC64_FS2 20
+#define VC64_FS2 22
 #endif
 #ifndef VC64_AHEAD2
-#define VC64_AHEAD2 3
+#define VC64_AHEAD2 2
 #endif
 #ifndef VC64_AGPR2
 #define VC64_AGPR2 16
@@ -106,8 +114,8 @@ __device__ __forceinline__ void slot_chain(int nact, Fn &&f)
 }
 
 // DBG (diagnostic builds only, make EXTRA=-DVC64_DBG=n OUTDIR=../lib_t OBJDIR=../build_t; results are wrong by construction):
-// 1 operand values not evaluated, 2 no MFMAs, 3 no requests for X, 4 neither operand nor requests -- how the kernel's time
-// splits (profiles/r05_var64_parts.txt)
+// 1 operand values not evaluated, 2 no MFMAs, 3 no requests for X, 4 neither operand nor requests, 5 every request answered by
+// the L1 -- how the kernel's time splits (profiles/r05_var64_parts.txt, r06_var64_parts.txt)
 #ifndef VC64_DBG
 #define VC64_DBG 0
 #endif
@@ -196,7 +204,8 @@ __global__ __launch_bounds__(64 * CFG::WAVES, 1) void var_cols64_kernel(VarCols6
                         lo = f64x2{ax[0], ay[0]}, hi = f64x2{az[0], ax[CF64 - 1]};
                         return;
                     }
-                    const char *src = reinterpret_cast<const char *>(g.Xp + (xc - 256 * min(r, nact - 1))) + lane_off;
+                    // (DBG 5: every request reads the first fragment -- always an L1 hit: what the requests cost beyond the L1)
+                    const char *src = reinterpret_cast<const char *>(g.Xp + (DBG == 5 ? (xc & 1) : (xc - 256 * min(r, nact - 1)))) + lane_off;
                     lo = *reinterpret_cast<const f64x2 *>(src);
                     hi = *reinterpret_cast<const f64x2 *>(src + 1024);
                 };
@@ -381,7 +390,7 @@ void launch_var_cols64(const CovHost &h, int n, int np, const double *X, long ld
     g.k0 = h.k0;
     g.cov = lower_cov<double>(h);
     (void)np;
-    const bool two = gpxh::switches().var_cols64 == 2;  // (round 6, under measurement: two waves per SIMD)
+    const bool two = gpxh::switches().var_cols64 != 1;  // GPX_VAR_COLS64=1: the one-wave-per-SIMD form of round 5 (the tested twin)
     const long per_wg = two ? 16L * VC64Two::CF * VC64Two::WAVES : 16L * VC64One::CF * VC64One::WAVES;
     const long nblk = (nq + per_wg - 1) / per_wg;
     int devid = 0, ncu = 0;

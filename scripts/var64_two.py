@@ -1,4 +1,4 @@
-"""Small fp64 models: the one-wave-per-SIMD kernel (GPX_VAR_COLS64 unset) against the two-waves-per-SIMD form (GPX_VAR_COLS64=2,
+"""Small fp64 models: the one-wave-per-SIMD kernel of round 5 (GPX_VAR_COLS64=1) against the two-waves-per-SIMD form (the default,
 csrc/gpx_varcols64.hip: VC64Two), 2^21 queries, Gaussian(1,1) and Matern-5/2 on the Fibonacci cloud: kernel ms, fraction of the
 fp64 MFMA peak on the algorithmic triangle, and the largest difference of v and f between the two (relative to max |v|, |f|).
 Usage: python scripts/var64_two.py [sizes...]"""
@@ -22,7 +22,7 @@ for kn in ("gaussian", "matern52"):
     for n in sizes:
         m = gpx.Model(kern, *ds.fibonacci_training_set(n), precision=gpx.F64, prepare_variance=True)
         row, res = [], []
-        for mode in (None, "2"):
+        for mode in ("1", None):
             with gpx.switches(GPX_VAR_COLS64=mode):
                 ts = []
                 for i in range(4):

@@ -17,8 +17,15 @@ def _eval(m, q, cols64, **kw):
     """evaluate() with the kernel on or off (GPX_VAR_COLS64; the library re-reads its switches on gpx_debug_reload)"""
     import importlib
     gpx = importlib.import_module("gaussian-object-modelling_amd.gpx")
-    with gpx.switches(GPX_VAR_COLS64=None if cols64 else "0"):
+    with gpx.switches(GPX_VAR_COLS64=None if cols64 is True else ("1" if cols64 == "one-wave" else "0")):
         return m.evaluate(*q, want_v=True, **kw)
+
+
+def _same_as_one_wave_form(m, q, a):
+    """Round 6: the default is the two-waves-per-SIMD shape (16 queries and 22 row-fragment slots per wave); the one-wave shape of
+    round 5 (32 queries, the same 22 slots: GPX_VAR_COLS64=1) sums everything in the same order -- equal bit for bit."""
+    w = _eval(m, q, "one-wave")
+    assert np.array_equal(w["v"], a["v"]) and np.array_equal(w["f"], a["f"])
 
 
 @pytest.mark.parametrize("n", [16, 17, 33, 166, 277, 352, 353, 448, 512])
@@ -36,6 +43,7 @@ def test_small_fp64_variance_matches_the_oracle_and_the_general_path(gpu, orc, d
         assert verr_v(a["v"], b["v"]) < 1e-12, (n, kn, par)
         # the mean: carried by the variance kernel (a), from the mean kernel (b; and d: with a gradient always from the mean kernel)
         assert nerr(a["f"], ref["f"]) < 1e-10 and nerr(a["f"], b["f"]) < 1e-12, (n, kn, par)
+        _same_as_one_wave_form(m, q, a)
         d = _eval(m, q, True, want_grad=True)
         assert nerr(d["f"], b["f"]) < 1e-13 and np.array_equal(d["v"], a["v"])
         assert nerr(d["grad"], om.evaluate(*q, want_grad=True)["grad"]) < 1e-9
@@ -86,6 +94,7 @@ def test_small_fp64_variance_kernel_up_to_its_routing_limit(gpu, orc, ds, n):
         m = gpu.Model(gpu.make_kernel(kn, *par), *data, precision=gpu.F64, prepare_variance=True)
         a, b = _eval(m, q, True), _eval(m, q, False)
         assert verr_v(a["v"], ref["v"]) < 1e-10 and verr_v(a["v"], b["v"]) < 1e-12, (n, kn)
+        _same_as_one_wave_form(m, q, a)
         m.close()
 
 
@@ -110,6 +119,7 @@ def test_small_fp64_variance_on_random_clouds_kernels_and_query_counts(gpu, orc)
         a, b = _eval(m, q, True), _eval(m, q, False)
         # (the mean of a thin-plate model is an alternating sum of terms ~R^3: two summation orders differ by 1e-16 of THAT)
         assert verr_v(a["v"], b["v"]) < 1e-11 and nerr(a["f"], b["f"]) < 1e-9, (case, n, kn, par, nq)
+        _same_as_one_wave_form(m, q, a)
         if n <= 300:
             ref = orc.Model(orc.make_kernel(kn, *par), *cols).evaluate(*q, want_v=True)
             assert verr_v(a["v"], ref["v"]) < 1e-9 and nerr(a["f"], ref["f"]) < 1e-9, (case, n, kn, par, nq)
