@@ -16,6 +16,12 @@
 //     (A from its own tile, B = the inverse block);
 //   * flags, write-through publication, ordinary loads on the consumer side, time budgets of the waits and the give-up path: as gpx_dataflow.hpp.
 // No inverse-factor jobs: every wait is for a workgroup with a lower index.
+// Where the time goes (round 6, make EXTRA=-DWIDE_TIMING; profiles/r06_wide_timing.txt; N = 16384 fp32, 15.6 ms, every CU busy throughout): waits for
+// tile flags 2.5 %, operands into LDS + first barrier 10 %, MFMAs + second barrier 78 % (the matrix pipe 83 % busy inside it), kernel-matrix
+// entries / stores / the rest 9.5 % -- neither the bytes (2.3 TB/s) nor the waits set the time.  Two forms that overlap the staging with the
+// MFMAs were built on two sets of LDS buffers (147 KB) and are SLOWER: slice s + 1 written behind the MFMAs of slice s, one barrier per slice
+// (22.1 ms), and the present order without the second barrier (21.3 ms) -- once the waves of a workgroup drift apart, the ds_write bursts of
+// one wave sit in the LDS queue in front of the operand reads the other waves' MFMAs wait for; the two barriers keep the phases apart.
 #pragma once
 #include "gpx_dataflow.hpp"
 #include "gpx_diag128.hpp"
@@ -24,15 +30,15 @@ namespace gpx {
 namespace dataflow {
 
 constexpr int WT = TILE;  // 128
+constexpr int WIDE_TIMING_MAX_TILES = 16384;
 constexpr int WIDE_THREADS = 512;
 // LDS: two operands of 128 x 64 in the wide layout (8 blocks of 32 x 36 each) -- or the diagonal-block routine's own layout
 constexpr int WIDE_OPERAND_ELEMS = 16 * WBLK;
 template <typename T>
 constexpr size_t wide_lds_bytes()
 {
-    return (size_t)WIDE_OPERAND_ELEMS * sizeof(T) > (sizeof(T) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD))
-               ? (size_t)WIDE_OPERAND_ELEMS * sizeof(T)
-               : sizeof(T) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);
+    constexpr size_t op = (size_t)WIDE_OPERAND_ELEMS * sizeof(T);
+    return op > (sizeof(T) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD)) ? op : sizeof(T) * (size_t)(TILE + 12 * NB * PLD + 96 * PLD);
 }
 
 // 128 x 64 slice at g (leading dimension ld): element e of thread t (512 threads) is (row 8 e + (t >> 6), column t & 63)
@@ -56,9 +62,35 @@ __device__ __forceinline__ void slice_to_lds(T *buf, const T (&v)[16], T s)
     }
 }
 
+// make EXTRA=-DWIDE_TIMING OUTDIR=../lib_t OBJDIR=../build_t: shader-clock split of every workgroup of the wide launch -- [0] whole
+// workgroup, [1] waits for tile flags, [2] operands into LDS + first barrier of a slice, [3] MFMAs + second barrier, [4] the
+// diagonal-block routine; mid_factor_t (gpx_small.hip) sums them over the launch and prints one line (scripts/ldlt_sweep.py)
+#ifdef WIDE_TIMING
+__device__ unsigned long long wide_timing[WIDE_TIMING_MAX_TILES * 8];
+#define WT_NOW() clock64()
+#define WT_ADD(k, t0) wt_acc[k] += clock64() - (t0)
+#else
+#define WT_NOW() 0ull
+#define WT_ADD(k, t0) (void)(t0)
+#endif
+
 template <typename T, int KID>
 __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *info, T *sm)
 {
+#ifdef WIDE_TIMING
+    unsigned long long wt_acc[5] = {0, 0, 0, 0, 0};
+    const unsigned long long wt_start = clock64();
+    struct WtFlush {
+        unsigned long long *acc, start;
+        __device__ ~WtFlush()
+        {
+            acc[0] = clock64() - start;
+            if (threadIdx.x == 0 && blockIdx.x < WIDE_TIMING_MAX_TILES)
+                for (int k = 0; k < 5; ++k)
+                    wide_timing[(size_t)blockIdx.x * 8 + k] = acc[k];
+        }
+    } wt_flush{wt_acc, wt_start};
+#endif
     __shared__ int s_ok, s_next;
     __shared__ double s_best[8];
     __shared__ int s_bi[8], s_bj[8];
@@ -174,7 +206,10 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
         auto block_for = [&](int s) -> bool {
             const u64 *fa = flag_a(s >> 1), *fb = flag_b(s >> 1);
             if (fa || fb) {
-                if (!wait_tiles(fa ? fa : fb, fa ? fb : nullptr, f, &s_ok))
+                const unsigned long long tw0 = WT_NOW();
+                const bool okw = wait_tiles(fa ? fa : fb, fa ? fb : nullptr, f, &s_ok);
+                WT_ADD(1, tw0);
+                if (!okw)
                     return false;
             }
             sready = max(sready, (s | 1) + 1);
@@ -184,6 +219,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
             return false;
         issue(0);
         for (int s = 0; s < nsl; ++s) {
+            const unsigned long long tl0 = WT_NOW();
             slice_to_lds(bufA, va, sign * dk);
             slice_to_lds(bufB, vb, T(1));
             // a cheap look one tile column ahead (thread 0, one or two flag loads issued here, used after the products)
@@ -195,6 +231,8 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
                 pb = fb ? ld_flag(fb) : f.epoch;
             }
             __syncthreads();
+            WT_ADD(2, tl0);
+            const unsigned long long tm0 = WT_NOW();
             const bool ready = s + 1 < nsl && s + 1 < sready;
             if (ready)
                 issue_a(s + 1);  // in flight while the matrix cores work on slice s
@@ -218,6 +256,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
             if (look && tid == 0)
                 s_next = (pa == f.epoch && pb == f.epoch) ? 1 : 0;
             __syncthreads();
+            WT_ADD(3, tm0);
             if (!ready && s + 1 < nsl) {
                 if (look && s_next)
                     sready = max(sready, ((s + 1) | 1) + 1);
@@ -252,7 +291,9 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
     __syncthreads();
     if (I == J) {
         // ---- diagonal tile: LDL^T + inverse of the 128 x 128 block by the launch chain's routine, in place ----
+        const unsigned long long td0 = WT_NOW();
         diag_ldlm_body<T, WIDE_THREADS>(Ktile, np, f.linv, f.d, f.dinv, info, I, reinterpret_cast<unsigned char *>(sm));
+        WT_ADD(4, td0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
