@@ -149,7 +149,7 @@ def cpu_baseline(n_train, nq, kernel_name, kernel_par):
 
 
 # committed PMC passes per variance tile (GPX_VAR_TILE): file, kernel-name prefix of that tile's instantiation
-PMC_TRAFFIC = {"6": ("r05_pmc_traffic_w1.json", "gpx::var_w1_kernel<true"),    # one-wave tile (default; the round-5 build)
+PMC_TRAFFIC = {"6": ("r06_pmc_traffic_w1.json", "gpx::var_w1_kernel<true"),    # one-wave tile (default; the round-6 build)
                "3": ("r03_pmc_traffic.json", "gpx::gemm_kernel<float, false, 2, 4, 4, 2, 2, 64")}   # LDS-staged fallback
 
 
