@@ -448,7 +448,8 @@ def guard_mfma_result_hazards(lib_path, tmp_dir):
             text = [l.split("//")[0].strip() for l in lines]
             idx = [i for i, t in enumerate(text) if t.startswith(("v_mfma_f64_16x16x4_f64", "v_mfma_f32_32x32x2_f32"))
                    and i + 2 < len(text) and text[i + 1] == "s_nop 15" and text[i + 2] == "s_nop 1"]
-            assert len(idx) >= 2 * 32, (sym, len(idx))
+            # (fp32: one per column and sub-block = 2 x 32; fp64, rank-4 panels: 8 + 4 transforms and 4 + 6 updates per sub-block = 2 x 22)
+            assert len(idx) >= 2 * 22, (sym, len(idx))
             pairs += 1
     assert seen >= 50 and pairs >= 12, (seen, pairs)
 

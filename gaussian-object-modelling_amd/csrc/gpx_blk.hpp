@@ -256,9 +256,10 @@ __device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, doubl
 // Lx and then the step count in *prog (LDS operations of a wave execute in order); wave 1 -- on another SIMD -- waits for the
 // count, reads the column back as its A operand and applies it to its rows of X.  prog counts from `base` (the caller zeroes it
 // behind a barrier and passes 32 * (number of sub-blocks done)).  Same arithmetic as subblock_ldl (the pivot of the next step is
-// formed ahead of the update, by the same fused multiply-add).  Measured: 7.3 -> 6.0 us per sub-block -- the step is a chain of
-// latencies (MFMA result -> lane broadcast -> scaled column -> MFMA), not of MFMA issue slots: wave 0 alone, with neither the
-// inverse nor the reciprocal on its chain, still needs 6.2 us.
+// formed ahead of the update, by the same fused multiply-add).  Measured (rank-1 steps, the fp32 form below): 7.3 -> 6.0 us per
+// sub-block -- the step is a chain of latencies (MFMA result -> lane broadcast -> scaled column -> MFMA), not of MFMA issue slots:
+// wave 0 alone, with neither the inverse nor the reciprocal on its chain, still needs 6.2 us.  The fp64 form takes RANK-4 steps
+// (further down): 4.3 us.
 //
 // WAVE 1's MFMAs ARE INLINE ASM WITH THEIR OWN WAIT STATES, and that is the point (round 6).  gfx950 does not
 // interlock a read of an MFMA result still in the pipe; the ISA asks for 11 (fp64 16x16x4; 18 for LDS / memory reads) or 18
@@ -317,12 +318,77 @@ __device__ __forceinline__ void ldl_x_update(f32x16 &x, float a, float b)
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 1" : "+a"(x) : "v"(a), "v"(b));
 }
 
+// ---- round 6: the fp64 pair in RANK-4 steps --------------------------------------------------------------------------------------
+// A rank-1 step uses one of the four k slots of v_mfma_f64_16x16x4_f64 and pays, per COLUMN, the chain MFMA result -> pivot ->
+// reciprocal -> scaled column -> MFMA (6.0 us per 32 x 32 sub-block: 450 cycles a column, the matrix pipe busy with 3 x 64 of them).
+// In the accumulator layout the four rows 4 p + g (g = lane group) of a tile are register p of the four lane groups -- the B operand
+// of a FULL-k MFMA as it stands.  A panel of four columns is therefore eliminated at once:
+//   1. the panel's 4 x 4 diagonal block G (ten lane broadcasts) is factorised by every lane alike, G = L4 D4 L4^T, and W = L4^-1 formed;
+//   2. ONE MFMA per tile applies W to the panel rows: U = W T_panel are the rows as the four rank-1 steps would have left them
+//      (A operand: W in the lanes of rows 0-3, zero elsewhere; result row g in register 0 of lane group g -- the panel's own layout);
+//   3. l = U / d are the four columns of L (published for wave 1 with ONE count), and ONE MFMA per tile subtracts all four from the
+//      trailing rows (A = -l of the lane's own (row, k), zero for the rows of the panel and above; B = U).
+// First half of the sub-block: 2 + 3 MFMAs per panel instead of 12, second half 1 + 1 instead of 4, and the chain per FOUR columns is
+// broadcasts -> 4 x 4 factorisation (four reciprocals in sequence) -> two MFMA latencies.  Wave 1 applies the same panels to the inverse:
+// the panel rows of X are REPLACED by W X_panel (they are final), the rows below take -l X'_panel; it rebuilds W from the six
+// multipliers of the panel's 4 x 4 block that wave 0 published with the columns.  Same factorisation as the rank-1 form to rounding
+// (the sums inside a panel are taken in another order); measured: profiles/r06_ldl_rank4.txt.
+struct LdlPanel4 {
+    double d[4], r[4], w10, w20, w21, w30, w31, w32;
+};
+// (g_ab = element (a, b) of the symmetric 4 x 4 block, a >= b)
+__device__ __forceinline__ LdlPanel4 ldl_panel4(double g00, double g10, double g11, double g20, double g21, double g22, double g30,
+                                                double g31, double g32, double g33)
+{
+    LdlPanel4 P;
+    P.d[0] = g00, P.r[0] = fast_rcp(g00);
+    const double l10 = g10 * P.r[0], l20 = g20 * P.r[0], l30 = g30 * P.r[0];
+    P.d[1] = fma(-l10, g10, g11), P.r[1] = fast_rcp(P.d[1]);
+    const double u21 = fma(-l20, g10, g21), u31 = fma(-l30, g10, g31);
+    const double l21 = u21 * P.r[1], l31 = u31 * P.r[1];
+    P.d[2] = fma(-l21, u21, fma(-l20, g20, g22)), P.r[2] = fast_rcp(P.d[2]);
+    const double u32 = fma(-l31, u21, fma(-l30, g20, g32));
+    const double l32 = u32 * P.r[2];
+    P.d[3] = fma(-l32, u32, fma(-l31, u31, fma(-l30, g30, g33))), P.r[3] = fast_rcp(P.d[3]);
+    P.w10 = -l10, P.w21 = -l21, P.w32 = -l32;
+    P.w20 = fma(-l21, P.w10, -l20);
+    P.w31 = fma(-l32, P.w21, -l31);
+    P.w30 = fma(-l32, P.w20, fma(-l31, P.w10, -l30));
+    return P;
+}
+// W = L4^-1 from the six multipliers of a unit lower 4 x 4 block
+__device__ __forceinline__ void ldl_w_from_l(double l10, double l20, double l21, double l30, double l31, double l32, LdlPanel4 &P)
+{
+    P.w10 = -l10, P.w21 = -l21, P.w32 = -l32;
+    P.w20 = fma(-l21, P.w10, -l20);
+    P.w31 = fma(-l32, P.w21, -l31);
+    P.w30 = fma(-l32, P.w20, fma(-l31, P.w10, -l30));
+}
+// the lane's element of the A operand that applies W to a panel: A[i][k] = W[i][k] for i < 4 (lane (k, i) = (g, c)), zero below
+__device__ __forceinline__ double ldl_w_operand(const LdlPanel4 &P, int g, int c)
+{
+    double a = (c < 4 && c == g) ? 1.0 : 0.0;
+    a = (c == 1 && g == 0) ? P.w10 : a;
+    a = (c == 2 && g == 0) ? P.w20 : a;
+    a = (c == 2 && g == 1) ? P.w21 : a;
+    a = (c == 3 && g == 0) ? P.w30 : a;
+    a = (c == 3 && g == 1) ? P.w31 : a;
+    a = (c == 3 && g == 2) ? P.w32 : a;
+    return a;
+}
+// wave 1: W X_panel into a VGPR tile, with the wait states of an asm MFMA (see ldl_x_update)
+__device__ __forceinline__ double ldl_x_transform(double aw, double xp)
+{
+    f64x4_blk t;
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 1" : "=v"(t) : "v"(aw), "v"(xp));
+    return t[0];
+}
+
 __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, double *Xdb, int lane, int wave, double &dvec,
                                                   volatile int *prog, int base)
 {
     typedef double T;
     const int g = lane >> 4, c = lane & 15;
-    // (stores of the columns through the LDS address space as well: a flat store and a ds_write of one wave are NOT ordered)
     GPX_LDS(T) *LxL = (GPX_LDS(T) *)Lx;
     if (wave == 0) {
         f64x4 T00, T01, T11;
@@ -338,55 +404,53 @@ __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, 
                 T11[r] = row > c ? lo11 : up11;
             }
         }
-        // The pivot of step j + 1 does not wait for the MFMAs of step j: it is element (j + 1, j + 1) minus l_{j+1,j} times
-        // element (j, j + 1), both known before them -- the same fused multiply-add the matrix core applies to that element --
-        // so its reciprocal (an estimate and two Newton steps, the longest part of the chain between two steps) is formed
-        // while the update is in the pipe.
-        T dj = bcast_lane(T00[0], 0);
-        T rinv = fast_rcp(dj);
+        const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int r = j >> 2, gj = j & 3;
-            const T row0 = T00[r], row1 = T01[r];
-            const T l0 = row0 * rinv, l1 = row1 * rinv;
-            const bool ing = g == gj, act = ing && c > j;
-            const T a0 = act ? -l0 : 0.0, a1 = ing ? -l1 : 0.0;
-            if (lane == j)
-                dvec = dj;
-            if (act)
-                LxL[c * PLD + j] = l0;
-            if (ing)
-                LxL[(16 + c) * PLD + j] = l1;
-            ldl_publish(prog, base + j + 1);
-            // next pivot: j + 1 < 16 in T00 (row j + 1 = register (j + 1) / 4 of lane group (j + 1) % 4), else (16, 16) in T11
-            const T m = j < 15 ? bcast_lane(row0, 16 * gj + j + 1) : bcast_lane(row1, 16 * gj);
-            const T old = j < 15 ? bcast_lane(T00[(j + 1) >> 2], 16 * ((j + 1) & 3) + j + 1) : bcast_lane(T11[0], 0);
-            T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row0, T00, 0, 0, 0);
-            T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row1, T01, 0, 0, 0);
-            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-            dj = fma(-(m * rinv), m, old);
-            rinv = fast_rcp(dj);
+        for (int p = 0; p < 4; ++p) {  // columns 4 p .. 4 p + 3: rows 4 p + g of T00 | T01 are register p
+            const T tp0 = T00[p], tp1 = T01[p];
+            const int c0 = 4 * p;
+            const LdlPanel4 P = ldl_panel4(bcast_lane(tp0, c0), bcast_lane(tp0, 16 + c0), bcast_lane(tp0, 16 + c0 + 1),
+                                           bcast_lane(tp0, 32 + c0), bcast_lane(tp0, 32 + c0 + 1), bcast_lane(tp0, 32 + c0 + 2),
+                                           bcast_lane(tp0, 48 + c0), bcast_lane(tp0, 48 + c0 + 1), bcast_lane(tp0, 48 + c0 + 2),
+                                           bcast_lane(tp0, 48 + c0 + 3));
+            const T aw = ldl_w_operand(P, g, c);
+            const T u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp0, zero4, 0, 0, 0)[0];
+            const T u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp1, zero4, 0, 0, 0)[0];
+            const T rk = g == 0 ? P.r[0] : (g == 1 ? P.r[1] : (g == 2 ? P.r[2] : P.r[3]));
+            const T l0 = u0 * rk, l1 = u1 * rk;  // l[c][4 p + g], l[16 + c][4 p + g]
+            if (lane >= c0 && lane < c0 + 4)
+                dvec = (lane & 3) == 0 ? P.d[0] : ((lane & 3) == 1 ? P.d[1] : ((lane & 3) == 2 ? P.d[2] : P.d[3]));
+            if (c > c0 + g)
+                LxL[c * PLD + c0 + g] = l0;
+            LxL[(16 + c) * PLD + c0 + g] = l1;
+            ldl_publish(prog, base + c0 + 4);
+            const T a00 = c > c0 + 3 ? -l0 : 0.0, a01 = -l1;
+            T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, u0, T00, 0, 0, 0);
+            T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, u1, T01, 0, 0, 0);
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, u1, T11, 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 16; j < NB; ++j) {
-            const int jj = j - 16, r = jj >> 2, gj = jj & 3;
-            const T row1 = T11[r];
-            const T l1 = row1 * rinv;
-            const bool act = g == gj && c > jj;
-            const T a1 = act ? -l1 : 0.0;
-            if (lane == j)
-                dvec = dj;
-            if (act)
-                LxL[(16 + c) * PLD + j] = l1;
-            ldl_publish(prog, base + j + 1);
-            const T m = jj < 15 ? bcast_lane(row1, 16 * gj + jj + 1) : 0.0;
-            const T old = jj < 15 ? bcast_lane(T11[(jj + 1) >> 2], 16 * ((jj + 1) & 3) + jj + 1) : 1.0;
-            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-            dj = fma(-(m * rinv), m, old);
-            rinv = fast_rcp(dj);
+        for (int p = 0; p < 4; ++p) {  // columns 16 + 4 p .. + 3: rows 16 + 4 p + g of T11
+            const T tp = T11[p];
+            const int c0 = 4 * p;
+            const LdlPanel4 P = ldl_panel4(bcast_lane(tp, c0), bcast_lane(tp, 16 + c0), bcast_lane(tp, 16 + c0 + 1),
+                                           bcast_lane(tp, 32 + c0), bcast_lane(tp, 32 + c0 + 1), bcast_lane(tp, 32 + c0 + 2),
+                                           bcast_lane(tp, 48 + c0), bcast_lane(tp, 48 + c0 + 1), bcast_lane(tp, 48 + c0 + 2),
+                                           bcast_lane(tp, 48 + c0 + 3));
+            const T aw = ldl_w_operand(P, g, c);
+            const T u = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp, zero4, 0, 0, 0)[0];
+            const T rk = g == 0 ? P.r[0] : (g == 1 ? P.r[1] : (g == 2 ? P.r[2] : P.r[3]));
+            const T l = u * rk;  // l[16 + c][16 + 4 p + g]
+            if (lane >= 16 + c0 && lane < 16 + c0 + 4)
+                dvec = (lane & 3) == 0 ? P.d[0] : ((lane & 3) == 1 ? P.d[1] : ((lane & 3) == 2 ? P.d[2] : P.d[3]));
+            if (c > c0 + g)
+                LxL[(16 + c) * PLD + 16 + c0 + g] = l;
+            ldl_publish(prog, base + 16 + c0 + 4);
+            if (p < 3)
+                T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(c > c0 + 3 ? -l : 0.0, u, T11, 0, 0, 0);
         }
     } else {
-        f64x4 X00, X10, X11;
+        f64x4_blk X00, X10, X11;
         int seen = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -395,22 +459,37 @@ __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, 
             X11[r] = 4 * r + g == c ? 1.0 : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int r = j >> 2, gj = j & 3;
-            const bool ing = g == gj, act = ing && c > j;
-            const T a0 = -ldl_column(prog, base + j + 1, seen, Lx + c * PLD + j, act);
-            const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, ing);
-            const T xr = X00[r];
-            ldl_x_update2(X00, X10, a0, a1, xr);
+        for (int p = 0; p < 4; ++p) {
+            const int c0 = 4 * p, need = base + c0 + 4;
+            // the lane's multipliers of the four columns (rows c / 16 + c, column 4 p + g) and the panel's own 4 x 4 block
+            const T a00 = -ldl_column(prog, need, seen, Lx + c * PLD + c0 + g, c > c0 + 3);
+            const T a01 = -ldl_column(prog, need, seen, Lx + (16 + c) * PLD + c0 + g, true);
+            LdlPanel4 P;
+            ldl_w_from_l(ldl_column(prog, need, seen, Lx + (c0 + 1) * PLD + c0, true), ldl_column(prog, need, seen, Lx + (c0 + 2) * PLD + c0, true),
+                         ldl_column(prog, need, seen, Lx + (c0 + 2) * PLD + c0 + 1, true), ldl_column(prog, need, seen, Lx + (c0 + 3) * PLD + c0, true),
+                         ldl_column(prog, need, seen, Lx + (c0 + 3) * PLD + c0 + 1, true),
+                         ldl_column(prog, need, seen, Lx + (c0 + 3) * PLD + c0 + 2, true), P);
+            const T aw = ldl_w_operand(P, g, c);
+            const T xp = ldl_x_transform(aw, X00[p]);  // rows 4 p + g of X: final
+            X00[p] = xp;
+            ldl_x_update2(X00, X10, a00, a01, xp);
         }
 #pragma unroll
-        for (int j = 16; j < NB; ++j) {
-            const int jj = j - 16, r = jj >> 2, gj = jj & 3;
-            const bool act = g == gj && c > jj;
-            const T a1 = -ldl_column(prog, base + j + 1, seen, Lx + (16 + c) * PLD + j, act);
-            const T x10r = X10[r], x11r = X11[r];
-            ldl_x_update(X10, a1, x10r);
-            ldl_x_update(X11, a1, x11r);
+        for (int p = 0; p < 4; ++p) {
+            const int c0 = 4 * p, need = base + 16 + c0 + 4;
+            const T a11 = -ldl_column(prog, need, seen, Lx + (16 + c) * PLD + 16 + c0 + g, c > c0 + 3);
+            LdlPanel4 P;
+            const T *Lb = Lx + (16 + c0) * PLD + 16 + c0;  // the panel's 4 x 4 block of L11's lower right tile
+            ldl_w_from_l(ldl_column(prog, need, seen, Lb + PLD, true), ldl_column(prog, need, seen, Lb + 2 * PLD, true),
+                         ldl_column(prog, need, seen, Lb + 2 * PLD + 1, true), ldl_column(prog, need, seen, Lb + 3 * PLD, true),
+                         ldl_column(prog, need, seen, Lb + 3 * PLD + 1, true), ldl_column(prog, need, seen, Lb + 3 * PLD + 2, true), P);
+            const T aw = ldl_w_operand(P, g, c);
+            const T x10p = ldl_x_transform(aw, X10[p]), x11p = ldl_x_transform(aw, X11[p]);
+            X10[p] = x10p, X11[p] = x11p;
+            if (p < 3) {
+                ldl_x_update(X10, a11, x10p);
+                ldl_x_update(X11, a11, x11p);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
