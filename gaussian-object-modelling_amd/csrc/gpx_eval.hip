@@ -634,11 +634,16 @@ int run_slabs(int n, const std::vector<size_t> &len, F work)
             first = i;
             continue;
         }
-        th.emplace_back([&, i]() {
+        auto job = [&, i]() {
             rcs[(size_t)i] = work(i);
             if (rcs[(size_t)i])
                 errs[(size_t)i] = g_err;
-        });
+        };
+        try {
+            th.emplace_back(job);
+        } catch (...) {  // (no thread to be had: the slab runs on the caller's thread -- nothing may throw across the C boundary)
+            job();
+        }
     }
     if (first >= 0) {
         rcs[(size_t)first] = work(first);
