@@ -417,9 +417,19 @@ def mfma_hazard_violations(lines):
             else:
                 src = toks[j] if op.startswith(stores) else toks[j][1:]
                 touched = set().union(*[_reg_set(t) for t in src]) if src else set()
-                if toks[j] and not op.startswith(stores):
-                    touched |= _reg_set(toks[j][0])  # overwriting a result in flight is the same hazard
                 need = need_valu if op.startswith("v_") else need_mem
+                if toks[j] and not op.startswith(stores):
+                    over = _reg_set(toks[j][0])  # overwriting a result in flight is the same hazard ...
+                    if op.startswith("v_"):
+                        touched |= over
+                    elif over & dst and not (touched & dst):
+                        # ... for a VALU write.  A LOAD that only overwrites (dead) registers of the destination writes them when its
+                        # data returns, at least an LDS / L1 latency (> 16 wait states) after its issue: LLVM's recogniser does not
+                        # count it at all; here it must still sit behind the wait states of a VALU read (round 6: the rank-4 LDL^T
+                        # reads element 0 of a transform MFMA's tile, a ds_read2_b64 reused the tile's last registers 15 wait states
+                        # behind a DGEMM that needs 11 / 18)
+                        touched |= over
+                        need = need_valu
             if w < need and touched & dst:
                 out.append((ins[i][1], ins[j][1], w, need))
                 continue

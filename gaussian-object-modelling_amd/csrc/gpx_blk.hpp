@@ -180,76 +180,8 @@ __device__ __forceinline__ void subblock_ldl(const float *Dn, float *Lx, float *
 // half: the mirror image of the lower-left tile, which is never needed because the steps read ROWS) and T11 -- and its
 // inverse three more (X00, X10, X11).  Element (row 4 r + g, col c) of a tile is register r of lane 16 g + c, so row j is
 // register j / 4 of lane group j % 4: again the B operand as it stands (k = lane group) and, scaled, the A operand.
-// Steps 0-15: 3 + 2 MFMAs, steps 16-31: 1 + 2.
+// The one-wave fp64 routine follows the two-wave one below (it shares the rank-4 panel helpers).
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, double *Xdb, int lane, double &dvec)
-{
-    typedef double T;
-    const int g = lane >> 4, c = lane & 15;
-    f64x4 T00, T01, T11, X00, X10, X11;
-    {
-        const T *b1 = Dn + g * PLD + c, *b2 = Dn + c * PLD + g;  // (row 4 r + g, col c) and its mirror image
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * r + g;
-            const T lo = b1[4 * r * PLD], up = b2[4 * r];
-            const T lo11 = b1[(16 + 4 * r) * PLD + 16], up11 = b2[16 * PLD + 16 + 4 * r];
-            T00[r] = row > c ? lo : up;
-            T01[r] = b2[16 * PLD + 4 * r];           // (row, 16 + c) = mirror of (16 + c, row)
-            T11[r] = row > c ? lo11 : up11;
-            X00[r] = row == c ? 1.0 : 0.0;
-            X10[r] = 0.0;
-            X11[r] = row == c ? 1.0 : 0.0;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = j >> 2, gj = j & 3;
-        const T row0 = T00[r], row1 = T01[r];
-        const T dj = bcast_lane(row0, 16 * gj + j);
-        const T rinv = fast_rcp(dj);
-        const T l0 = row0 * rinv, l1 = row1 * rinv;
-        const bool ing = g == gj, act = ing && c > j;
-        const T a0 = act ? -l0 : 0.0, a1 = ing ? -l1 : 0.0;
-        if (lane == j)
-            dvec = dj;
-        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row0, T00, 0, 0, 0);
-        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, row1, T01, 0, 0, 0);
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-        const T xr = X00[r];
-        X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xr, X00, 0, 0, 0);
-        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xr, X10, 0, 0, 0);
-        if (act)
-            Lx[c * PLD + j] = l0;
-        if (ing)
-            Lx[(16 + c) * PLD + j] = l1;
-    }
-#pragma unroll
-    for (int j = 16; j < NB; ++j) {
-        const int jj = j - 16, r = jj >> 2, gj = jj & 3;
-        const T row1 = T11[r];
-        const T dj = bcast_lane(row1, 16 * gj + jj);
-        const T l1 = row1 * fast_rcp(dj);
-        const bool act = g == gj && c > jj;
-        const T a1 = act ? -l1 : 0.0;
-        if (lane == j)
-            dvec = dj;
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, row1, T11, 0, 0, 0);
-        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X10[r], X10, 0, 0, 0);
-        X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, X11[r], X11, 0, 0, 0);
-        if (act)
-            Lx[(16 + c) * PLD + j] = l1;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * r + g;
-        Xdb[row * PLD + c] = X00[r];
-        Xdb[row * PLD + 16 + c] = 0.0;
-        Xdb[(16 + row) * PLD + c] = X10[r];
-        Xdb[(16 + row) * PLD + 16 + c] = X11[r];
-    }
-}
-
 // ---- the same on TWO waves: wave 0 factorises, wave 1 inverts one step behind -----------------------------------------------
 // The updates of X = L11^-1 take the same A operand as those of the block (the scaled column l_j) but feed nothing back into the
 // chain of pivots, and they are 2 of the 3-5 MFMAs of a step.  Wave 0 keeps the block: per step it publishes column j of L in
@@ -499,6 +431,92 @@ __device__ __forceinline__ void subblock_ldl_pair(const double *Dn, double *Lx, 
             Xdb[(16 + row) * PLD + c] = X10[r];
             Xdb[(16 + row) * PLD + 16 + c] = X11[r];
         }
+    }
+}
+
+// The one-wave form (the 128 x 128 diagonal-block routine of the launch chain and of wide_factor_kernel, gpx_diag128.hpp) in the same
+// rank-4 panels: block and inverse in one wave, 3 + 5 MFMAs per panel in the first half (rank-1 steps: 20), 3 + 3 in the second (12).
+__device__ __forceinline__ void subblock_ldl(const double *Dn, double *Lx, double *Xdb, int lane, double &dvec)
+{
+    typedef double T;
+    const int g = lane >> 4, c = lane & 15;
+    f64x4 T00, T01, T11, X00, X10, X11;
+    {
+        const T *b1 = Dn + g * PLD + c, *b2 = Dn + c * PLD + g;  // (row 4 r + g, col c) and its mirror image
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * r + g;
+            const T lo = b1[4 * r * PLD], up = b2[4 * r];
+            const T lo11 = b1[(16 + 4 * r) * PLD + 16], up11 = b2[16 * PLD + 16 + 4 * r];
+            T00[r] = row > c ? lo : up;
+            T01[r] = b2[16 * PLD + 4 * r];           // (row, 16 + c) = mirror of (16 + c, row)
+            T11[r] = row > c ? lo11 : up11;
+            X00[r] = row == c ? 1.0 : 0.0;
+            X10[r] = 0.0;
+            X11[r] = row == c ? 1.0 : 0.0;
+        }
+    }
+    const f64x4 zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const T tp0 = T00[p], tp1 = T01[p];
+        const int c0 = 4 * p;
+        const LdlPanel4 P = ldl_panel4(bcast_lane(tp0, c0), bcast_lane(tp0, 16 + c0), bcast_lane(tp0, 16 + c0 + 1),
+                                       bcast_lane(tp0, 32 + c0), bcast_lane(tp0, 32 + c0 + 1), bcast_lane(tp0, 32 + c0 + 2),
+                                       bcast_lane(tp0, 48 + c0), bcast_lane(tp0, 48 + c0 + 1), bcast_lane(tp0, 48 + c0 + 2),
+                                       bcast_lane(tp0, 48 + c0 + 3));
+        const T aw = ldl_w_operand(P, g, c);
+        const T u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp0, zero4, 0, 0, 0)[0];
+        const T u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp1, zero4, 0, 0, 0)[0];
+        const T xp = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, X00[p], zero4, 0, 0, 0)[0];  // rows 4 p + g of the inverse: final
+        const T rk = g == 0 ? P.r[0] : (g == 1 ? P.r[1] : (g == 2 ? P.r[2] : P.r[3]));
+        const T l0 = u0 * rk, l1 = u1 * rk;
+        if (lane >= c0 && lane < c0 + 4)
+            dvec = (lane & 3) == 0 ? P.d[0] : ((lane & 3) == 1 ? P.d[1] : ((lane & 3) == 2 ? P.d[2] : P.d[3]));
+        if (c > c0 + g)
+            Lx[c * PLD + c0 + g] = l0;
+        Lx[(16 + c) * PLD + c0 + g] = l1;
+        const T a00 = c > c0 + 3 ? -l0 : 0.0, a01 = -l1;
+        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, u0, T00, 0, 0, 0);
+        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, u1, T01, 0, 0, 0);
+        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, u1, T11, 0, 0, 0);
+        X00[p] = xp;
+        X00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, xp, X00, 0, 0, 0);
+        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, xp, X10, 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const T tp = T11[p];
+        const int c0 = 4 * p;
+        const LdlPanel4 P = ldl_panel4(bcast_lane(tp, c0), bcast_lane(tp, 16 + c0), bcast_lane(tp, 16 + c0 + 1),
+                                       bcast_lane(tp, 32 + c0), bcast_lane(tp, 32 + c0 + 1), bcast_lane(tp, 32 + c0 + 2),
+                                       bcast_lane(tp, 48 + c0), bcast_lane(tp, 48 + c0 + 1), bcast_lane(tp, 48 + c0 + 2),
+                                       bcast_lane(tp, 48 + c0 + 3));
+        const T aw = ldl_w_operand(P, g, c);
+        const T u = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, tp, zero4, 0, 0, 0)[0];
+        const T x10p = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, X10[p], zero4, 0, 0, 0)[0];
+        const T x11p = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, X11[p], zero4, 0, 0, 0)[0];
+        const T rk = g == 0 ? P.r[0] : (g == 1 ? P.r[1] : (g == 2 ? P.r[2] : P.r[3]));
+        const T l = u * rk;
+        if (lane >= 16 + c0 && lane < 16 + c0 + 4)
+            dvec = (lane & 3) == 0 ? P.d[0] : ((lane & 3) == 1 ? P.d[1] : ((lane & 3) == 2 ? P.d[2] : P.d[3]));
+        if (c > c0 + g)
+            Lx[(16 + c) * PLD + 16 + c0 + g] = l;
+        X10[p] = x10p, X11[p] = x11p;
+        if (p < 3) {
+            const T a11 = c > c0 + 3 ? -l : 0.0;
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, u, T11, 0, 0, 0);
+            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, x10p, X10, 0, 0, 0);
+            X11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, x11p, X11, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + g;
+        Xdb[row * PLD + c] = X00[r];
+        Xdb[row * PLD + 16 + c] = 0.0;
+        Xdb[(16 + row) * PLD + c] = X10[r];
+        Xdb[(16 + row) * PLD + 16 + c] = X11[r];
     }
 }
 
