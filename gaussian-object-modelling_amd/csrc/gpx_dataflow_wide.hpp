@@ -78,7 +78,7 @@ template <typename T, int KID>
 __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *info, T *sm)
 {
 #ifdef WIDE_TIMING
-    unsigned long long wt_acc[5] = {0, 0, 0, 0, 0};
+    unsigned long long wt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long wt_start = clock64();
     struct WtFlush {
         unsigned long long *acc, start;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
         {
             acc[0] = clock64() - start;
             if (threadIdx.x == 0 && blockIdx.x < WIDE_TIMING_MAX_TILES)
-                for (int k = 0; k < 5; ++k)
+                for (int k = 0; k < 8; ++k)
                     wide_timing[(size_t)blockIdx.x * 8 + k] = acc[k];
         }
     } wt_flush{wt_acc, wt_start};
@@ -94,6 +94,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
     __shared__ int s_ok, s_next;
     __shared__ double s_best[8];
     __shared__ int s_bi[8], s_bj[8];
+    const unsigned long long wt_start0 = WT_NOW();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int np = f.np, n = f.n;
@@ -180,6 +181,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
         }
         __syncthreads();  // (rowp / colp are about to be overwritten by the operands)
     }
+    WT_ADD(5, wt_start0);  // [5] prologue: points, the tile's kernel-matrix entries, arg-max
     T *bufA = sm, *bufB = sm + 8 * WBLK;
     // one product loop over `nsl` 64-wide k slices: acc += A_slice B_slice^T with A rows from gA (scaled per column by dsc, or 1),
     // B rows from gB; slice s of both starts s * 64 elements further along their rows.  ready(s): the producers' flags of slice s.
@@ -284,11 +286,13 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
             return;
     }
     // ---- the finished sums go to the tile's place in K (read back by this workgroup only: same L2) ----
+    const unsigned long long wt_mid0 = WT_NOW();
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
         acc[cb].store(T(1), (T *)nullptr, Ktile + (size_t)(32 * wi) * np + 64 * wj + 32 * cb, np, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    WT_ADD(6, wt_mid0);  // [6] sums stored and drained
     if (I == J) {
         // ---- diagonal tile: LDL^T + inverse of the 128 x 128 block by the launch chain's routine, in place ----
         const unsigned long long td0 = WT_NOW();
@@ -312,6 +316,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
         if (!ok)
             return;
     }
+    const unsigned long long wt_epi0 = WT_NOW();
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -324,6 +329,7 @@ __device__ __forceinline__ void wide_factor_tile(const FactorArgs<T> &f, int *in
         store_blk_cg<T>(acc[cb], T(1), nullptr, Ktile + (size_t)(32 * wi) * np + 64 * wj + 32 * cb, np, lane);
     }
     publish_tile(Ff + tidx(I, J), f.epoch);
+    WT_ADD(7, wt_epi0);  // [7] scaled, stored write-through, acknowledged, flag up
 }
 
 }  // namespace dataflow

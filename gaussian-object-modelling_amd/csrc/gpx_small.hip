@@ -464,21 +464,22 @@ static void mid_factor_t(const CovHost &h, const MidFactorArgs &m, hipStream_t s
             (void)hipStreamSynchronize(st);
             std::vector<unsigned long long> hs((size_t)f.ntiles * 8);
             (void)hipMemcpyFromSymbol(hs.data(), HIP_SYMBOL(wide_timing), hs.size() * sizeof(unsigned long long));
-            double sum[5] = {0, 0, 0, 0, 0}, diag[5] = {0, 0, 0, 0, 0};
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int nd = 0;
             for (int t = 0, J = 0, rem = 0; t < f.ntiles && t < WIDE_TIMING_MAX_TILES; ++t) {
                 for (J = 0, rem = t; rem >= f.nbt - J; rem -= f.nbt - J, ++J) {
                 }
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     sum[k] += (double)hs[(size_t)t * 8 + k];
                     if (rem == 0)
                         diag[k] += (double)hs[(size_t)t * 8 + k];
                 }
                 nd += rem == 0;
             }
-            std::fprintf(stderr, "wide_timing %s np=%d tiles=%d: workgroup cycles %.4g | flag waits %.1f %% | operands to LDS + barrier %.1f %% | MFMAs + barrier %.1f %% | diag routine %.1f %% | rest %.1f %%  (diagonal tiles: %.0f cycles each, %.0f in the routine, %.0f waiting)\n",
+            std::fprintf(stderr, "wide_timing %s np=%d tiles=%d: workgroup cycles %.4g | flag waits %.1f %% | operands to LDS + barrier %.1f %% | MFMAs + barrier %.1f %% | diag routine %.1f %% | prologue %.1f %% | sums stored %.1f %% | epilogue + publish %.1f %% | rest %.1f %%  (diagonal tiles: %.0f cycles each, %.0f in the routine, %.0f waiting)\n",
                          sizeof(T) == 4 ? "fp32" : "fp64", f.np, f.ntiles, sum[0], 100 * sum[1] / sum[0], 100 * sum[2] / sum[0], 100 * sum[3] / sum[0],
-                         100 * sum[4] / sum[0], 100 * (sum[0] - sum[1] - sum[2] - sum[3] - sum[4]) / sum[0], diag[0] / nd, diag[4] / nd, diag[1] / nd);
+                         100 * sum[4] / sum[0], 100 * sum[5] / sum[0], 100 * sum[6] / sum[0], 100 * sum[7] / sum[0],
+                         100 * (sum[0] - sum[1] - sum[2] - sum[3] - sum[4] - sum[5] - sum[6] - sum[7]) / sum[0], diag[0] / nd, diag[4] / nd, diag[1] / nd);
         }
 #endif
         hipLaunchKernelGGL(mid_finish_kernel, dim3(1), dim3(256), 0, st, f.nbt, f.nb, f.ntiles, (const int *)nullptr, (const int *)nullptr,
