@@ -321,25 +321,28 @@ def surface_config(torch, gpx, ds, dev, local_rank, kern, data, n_train):
             "survivor_variance_ms": st["t_var_ms"], "survivor_mean_ms": st["t_mean_ms"]}
 
 
-def sharded_call_config(gpx, ds, kern, data, n_train, local_rank):
-    """gpx_model_evaluate_sharded / gpx_model_sample_surface_sharded on the headline model with TWO replicas on this one ordinal
-    (what a one-GPU box can run: no scaling claim, a second ordinal has not run) against the single call: are the results equal bit
-    for bit, and what does the cut cost on one device.  Host arrays in and out; 2^20 queries (four 2^18-query slices: two per
-    replica) for evaluate(f, v), the 64^3 lattice for sampleSurface."""
+def sharded_call_config(gpx, ds, local_rank):
+    """gpx_model_evaluate_sharded / gpx_model_sample_surface_sharded with TWO replicas on this one ordinal (what a one-GPU box can
+    run: no scaling claim, a second ordinal has not run) against the single calls: are the results equal bit for bit, and what does
+    the cut cost on one device.  A model of the reference's own size (N = 724, fp32 mode: the small-model kernels -- the two
+    replicas run at the same time, and with the headline model their launches would sit in the profiler's average of the dominant
+    kernel), host arrays in and out; 2^20 queries (four 2^18-query slices: two per replica) for evaluate(f, v), the 128^3 lattice
+    for sampleSurface."""
     import numpy as np
-    m = gpx.Model(kern, *data, precision=gpx.F32, prepare_variance=True, device=local_rank)
+    n = 724
+    m = gpx.Model(gpx.make_kernel("gaussian", 1.0, 1.0), *ds.fibonacci_training_set(n), precision=gpx.F32, prepare_variance=True, device=local_rank)
     reps = [m] + m.replicate([local_rank])
     tt = np.linspace(-1.01, 1.01, GRID)
     gx, gy, gz = np.meshgrid(tt[:64], tt, tt, indexing="ij")
     q = (gx.ravel().copy(), gy.ravel().copy(), gz.ravel().copy())
+    m.evaluate(q[0][:4096], q[1][:4096], q[2][:4096], want_v=True)
     t0 = time.perf_counter()
     one = m.evaluate(*q, want_v=True)
     t1 = time.perf_counter()
     many = gpx.evaluate_sharded(reps, *q, want_v=True)
     t2 = time.perf_counter()
     same_eval = bool(np.array_equal(one["f"], many["f"]) and np.array_equal(one["v"], many["v"]))
-    t64 = np.linspace(-1.01, 1.01, 64)
-    sx, sy, sz = (a.ravel().copy() for a in np.meshgrid(t64, t64, t64, indexing="ij"))
+    sx, sy, sz = (a.ravel().copy() for a in np.meshgrid(tt, tt, tt, indexing="ij"))
     t3 = time.perf_counter()
     s_one = m.sample_surface(sx, sy, sz, f_tol=0.01)
     t4 = time.perf_counter()
@@ -350,8 +353,8 @@ def sharded_call_config(gpx, ds, kern, data, n_train, local_rank):
     for r in reps[1:]:
         r.close()
     m.close()
-    return {"workload": "C3 model (N=%d fp32 matern52): gpx_model_evaluate_sharded(f, v) on %d queries and gpx_model_sample_surface_sharded "
-                        "on the 64^3 lattice over 2 replicas on ONE ordinal, against the single calls (host arrays in and out)" % (n_train, q[0].size),
+    return {"workload": "N=%d Gaussian(1,1) fp32 mode: gpx_model_evaluate_sharded(f, v) on %d queries and gpx_model_sample_surface_sharded "
+                        "on the 128^3 lattice over 2 replicas on ONE ordinal, against the single calls (host arrays in and out)" % (n, q[0].size),
             "replicas": 2, "ordinals": 1, "evaluate_bit_identical": same_eval, "surface_bit_identical": same_surf,
             "evaluate_ms": {"single": (t1 - t0) * 1e3, "sharded": (t2 - t1) * 1e3},
             "surface_ms": {"single": (t4 - t3) * 1e3, "sharded": (t5 - t4) * 1e3, "survivors": int(s_one["n_total"])},
@@ -1049,9 +1052,9 @@ def main():
             except Exception as e:
                 out["configs"]["C3_surface"] = {"error": str(e)}
             try:  # ONE evaluate / sampleSurface call cut over replicas from the C boundary: two replicas on THIS ordinal
-                out["configs"]["C3_sharded_call"] = sharded_call_config(gpx, ds, kern, (x, y, z, lab, s2), n_train, local_rank)
+                out["configs"]["sharded_call"] = sharded_call_config(gpx, ds, local_rank)
             except Exception as e:
-                out["configs"]["C3_sharded_call"] = {"error": str(e)}
+                out["configs"]["sharded_call"] = {"error": str(e)}
             try:
                 out["configs"]["C1_node"] = node_pattern_config()
             except Exception as e:
