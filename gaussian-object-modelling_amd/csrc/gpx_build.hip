@@ -1153,6 +1153,19 @@ int build_model(gpx_model *m, kept_factor *keep, bool no_dataflow)
         int rc = compute_alpha(false, &gave_up);
         if (rc)
             return rc;
+        if (used_dataflow) {
+            // (a dataflow factorisation that gave up leaves a void factor -- seen HERE, at the first host sync behind it,
+            // instead of after a second substitution, the normals and the statistics have run on it)
+            int df_gave_up = 0;
+            HIPCHK(hipMemcpy(&df_gave_up, m->d_info + 6, sizeof(int), hipMemcpyDeviceToHost));
+            if (df_gave_up) {
+                HIPCHK(hipMemsetAsync(m->d_info, 0, sizeof(int) * 8, s));
+                mid_ws.reset();
+                const int rc2 = build_model(m, nullptr, true);
+                m->stats.solve_fallbacks += 1;
+                return rc2;
+            }
+        }
         if (gave_up) {
             // the one-launch substitution relies on lower block rows making progress; when a poll ran out of
             // patience its result is void: clear the flag and redo alpha with one launch per block step
