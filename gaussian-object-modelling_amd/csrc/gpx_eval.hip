@@ -700,15 +700,21 @@ extern "C" int gpx_model_sample_surface_sharded(const gpx_model *const *replicas
         return fail(GPX_E_BAD_ARG, "f_tol must be non-negative");
     const size_t nr = (size_t)n_replicas;
     std::vector<size_t> lo(nr), len(nr), got(nr, 0);
-    std::vector<std::vector<int64_t>> sidx(nr);
-    std::vector<std::vector<double>> sf(nr), sv(nr);
     for (size_t i = 0; i < nr; ++i) {
         size_t hi;
         gpx_slab_range(nq, (int)i, n_replicas, &lo[i], &hi);
         len[i] = hi - lo[i];
     }
+    // capacity >= nq (what the header shim passes): slab i writes its survivors straight into the caller's arrays at its own offset
+    // lo_i -- it has at most len_i of them -- and the slabs are closed up afterwards; a smaller capacity takes staging per slab
+    const bool in_place = capacity >= nq;
+    std::vector<std::vector<int64_t>> sidx(in_place ? 0 : nr);
+    std::vector<std::vector<double>> sf(in_place ? 0 : nr), sv(in_place ? 0 : nr);
     rc = run_slabs(n_replicas, len, [&](int ii) {
         const size_t i = (size_t)ii, a = lo[i], cap = std::min(capacity, len[i]);
+        if (in_place)
+            return gpx_model_sample_surface(replicas[i], len[i], qx + a, qy + a, qz + a, f_tol, len[i], idx + a, f + a, v ? v + a : nullptr,
+                                            &got[i]);
         sidx[i].resize(cap + 1);  // (+1: never a null data() for a capacity of 0)
         sf[i].resize(cap + 1);
         if (v)
@@ -721,11 +727,23 @@ extern "C" int gpx_model_sample_surface_sharded(const gpx_model *const *replicas
     size_t total = 0, w = 0;
     for (size_t i = 0; i < nr; ++i) {
         const size_t have = std::min(got[i], std::min(capacity, len[i]));
-        for (size_t k = 0; k < have && w < capacity; ++k, ++w) {
-            idx[w] = sidx[i][k] + (int64_t)lo[i];
-            f[w] = sf[i][k];
-            if (v)
-                v[w] = sv[i][k];
+        if (in_place) {
+            for (size_t k = 0; k < have; ++k)
+                idx[lo[i] + k] += (int64_t)lo[i];
+            if (w != lo[i] && have) {  // (w <= lo_i: the regions may overlap, the move runs upwards)
+                std::memmove(idx + w, idx + lo[i], sizeof(int64_t) * have);
+                std::memmove(f + w, f + lo[i], sizeof(double) * have);
+                if (v)
+                    std::memmove(v + w, v + lo[i], sizeof(double) * have);
+            }
+            w += have;
+        } else {
+            for (size_t k = 0; k < have && w < capacity; ++k, ++w) {
+                idx[w] = sidx[i][k] + (int64_t)lo[i];
+                f[w] = sf[i][k];
+                if (v)
+                    v[w] = sv[i][k];
+            }
         }
         total += got[i];
     }
